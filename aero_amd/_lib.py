@@ -1,0 +1,119 @@
+"""ctypes binding of the C ABI in include/aero_hip.h (the "reference-side stub" of INTEGRATION.md).
+
+`load()` opens aero_amd/libaero_hip.so, the hipcc/gfx950 build.  There is no fallback: if the
+library is missing or a symbol is absent the import fails loudly.  (tests/ may pass an explicit
+path to the CPU-emulated test double; product code never does.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, 'libaero_hip.so')
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_GLU, ACT_SNAKE = 0, 1, 2, 3, 4
+
+i32, i64, vp, fp, dp = C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('src0', vp), ('s0_b', i64), ('s0_f', i64), ('s0_t', i64), ('C0', i32),
+                ('src1', vp), ('s1_b', i64), ('s1_f', i64), ('s1_t', i64), ('C1', i32),
+                ('weight', vp), ('bias', fp),
+                ('dst', vp), ('d_b', i64), ('d_f', i64), ('d_t', i64),
+                ('dst_f32', i32), ('dst_f_off', i32), ('dst_F', i32),
+                ('B', i32), ('Fin', i32), ('Fout', i32), ('T', i32), ('M', i32),
+                ('transposed', i32), ('fstride', i32),
+                ('ntaps', i32), ('df', i32 * 9), ('dt', i32 * 9),
+                ('act', i32),
+                ('res', vp), ('r_b', i64), ('r_f', i64), ('r_t', i64),
+                ('post_add', fp), ('batch_scale', fp), ('batch_shift', fp)]
+
+
+class NormDesc(C.Structure):
+    _fields_ = [('src', vp), ('s_b', i64), ('s_f', i64), ('s_t', i64),
+                ('B', i32), ('F', i32), ('T', i32), ('C', i32), ('G', i32), ('per_row', i32),
+                ('eps', C.c_float), ('stats', fp), ('gamma', fp), ('beta', fp),
+                ('act', i32), ('snake_a', fp), ('layer_scale', fp),
+                ('res', vp), ('r_b', i64), ('r_f', i64), ('r_t', i64),
+                ('dst', vp), ('d_b', i64), ('d_f', i64), ('d_t', i64)]
+
+
+class LstmDesc(C.Structure):
+    _fields_ = [('xproj', vp), ('xbias', vp), ('whh', vp), ('out', vp),
+                ('H', i32), ('nseq', i32), ('W', i32), ('in_mode', i32), ('out_mode', i32),
+                ('nframes', i32), ('S', i32), ('T', i32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [('qkvd', vp), ('ld', i64), ('out', vp),
+                ('R', i32), ('T', i32), ('C', i32), ('heads', i32), ('ndecay', i32)]
+
+
+class FreqFcDesc(C.Structure):
+    _fields_ = [('x', vp), ('w', vp), ('gate', vp), ('dst', vp),
+                ('B', i32), ('F', i32), ('T', i32), ('C', i32)]
+
+
+_PROTOS = {
+    'aero_version': (C.c_char_p, []),
+    'aero_last_error': (C.c_char_p, []),
+    'aero_stft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, i32, fp, i32, dp, i32, vp]),
+    'aero_spec_normalize': (i32, [fp, i32, i64, dp, vp, fp, vp]),
+    'aero_istft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, fp, fp, i32, vp]),
+    'aero_conv_fwd': (i32, [C.POINTER(ConvDesc), vp]),
+    'aero_norm_stats': (i32, [C.POINTER(NormDesc), vp]),
+    'aero_norm_apply': (i32, [C.POINTER(NormDesc), vp]),
+    'aero_lstm_fwd': (i32, [C.POINTER(LstmDesc), vp]),
+    'aero_lstm_geometry': (i32, [i32, C.POINTER(i32), C.POINTER(i32)]),
+    'aero_localstate_fwd': (i32, [C.POINTER(AttnDesc), vp]),
+    'aero_freqfc_fwd': (i32, [C.POINTER(FreqFcDesc), vp]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+
+class AeroHipError(RuntimeError):
+    pass
+
+
+class Lib:
+    """Loaded C-ABI library with checked calls."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise ImportError(
+                f'{path} not found: build the gfx950 kernels first (python -c "import __graft_entry__ as g; '
+                f'g.build()").  aero_amd has no CPU or eager fallback.')
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, (res, args) in _PROTOS.items():
+            try:
+                fn = getattr(self.cdll, name)
+            except AttributeError as e:
+                raise ImportError(f'{path} does not export {name}') from e
+            fn.restype = res
+            fn.argtypes = args
+        self.version = self.cdll.aero_version().decode()
+        self.is_emulator = 'emulation' in self.version
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise AeroHipError(f'{what} failed ({rc}): {self.cdll.aero_last_error().decode()}')
+
+    def call(self, name, *args):
+        self.check(getattr(self.cdll, name)(*args), name)
+
+    def lstm_geometry(self, H):
+        mp, kp = i32(0), i32(0)
+        self.check(self.cdll.aero_lstm_geometry(H, C.byref(mp), C.byref(kp)), 'aero_lstm_geometry')
+        return mp.value, kp.value
+
+
+_cached = {}
+
+
+def load(path=None):
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path not in _cached:
+        _cached[path] = Lib(path)
+    return _cached[path]

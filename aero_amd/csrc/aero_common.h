@@ -1,0 +1,65 @@
+// aero_common.h -- shared types/helpers for the gfx950 kernels of the AERO spectral path.
+//
+// Activations are fp16, channels-last: element (b, f, t, c) of a tensor lives at
+//   base + b*sb + f*sf + t*st + c            (strides in elements, channel stride 1)
+// so one (b, f) "row" is a [T, C] slab that is contiguous along time.  GEMM operands are
+// K-contiguous on both sides (weights [M][K], activations [pos][C]) which is what the
+// 16x16x32 f16 MFMA fragments want (8 consecutive k per lane = one 16-byte load).
+#pragma once
+#include <stdint.h>
+
+#ifdef AERO_EMU
+#include "hip_emu.h"
+#define aero_fast_exp(x) expf(x)
+#else
+#define aero_fast_exp(x) __expf(x)
+#include <hip/hip_runtime.h>
+#define AERO_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
+#endif
+
+#include "../../include/aero_hip.h"
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define AERO_LDS_ALIGN __attribute__((aligned(16)))
+
+static __device__ __forceinline__ int aero_lane() { return threadIdx.x & 63; }
+static __device__ __forceinline__ int aero_wave() { return threadIdx.x >> 6; }
+
+// Bijective XCD-aware remap (MI355X: block b runs on XCD b % 8, each XCD has a private L2):
+// give every XCD a contiguous chunk of the logical grid so neighbouring tiles share L2.
+static __device__ __forceinline__ int aero_xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static __device__ __forceinline__ float aero_sigmoid(float x) { return 1.0f / (1.0f + aero_fast_exp(-x)); }
+static __device__ __forceinline__ float aero_tanh(float x) {
+    // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
+    float e = aero_fast_exp(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+static __device__ __forceinline__ float aero_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <class T>
+static __device__ __forceinline__ T aero_wave_sum(T v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// LDS image of a [rows][32] fp16 tile (64-byte rows).  ds_read_b128 is serviced in four 16-lane
+// groups over a 256-byte bank row; fragment reads put lane (l&15) on row (l&15) at 16-byte slot
+// q = l>>4, so un-swizzled rows r, r+4, r+8, r+12 collide.  slot' = q ^ ((-(r>>2)) & 3) makes every
+// group conflict free (checked against the gfx950 lane-group table in the design notes).
+static __device__ __forceinline__ int aero_tile_off(int row, int q) {
+    return row * 32 + ((q ^ ((0 - (row >> 2)) & 3)) << 3);
+}
+
+static inline int aero_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,112 @@
+// aero_hip.hip -- the C-ABI shared library (include/aero_hip.h) over the gfx950 kernels.
+// Built with:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC  (see __graft_entry__.build()).
+// gfx950 only: no other offload arch, no CUDA path, no CPU fallback.  (tests/emu builds the same
+// translation unit against a CPU emulation of the HIP subset, as a test double -- never loaded by
+// the product.)
+#include "aero_common.h"
+#include "k_attn.h"
+#include "k_conv.h"
+#include "k_ftb.h"
+#include "k_lstm.h"
+#include "k_norm.h"
+#include "k_stft.h"
+
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+static int aero_fail(int rc, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "unknown error");
+    return rc;
+}
+
+static int aero_finish(int rc, const char* err) {
+    if (rc != AERO_OK) return aero_fail(rc, err);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", hipGetErrorString(e));
+        return AERO_ERR_LAUNCH;
+    }
+    return AERO_OK;
+}
+
+extern "C" {
+
+const char* aero_version(void) {
+#ifdef AERO_EMU
+    return "aero_hip 0.1 (CPU emulation build -- tests only)";
+#else
+    return "aero_hip 0.1 (gfx950)";
+#endif
+}
+
+const char* aero_last_error(void) { return g_err; }
+
+int aero_stft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, const float* window,
+                  int32_t n_bins, float* spec, int32_t T, double* stats, int32_t sig_per_item, void* stream) {
+    const char* err = "";
+    int rc = aero_stft_launch(x, nsig, L, Lp, n_fft, hop, window, n_bins, spec, T, stats, sig_per_item,
+                              (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_spec_normalize(const float* spec, int32_t nitems, int64_t n_per_item, const double* stats, void* xn,
+                        float* mean_std, void* stream) {
+    const char* err = "";
+    int rc = aero_spec_normalize_launch(spec, nitems, n_per_item, stats, xn, mean_std, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_istft_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_t n_fft, int32_t hop, const float* window,
+                   const float* inv_env, float* y, int32_t Lout, void* stream) {
+    const char* err = "";
+    int rc = aero_istft_launch(spec, nsig, F, T, n_fft, hop, window, inv_env, y, Lout, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_conv_fwd(const aero_conv_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_conv_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_norm_stats(const aero_norm_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_norm_stats_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_norm_apply(const aero_norm_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_norm_apply_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_lstm_geometry(int32_t H, int32_t* MP, int32_t* KP) {
+    int tpw, kt;
+    if (aero_lstm_pick(H, &tpw, &kt)) return aero_fail(AERO_ERR_UNSUPPORTED, "lstm: hidden size > 128 unsupported");
+    if (MP) *MP = 64 * tpw;
+    if (KP) *KP = 32 * kt;
+    return AERO_OK;
+}
+
+int aero_lstm_fwd(const aero_lstm_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_lstm_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_localstate_fwd(const aero_attn_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_attn_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_freqfc_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// k_conv.h -- implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_16x16x32_f16).
+//
+// One kernel family serves every dense contraction of the path (see include/aero_hip.h,
+// aero_conv_fwd).  GEMM view per output row (b, fo):
+//     D[m][n] = sum_k A[m][k] * Bm[k][n],   m = output channel, n = time step, k = (tap, channel)
+// A = packed weights [Mpad][ntaps*Cp] (K contiguous), Bm = activations gathered from the source
+// row(s) fi(fo, tap) shifted by dt(tap) -- a contiguous [T, C] slab per tap, so HBM reads are
+// coalesced along time and every K-chunk of 32 channels is 4 x 16-byte loads per position.
+// A block owns BM output channels x 128 time steps of ONE (b, fo) row: padding validity, the
+// transposed-conv weight set and the source row are block-uniform; invalid taps and the
+// structurally-zero source of the first decoder are skipped entirely.
+//
+// Roofline: MFMA (fp16 in, fp32 accumulate).  Algorithmic FLOPs = 2*M*ntaps*(C0+C1) per output
+// position.  v1 pipeline: register-staged global->LDS, one LDS buffer,
+// next K-chunk prefetched into VGPRs while the current one feeds the MFMAs.
+#pragma once
+#include "aero_common.h"
+
+struct AeroConvK {
+    aero_conv_desc d;
+    int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec_out;
+};
+
+template <int MF, int WM>
+__global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
+    constexpr int WN = 4 / WM;
+    constexpr int NF = 8 / WN;
+    constexpr int BM = 16 * MF * WM;
+    constexpr int BN = 128;
+    constexpr int AV = (BM * 4 + 255) / 256;
+    __shared__ AERO_LDS_ALIGN h16 As[BM * 32];
+    __shared__ AERO_LDS_ALIGN h16 Bs[BN * 32];
+
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const int mt = id % p.nmt;
+    id /= p.nmt;
+    const int tt = id % p.ntt;
+    const int row = id / p.ntt;
+    const int b = row / d.Fout, fo = row % d.Fout;
+    const int fdst = fo - d.dst_f_off;
+    if (fdst < 0 || fdst >= d.dst_F) return;  // trimmed row: block-uniform exit
+    const int m0 = mt * BM, t0 = tt * BN;
+    const int wset = d.transposed ? (fo % d.fstride) : 0;
+    const int fbase = d.transposed ? (fo / d.fstride) : (fo * d.fstride);
+    const h16* Wp = (const h16*)d.weight + ((int64_t)wset * p.Mpad + m0) * p.Ktot;
+    const h16* s0 = (const h16*)d.src0;
+    const h16* s1 = (const h16*)d.src1;
+    const int C0 = d.C0, C1 = d.C1, T = d.T;
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    h16x8 ra[AV], rb[2];
+    int j = -1, cc = p.cpt - 1, fi = 0;  // chunk iterator state: tap j, channel chunk cc
+
+    auto next_chunk = [&]() -> bool {
+        for (;;) {
+            ++cc;
+            if (cc == p.cpt) {
+                cc = 0;
+                ++j;
+                while (j < d.ntaps) {
+                    fi = fbase + d.df[j];
+                    if (fi >= 0 && fi < d.Fin) break;
+                    ++j;
+                }
+            }
+            if (j >= d.ntaps) return false;
+            // chunk lies entirely inside a NULL (all-zero) first source: nothing to add
+            if (s0 == nullptr && (cc + 1) * 32 <= C0) continue;
+            return true;
+        }
+    };
+
+    auto fetch_b = [&](int t, int c) -> h16x8 {
+        h16x8 z = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < 0 || t >= T) return z;
+        if (p.vec_in) {
+            if (c < C0) {
+                if (s0) z = *(const h16x8*)(s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)t * d.s0_t + c);
+            } else if (c - C0 < C1) {
+                z = *(const h16x8*)(s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)t * d.s1_t + (c - C0));
+            }
+        } else {
+            const h16* p0 = s0 ? s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)t * d.s0_t : nullptr;
+            const h16* p1 = s1 ? s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)t * d.s1_t : nullptr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ce = c + e;
+                h16 v = (h16)0;
+                if (ce < C0) {
+                    if (p0) v = p0[ce];
+                } else if (ce - C0 < C1) {
+                    v = p1[ce - C0];
+                }
+                z[e] = v;
+            }
+        }
+        return z;
+    };
+
+    auto load_chunk = [&]() {
+        const int kofs = j * p.Cp + cc * 32;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int v = tid + 256 * i;
+            if (v < BM * 4) ra[i] = *(const h16x8*)(Wp + (int64_t)(v >> 2) * p.Ktot + kofs + (v & 3) * 8);
+        }
+        const int dtj = d.dt[j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i;
+            rb[i] = fetch_b(t0 + (v >> 2) + dtj, cc * 32 + (v & 3) * 8);
+        }
+    };
+
+    bool have = next_chunk();
+    if (have) load_chunk();
+    while (have) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int v = tid + 256 * i;
+            if (v < BM * 4) *(h16x8*)&As[aero_tile_off(v >> 2, v & 3)] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i;
+            *(h16x8*)&Bs[aero_tile_off(v >> 2, v & 3)] = rb[i];
+        }
+        __syncthreads();
+        have = next_chunk();
+        if (have) load_chunk();  // next chunk's global loads fly while this one feeds the MFMAs
+        h16x8 af[MF], bf[NF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af[i] = *(const h16x8*)&As[aero_tile_off((wm * MF + i) * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+        for (int n = 0; n < NF; ++n) bf[n] = *(const h16x8*)&Bs[aero_tile_off((wn * NF + n) * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[n], acc[i][n], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: D[m = (lane>>4)*4 + r][n = lane&15] per fragment ----------------
+    const int M = d.M;
+    const bool glu = d.act == AERO_ACT_GLU;
+    const int Mout = glu ? (M >> 1) : M;
+    const int nout = glu ? 2 : 4;
+    h16* dst16 = (h16*)d.dst;
+    float* dst32 = (float*)d.dst;
+    const h16* res = (const h16*)d.res;
+    const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
+    const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int mbase = m0 + (wm * MF + i) * 16 + (lane >> 4) * 4;
+        if (mbase >= M) continue;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (d.bias && mbase + r < M) ? d.bias[mbase + r] : 0.f;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int t = t0 + (wn * NF + n) * 16 + (lane & 15);
+            if (t >= T) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = acc[i][n][r] + bv[r];
+            int cbase = mbase;
+            if (glu) {
+                o[0] = o[0] * aero_sigmoid(o[1]);
+                o[1] = o[2] * aero_sigmoid(o[3]);
+                cbase = mbase >> 1;
+            } else if (d.act == AERO_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+            } else if (d.act == AERO_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = aero_gelu(o[r]);
+            }
+            const int64_t doff = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * d.d_t + cbase;
+            const int64_t roff = (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + (int64_t)t * d.r_t + cbase;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r >= nout || cbase + r >= Mout) continue;
+                float x = o[r];
+                if (res) x += (float)res[roff + r];
+                if (d.post_add) x += d.post_add[(int64_t)fo * Mout + cbase + r];
+                o[r] = x * bsc + bsh;
+            }
+            if (p.vec_out && cbase + nout <= Mout) {
+                if (d.dst_f32) {
+                    if (glu) *(f32x2*)(dst32 + doff) = (f32x2){o[0], o[1]};
+                    else *(f32x4*)(dst32 + doff) = (f32x4){o[0], o[1], o[2], o[3]};
+                } else {
+                    if (glu) *(h16x2*)(dst16 + doff) = (h16x2){(h16)o[0], (h16)o[1]};
+                    else *(h16x4*)(dst16 + doff) = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r >= nout || cbase + r >= Mout) continue;
+                    if (d.dst_f32) dst32[doff + r] = o[r];
+                    else dst16[doff + r] = (h16)o[r];
+                }
+            }
+        }
+    }
+}
+
+static int aero_conv_pick_bm(int M, int Mpad) {
+    const int cand[5] = {128, 64, 48, 32, 16};
+    int best = 128;
+    long best_cost = -1;
+    for (int i = 0; i < 5; ++i) {
+        const int bm = cand[i];
+        const int tiles = (M + bm - 1) / bm;
+        if (tiles * bm > Mpad) continue;
+        const long cost = (long)tiles * (bm + 40);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = bm;
+        }
+    }
+    return best;
+}
+
+static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const char** err) {
+    if (!d || !d->weight || !d->dst) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
+    if (d->ntaps < 1 || d->ntaps > 9) { *err = "conv: ntaps must be 1..9"; return AERO_ERR_ARG; }
+    if (d->C0 < 0 || d->C1 < 0 || d->C0 + d->C1 <= 0 || d->M <= 0) { *err = "conv: bad channel counts"; return AERO_ERR_ARG; }
+    if (d->C1 > 0 && !d->src1) { *err = "conv: src1 NULL with C1>0"; return AERO_ERR_ARG; }
+    if (d->C1 == 0 && !d->src0) { *err = "conv: no source"; return AERO_ERR_ARG; }
+    if (d->fstride < 1 || d->B < 1 || d->Fout < 1 || d->T < 1) { *err = "conv: bad geometry"; return AERO_ERR_ARG; }
+    if (d->act == AERO_ACT_GLU && (d->M & 1)) { *err = "conv: GLU needs even M"; return AERO_ERR_ARG; }
+    if (d->act < 0 || d->act > AERO_ACT_GLU) { *err = "conv: unsupported act"; return AERO_ERR_UNSUPPORTED; }
+    AeroConvK p;
+    p.d = *d;
+    p.Cp = (d->C0 + d->C1 + 31) / 32 * 32;
+    p.cpt = p.Cp / 32;
+    p.Ktot = d->ntaps * p.Cp;
+    p.Mpad = (d->M + 127) / 128 * 128;
+    const int bm = aero_conv_pick_bm(d->M, p.Mpad);
+    p.nmt = (d->M + bm - 1) / bm;
+    p.ntt = (d->T + 127) / 128;
+    auto al8 = [](int64_t v) { return (v & 7) == 0; };
+    int vin = (d->C0 % 8 == 0) && (d->C1 % 8 == 0);
+    if (d->src0) vin = vin && al8(d->s0_b) && al8(d->s0_f) && al8(d->s0_t) && (((uintptr_t)d->src0 & 15) == 0);
+    if (d->src1) vin = vin && al8(d->s1_b) && al8(d->s1_f) && al8(d->s1_t) && (((uintptr_t)d->src1 & 15) == 0);
+    p.vec_in = vin;
+    const int Mout = d->act == AERO_ACT_GLU ? d->M / 2 : d->M;
+    const int nout = d->act == AERO_ACT_GLU ? 2 : 4;
+    const int esz = d->dst_f32 ? 4 : 2;
+    p.vec_out = (Mout % nout == 0) && (d->d_b % nout == 0) && (d->d_f % nout == 0) && (d->d_t % nout == 0) &&
+                (((uintptr_t)d->dst % (uintptr_t)(esz * nout)) == 0);
+    const long nwg = (long)d->B * d->Fout * p.ntt * p.nmt;
+    if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
+    dim3 grid((unsigned)nwg), block(256);
+    switch (bm) {
+        case 128: AERO_LAUNCH((aero_conv_kernel<4, 2>), grid, block, stream, p); break;
+        case 64: AERO_LAUNCH((aero_conv_kernel<4, 1>), grid, block, stream, p); break;
+        case 48: AERO_LAUNCH((aero_conv_kernel<3, 1>), grid, block, stream, p); break;
+        case 32: AERO_LAUNCH((aero_conv_kernel<2, 1>), grid, block, stream, p); break;
+        default: AERO_LAUNCH((aero_conv_kernel<1, 1>), grid, block, stream, p); break;
+    }
+    return AERO_OK;
+}

@@ -1,0 +1,289 @@
+// k_stft.h -- STFT / iSTFT front-end kernels (HBM-bound; fp32 throughout).
+//
+// STFT  (reference spec.py:9-22 via aero.py:409-421): real FFT of size n_fft computed as a complex
+//        Stockham radix-2 FFT of size n = n_fft/2 on the even/odd packed frame, one frame per
+//        wavefront, butterflies staged through LDS; a block's frames are transposed through an LDS
+//        tile so spectrogram writes are contiguous runs along the frame axis.
+// iSTFT (spec.py:25-39 via aero.py:423-428): Hermitian unpack -> complex FFT (conjugate trick) ->
+//        window -> output-stationary overlap-add in LDS (every output sample is produced by exactly
+//        one thread; no atomics) -> divide by the window envelope -> trim/crop.
+// Algorithmic bytes: STFT reads 4 B/sample, writes 8 B/(bin,frame);
+// iSTFT reads 8 B/(bin,frame), writes 4 B/sample.
+#pragma once
+#include "aero_common.h"
+
+#define AERO_FFT_MAX_N 512   /* complex points = n_fft/2  ->  n_fft <= 1024 */
+
+static __device__ __forceinline__ f32x2 aero_cmul(f32x2 a, f32x2 b) {
+    return (f32x2){a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]};
+}
+
+// tw[k] = exp(-2*pi*i*k/n_fft), k in [0, n_fft/2)
+static __device__ __forceinline__ void aero_fft_init_twiddles(f32x2* tw, int n_fft) {
+    for (int k = threadIdx.x; k < n_fft / 2; k += 256) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)n_fft;
+        tw[k] = (f32x2){(float)cos(a), (float)sin(a)};
+    }
+}
+
+// Stockham radix-2 autosort FFT of n points, one problem per wavefront, all 4 waves in lockstep.
+// Returns the buffer (a or b) that holds the natural-order result.
+static __device__ __forceinline__ f32x2* aero_fft_wave(f32x2* a, f32x2* b, int n, int n_fft, const f32x2* tw) {
+    const int lane = aero_lane();
+    const int half = n >> 1;
+    f32x2* src = a;
+    f32x2* dst = b;
+    for (int p = 1; p < n; p <<= 1) {
+        const int tws = n_fft / (2 * p);
+        for (int i = lane; i < half; i += 64) {
+            const int k = i & (p - 1);
+            const f32x2 u0 = src[i];
+            const f32x2 v = aero_cmul(tw[k * tws], src[i + half]);
+            const int jj = ((i - k) << 1) + k;
+            dst[jj] = u0 + v;
+            dst[jj + p] = u0 - v;
+        }
+        __syncthreads();
+        f32x2* tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    return src;
+}
+
+struct AeroStftK {
+    const float* x; const float* window; float* spec; double* stats;
+    int nsig, L, Lp, n_fft, hop, n_bins, T, sig_per_item, FPB;
+};
+
+__global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
+    __shared__ AERO_LDS_ALIGN f32x2 tw[AERO_FFT_MAX_N];
+    __shared__ AERO_LDS_ALIGN f32x2 bufA[4][AERO_FFT_MAX_N];
+    __shared__ AERO_LDS_ALIGN f32x2 bufB[4][AERO_FFT_MAX_N];
+    __shared__ AERO_LDS_ALIGN f32x2 tile[2048 + 64];
+    __shared__ double red[2][4];
+    const int n = p.n_fft >> 1;
+    const int lane = aero_lane(), wave = aero_wave();
+    const int sig = blockIdx.y;
+    const int tbase = blockIdx.x * p.FPB;
+    const float* xs = p.x + (int64_t)sig * p.L;
+    const float scale = 1.0f / sqrtf((float)p.n_fft);
+    aero_fft_init_twiddles(tw, p.n_fft);
+    float s = 0.f, ss = 0.f;
+    const int rounds = (p.FPB + 3) / 4;
+    for (int r = 0; r < rounds; ++r) {
+        const int fr = r * 4 + wave;
+        const int t = tbase + fr;
+        const bool live = fr < p.FPB && t < p.T;
+        for (int m = lane; m < n; m += 64) {
+            f32x2 g = (f32x2){0.f, 0.f};
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int ni = 2 * m + e;
+                    const float w = p.window[ni];
+                    if (w != 0.f) {
+                        int xi = t * p.hop + ni - n;             // index into the hop-padded signal
+                        if (xi < 0) xi = -xi;                    // reflect (no edge repeat)
+                        if (xi >= p.Lp) xi = 2 * (p.Lp - 1) - xi;
+                        g[e] = (xi < p.L) ? w * xs[xi] : 0.f;    // [L, Lp) is the zero pad of aero.py:410
+                    }
+                }
+            }
+            bufA[wave][m] = g;
+        }
+        __syncthreads();
+        const f32x2* R = aero_fft_wave(bufA[wave], bufB[wave], n, p.n_fft, tw);
+        if (fr < p.FPB) {
+            for (int k = lane; k < p.n_bins; k += 64) {
+                f32x2 X;
+                if (k == 0) {
+                    X = (f32x2){R[0][0] + R[0][1], 0.f};
+                } else if (k == n) {
+                    X = (f32x2){R[0][0] - R[0][1], 0.f};
+                } else {
+                    const f32x2 zk = R[k];
+                    const f32x2 zc = (f32x2){R[n - k][0], -R[n - k][1]};
+                    const f32x2 E = (zk + zc) * 0.5f;
+                    const f32x2 D = (zk - zc) * 0.5f;
+                    const f32x2 O = (f32x2){D[1], -D[0]};
+                    X = E + aero_cmul(tw[k], O);
+                }
+                X = X * scale;
+                tile[k * p.FPB + fr] = X;
+                if (live) { s += X[0] + X[1]; ss += X[0] * X[0] + X[1] * X[1]; }
+            }
+        }
+        __syncthreads();
+    }
+    const int total = p.n_bins * p.FPB;
+    f32x2* out = (f32x2*)p.spec + (int64_t)sig * p.n_bins * p.T;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int k = idx / p.FPB, fr = idx % p.FPB;
+        const int t = tbase + fr;
+        if (t < p.T) out[(int64_t)k * p.T + t] = tile[idx];
+    }
+    if (p.stats) {
+        double ds = aero_wave_sum((double)s), dss = aero_wave_sum((double)ss);
+        if (lane == 0) { red[0][wave] = ds; red[1][wave] = dss; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* st = p.stats + 2 * (int64_t)(sig / p.sig_per_item);
+            atomicAdd(st, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            atomicAdd(st + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void aero_spec_normalize_kernel(const float* spec, int64_t n_per_item, const double* stats,
+                                                                  h16* xn, float* mean_std) {
+    const int item = blockIdx.y;
+    const double N = (double)n_per_item;
+    const double S = stats[2 * item], SS = stats[2 * item + 1];
+    const double mean = S / N;
+    double var = (SS - S * S / N) / (N - 1.0);     // unbiased (torch.std default, aero.py:463)
+    if (var < 0) var = 0;
+    const float fm = (float)mean, fs = (float)sqrt(var);
+    const float inv = 1.0f / (1e-5f + fs);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { mean_std[2 * item] = fm; mean_std[2 * item + 1] = fs; }
+    const float* src = spec + (int64_t)item * n_per_item;
+    h16* dst = xn + (int64_t)item * n_per_item;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; e < n_per_item; e += (int64_t)gridDim.x * 512) {
+        const f32x2 v = *(const f32x2*)(src + e);
+        *(h16x2*)(dst + e) = (h16x2){(h16)((v[0] - fm) * inv), (h16)((v[1] - fm) * inv)};
+    }
+}
+
+struct AeroIstftK {
+    const float* spec; const float* window; const float* inv_env; float* y;
+    int nsig, F, T, n_fft, hop, Lout, FPB, SEG;
+};
+
+__global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
+    __shared__ AERO_LDS_ALIGN f32x2 tw[AERO_FFT_MAX_N];
+    __shared__ AERO_LDS_ALIGN f32x2 fbuf[4096];            // [FPB][n], FPB*n <= 4096
+    __shared__ AERO_LDS_ALIGN f32x2 sbuf[4][AERO_FFT_MAX_N];
+    const int n = p.n_fft >> 1;
+    const int lane = aero_lane(), wave = aero_wave();
+    const int sig = blockIdx.y;
+    const int o0 = blockIdx.x * p.SEG;
+    const int i0 = o0 + n;                                  // first overlap-add index of this block
+    const int num = i0 - p.n_fft + p.hop;
+    const int t_lo = num > 0 ? num / p.hop : 0;
+    int t_hi = (i0 + p.SEG - 1) / p.hop;
+    if (t_hi > p.T - 1) t_hi = p.T - 1;
+    const int nfr = t_hi - t_lo + 1;                        // <= FPB by construction of SEG
+    aero_fft_init_twiddles(tw, p.n_fft);
+    __syncthreads();
+    const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * p.T;
+    // phase 1: Hermitian unpack of each frame into conj(Z), Z = E + iO  (frames are the fast index)
+    for (int idx = threadIdx.x; idx < p.FPB * n; idx += 256) {
+        const int fr = idx % p.FPB, k = idx / p.FPB;
+        f32x2 zc = (f32x2){0.f, 0.f};
+        if (fr < nfr) {
+            const int t = t_lo + fr;
+            f32x2 xa = X[(int64_t)k * p.T + t];
+            f32x2 xb = (f32x2){0.f, 0.f};                   // conj(X[n-k]); X[n] is the implicit zero Nyquist bin
+            if (k == 0) {
+                xa[1] = 0.f;                                 // irfft ignores the imaginary part of DC
+            } else {
+                const f32x2 q = X[(int64_t)(n - k) * p.T + t];
+                xb = (f32x2){q[0], -q[1]};
+            }
+            const f32x2 E = (xa + xb) * 0.5f;
+            const f32x2 D = (xa - xb) * 0.5f;
+            const f32x2 O = aero_cmul(D, (f32x2){tw[k][0], -tw[k][1]});
+            zc = (f32x2){E[0] - O[1], -(E[1] + O[0])};
+        }
+        fbuf[fr * n + k] = zc;
+    }
+    __syncthreads();
+    // phase 2: one frame per wave per round
+    const int rounds = (p.FPB + 3) / 4;
+    for (int r = 0; r < rounds; ++r) {
+        const int fr = r * 4 + wave;
+        f32x2* a = fr < p.FPB ? fbuf + fr * n : sbuf[wave];  // (FPB is a multiple of 4 in practice)
+        f32x2* R = aero_fft_wave(a, sbuf[wave], n, p.n_fft, tw);
+        if (R != a) {
+            for (int m = lane; m < n; m += 64) a[m] = R[m];
+        }
+        __syncthreads();
+    }
+    // phase 3: output-stationary overlap-add
+    const float scale = sqrtf((float)p.n_fft) / (float)n;
+    float* ys = p.y + (int64_t)sig * p.Lout;
+    for (int o = threadIdx.x; o < p.SEG; o += 256) {
+        const int oo = o0 + o;
+        if (oo >= p.Lout) break;
+        const int i = oo + n;
+        const int num2 = i - p.n_fft + p.hop;
+        int ta = num2 > 0 ? num2 / p.hop : 0;
+        if (ta < t_lo) ta = t_lo;
+        int tb = i / p.hop;
+        if (tb > t_hi) tb = t_hi;
+        float acc = 0.f;
+        for (int t = ta; t <= tb; ++t) {
+            const int ni = i - t * p.hop;
+            const f32x2 R = fbuf[(t - t_lo) * n + (ni >> 1)];
+            const float g = (ni & 1) ? -R[1] : R[0];
+            acc += p.window[ni] * g;
+        }
+        ys[oo] = acc * scale * p.inv_env[i];
+    }
+}
+
+static int aero_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+static int aero_stft_launch(const float* x, int nsig, int L, int Lp, int n_fft, int hop, const float* window, int n_bins,
+                            float* spec, int T, double* stats, int sig_per_item, hipStream_t stream, const char** err) {
+    if (!x || !window || !spec) { *err = "stft: null pointer"; return AERO_ERR_ARG; }
+    const int n = n_fft / 2;
+    if (n_fft < 16 || (1 << aero_ilog2(n_fft)) != n_fft || n > AERO_FFT_MAX_N) { *err = "stft: n_fft must be a power of two in [16,1024]"; return AERO_ERR_UNSUPPORTED; }
+    if (hop < 1 || Lp < L || T != 1 + Lp / hop) { *err = "stft: inconsistent L/Lp/hop/T"; return AERO_ERR_ARG; }
+    if (Lp <= n) { *err = "stft: signal shorter than the reflect pad"; return AERO_ERR_ARG; }
+    if (n_bins != n && n_bins != n + 1) { *err = "stft: n_bins must be n_fft/2 or n_fft/2+1"; return AERO_ERR_ARG; }
+    if (stats && sig_per_item < 1) { *err = "stft: sig_per_item"; return AERO_ERR_ARG; }
+    AeroStftK p;
+    p.x = x; p.window = window; p.spec = spec; p.stats = stats;
+    p.nsig = nsig; p.L = L; p.Lp = Lp; p.n_fft = n_fft; p.hop = hop; p.n_bins = n_bins; p.T = T;
+    p.sig_per_item = sig_per_item > 0 ? sig_per_item : 1;
+    int fpb = 2048 / n;
+    if (fpb > 32) fpb = 32;
+    if (fpb < 4) fpb = 4;
+    p.FPB = fpb;
+    dim3 grid((unsigned)((T + fpb - 1) / fpb), (unsigned)nsig), block(256);
+    AERO_LAUNCH(aero_stft_kernel, grid, block, stream, p);
+    return AERO_OK;
+}
+
+static int aero_spec_normalize_launch(const float* spec, int nitems, int64_t n_per_item, const double* stats, void* xn,
+                                      float* mean_std, hipStream_t stream, const char** err) {
+    if (!spec || !stats || !xn || !mean_std) { *err = "spec_normalize: null pointer"; return AERO_ERR_ARG; }
+    if (n_per_item < 2 || (n_per_item & 1)) { *err = "spec_normalize: n_per_item must be even"; return AERO_ERR_ARG; }
+    int64_t nb = (n_per_item / 2 + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    dim3 grid((unsigned)nb, (unsigned)nitems), block(256);
+    AERO_LAUNCH(aero_spec_normalize_kernel, grid, block, stream, spec, n_per_item, stats, (h16*)xn, mean_std);
+    return AERO_OK;
+}
+
+static int aero_istft_launch(const float* spec, int nsig, int F, int T, int n_fft, int hop, const float* window,
+                             const float* inv_env, float* y, int Lout, hipStream_t stream, const char** err) {
+    if (!spec || !window || !inv_env || !y) { *err = "istft: null pointer"; return AERO_ERR_ARG; }
+    const int n = n_fft / 2;
+    if (n_fft < 16 || (1 << aero_ilog2(n_fft)) != n_fft || n > AERO_FFT_MAX_N) { *err = "istft: n_fft must be a power of two in [16,1024]"; return AERO_ERR_UNSUPPORTED; }
+    if (F != n) { *err = "istft: F must be n_fft/2"; return AERO_ERR_ARG; }
+    if (hop < 1 || hop > n_fft || T < 1 || Lout < 1 || Lout > hop * (T - 1)) { *err = "istft: bad hop/T/Lout"; return AERO_ERR_ARG; }
+    AeroIstftK p;
+    p.spec = spec; p.window = window; p.inv_env = inv_env; p.y = y;
+    p.nsig = nsig; p.F = F; p.T = T; p.n_fft = n_fft; p.hop = hop; p.Lout = Lout;
+    int fpb = 4096 / n;
+    if (fpb > 32) fpb = 32;
+    const int need = (n_fft + hop - 1) / hop;              // frames overlapping one sample
+    if (fpb <= need) { *err = "istft: hop too small for the LDS frame ring"; return AERO_ERR_UNSUPPORTED; }
+    p.FPB = fpb;
+    p.SEG = (fpb - need) * hop;
+    dim3 grid((unsigned)((Lout + p.SEG - 1) / p.SEG), (unsigned)nsig), block(256);
+    AERO_LAUNCH(aero_istft_kernel, grid, block, stream, p);
+    return AERO_OK;
+}

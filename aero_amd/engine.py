@@ -1,0 +1,480 @@
+"""HipEngine -- runs Aero.forward (reference aero.py:446-523) through the gfx950 kernels.
+
+Host plumbing only: it packs weights once (aero_amd.pack), allocates device buffers with the
+PyTorch caching allocator and issues the C-ABI calls of include/aero_hip.h on the current HIP
+stream.  No arithmetic of the path is done with ATen ops here, and there is no CPU fallback:
+inputs must live on the MI355X (`cuda`) device.
+
+Internal activation layout: fp16 channels-last [B, F, T, C] (see aero_amd/csrc/aero_common.h).
+The complex spectrograms handed back to the caller are exactly the reference's complex64
+[B, 1, nfft/2, T] tensors (same memory as the fp32 [B, F, T, 2] buffers the kernels write).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, pack
+from ._lib import ACT_GELU, ACT_GLU, ACT_NONE, ACT_RELU, ACT_SNAKE
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _strides4(t):
+    """element strides (b, f, t) of a channels-last [B,F,T,C] tensor (channel stride must be 1)."""
+    assert t.dim() == 4 and (t.shape[3] == 1 or t.stride(3) == 1), (t.shape, t.stride())
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+class Ops:
+    """Tensor-level wrappers over the C ABI (used by the engine and by the op-level tests)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    @staticmethod
+    def stream(t):
+        return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+    # -- K1/K2/K15 ---------------------------------------------------------------------------
+    def stft(self, x, L, Lp, n_fft, hop, window, n_bins, stats=None, sig_per_item=1):
+        nsig = x.shape[0]
+        T = 1 + Lp // hop
+        spec = torch.empty(nsig, n_bins, T, 2, dtype=torch.float32, device=x.device)
+        self.lib.call('aero_stft_fwd', _ptr(x), nsig, L, Lp, n_fft, hop, _ptr(window), n_bins, _ptr(spec), T,
+                      _ptr(stats), sig_per_item, self.stream(x))
+        return spec
+
+    def spec_normalize(self, spec, nitems, stats):
+        n_per = spec.numel() // nitems
+        xn = torch.empty(spec.shape, dtype=torch.float16, device=spec.device)
+        mean_std = torch.empty(nitems, 2, dtype=torch.float32, device=spec.device)
+        self.lib.call('aero_spec_normalize', _ptr(spec), nitems, n_per, _ptr(stats), _ptr(xn), _ptr(mean_std),
+                      self.stream(spec))
+        return xn, mean_std
+
+    def istft(self, spec, n_fft, hop, window, inv_env, Lout):
+        nsig, F, T, _ = spec.shape
+        y = torch.empty(nsig, Lout, dtype=torch.float32, device=spec.device)
+        self.lib.call('aero_istft_fwd', _ptr(spec), nsig, F, T, n_fft, hop, _ptr(window), _ptr(inv_env), _ptr(y), Lout,
+                      self.stream(spec))
+        return y
+
+    # -- convolution family --------------------------------------------------------------------
+    def conv(self, spec, src0, src1, B, Fin, Fout, T, dst=None, dst_f32=False, dst_f_off=0, dst_F=None, res=None,
+             post_add=None, batch_scale=None, batch_shift=None, act=None, dst_strides=None, src0_strides=None):
+        """src0/src1: channels-last [B,Fin,T,C] tensors (src0 may be None = zeros).  Returns dst."""
+        dev = spec.weight.device
+        act = spec.act if act is None else act
+        Mout = spec.M // 2 if act == ACT_GLU else spec.M
+        dst_F = Fout if dst_F is None else dst_F
+        if dst is None:
+            dst = torch.empty(B, dst_F, T, Mout, dtype=torch.float32 if dst_f32 else torch.float16, device=dev)
+        d = _lib.ConvDesc()
+        d.src0 = _ptr(src0)
+        if src0 is not None:
+            d.s0_b, d.s0_f, d.s0_t = src0_strides if src0_strides else _strides4(src0)
+        d.C0 = spec.C0
+        d.src1 = _ptr(src1)
+        if src1 is not None:
+            d.s1_b, d.s1_f, d.s1_t = _strides4(src1)
+        d.C1 = spec.C1
+        d.weight = _ptr(spec.weight)
+        d.bias = _ptr(spec.bias)
+        d.dst = _ptr(dst)
+        d.d_b, d.d_f, d.d_t = dst_strides if dst_strides else _strides4(dst)
+        d.dst_f32 = int(dst.dtype == torch.float32)
+        d.dst_f_off, d.dst_F = dst_f_off, dst_F
+        d.B, d.Fin, d.Fout, d.T, d.M = B, Fin, Fout, T, spec.M
+        d.transposed, d.fstride = spec.transposed, spec.fstride
+        d.ntaps = len(spec.df)
+        for i, (a, b_) in enumerate(zip(spec.df, spec.dt)):
+            d.df[i], d.dt[i] = a, b_
+        d.act = act
+        d.res = _ptr(res)
+        if res is not None:
+            d.r_b, d.r_f, d.r_t = _strides4(res)
+        d.post_add = _ptr(post_add)
+        d.batch_scale, d.batch_shift = _ptr(batch_scale), _ptr(batch_shift)
+        self.lib.call('aero_conv_fwd', C.byref(d), self.stream(dst))
+        return dst
+
+    # -- GroupNorm + activation ----------------------------------------------------------------
+    def norm_act(self, x, G, per_row, gamma, beta, act, snake_a=None, layer_scale=None, res=None, normalize=True,
+                 f_lo=0, f_cnt=None, eps=1e-5):
+        """x [B,F,T,C] fp16.  Statistics over all F rows; output only rows [f_lo, f_lo+f_cnt)."""
+        B, F, T, Cc = x.shape
+        d = _lib.NormDesc()
+        d.src = _ptr(x)
+        d.s_b, d.s_f, d.s_t = _strides4(x)
+        d.B, d.F, d.T, d.C, d.G, d.per_row, d.eps = B, F, T, Cc, G, int(per_row), eps
+        stats = None
+        if normalize:
+            items = B * F if per_row else B
+            stats = torch.empty(items * G, 2, dtype=torch.float32, device=x.device)
+            d.stats = _ptr(stats)
+            self.lib.call('aero_norm_stats', C.byref(d), self.stream(x))
+        f_cnt = F if f_cnt is None else f_cnt
+        assert not (per_row and (f_lo or f_cnt != F))
+        Cout = Cc // 2 if act == ACT_GLU else Cc
+        out = torch.empty(B, f_cnt, T, Cout, dtype=torch.float16, device=x.device)
+        d.src = x.data_ptr() + f_lo * x.stride(1) * x.element_size()
+        d.F = f_cnt
+        d.gamma, d.beta = _ptr(gamma), _ptr(beta)
+        d.act = act
+        d.snake_a, d.layer_scale = _ptr(snake_a), _ptr(layer_scale)
+        d.res = _ptr(res)
+        if res is not None:
+            d.r_b, d.r_f, d.r_t = _strides4(res)
+        d.dst = _ptr(out)
+        d.d_b, d.d_f, d.d_t = _strides4(out)
+        self.lib.call('aero_norm_apply', C.byref(d), self.stream(x))
+        return out
+
+    # -- LSTM / attention / FTB ----------------------------------------------------------------
+    def lstm(self, xproj, xbias, whh, H, nseq, W, in_mode, out_mode, nframes, S, T, out):
+        d = _lib.LstmDesc()
+        d.xproj, d.xbias, d.whh, d.out = _ptr(xproj), _ptr(xbias), _ptr(whh), _ptr(out)
+        d.H, d.nseq, d.W, d.in_mode, d.out_mode, d.nframes, d.S, d.T = H, nseq, W, in_mode, out_mode, nframes, S, T
+        self.lib.call('aero_lstm_fwd', C.byref(d), self.stream(out))
+        return out
+
+    def localstate(self, qkvd, R, T, Cc, heads, ndecay):
+        out = torch.empty(R, T, Cc, dtype=torch.float16, device=qkvd.device)
+        d = _lib.AttnDesc()
+        d.qkvd, d.ld, d.out = _ptr(qkvd), qkvd.shape[-1], _ptr(out)
+        d.R, d.T, d.C, d.heads, d.ndecay = R, T, Cc, heads, ndecay
+        self.lib.call('aero_localstate_fwd', C.byref(d), self.stream(out))
+        return out
+
+    def freqfc(self, x, w, gate):
+        B, F, T, Cc = x.shape
+        assert x.is_contiguous() and gate.is_contiguous()
+        out = torch.empty_like(x)
+        d = _lib.FreqFcDesc()
+        d.x, d.w, d.gate, d.dst = _ptr(x), _ptr(w), _ptr(gate), _ptr(out)
+        d.B, d.F, d.T, d.C = B, F, T, Cc
+        self.lib.call('aero_freqfc_fwd', C.byref(d), self.stream(out))
+        return out
+
+
+def _hann_padded(win_length, n_fft, device):
+    w = torch.zeros(n_fft, dtype=torch.float32)
+    left = (n_fft - win_length) // 2
+    w[left:left + win_length] = torch.hann_window(win_length, periodic=True, dtype=torch.float32)
+    return w.to(device)
+
+
+class HipEngine:
+    def __init__(self, model, lib=None):
+        self.model = model
+        self.lib = lib if lib is not None else _lib.load()
+        self.ops = Ops(self.lib)
+        self._key = None
+        self._tables = {}
+
+    # ------------------------------------------------------------------ weights
+    def _weights_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.model.state_dict(keep_vars=True).values())
+
+    def _prepare(self, device):
+        key = self._weights_key(device)
+        if key != self._key:
+            self._pack(device)
+            self._key = key
+
+    def _pack(self, device):
+        m = self.model
+        sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+        P = {}
+        mk = pack.make_conv_spec
+        for i, enc in enumerate(m.encoder):
+            p = f'encoder.{i}'
+            L = {}
+            if enc.is_first:
+                w, df, dt = pack.conv2d_taps(sd[f'{p}.pre_conv.weight'], 0, 0)
+                L['pre'] = mk(w, sd[f'{p}.pre_conv.bias'], w.shape[-1], 0, df, dt, device)
+            if enc.freq_attn:
+                q = f'{p}.freq_attn_block'
+                Fd, Cc, r = enc.freq_attn_block.input_dim, enc.freq_attn_block.in_channel, enc.freq_attn_block.r_channel
+                rp = 8 * ((r + 7) // 8)
+                w, b = pack.bn_fold(sd[f'{q}.conv1.0.weight'], sd[f'{q}.conv1.0.bias'], sd[f'{q}.conv1.1.weight'],
+                                    sd[f'{q}.conv1.1.bias'], sd[f'{q}.conv1.1.running_mean'], sd[f'{q}.conv1.1.running_var'])
+                w, df, dt = pack.conv2d_taps(w, 0, 0)
+                L['ftb_c1'] = mk(w, b, Cc, 0, df, dt, device, act=ACT_RELU)
+                w, b = pack.bn_fold(sd[f'{q}.conv1d.0.weight'], sd[f'{q}.conv1d.0.bias'], sd[f'{q}.conv1d.1.weight'],
+                                    sd[f'{q}.conv1d.1.bias'], sd[f'{q}.conv1d.1.running_mean'], sd[f'{q}.conv1d.1.running_var'])
+                k9 = w.shape[-1]
+                # reference input channel = c*F + f (modules.py:309); ours = f*rp + c (rp = r padded to 8)
+                w = w.view(Cc, r, Fd, k9).permute(0, 3, 2, 1)              # [M, k, F, r]
+                wp = torch.zeros(Cc, k9, Fd, rp)
+                wp[..., :r] = w
+                L['ftb_c1d'] = mk(wp.reshape(1, Cc, k9, Fd * rp), b, Fd * rp, 0, [0] * k9,
+                                  [j - (k9 // 2) for j in range(k9)], device, act=ACT_RELU)
+                L['ftb_rp'] = rp
+                wfc = sd[f'{q}.freq_fc.weight']
+                img = torch.zeros(pack._round_up(Fd, 128), pack._round_up(Fd, 32))
+                img[:Fd, :Fd] = wfc
+                L['ftb_fc'] = img.to(device=device, dtype=torch.float16).contiguous()
+                w, b = pack.bn_fold(sd[f'{q}.conv2.0.weight'], sd[f'{q}.conv2.0.bias'], sd[f'{q}.conv2.1.weight'],
+                                    sd[f'{q}.conv2.1.bias'], sd[f'{q}.conv2.1.running_mean'], sd[f'{q}.conv2.1.running_var'])
+                w, df, dt = pack.conv2d_taps(w, 0, 0)
+                L['ftb_c2'] = mk(w, b, Cc, Cc, df, dt, device, act=ACT_RELU)
+            w, df, dt = pack.conv2d_taps(sd[f'{p}.conv.weight'], enc.pad, 0)
+            L['conv'] = mk(w, sd[f'{p}.conv.bias'], w.shape[-1], 0, df, dt, device, fstride=enc.stride,
+                           act=ACT_NONE if enc.norm else ACT_GELU)
+            if enc.norm:
+                L['norm1'] = (sd[f'{p}.norm1.weight'].to(device), sd[f'{p}.norm1.bias'].to(device))
+            if enc.dconv is not None:
+                L['dconv'] = self._pack_dconv(sd, f'{p}.dconv', enc.dconv, device)
+            if enc.rewrite is not None:
+                w, df, dt = pack.conv2d_taps(sd[f'{p}.rewrite.weight'], enc.context, enc.context)
+                L['rewrite'] = mk(w, sd[f'{p}.rewrite.bias'], w.shape[-1], 0, df, dt, device,
+                                  act=ACT_NONE if enc.norm else ACT_GLU)
+                if enc.norm:
+                    L['norm2'] = (sd[f'{p}.norm2.weight'].to(device), sd[f'{p}.norm2.bias'].to(device))
+            P[p] = L
+        for j, dec in enumerate(m.decoder):
+            p = f'decoder.{j}'
+            L = {}
+            half = dec.chin // 2
+            if dec.rewrite is not None:
+                w, df, dt = pack.conv2d_taps(sd[f'{p}.rewrite.weight'], dec.context, dec.context)
+                L['rewrite'] = mk(w, sd[f'{p}.rewrite.bias'], half, half, df, dt, device,
+                                  act=ACT_NONE if dec.norm else ACT_GLU)
+                if dec.norm:
+                    L['norm1'] = (sd[f'{p}.norm1.weight'].to(device), sd[f'{p}.norm1.bias'].to(device))
+            w, df, dt = pack.convtr_taps(sd[f'{p}.conv_tr.weight'], dec.stride)
+            act = ACT_NONE if (dec.norm or dec.last) else ACT_GELU
+            L['conv_tr'] = mk(w, sd[f'{p}.conv_tr.bias'], w.shape[-1], 0, df, dt, device, transposed=1,
+                              fstride=dec.stride, act=act)
+            if dec.norm:
+                L['norm2'] = (sd[f'{p}.norm2.weight'].to(device), sd[f'{p}.norm2.bias'].to(device))
+            if dec.dconv is not None:
+                raise NotImplementedError('decoder DConv (dconv_mode & 2) is not used by any reference config')
+            P[p] = L
+        if m.freq_emb is not None:
+            emb = sd['freq_emb.embedding.weight'] * m.freq_emb.scale * m.freq_emb_scale      # [F1, C]
+            P['freq_emb'] = emb.to(device).contiguous()
+        self.P = P
+
+    def _pack_dconv(self, sd, p, dc, device):
+        mk = pack.make_conv_spec
+        out = []
+        for d in range(dc.depth):
+            q = f'{p}.layers.{d}'
+            dil = 2 ** d if dc.dilate else 1
+            L = {}
+            w, df, dt = pack.conv1d_taps(sd[f'{q}.conv1.0.weight'], dil, dil * (dc.kernel // 2))
+            L['conv1'] = mk(w, sd[f'{q}.conv1.0.bias'], w.shape[-1], 0, df, dt, device)
+            L['gn1'] = (sd[f'{q}.conv1.1.weight'].to(device), sd[f'{q}.conv1.1.bias'].to(device)) if dc.norm else None
+            if dc.act_func == 'snake':
+                L['snake_a'] = sd[f'{q}.act.a'].reshape(-1).to(device).contiguous()
+            if dc.lstm:
+                H = dc.hidden
+                L['lstm'] = [pack.pack_lstm_layer(self.lib, sd, f'{q}.lstm.lstm', l, H, device) for l in range(2)]
+                w = sd[f'{q}.lstm.linear.weight']
+                L['lstm_lin'] = mk(w[None, :, None, :], sd[f'{q}.lstm.linear.bias'], w.shape[1], 0, [0], [0], device)
+            if dc.time_attn:
+                a = f'{q}.time_attn'
+                w = torch.cat([sd[f'{a}.{n}.weight'][:, :, 0] for n in ('query', 'key', 'content', 'query_decay')], 0)
+                b = torch.cat([sd[f'{a}.{n}.bias'] for n in ('query', 'key', 'content', 'query_decay')], 0)
+                L['attn_qkvd'] = mk(w[None, :, None, :], b, w.shape[1], 0, [0], [0], device)
+                w = sd[f'{a}.proj.weight'][:, :, 0]
+                L['attn_proj'] = mk(w[None, :, None, :], sd[f'{a}.proj.bias'], w.shape[1], 0, [0], [0], device)
+                mod = dc.layers[d]['time_attn']
+                L['attn_geom'] = (mod.heads, mod.ndecay)
+            w, df, dt = pack.conv1d_taps(sd[f'{q}.conv2.0.weight'], 1, 0)
+            L['conv2'] = mk(w, sd[f'{q}.conv2.0.bias'], w.shape[-1], 0, df, dt, device)
+            L['gn2'] = (sd[f'{q}.conv2.1.weight'].to(device), sd[f'{q}.conv2.1.bias'].to(device)) if dc.norm else None
+            L['scale'] = sd[f'{q}.conv2.3.scale'].to(device).contiguous()
+            out.append(L)
+        return out
+
+    # ------------------------------------------------------------------ tables
+    def _window(self, win_length, device):
+        key = ('win', win_length, self.model.nfft, str(device))
+        if key not in self._tables:
+            self._tables[key] = _hann_padded(win_length, self.model.nfft, device)
+        return self._tables[key]
+
+    def _inv_env(self, win_length, hop, T, device):
+        key = ('env', win_length, hop, T, self.model.nfft, str(device))
+        if key not in self._tables:
+            n_fft = self.model.nfft
+            w = _hann_padded(win_length, n_fft, 'cpu')
+            w2 = (w * w).double()
+            env = torch.zeros(n_fft + hop * (T - 1), dtype=torch.float64)
+            for t in range(T):
+                env[t * hop:t * hop + n_fft] += w2
+            inv = torch.where(env > 1e-11, 1.0 / env, torch.zeros_like(env))
+            self._tables[key] = inv.float().to(device)
+        return self._tables[key]
+
+    def _check_input(self, x):
+        if not self.lib.is_emulator and not x.is_cuda:
+            raise RuntimeError('aero_amd runs on the MI355X only: move the model and the input to "cuda" '
+                               '(there is no CPU path in the product)')
+        if x.dtype != torch.float32:
+            raise TypeError('expected a float32 waveform')
+
+    # ------------------------------------------------------------------ public pieces
+    def spec(self, x, scale=False, stats=None):
+        """Aero._spec (aero.py:409-421): [B, C, L] -> complex64 [B, C, nfft/2, T]."""
+        m = self.model
+        self._check_input(x)
+        B, Cc, L = x.shape
+        hop, win = m.hop_length, m.win_length
+        pad = (hop - L % hop) % hop                    # aero.py:410-411 uses the INPUT hop for both variants
+        Lp = L + pad
+        if scale:
+            hop, win = int(hop * m.scale), int(win * m.scale)
+        z = self.ops.stft(x.reshape(B * Cc, L).contiguous(), L, Lp, m.nfft, hop, self._window(win, x.device),
+                          m.nfft // 2, stats=stats, sig_per_item=Cc)
+        return torch.view_as_complex(z).view(B, Cc, m.nfft // 2, -1)
+
+    def ispec(self, z):
+        """Aero._ispec (aero.py:423-428): complex64 [B, C, nfft/2, T] -> [B, C, hop_out*(T-1)]."""
+        m = self.model
+        B, Cc, F, T = z.shape
+        hop, win = int(m.hop_length * m.scale), int(m.win_length * m.scale)
+        zr = torch.view_as_real(z.contiguous()).view(B * Cc, F, T, 2)
+        y = self.ops.istft(zr, m.nfft, hop, self._window(win, z.device), self._inv_env(win, hop, T, z.device),
+                           hop * (T - 1))
+        return y.view(B, Cc, -1)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, mix, want_spec=False, want_lr_spec=False):
+        m, ops, P = self.model, self.ops, None
+        self._check_input(mix)
+        if m.in_channels != 1 or m.out_channels != 1:
+            raise NotImplementedError('only in_channels = out_channels = 1 (all reference configs)')
+        dev = mix.device
+        self._prepare(dev)
+        P = self.P
+        B, _, L = mix.shape
+        mix = mix.contiguous()
+        stats = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+        zc = self.spec(mix, stats=stats)                                   # complex64 [B,1,F0,T]
+        F0, T = zc.shape[2], zc.shape[3]
+        z = torch.view_as_real(zc).view(B, F0, T, 2)
+        x, mean_std = ops.spec_normalize(z, B, stats)                      # fp16 [B,F0,T,2]
+        mean = mean_std[:, 0].contiguous()
+        std = mean_std[:, 1].contiguous()
+
+        saved = []
+        Fq = F0
+        for i, enc in enumerate(m.encoder):
+            x, Fq = self._encode(i, enc, P[f'encoder.{i}'], x, B, Fq, T)
+            saved.append((x, Fq))
+        x = None
+        for j, dec in enumerate(m.decoder):
+            skip, Fs = saved.pop()
+            x = self._decode(j, dec, P[f'decoder.{j}'], x, skip, B, Fs, T, mean, std)
+        assert not saved
+        spec_out = x                                                       # fp32 [B,F0,T,2] de-normalised
+        hop, win = int(m.hop_length * m.scale), int(m.win_length * m.scale)
+        Lout = min(hop * (T - 1), int(L * m.scale))
+        y = ops.istft(spec_out, m.nfft, hop, self._window(win, dev), self._inv_env(win, hop, T, dev), Lout)
+        y = y.view(B, 1, Lout)
+        out_spec = torch.view_as_complex(spec_out).view(B, 1, F0, T) if want_spec else None
+        return y, out_spec, (zc if want_lr_spec else None)
+
+    def _encode(self, i, enc, L, x, B, Fq, T):
+        ops = self.ops
+        if 'pre' in L:
+            x = ops.conv(L['pre'], x, None, B, Fq, Fq, T)
+        if 'ftb_c1' in L:
+            Cc, rp = L['ftb_c2'].M, L['ftb_rp']
+            c1 = torch.zeros(B, T, Fq * rp, dtype=torch.float16, device=x.device)
+            ops.conv(L['ftb_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
+            gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)      # [B,1,T,Cc]
+            fc = ops.freqfc(x, L['ftb_fc'], gate.view(B, T, Cc))
+            x = ops.conv(L['ftb_c2'], fc, x, B, Fq, Fq, T)
+        Fo = (Fq + 2 * enc.pad - enc.kernel_size) // enc.stride + 1
+        y = ops.conv(L['conv'], x, None, B, Fq, Fo, T)
+        if enc.norm:
+            y = ops.norm_act(y, enc.norm_groups, False, L['norm1'][0], L['norm1'][1], ACT_GELU)
+        if 'dconv' in L:
+            y = self._dconv(enc.dconv, L['dconv'], y, B, Fo, T)
+        if 'rewrite' in L:
+            emb = self.P.get('freq_emb') if i == 0 else None
+            if enc.norm:
+                if emb is not None:
+                    raise NotImplementedError('GroupNorm on encoder 0 together with the frequency embedding')
+                r = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T)
+                y = ops.norm_act(r, enc.norm_groups, False, L['norm2'][0], L['norm2'][1], ACT_GLU)
+            else:
+                y = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, post_add=emb)
+        elif i == 0 and 'freq_emb' in self.P:
+            raise NotImplementedError('frequency embedding without a rewrite conv')
+        return y, Fo
+
+    def _dconv(self, dc, layers, x, B, Fo, T):
+        ops = self.ops
+        act = {'snake': ACT_SNAKE, 'gelu': ACT_GELU}.get(dc.act_func, ACT_RELU)
+        for L in layers:
+            h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T)
+            g1 = L['gn1']
+            h = ops.norm_act(h, 1, True, g1[0] if g1 else None, g1[1] if g1 else None, act,
+                             snake_a=L.get('snake_a'), normalize=g1 is not None)
+            if 'lstm' in L:
+                h = self._blstm(dc, L, h, B, Fo, T)
+            if 'attn_qkvd' in L:
+                heads, ndecay = L['attn_geom']
+                qkvd = ops.conv(L['attn_qkvd'], h, None, B, Fo, Fo, T)
+                att = ops.localstate(qkvd, B * Fo, T, dc.hidden, heads, ndecay)
+                h = ops.conv(L['attn_proj'], att.view(B, Fo, T, dc.hidden), None, B, Fo, Fo, T, res=h)
+            g = ops.conv(L['conv2'], h, None, B, Fo, Fo, T)
+            g2 = L['gn2']
+            x = ops.norm_act(g, 1, True, g2[0] if g2 else None, g2[1] if g2 else None, ACT_GLU,
+                             layer_scale=L['scale'], res=x, normalize=g2 is not None)
+        return x
+
+    def _blstm(self, dc, L, h, B, Fo, T):
+        """BLSTM (modules.py:32-65): framing and stitching are index arithmetic inside the LSTM kernel."""
+        ops = self.ops
+        H = dc.hidden
+        R = B * Fo
+        max_steps = 200
+        framed = T > max_steps
+        if framed:
+            W, S = max_steps, max_steps // 2
+            nframes = math.ceil(T / S)                      # models/utils.py:29
+        else:
+            W, S, nframes = T, 1, 1
+        nseq = R * nframes
+        (pj0, xb0, whh0), (pj1, xb1, whh1) = L['lstm']
+        xp0 = ops.conv(pj0, h, None, B, Fo, Fo, T)                                  # [B,Fo,T,8H]
+        out0 = torch.empty(nseq, W, 2 * H, dtype=torch.float16, device=h.device)
+        ops.lstm(xp0, xb0, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0)
+        xp1 = ops.conv(pj1, out0.view(nseq, 1, W, 2 * H), None, nseq, 1, 1, W)      # [nseq,1,W,8H]
+        out1 = torch.empty(R, T, 2 * H, dtype=torch.float16, device=h.device)
+        ops.lstm(xp1, xb1, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1)
+        return ops.conv(L['lstm_lin'], out1.view(B, Fo, T, 2 * H), None, B, Fo, Fo, T, res=h)
+
+    def _decode(self, j, dec, L, x, skip, B, Fq, T, mean, std):
+        ops = self.ops
+        if 'rewrite' in L:
+            r = ops.conv(L['rewrite'], x, skip, B, Fq, Fq, T)
+            if dec.norm:
+                y = ops.norm_act(r, dec.norm_groups, False, L['norm1'][0], L['norm1'][1], ACT_GLU)
+            else:
+                y = r
+        else:
+            raise NotImplementedError('decoder without rewrite conv')
+        Fu = (Fq - 1) * dec.stride + dec.kernel_size          # untrimmed rows of the transposed conv
+        Ft = Fu - 2 * dec.pad
+        if dec.norm:
+            if dec.last:
+                raise NotImplementedError('GroupNorm on the last decoder layer (norm_starts = 0)')
+            z = ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T)
+            return ops.norm_act(z, dec.norm_groups, False, L['norm2'][0], L['norm2'][1],
+                                ACT_NONE if dec.last else ACT_GELU, f_lo=dec.pad, f_cnt=Ft)
+        if dec.last:
+            # aero.py:497-498: x*std + mean fused into the last epilogue; fp32 [B,F0,T,2] == complex64 [B,1,F0,T]
+            return ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T, dst_f32=True, dst_f_off=dec.pad, dst_F=Ft,
+                            batch_scale=std, batch_shift=mean)
+        return ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T, dst_f_off=dec.pad, dst_F=Ft)

@@ -1,0 +1,123 @@
+"""Weight packing for the gfx950 kernels (host plumbing; runs once per set of weights).
+
+Turns the reference-layout fp32 parameters (conv [Cout,Cin,kF,kT], conv-transpose
+[Cin,Cout,kF,1], LSTM [4H,in] with gate order i,f,g,o -- SURVEY 8b) into the fp16, K-contiguous,
+zero-padded images that include/aero_hip.h documents.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class ConvSpec:
+    weight: torch.Tensor                # fp16 [nwset, Mpad, ntaps*Cp]
+    bias: Optional[torch.Tensor]        # fp32 [M]
+    M: int
+    C0: int
+    C1: int
+    df: List[int]
+    dt: List[int]
+    transposed: int = 0
+    fstride: int = 1
+    act: int = _lib.ACT_NONE
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def Mout(self):
+        return self.M // 2 if self.act == _lib.ACT_GLU else self.M
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def glu_interleave(t):
+    """Reorder rows (a_0..a_{n-1}, b_0..b_{n-1}) -> (a_0, b_0, a_1, b_1, ...) so that one MFMA
+    accumulator quad holds both halves of two GLU outputs (k_conv.h epilogue)."""
+    n = t.shape[0] // 2
+    idx = torch.stack([torch.arange(n), torch.arange(n) + n], 1).reshape(-1)
+    return t[idx]
+
+
+def make_conv_spec(w_taps, bias, C0, C1, df, dt, device, transposed=0, fstride=1, act=_lib.ACT_NONE):
+    """w_taps fp32 [nwset, M, ntaps, C0+C1] -> ConvSpec with the padded fp16 image."""
+    nw, M, nt, Ct = w_taps.shape
+    assert Ct == C0 + C1 and nt == len(df) == len(dt) and 1 <= nt <= 9
+    if act == _lib.ACT_GLU:
+        w_taps = torch.stack([glu_interleave(w_taps[i]) for i in range(nw)])
+        if bias is not None:
+            bias = glu_interleave(bias)
+    Cp = _round_up(Ct, 32)
+    Mpad = _round_up(M, 128)
+    img = torch.zeros(nw, Mpad, nt, Cp, dtype=torch.float32)
+    img[:, :M, :, :Ct] = w_taps
+    return ConvSpec(weight=img.reshape(nw, Mpad, nt * Cp).to(device=device, dtype=torch.float16).contiguous(),
+                    bias=None if bias is None else bias.detach().float().to(device).contiguous(),
+                    M=M, C0=C0, C1=C1, df=list(df), dt=list(dt), transposed=transposed, fstride=fstride, act=act)
+
+
+def bn_fold(w, b, bn_w, bn_b, rm, rv, eps=1e-5):
+    """Eval-mode BatchNorm folded into the preceding conv (modules.py:287,293,300)."""
+    s = bn_w / torch.sqrt(rv + eps)
+    shape = [-1] + [1] * (w.dim() - 1)
+    return w * s.view(shape), (b - rm) * s + bn_b
+
+
+def conv2d_taps(w, pad_f, pad_t):
+    """nn.Conv2d weight [M, C, kF, kT] -> ([1, M, kF*kT, C], df, dt)."""
+    M, Cc, kF, kT = w.shape
+    taps = w.permute(0, 2, 3, 1).reshape(1, M, kF * kT, Cc)
+    df = [jf - pad_f for jf in range(kF) for _ in range(kT)]
+    dt = [jt - pad_t for _ in range(kF) for jt in range(kT)]
+    return taps, df, dt
+
+
+def conv1d_taps(w, dilation, padding):
+    """nn.Conv1d weight [M, C, k] (time axis) -> ([1, M, k, C], df, dt)."""
+    M, Cc, k = w.shape
+    return w.permute(0, 2, 1).reshape(1, M, k, Cc), [0] * k, [j * dilation - padding for j in range(k)]
+
+
+def convtr_taps(w, stride):
+    """nn.ConvTranspose2d weight [Cin, Cout, K, 1] along frequency -> `stride` interleaved convolutions:
+    output row fo uses kernel rows kk = fo%stride + j*stride with source row fo//stride - j."""
+    Cin, Cout, K, kT = w.shape
+    assert kT == 1
+    nt = math.ceil(K / stride)
+    taps = torch.zeros(stride, Cout, nt, Cin)
+    for r in range(stride):
+        for j in range(nt):
+            kk = r + j * stride
+            if kk < K:
+                taps[r, :, j, :] = w[:, :, kk, 0].t()
+    return taps, [-j for j in range(nt)], [0] * nt
+
+
+def lstm_gate_perm(H):
+    """row index 4*j+gate of the kernel <- row gate*H + j of nn.LSTM (i,f,g,o blocks)."""
+    j = torch.arange(H)
+    return torch.stack([g * H + j for g in range(4)], 1).reshape(-1)
+
+
+def pack_lstm_layer(lib, sd, prefix, layer, H, device):
+    """-> (ConvSpec for the input projection of both directions, xbias fp16 [8H], whh fp16 [2,MP,KP])."""
+    perm = lstm_gate_perm(H)
+    w_ih, b, w_hh = [], [], []
+    for sfx in ('', '_reverse'):
+        w_ih.append(sd[f'{prefix}.weight_ih_l{layer}{sfx}'].float()[perm])
+        b.append((sd[f'{prefix}.bias_ih_l{layer}{sfx}'].float() + sd[f'{prefix}.bias_hh_l{layer}{sfx}'].float())[perm])
+        w_hh.append(sd[f'{prefix}.weight_hh_l{layer}{sfx}'].float()[perm])
+    w_ih = torch.cat(w_ih, 0)                                  # [8H, in]
+    b = torch.cat(b, 0)
+    spec = make_conv_spec(w_ih[None, :, None, :], b, w_ih.shape[1], 0, [0], [0], device)
+    MP, KP = lib.lstm_geometry(H)
+    whh = torch.zeros(2, MP, KP)
+    for dr in range(2):
+        whh[dr, :4 * H, :H] = w_hh[dr]
+    return spec, b.to(device=device, dtype=torch.float16).contiguous(), \
+        whh.to(device=device, dtype=torch.float16).contiguous()

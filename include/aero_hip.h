@@ -1,0 +1,156 @@
+/* aero_hip.h -- C ABI of libaero_hip.so: the gfx950 (MI355X) kernels of AERO's spectral path.
+ *
+ * The reference (slp-rl/aero) has no native/FFI layer: its hot path is `Aero.forward`
+ * (src/models/aero.py:446-523) calling ATen ops.  The entry points below sit at those ATen
+ * seams; each one cites the reference call site it replaces.
+ * The Python binding a maintainer would add is the ctypes stub in INTEGRATION.md
+ * (aero_amd/_lib.py is that stub, in product form).
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer (tensor.data_ptr()); nothing is allocated,
+ *     freed or synchronised inside the library; scratch is caller provided;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - activations are fp16, channels-last: element (b,f,t,c) at base + b*sb + f*sf + t*st + c
+ *     (strides in ELEMENTS); spectrograms are complex64 interleaved [.., F, T] like torch;
+ *   - return 0 on success, negative on error; message via aero_last_error() (thread local);
+ *     no C++ exception crosses the ABI; all functions are re-entrant.
+ */
+#ifndef AERO_HIP_H
+#define AERO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AERO_OK 0
+#define AERO_ERR_ARG (-1)
+#define AERO_ERR_LAUNCH (-2)
+#define AERO_ERR_UNSUPPORTED (-3)
+
+enum { AERO_ACT_NONE = 0, AERO_ACT_RELU = 1, AERO_ACT_GELU = 2, AERO_ACT_GLU = 3, AERO_ACT_SNAKE = 4 };
+
+const char* aero_version(void);
+const char* aero_last_error(void);
+
+/* K1 -- torch.stft(center=True, reflect, normalized=True) of spec.py:12-20 as called by
+ * Aero._spec (aero.py:409-421).  x [nsig][L] fp32; the signal is treated as right-zero-padded
+ * to Lp (a multiple of hop, aero.py:410-411) and then reflect padded by n_fft/2.
+ * window: [n_fft] fp32, the analysis window already centred/zero padded to n_fft.
+ * spec: complex64 [nsig][n_bins][T], T = 1 + Lp/hop, n_bins = n_fft/2 (Nyquist dropped,
+ * aero.py:420) or n_fft/2+1.  If stats != NULL, sum and sum-of-squares of all real/imag
+ * values of signal group i/sig_per_item are atomically added to stats[2*item], [2*item+1]
+ * (doubles, caller zeroes them) -- the per-item mean/std of aero.py:462-463. */
+int aero_stft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop,
+                  const float* window, int32_t n_bins, float* spec, int32_t T, double* stats,
+                  int32_t sig_per_item, void* stream);
+
+/* K2 -- aero.py:430-434,462-464: complex -> 2 channels + per-item normalisation.
+ * spec viewed as [nitems][n_per_item] fp32; xn fp16 same shape = (v-mean)/(1e-5+std) with the
+ * unbiased std; mean_std[2*i], [2*i+1] receive mean and std (used again by K14). */
+int aero_spec_normalize(const float* spec, int32_t nitems, int64_t n_per_item, const double* stats,
+                        void* xn, float* mean_std, void* stream);
+
+/* K14+K15 -- Aero._ispec / torch.istft (aero.py:423-428, spec.py:30-37): spec complex64
+ * [nsig][F][T] with F = n_fft/2 (the Nyquist bin is the implicit zero of aero.py:426, the imaginary
+ * part of DC is ignored), window [n_fft] synthesis window centred/zero padded, inv_env
+ * [n_fft + hop*(T-1)] = 1 / overlap-added window^2.  y [nsig][Lout] receives samples
+ * n_fft/2 .. n_fft/2+Lout-1 of the overlap-add (Lout <= hop*(T-1); crop of aero.py:513 included). */
+int aero_istft_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_t n_fft, int32_t hop,
+                   const float* window, const float* inv_env, float* y, int32_t Lout, void* stream);
+
+/* K3/K4/K5/K6/K9 and every 1x1 -- one implicit-GEMM MFMA kernel family replaces nn.Conv2d
+ * (aero.py:89,95,101,179), nn.ConvTranspose2d (aero.py:172), nn.Conv1d (modules.py:206,209,
+ * 72-79,291-292) and nn.Linear (modules.py:29).  Output row (b,fo), step t, channel m:
+ *   out = epilogue( bias[m] + sum_{tap j} sum_{c} W[wset][m][j][c] * in[b][fi(fo,j)][t+dt[j]][c] )
+ * with in = concat(src0, src1) on channels, zero outside [0,Fin)x[0,T);
+ *   transposed == 0:  fi = fo*fstride + df[j],            wset = 0
+ *   transposed == 1:  fi = fo/fstride + df[j] (floor),    wset = fo % fstride   (conv-transpose
+ *                     rewritten as fstride interleaved ordinary convolutions).
+ * weight: fp16 [nwset][Mpad][ntaps*Cp], Cp = roundup(C0+C1,32), Mpad = roundup(M,128), zero padded.
+ * src0 == NULL with C0 > 0 means "C0 channels of zeros" (first decoder input, aero.py:484).
+ * Epilogue order: +bias, act (GLU pairs rows 2u,2u+1 -> channel u, Mout = M/2), +res, +post_add[fo][.],
+ * per-b affine v*batch_scale[b]+batch_shift[b]; store fp16 or fp32 at row f = fo - dst_f_off when
+ * 0 <= f < dst_F (the trim of aero.py:207-209). */
+typedef struct {
+    const void* src0; int64_t s0_b, s0_f, s0_t; int32_t C0;
+    const void* src1; int64_t s1_b, s1_f, s1_t; int32_t C1;
+    const void* weight;
+    const float* bias;
+    void* dst; int64_t d_b, d_f, d_t;
+    int32_t dst_f32, dst_f_off, dst_F;
+    int32_t B, Fin, Fout, T, M;
+    int32_t transposed, fstride;
+    int32_t ntaps; int32_t df[9]; int32_t dt[9];
+    int32_t act;
+    const void* res; int64_t r_b, r_f, r_t;
+    const float* post_add;
+    const float* batch_scale; const float* batch_shift;
+} aero_conv_desc;
+int aero_conv_fwd(const aero_conv_desc* d, void* stream);
+
+/* K7+K8 -- nn.GroupNorm (aero.py:56,148; modules.py:189) followed by GELU / GLU(+LayerScale
+ * +residual) / Snake (aero.py:127,133,198,214; modules.py:141,232-236,244; snake.py:67).
+ * per_row == 0: statistics per (b, group) over (f, t, c in group)   [GroupNorm on B,C,F,T]
+ * per_row == 1: statistics per (b, f) row and group                 [GroupNorm on B*F,C,T]
+ * aero_norm_stats writes stats[(item*G+g)*2 + {0,1}] = mean, rstd; aero_norm_apply computes
+ *   y = act((x-mean)*rstd*gamma[c]+beta[c]); GLU: y[c] = a[c]*sigmoid(a[c+C/2]) * layer_scale[c];
+ *   Snake: y + sin^2(a_f y)/a_f;  then + res.  stats == NULL in apply means identity norm. */
+typedef struct {
+    const void* src; int64_t s_b, s_f, s_t;
+    int32_t B, F, T, C, G, per_row;
+    float eps;
+    float* stats;
+    const float* gamma; const float* beta;
+    int32_t act;
+    const float* snake_a;
+    const float* layer_scale;
+    const void* res; int64_t r_b, r_f, r_t;
+    void* dst; int64_t d_b, d_f, d_t;
+} aero_norm_desc;
+int aero_norm_stats(const aero_norm_desc* d, void* stream);
+int aero_norm_apply(const aero_norm_desc* d, void* stream);
+
+/* K10 -- the recurrent part of nn.LSTM(bidirectional) inside BLSTM (modules.py:28,46), both
+ * directions of ONE layer per call; the input projection is an aero_conv_fwd 1x1.
+ * xproj fp16 [npos][8H]: gate pre-activations incl. both biases, channel = dir*4H + 4*j + gate
+ * (gate order i,f,g,o).  xbias [8H] fp16: the pre-activation of a zero input (padded steps of
+ * `unfold`, models/utils.py:29-31).  whh fp16 [2][MP][KP] rows 4*j+gate, zero padded; MP, KP from
+ * aero_lstm_geometry(H).  Sequence s, step tau reads position
+ *   in_mode 0: s*W + tau;   in_mode 1 (framed view of [R][T]): r = s/nframes, k = s%nframes,
+ *   t = k*S + tau, position r*T + t if t < T else xbias.
+ * Output h (fp16, channel dir*H + j):
+ *   out_mode 0: out[(s*W + tau)*2H + ..];  out_mode 1: stitched as modules.py:49-62 into
+ *   out[(r*T + t)*2H + ..] keeping tau in [0,W-S/2) / [S/2,W-S/2) / [S/2,W) of first/middle/last frame. */
+typedef struct {
+    const void* xproj; const void* xbias; const void* whh; void* out;
+    int32_t H, nseq, W, in_mode, out_mode, nframes, S, T;
+} aero_lstm_desc;
+int aero_lstm_fwd(const aero_lstm_desc* d, void* stream);
+/* padded W_hh geometry the kernel instantiation for hidden size H expects: MP rows, KP columns */
+int aero_lstm_geometry(int32_t H, int32_t* MP, int32_t* KP);
+
+/* K11 -- LocalState attention core (modules.py:101-124).  qkvd fp16 [R][T][ld] holds per position
+ * query | key | content (C each) | decay logits (heads*ndecay), produced by one aero_conv_fwd.
+ * out fp16 [R][T][C] = softmax_t( K_t.Q_s/sqrt(C/heads) - |t-s| * sum_f (f+1) sigmoid(d_fs)/(2 sqrt(ndecay)),
+ * diagonal forced to -100 ) applied to the content; the proj conv + residual (modules.py:127) is
+ * an aero_conv_fwd with `res`. */
+typedef struct {
+    const void* qkvd; int64_t ld; void* out;
+    int32_t R, T, C, heads, ndecay;
+} aero_attn_desc;
+int aero_localstate_fwd(const aero_attn_desc* d, void* stream);
+
+/* K12 (middle) -- FTB frequency mixing (modules.py:314-320): dst[b,fo,t,c] =
+ * gate[b,t,c] * sum_fi w[fo][fi] * x[b,fi,t,c]   (the gate does not depend on fi so it factors out).
+ * x, dst fp16 contiguous [B][F][T][C]; gate fp16 [B][T][C]; w fp16 [roundup(F,128)][roundup(F,32)]. */
+typedef struct {
+    const void* x; const void* w; const void* gate; void* dst;
+    int32_t B, F, T, C;
+} aero_freqfc_desc;
+int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AERO_HIP_H */

@@ -1,0 +1,262 @@
+"""Op-level parity cases shared by the CPU-emulator tests (tests/test_emu_ops.py) and the GPU tests
+(tests/test_gpu_ops.py).  Every case runs one C-ABI entry point through aero_amd.engine.Ops and checks
+it against the CPU oracle / plain fp32 torch on the same seeded inputs.
+
+Tolerances: STFT/iSTFT are fp32 -> 2e-6 rel-L2; everything that goes through fp16 operands/storage
+-> 2e-3 rel-L2 against the fp32 reference computed on the fp16-ROUNDED inputs (so the residual is only
+accumulation order + output rounding; the end-to-end budget of 1e-3 on the spectrogram is tested in
+test_*_model.py).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from aero_amd import _lib, pack
+from aero_amd.engine import Ops, _hann_padded
+from conftest import rel_l2
+from oracle import aero_oracle as O
+
+TOL16 = 2e-3
+TOL32 = 2e-6
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=_g(seed)) * scale
+
+
+def cl(x):
+    """reference layout [B,C,F,T] fp32 -> channels-last fp16 [B,F,T,C]"""
+    return x.permute(0, 2, 3, 1).contiguous().half()
+
+
+def uncl(y):
+    return y.float().permute(0, 3, 1, 2)
+
+
+def q16(x):
+    return x.half().float()
+
+
+# ------------------------------------------------------------------------------------------------
+def case_stft(lib, dev, nfft, hop, win, L, B=2):
+    ops = Ops(lib)
+    x = _rand((B, L), 1)
+    pad = (hop - L % hop) % hop
+    stats = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+    z = ops.stft(x.to(dev), L, L + pad, nfft, hop, _hann_padded(win, nfft, dev), nfft // 2, stats=stats)
+    zr = O.stft(F.pad(x, (0, pad)), nfft, hop, win)[..., :-1, :]
+    assert rel_l2(torch.view_as_complex(z.cpu()), zr) < TOL32
+    v = torch.view_as_real(zr).double()
+    ref = torch.stack([v.sum(dim=(1, 2, 3)), (v * v).sum(dim=(1, 2, 3))], 1)
+    assert torch.allclose(stats.cpu(), ref, rtol=1e-5, atol=1e-3)
+    # K2: normalisation
+    xn, ms = ops.spec_normalize(z, B, stats)
+    vr = torch.view_as_real(zr)
+    mean = vr.mean(dim=(1, 2, 3), keepdim=True)
+    std = vr.std(dim=(1, 2, 3), keepdim=True)
+    assert torch.allclose(ms.cpu(), torch.cat([mean.view(B, 1), std.view(B, 1)], 1), rtol=1e-5, atol=1e-6)
+    assert rel_l2(xn.cpu().float(), (vr - mean) / (1e-5 + std)) < 1e-3
+
+
+def case_istft(lib, dev, nfft, hop, win, T, crop=5, B=2):
+    ops = Ops(lib)
+    z = torch.complex(_rand((B, nfft // 2, T), 2), _rand((B, nfft // 2, T), 3))
+    w = _hann_padded(win, nfft, 'cpu')
+    env = torch.zeros(nfft + hop * (T - 1), dtype=torch.float64)
+    for t in range(T):
+        env[t * hop:t * hop + nfft] += (w * w).double()
+    Lout = hop * (T - 1) - crop
+    y = ops.istft(torch.view_as_real(z).contiguous().to(dev), nfft, hop, w.to(dev), (1 / env).float().to(dev), Lout)
+    yr = O.istft(F.pad(z, (0, 0, 0, 1)), hop, win)[..., :Lout]
+    assert rel_l2(y.cpu(), yr) < TOL32
+
+
+# ------------------------------------------------------------------------------------------------
+def case_conv2d(lib, dev, Cin, Cout, kF, kT, stride, padF, padT, Fin, T, act='none', B=2, split=None, null0=False,
+                residual=False, seed=10):
+    """Conv2d [kF,kT] stride [stride,1] against F.conv2d; optional concat of two sources, NULL first source,
+    fused GELU/RELU/GLU, residual add."""
+    ops = Ops(lib)
+    w = _rand((Cout, Cin, kF, kT), seed, 1.0 / math.sqrt(Cin * kF * kT))
+    b = _rand((Cout,), seed + 1)
+    x = _rand((B, Cin, Fin, T), seed + 2)
+    if null0:
+        x[:, :split] = 0
+    taps, df, dt = pack.conv2d_taps(q16(w), padF, padT)
+    actc = {'none': _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'gelu': _lib.ACT_GELU, 'glu': _lib.ACT_GLU}[act]
+    C0 = Cin if split is None else split
+    spec = pack.make_conv_spec(taps, b, C0, Cin - C0, df, dt, dev, fstride=stride, act=actc)
+    Fout = (Fin + 2 * padF - kF) // stride + 1
+    xcl = cl(x).to(dev)
+    s0 = None if null0 else xcl[..., :C0]
+    s1 = xcl[..., C0:] if split is not None else None
+    ref = F.conv2d(q16(x), q16(w), b, stride=(stride, 1), padding=(padF, padT))
+    ref = {'none': lambda v: v, 'relu': F.relu, 'gelu': F.gelu, 'glu': lambda v: F.glu(v, 1)}[act](ref)
+    res = None
+    if residual:
+        r = _rand(tuple(ref.shape), seed + 3)
+        res = cl(r).to(dev)
+        ref = ref + q16(r)
+    y = ops.conv(spec, s0, s1, B, Fin, Fout, T, res=res)
+    assert y.shape == (B, Fout, T, ref.shape[1])
+    assert rel_l2(uncl(y.cpu()), ref) < TOL16
+
+
+def case_conv1d(lib, dev, Cin, Cout, k, dil, R, T, seed=20):
+    ops = Ops(lib)
+    w = _rand((Cout, Cin, k), seed, 1.0 / math.sqrt(Cin * k))
+    b = _rand((Cout,), seed + 1)
+    x = _rand((R, Cin, T), seed + 2)
+    pad = dil * (k // 2)
+    taps, df, dt = pack.conv1d_taps(q16(w), dil, pad)
+    spec = pack.make_conv_spec(taps, b, Cin, 0, df, dt, dev)
+    xcl = x.permute(0, 2, 1).contiguous().half().view(1, R, T, Cin).to(dev)
+    y = ops.conv(spec, xcl, None, 1, R, R, T)
+    ref = F.conv1d(q16(x), q16(w), b, dilation=dil, padding=pad)
+    assert rel_l2(y.cpu().float()[0].permute(0, 2, 1), ref) < TOL16
+
+
+def case_convtr(lib, dev, Cin, Cout, K, stride, Fin, T, trim=True, f32_affine=False, B=2, seed=30):
+    ops = Ops(lib)
+    w = _rand((Cin, Cout, K, 1), seed, 1.0 / math.sqrt(Cin * K / stride))
+    b = _rand((Cout,), seed + 1)
+    x = _rand((B, Cin, Fin, T), seed + 2)
+    taps, df, dt = pack.convtr_taps(q16(w), stride)
+    spec = pack.make_conv_spec(taps, b, Cin, 0, df, dt, dev, transposed=1, fstride=stride)
+    Fu = (Fin - 1) * stride + K
+    pad = (K - stride) // 2 if trim else 0
+    ref = F.conv_transpose2d(q16(x), q16(w), b, stride=(stride, 1))
+    if pad:
+        ref = ref[:, :, pad:-pad]
+    kw = {}
+    if f32_affine:
+        sc, sh = _rand((B,), seed + 3).abs() + 0.5, _rand((B,), seed + 4)
+        kw = dict(dst_f32=True, batch_scale=sc.to(dev), batch_shift=sh.to(dev))
+        ref = ref * sc.view(B, 1, 1, 1) + sh.view(B, 1, 1, 1)
+    y = ops.conv(spec, cl(x).to(dev), None, B, Fin, Fu, T, dst_f_off=pad, dst_F=Fu - 2 * pad, **kw)
+    assert y.shape == (B, Fu - 2 * pad, T, Cout)
+    assert rel_l2(uncl(y.cpu()), ref) < TOL16
+
+
+def case_freq_emb_epilogue(lib, dev, seed=40):
+    """1x1 rewrite + fused GLU + frequency-embedding post-add (aero.py:133,475-480)."""
+    ops = Ops(lib)
+    B, Cc, Fq, T = 2, 16, 5, 37
+    w = _rand((2 * Cc, Cc, 1, 1), seed, 0.25)
+    b = _rand((2 * Cc,), seed + 1)
+    x = _rand((B, Cc, Fq, T), seed + 2)
+    emb = _rand((Fq, Cc), seed + 3)
+    taps, df, dt = pack.conv2d_taps(q16(w), 0, 0)
+    spec = pack.make_conv_spec(taps, b, Cc, 0, df, dt, dev, act=_lib.ACT_GLU)
+    y = ops.conv(spec, cl(x).to(dev), None, B, Fq, Fq, T, post_add=emb.to(dev))
+    ref = F.glu(F.conv2d(q16(x), q16(w), b), 1) + emb.t()[None, :, :, None]
+    assert rel_l2(uncl(y.cpu()), ref) < TOL16
+
+
+# ------------------------------------------------------------------------------------------------
+def case_groupnorm(lib, dev, Cc, G, Fq, T, act, per_row=False, B=2, trim=0, seed=50):
+    ops = Ops(lib)
+    x = _rand((B, Cc, Fq, T), seed) * 2 + 0.3
+    gamma, beta = _rand((Cc,), seed + 1) + 1, _rand((Cc,), seed + 2)
+    xq = q16(x)
+    if per_row:
+        rows = xq.permute(0, 2, 1, 3).reshape(B * Fq, Cc, T)
+        ref = F.group_norm(rows, G, gamma, beta, 1e-5).view(B, Fq, Cc, T).permute(0, 2, 1, 3)
+    else:
+        ref = F.group_norm(xq, G, gamma, beta, 1e-5)
+    kw = {}
+    if act == 'gelu':
+        ref, a = F.gelu(ref), _lib.ACT_GELU
+    elif act == 'glu':
+        ref, a = F.glu(ref, 1), _lib.ACT_GLU
+    elif act == 'glu_ls_res':
+        ls = _rand((Cc // 2,), seed + 3)
+        r = _rand((B, Cc // 2, Fq, T), seed + 4)
+        ref, a = q16(r) + ls.view(1, -1, 1, 1) * F.glu(ref, 1), _lib.ACT_GLU
+        kw = dict(layer_scale=ls.to(dev), res=cl(r).to(dev))
+    elif act == 'snake':
+        sa = torch.rand(Fq, generator=_g(seed + 5)) * 3 + 0.2
+        ref, a = O.snake(ref.permute(0, 1, 3, 2), sa).permute(0, 1, 3, 2), _lib.ACT_SNAKE
+        kw = dict(snake_a=sa.to(dev))
+    else:
+        a = _lib.ACT_NONE
+    if trim:
+        ref = ref[:, :, trim:-trim]
+        kw.update(f_lo=trim, f_cnt=Fq - 2 * trim)
+    y = ops.norm_act(cl(x).to(dev), G, per_row, gamma.to(dev), beta.to(dev), a, **kw)
+    assert rel_l2(uncl(y.cpu()), ref) < TOL16
+
+
+# ------------------------------------------------------------------------------------------------
+def _lstm_sd(H, seed):
+    sd = {}
+    k = 1.0 / math.sqrt(H)
+    i = 0
+    for l in range(2):
+        for sfx in ('', '_reverse'):
+            inp = H if l == 0 else 2 * H
+            for name, shape in (('weight_ih', (4 * H, inp)), ('weight_hh', (4 * H, H)), ('bias_ih', (4 * H,)),
+                                ('bias_hh', (4 * H,))):
+                sd[f'b.lstm.{name}_l{l}{sfx}'] = (torch.rand(*shape, generator=_g(seed + i)) * 2 - 1) * k
+                i += 1
+    sd['b.linear.weight'] = (torch.rand(H, 2 * H, generator=_g(seed + 90)) * 2 - 1) * k
+    sd['b.linear.bias'] = (torch.rand(H, generator=_g(seed + 91)) * 2 - 1) * k
+    return sd
+
+
+def case_blstm(lib, dev, H, R, T, seed=60):
+    """Whole BLSTM block (projection convs + 2 recurrent layers + linear + skip) against the oracle."""
+    from aero_amd.engine import HipEngine
+
+    class _DC:
+        hidden = H
+    sd = {k: q16(v) if 'weight' in k else v for k, v in _lstm_sd(H, seed).items()}
+    x = _rand((R, H, T), seed + 100)
+    ref = O.blstm(sd, 'b', q16(x))
+    eng = HipEngine.__new__(HipEngine)
+    eng.lib, eng.ops = lib, Ops(lib)
+    L = {'lstm': [pack.pack_lstm_layer(lib, sd, 'b.lstm', l, H, dev) for l in range(2)]}
+    w = sd['b.linear.weight']
+    L['lstm_lin'] = pack.make_conv_spec(w[None, :, None, :], sd['b.linear.bias'], 2 * H, 0, [0], [0], dev)
+    h = x.permute(0, 2, 1).contiguous().half().view(1, R, T, H).to(dev)
+    y = eng._blstm(_DC, L, h, 1, R, T)
+    assert rel_l2(y.cpu().float()[0].permute(0, 2, 1), ref) < 4e-3
+
+
+def case_localstate(lib, dev, Cc, heads, R, T, seed=70):
+    ops = Ops(lib)
+    nd = 4
+    sd = {}
+    for i, (n, m) in enumerate((('query', Cc), ('key', Cc), ('content', Cc), ('query_decay', heads * nd), ('proj', Cc))):
+        sd[f'a.{n}.weight'] = q16(_rand((m, Cc, 1), seed + i, 1.0 / math.sqrt(Cc)))
+        sd[f'a.{n}.bias'] = _rand((m,), seed + 10 + i, 0.1)
+    sd['a.query_decay.bias'] = sd['a.query_decay.bias'] - 1.0
+    x = _rand((R, Cc, T), seed + 20)
+    ref = O.local_state(sd, 'a', q16(x), heads, nd)
+    w = torch.cat([sd[f'a.{n}.weight'][:, :, 0] for n in ('query', 'key', 'content', 'query_decay')], 0)
+    b = torch.cat([sd[f'a.{n}.bias'] for n in ('query', 'key', 'content', 'query_decay')], 0)
+    qk = pack.make_conv_spec(w[None, :, None, :], b, Cc, 0, [0], [0], dev)
+    pj = pack.make_conv_spec(sd['a.proj.weight'][:, :, 0][None, :, None, :], sd['a.proj.bias'], Cc, 0, [0], [0], dev)
+    h = x.permute(0, 2, 1).contiguous().half().view(1, R, T, Cc).to(dev)
+    qkvd = ops.conv(qk, h, None, 1, R, R, T)
+    att = ops.localstate(qkvd, R, T, Cc, heads, nd)
+    y = ops.conv(pj, att.view(1, R, T, Cc), None, 1, R, R, T, res=h)
+    assert rel_l2(y.cpu().float()[0].permute(0, 2, 1), ref) < 3e-3
+
+
+def case_freqfc(lib, dev, Fq, Cc, T, B=2, seed=80):
+    ops = Ops(lib)
+    w = q16(_rand((Fq, Fq), seed, 1.0 / math.sqrt(Fq)))
+    x = _rand((B, Cc, Fq, T), seed + 1)
+    gate = _rand((B, Cc, T), seed + 2).abs()
+    img = torch.zeros(pack._round_up(Fq, 128), pack._round_up(Fq, 32))
+    img[:Fq, :Fq] = w
+    y = ops.freqfc(cl(x).to(dev), img.half().to(dev), gate.permute(0, 2, 1).contiguous().half().to(dev))
+    att = q16(gate)[:, :, None, :] * q16(x)
+    ref = (att.transpose(2, 3) @ w.t()).transpose(2, 3)
+    assert rel_l2(uncl(y.cpu()), ref) < TOL16

@@ -1,0 +1,84 @@
+"""CPU: every kernel's index logic / masks / epilogues exercised through the CPU emulation of the HIP
+subset (tests/emu) against the oracle.  This is a test double for the device -- the product never loads it.
+Shapes are small (the emulator runs one fiber per GPU thread)."""
+import pytest
+
+import op_cases as oc
+from aero_amd import _lib
+
+
+@pytest.fixture(scope='module')
+def emu():
+    from emu.build_emu import build
+    return _lib.load(build())
+
+
+DEV = 'cpu'
+
+
+@pytest.mark.parametrize('geom', [(128, 4, 32, 400), (512, 16, 128, 1000), (512, 64, 512, 1536), (1024, 64, 256, 2003),
+                                  (256, 8, 64, 799)])
+def test_stft(emu, geom):
+    oc.case_stft(emu, DEV, *geom)
+
+
+@pytest.mark.parametrize('geom', [(128, 16, 128, 26), (512, 64, 512, 33), (1024, 256, 1024, 9), (256, 32, 252, 40)])
+def test_istft(emu, geom):
+    oc.case_istft(emu, DEV, *geom)
+
+
+@pytest.mark.parametrize('kw', [
+    dict(Cin=2, Cout=48, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=5, T=150),                  # pre_conv, scalar loads
+    dict(Cin=48, Cout=5, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=3, T=70, act='relu'),      # FTB conv1, M=5
+    dict(Cin=16, Cout=24, kF=8, kT=1, stride=4, padF=2, padT=0, Fin=16, T=130, act='gelu'),    # encoder conv
+    dict(Cin=24, Cout=32, kF=8, kT=1, stride=2, padF=3, padT=0, Fin=8, T=40),
+    dict(Cin=32, Cout=64, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=4, T=140, split=16, act='glu'),   # dec rewrite
+    dict(Cin=64, Cout=128, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=3, T=50, split=32, null0=True),  # first decoder
+    dict(Cin=96, Cout=192, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=2, T=33, split=48),              # 48+48 chunks
+    dict(Cin=12, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=4, T=45, residual=True),
+    dict(Cin=4, Cout=2, kF=4, kT=1, stride=2, padF=1, padT=0, Fin=4, T=20),                    # tiny-model shapes
+])
+def test_conv2d(emu, kw):
+    oc.case_conv2d(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=48, Cout=12, k=3, dil=1, R=6, T=131), dict(Cin=16, Cout=4, k=3, dil=2, R=3, T=60),
+                                dict(Cin=40, Cout=16, k=9, dil=1, R=2, T=50)])
+def test_conv1d(emu, kw):
+    oc.case_conv1d(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=32, Cout=16, K=8, stride=2, Fin=4, T=40), dict(Cin=16, Cout=8, K=8, stride=4, Fin=5, T=33),
+                                dict(Cin=16, Cout=2, K=8, stride=4, Fin=6, T=70, f32_affine=True),
+                                dict(Cin=8, Cout=4, K=4, stride=2, Fin=3, T=20), dict(Cin=8, Cout=4, K=2, stride=2, Fin=2, T=20),
+                                dict(Cin=16, Cout=8, K=8, stride=2, Fin=4, T=30, trim=False)])
+def test_convtr(emu, kw):
+    oc.case_convtr(emu, DEV, **kw)
+
+
+def test_freq_emb_epilogue(emu):
+    oc.case_freq_emb_epilogue(emu, DEV)
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=16, G=4, Fq=3, T=50, act='gelu'), dict(Cc=32, G=4, Fq=2, T=45, act='glu'),
+                                dict(Cc=12, G=1, Fq=4, T=33, act='snake', per_row=True),
+                                dict(Cc=24, G=1, Fq=3, T=40, act='glu_ls_res', per_row=True),
+                                dict(Cc=8, G=4, Fq=10, T=21, act='gelu', trim=2), dict(Cc=2, G=1, Fq=3, T=20, act='snake', per_row=True),
+                                dict(Cc=8, G=4, Fq=6, T=17, act='none', trim=1)])
+def test_groupnorm(emu, kw):
+    oc.case_groupnorm(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(H=4, R=3, T=50), dict(H=8, R=2, T=251), dict(H=48, R=2, T=40), dict(H=24, R=18, T=30)])
+def test_blstm(emu, kw):
+    oc.case_blstm(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=8, heads=4, R=2, T=70), dict(Cc=48, heads=4, R=1, T=300), dict(Cc=4, heads=4, R=3, T=33)])
+def test_localstate(emu, kw):
+    oc.case_localstate(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Fq=16, Cc=8, T=20), dict(Fq=70, Cc=12, T=11), dict(Fq=4, Cc=4, T=9, B=1)])
+def test_freqfc(emu, kw):
+    oc.case_freqfc(emu, DEV, **kw)
