@@ -61,6 +61,7 @@ _PROTOS = {
     'aero_spec_normalize': (i32, [fp, i32, i64, dp, vp, fp, vp]),
     'aero_istft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, fp, fp, i32, vp]),
     'aero_conv_fwd': (i32, [C.POINTER(ConvDesc), vp]),
+    'aero_conv_tile_m': (i32, [i32]),
     'aero_norm_stats': (i32, [C.POINTER(NormDesc), vp]),
     'aero_norm_apply': (i32, [C.POINTER(NormDesc), vp]),
     'aero_lstm_fwd': (i32, [C.POINTER(LstmDesc), vp]),

@@ -71,6 +71,8 @@ int aero_conv_fwd(const aero_conv_desc* d, void* stream) {
     return aero_finish(rc, err);
 }
 
+int aero_conv_tile_m(int32_t M) { return aero_conv_pick_bm(M, (M + 127) / 128 * 128); }
+
 int aero_norm_stats(const aero_norm_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_norm_stats_launch(d, (hipStream_t)stream, &err);

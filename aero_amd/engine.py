@@ -33,33 +33,47 @@ class Ops:
 
     def __init__(self, lib):
         self.lib = lib
+        self.prof = None          # bench.py sets this to a list to collect per-launch HIP-event timings
 
     @staticmethod
     def stream(t):
         return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+    def _call(self, fn, kernel, flops, nbytes, *args):
+        """One C-ABI call = one kernel launch on the current stream; optionally bracketed by HIP events
+        (recorded on that same stream) for the roofline numbers of bench.py."""
+        if self.prof is None:
+            self.lib.call(fn, *args)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.lib.call(fn, *args)
+        e1.record()
+        self.prof.append((kernel, flops, nbytes, e0, e1))
 
     # -- K1/K2/K15 ---------------------------------------------------------------------------
     def stft(self, x, L, Lp, n_fft, hop, window, n_bins, stats=None, sig_per_item=1):
         nsig = x.shape[0]
         T = 1 + Lp // hop
         spec = torch.empty(nsig, n_bins, T, 2, dtype=torch.float32, device=x.device)
-        self.lib.call('aero_stft_fwd', _ptr(x), nsig, L, Lp, n_fft, hop, _ptr(window), n_bins, _ptr(spec), T,
-                      _ptr(stats), sig_per_item, self.stream(x))
+        self._call('aero_stft_fwd', 'aero_stft_kernel', 0, nsig * (L * 4 + n_bins * T * 8),
+                   _ptr(x), nsig, L, Lp, n_fft, hop, _ptr(window), n_bins, _ptr(spec), T,
+                   _ptr(stats), sig_per_item, self.stream(x))
         return spec
 
     def spec_normalize(self, spec, nitems, stats):
         n_per = spec.numel() // nitems
         xn = torch.empty(spec.shape, dtype=torch.float16, device=spec.device)
         mean_std = torch.empty(nitems, 2, dtype=torch.float32, device=spec.device)
-        self.lib.call('aero_spec_normalize', _ptr(spec), nitems, n_per, _ptr(stats), _ptr(xn), _ptr(mean_std),
-                      self.stream(spec))
+        self._call('aero_spec_normalize', 'aero_spec_normalize_kernel', 0, spec.numel() * 6,
+                   _ptr(spec), nitems, n_per, _ptr(stats), _ptr(xn), _ptr(mean_std), self.stream(spec))
         return xn, mean_std
 
     def istft(self, spec, n_fft, hop, window, inv_env, Lout):
         nsig, F, T, _ = spec.shape
         y = torch.empty(nsig, Lout, dtype=torch.float32, device=spec.device)
-        self.lib.call('aero_istft_fwd', _ptr(spec), nsig, F, T, n_fft, hop, _ptr(window), _ptr(inv_env), _ptr(y), Lout,
-                      self.stream(spec))
+        self._call('aero_istft_fwd', 'aero_istft_kernel', 0, nsig * (F * T * 8 + Lout * 4),
+                   _ptr(spec), nsig, F, T, n_fft, hop, _ptr(window), _ptr(inv_env), _ptr(y), Lout, self.stream(spec))
         return y
 
     # -- convolution family --------------------------------------------------------------------
@@ -98,7 +112,17 @@ class Ops:
             d.r_b, d.r_f, d.r_t = _strides4(res)
         d.post_add = _ptr(post_add)
         d.batch_scale, d.batch_shift = _ptr(batch_scale), _ptr(batch_shift)
-        self.lib.call('aero_conv_fwd', C.byref(d), self.stream(dst))
+        if self.prof is None:
+            self.lib.call('aero_conv_fwd', C.byref(d), self.stream(dst))
+        else:
+            bm = self.lib.cdll.aero_conv_tile_m(spec.M)
+            kname = {128: 'aero_conv_kernel<4,2>', 64: 'aero_conv_kernel<4,1>', 48: 'aero_conv_kernel<3,1>',
+                     32: 'aero_conv_kernel<2,1>', 16: 'aero_conv_kernel<1,1>'}[bm]
+            pos = B * dst_F * T
+            cin_exec = spec.C1 + (spec.C0 if src0 is not None else 0)
+            flops = 2.0 * pos * spec.M * len(spec.df) * cin_exec       # executed (NULL source skipped)
+            nbytes = pos * (Mout * dst.element_size()) + B * Fin * T * cin_exec * 2
+            self._call('aero_conv_fwd', kname, flops, nbytes, C.byref(d), self.stream(dst))
         return dst
 
     # -- GroupNorm + activation ----------------------------------------------------------------
@@ -115,7 +139,7 @@ class Ops:
             items = B * F if per_row else B
             stats = torch.empty(items * G, 2, dtype=torch.float32, device=x.device)
             d.stats = _ptr(stats)
-            self.lib.call('aero_norm_stats', C.byref(d), self.stream(x))
+            self._call('aero_norm_stats', 'aero_norm_stats_kernel', 0, x.numel() * 2, C.byref(d), self.stream(x))
         f_cnt = F if f_cnt is None else f_cnt
         assert not (per_row and (f_lo or f_cnt != F))
         Cout = Cc // 2 if act == ACT_GLU else Cc
@@ -130,7 +154,8 @@ class Ops:
             d.r_b, d.r_f, d.r_t = _strides4(res)
         d.dst = _ptr(out)
         d.d_b, d.d_f, d.d_t = _strides4(out)
-        self.lib.call('aero_norm_apply', C.byref(d), self.stream(x))
+        self._call('aero_norm_apply', 'aero_norm_apply_kernel', 0,
+                   B * f_cnt * T * (Cc + Cout + (Cout if res is not None else 0)) * 2, C.byref(d), self.stream(x))
         return out
 
     # -- LSTM / attention / FTB ----------------------------------------------------------------
@@ -138,7 +163,8 @@ class Ops:
         d = _lib.LstmDesc()
         d.xproj, d.xbias, d.whh, d.out = _ptr(xproj), _ptr(xbias), _ptr(whh), _ptr(out)
         d.H, d.nseq, d.W, d.in_mode, d.out_mode, d.nframes, d.S, d.T = H, nseq, W, in_mode, out_mode, nframes, S, T
-        self.lib.call('aero_lstm_fwd', C.byref(d), self.stream(out))
+        self._call('aero_lstm_fwd', 'aero_lstm_kernel', 2.0 * nseq * W * 2 * 4 * H * H, xproj.numel() * 2 + out.numel() * 2,
+                   C.byref(d), self.stream(out))
         return out
 
     def localstate(self, qkvd, R, T, Cc, heads, ndecay):
@@ -146,7 +172,8 @@ class Ops:
         d = _lib.AttnDesc()
         d.qkvd, d.ld, d.out = _ptr(qkvd), qkvd.shape[-1], _ptr(out)
         d.R, d.T, d.C, d.heads, d.ndecay = R, T, Cc, heads, ndecay
-        self.lib.call('aero_localstate_fwd', C.byref(d), self.stream(out))
+        self._call('aero_localstate_fwd', 'aero_attn_kernel', 4.0 * R * T * T * Cc, qkvd.numel() * 2 + out.numel() * 2,
+                   C.byref(d), self.stream(out))
         return out
 
     def freqfc(self, x, w, gate):
@@ -156,7 +183,8 @@ class Ops:
         d = _lib.FreqFcDesc()
         d.x, d.w, d.gate, d.dst = _ptr(x), _ptr(w), _ptr(gate), _ptr(out)
         d.B, d.F, d.T, d.C = B, F, T, Cc
-        self.lib.call('aero_freqfc_fwd', C.byref(d), self.stream(out))
+        self._call('aero_freqfc_fwd', 'aero_freqfc_kernel', 2.0 * B * F * F * T * Cc, x.numel() * 4,
+                   C.byref(d), self.stream(out))
         return out
 
 

@@ -1,0 +1,163 @@
+"""bench.py -- real-time factor of Aero.forward (STFT + U-Net + iSTFT) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward pass of the hot path over one batch of synthetic clips already resident in
+HBM (BASELINE.json configs[1]: batch 64 x 2 s white noise, 4->16 kHz, nfft 512, hop 64, random-init
+weights, seed 2036).  Clips are independent units: with N ranks every rank processes its own 64
+clips (weak scaling, no data-path collective; clip i -> rank i mod N as reference distrib.py:100);
+timing is barrier + synchronize on both sides, max over ranks.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FULL_CFG = dict(in_channels=1, out_channels=1, channels=48, growth=2, nfft=512, hop_length=64, end_iters=0,
+                cac=True, rewrite=True, hybrid=False, hybrid_old=False, freq_emb=0.2, emb_scale=10,
+                emb_smooth=True, kernel_size=8, strides=[4, 4, 2, 2], context=1, context_enc=0, freq_ends=4,
+                enc_freq_attn=0, norm_starts=2, norm_groups=4, dconv_mode=1, dconv_depth=2, dconv_comp=4,
+                dconv_time_attn=2, dconv_lstm=2, dconv_init=1e-3, rescale=0.1, lr_sr=4000, hr_sr=16000,
+                spec_upsample=True, act_func='snake', debug=False)
+
+PEAK_MFMA_F16_TFLOPS = 2500.0      # dense fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0              # HBM3E spec peak, same table
+
+
+def cpu_baseline(batch, seconds_per_clip, lr_sr, reps):
+    """The oracle (a port of the reference's CPU path) timed on this box's host cores: bounded sample."""
+    from oracle import aero_oracle as O
+    from aero_amd import Aero
+    torch.manual_seed(2036)
+    model = Aero(**FULL_CFG).eval()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    x = torch.randn(batch, 1, int(seconds_per_clip * lr_sr), generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        O.aero_forward(sd, FULL_CFG, x, fast=True)                     # warm-up
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            O.aero_forward(sd, FULL_CFG, x, fast=True)
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {'value': round(batch * seconds_per_clip / med, 3), 'unit': 'audio-sec/wall-sec', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': f'oracle/aero_oracle.py fp32, batch {batch} x {seconds_per_clip:g} s clips, median of {reps} after 1 warm-up'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU (BASELINE config 2: 64)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP-event pass')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU path in the product)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    from aero_amd import distrib
+    distrib.init_from_env()                                   # RCCL process group when WORLD_SIZE > 1
+    assert world == args.gpus or world == 1, (world, args.gpus)
+
+    from aero_amd import Aero
+    torch.manual_seed(2036)
+    model = Aero(**FULL_CFG).eval().to(dev)
+    B, L, secs = args.batch, 8000, 2.0
+    # global batch = world*B clips; clip i -> rank i mod world (reference distrib.py:100)
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(B, 1, L, generator=g).to(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = model(x)
+        distrib.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(x)
+        torch.cuda.synchronize()
+        distrib.barrier()
+        dt = time.perf_counter() - t0
+    dt = distrib.max_over_ranks(dt, dev)
+    assert y.shape == (B, 1, 4 * L) and bool(torch.isfinite(y).all())
+
+    # ---- per-launch HIP events over K more steps: roofline of the dominant kernel ------------------------------
+    roof = None
+    kernels = {}
+    if not args.no_kernel_events:
+        eng = model._get_engine()
+        eng.ops.prof = []
+        with torch.no_grad():
+            for _ in range(max(1, min(args.steps, 5))):
+                model(x)
+        torch.cuda.synchronize()
+        for kname, flops, nbytes, e0, e1 in eng.ops.prof:
+            k = kernels.setdefault(kname, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            k['launches'] += 1
+            k['ms'] += e0.elapsed_time(e1)
+            k['flops'] += flops
+            k['bytes'] += nbytes
+        eng.ops.prof = None
+        dom = max(kernels, key=lambda n: kernels[n]['ms'])
+        k = kernels[dom]
+        avg_ms = k['ms'] / k['launches']
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom)
+            except Exception:
+                traffic = None
+        if k['flops'] > 0:
+            ach = k['flops'] / k['launches'] / (avg_ms * 1e-3) / 1e12
+            roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_MFMA_F16_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_MFMA_F16_TFLOPS, 4), 'traffic': traffic,
+                    'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': k['launches'] // max(1, min(args.steps, 5)),
+                    'flops_per_launch': k['flops'] / k['launches'],
+                    'note': 'executed FLOPs (2*MAC; structurally-zero first-decoder input skipped) / HIP-event time'}
+        else:
+            ach = k['bytes'] / k['launches'] / (avg_ms * 1e-3) / 1e9
+            roof = {'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_ms, 4)}
+
+    if rank != 0:
+        distrib.close()
+        return
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(batch=8, seconds_per_clip=secs, lr_sr=FULL_CFG['lr_sr'], reps=3)
+    audio_s = world * B * secs * args.steps
+    out = {
+        'metric': 'real-time-factor (audio-sec/wall-sec), Aero.forward STFT+U-Net+iSTFT, 4->16kHz nfft=512 hop=64 batch=64 per GPU',
+        'value': round(audio_s / dt, 2), 'unit': 'audio-sec/wall-sec', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+        'config': {'workload': f'batch={B} synthetic 2s white-noise clips per GPU, 4->16 kHz, aero_4-16_512_64 '
+                               f'(nfft=512 hop=64), random-init weights seed 2036, inference, inputs resident in HBM',
+                   'global_batch': world * B, 'clip_samples': L, 'frames': 501, 'parallelism': f'clips sharded over {world} GPU(s), no data-path collective',
+                   'precision': 'fp16 operands/storage, fp32 accumulate; STFT/iSTFT/statistics fp32'},
+        'roofline': roof, 'cpu_baseline': cpu,
+        'kernels_ms_per_step': {n: round(v['ms'] / max(1, min(args.steps, 5)), 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
+    }
+    print(json.dumps(out))
+    distrib.close()
+
+
+if __name__ == '__main__':
+    main()

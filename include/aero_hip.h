@@ -88,6 +88,8 @@ typedef struct {
     const float* batch_scale; const float* batch_shift;
 } aero_conv_desc;
 int aero_conv_fwd(const aero_conv_desc* d, void* stream);
+/* rows per block (16/32/48/64/128) of the kernel instantiation aero_conv_fwd picks for M output channels */
+int aero_conv_tile_m(int32_t M);
 
 /* K7+K8 -- nn.GroupNorm (aero.py:56,148; modules.py:189) followed by GELU / GLU(+LayerScale
  * +residual) / Snake (aero.py:127,133,198,214; modules.py:141,232-236,244; snake.py:67).

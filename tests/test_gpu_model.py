@@ -1,0 +1,110 @@
+"""GPU (-m gpu): Aero.forward on the MI355X against the golden vectors captured from the reference
+(tests/golden, made by oracle/make_golden.py) and against the CPU oracle.
+Tolerance (north_star): <= 1e-3 relative L2 on the complex spectrogram; STFT (fp32) <= 2e-6."""
+import pytest
+import torch
+
+from conftest import build_model, load_npz, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _fwd(m, x):
+    with torch.no_grad():
+        y, s, lr = m(x.cuda(), return_spec=True, return_lr_spec=True)
+    torch.cuda.synchronize()
+    return y.cpu(), s.cpu(), lr.cpu()
+
+
+def test_native_library_is_the_gfx950_build():
+    from aero_amd import _lib
+    lib = _lib.load()
+    assert 'gfx950' in lib.version and not lib.is_emulator
+
+
+@pytest.mark.parametrize('L', [400, 1000, 999])
+def test_tiny_model_golden(meta, L):
+    m = build_model(meta, 'tiny').cuda()
+    io = load_npz('tiny_io.npz')
+    y, s, lr = _fwd(m, torch.from_numpy(io[f'x_{L}']))
+    assert rel_l2(lr, io[f'lr_{L}']) < 2e-6
+    assert rel_l2(s, io[f'spec_{L}']) < 1e-3
+    assert rel_l2(y, io[f'y_{L}']) < 5e-3
+
+
+@pytest.mark.parametrize('L', [800, 2003])
+def test_small_model_golden(meta, L):
+    m = build_model(meta, 'small').cuda()
+    io = load_npz('small_io.npz')
+    y, s, lr = _fwd(m, torch.from_numpy(io[f'x_{L}']))
+    assert rel_l2(lr, io[f'lr_{L}']) < 2e-6
+    assert rel_l2(s, io[f'spec_{L}']) < 1e-3
+    assert rel_l2(y, io[f'y_{L}']) < 5e-3
+
+
+def test_full_model_golden(meta):
+    """aero_4-16_512_64, seed 2036: the first two clips of BASELINE config 2's input."""
+    m = build_model(meta, 'full').cuda()
+    io = load_npz('full_io.npz')
+    x = torch.randn(2, 1, 8000, generator=torch.Generator().manual_seed(0))
+    y, s, lr = _fwd(m, x)
+    assert y.shape == (2, 1, 32000) and s.shape == (2, 1, 256, 501)
+    assert rel_l2(lr[:, :, ::8, ::5], io['lr']) < 2e-6
+    e_spec, e_wav = rel_l2(s, io['spec']), rel_l2(y, io['y'])
+    print(f'full model: spectrogram rel-L2 {e_spec:.3e}, waveform rel-L2 {e_wav:.3e}')
+    assert e_spec < 1e-3
+    assert e_wav < 5e-3
+
+
+def test_full_model_batch64_matches_golden_and_is_batch_invariant(meta):
+    """BASELINE config 2 size (B=64): clips 0,1 are the golden clips; every clip's result must not depend
+    on its batch neighbours (clips are independent units -- the property the multi-GPU sharding relies on)."""
+    m = build_model(meta, 'full').cuda()
+    io = load_npz('full_io.npz')
+    g = torch.Generator().manual_seed(0)
+    x2 = torch.randn(2, 1, 8000, generator=g)
+    rest = torch.randn(62, 1, 8000, generator=torch.Generator().manual_seed(1))
+    x = torch.cat([x2, rest], 0)
+    y, s, _ = _fwd(m, x)
+    assert rel_l2(s[:2], io['spec']) < 1e-3
+    # permute the batch: results follow the clips (bit-exact: same kernels, same per-clip arithmetic)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(2))
+    yp, sp, _ = _fwd(m, x[perm])
+    assert torch.equal(sp, s[perm])
+    assert torch.equal(yp, y[perm])
+    assert torch.isfinite(y).all()
+
+
+def test_wide_band_geometry_golden(meta):
+    """BASELINE config 4 geometry (12->48 kHz, nfft 1024, hop 256)."""
+    m = build_model(meta, 'wide').cuda()
+    io = load_npz('wide_io.npz')
+    x = torch.randn(1, 1, 6000, generator=torch.Generator().manual_seed(31))
+    y, s, _ = _fwd(m, x)
+    assert rel_l2(s, io['spec']) < 1e-3
+    assert rel_l2(y, io['y']) < 5e-3
+
+
+def test_stft_istft_round_trip_full_size():
+    """Size-independent property at BASELINE size: iSTFT(STFT(x)) == x for a COLA window (hann, hop = n/8)."""
+    from aero_amd import Aero
+    m = Aero(nfft=512, hop_length=64, lr_sr=16000, hr_sr=16000).eval().cuda()     # scale 1: same geometry both ways
+    x = torch.randn(64, 1, 32000, generator=torch.Generator().manual_seed(9)).cuda()
+    z = m._spec(x)
+    # Nyquist is dropped by _spec (aero.py:420) so remove it from x first: compare against the oracle instead
+    from oracle import aero_oracle as O
+    cfg = {**O.DEFAULT_CFG, 'lr_sr': 16000, 'hr_sr': 16000}
+    zr = O.spec(x[:2].cpu(), cfg)
+    assert rel_l2(z[:2].cpu(), zr) < 2e-6
+    y = m._ispec(z)
+    yr = O.ispec(zr, cfg)
+    assert rel_l2(y[:2].cpu(), yr) < 2e-6
+    # linearity of the STFT kernel at full size
+    a = m._spec(2.0 * x) - 2.0 * z
+    assert float(a.abs().max()) < 1e-4
+
+
+def test_cpu_tensor_is_refused(meta):
+    m = build_model(meta, 'tiny').cuda()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 400))

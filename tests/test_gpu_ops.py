@@ -1,0 +1,87 @@
+"""GPU (-m gpu): op-level parity of every C-ABI entry point on the MI355X against the oracle, at the
+shapes of aero_4-16_512_64 (reduced batch) -- same cases as tests/test_emu_ops.py, real kernels."""
+import pytest
+import torch
+
+import op_cases as oc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from aero_amd import _lib
+    assert torch.cuda.is_available()
+    lib = _lib.load()                       # aero_amd/libaero_hip.so -- fails loudly if missing
+    assert not lib.is_emulator
+    return lib
+
+
+@pytest.mark.parametrize('geom', [(512, 16, 128, 8000), (512, 64, 512, 32000), (1024, 64, 256, 24000), (128, 4, 32, 999),
+                                  (512, 16, 128, 7999)])
+def test_stft(lib, geom):
+    oc.case_stft(lib, DEV, *geom, B=3)
+
+
+@pytest.mark.parametrize('geom', [(512, 64, 512, 501), (1024, 256, 1024, 376), (128, 16, 128, 101), (512, 128, 512, 251)])
+def test_istft(lib, geom):
+    oc.case_istft(lib, DEV, *geom, B=3)
+
+
+@pytest.mark.parametrize('kw', [
+    dict(Cin=2, Cout=48, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=256, T=501),
+    dict(Cin=48, Cout=5, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=64, T=501, act='relu'),
+    dict(Cin=48, Cout=48, kF=8, kT=1, stride=4, padF=2, padT=0, Fin=256, T=501, act='gelu'),
+    dict(Cin=96, Cout=192, kF=8, kT=1, stride=2, padF=3, padT=0, Fin=16, T=501),
+    dict(Cin=192, Cout=384, kF=8, kT=1, stride=2, padF=3, padT=0, Fin=8, T=501),
+    dict(Cin=768, Cout=1536, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=4, T=501, split=384, null0=True, B=1),
+    dict(Cin=384, Cout=768, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=8, T=501, split=192, B=1),
+    dict(Cin=192, Cout=384, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=16, T=501, split=96, act='glu', B=1),
+    dict(Cin=96, Cout=192, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=64, T=501, split=48, act='glu', B=1),
+    dict(Cin=48, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=64, T=501, act='glu'),
+    dict(Cin=12, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=64, T=501, residual=True),
+    dict(Cin=4, Cout=2, kF=4, kT=1, stride=2, padF=1, padT=0, Fin=4, T=20),
+])
+def test_conv2d(lib, kw):
+    oc.case_conv2d(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=48, Cout=12, k=3, dil=1, R=128, T=501), dict(Cin=384, Cout=96, k=3, dil=2, R=8, T=501),
+                                dict(Cin=512, Cout=48, k=9, dil=1, R=2, T=501)])
+def test_conv1d(lib, kw):
+    oc.case_conv1d(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=768, Cout=192, K=8, stride=2, Fin=4, T=501), dict(Cin=192, Cout=48, K=8, stride=4, Fin=16, T=501),
+                                dict(Cin=96, Cout=2, K=8, stride=4, Fin=64, T=501, f32_affine=True),
+                                dict(Cin=8, Cout=4, K=2, stride=2, Fin=2, T=20), dict(Cin=384, Cout=96, K=8, stride=2, Fin=8, T=501, trim=False)])
+def test_convtr(lib, kw):
+    oc.case_convtr(lib, DEV, **kw)
+
+
+def test_freq_emb_epilogue(lib):
+    oc.case_freq_emb_epilogue(lib, DEV)
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=192, G=4, Fq=8, T=501, act='gelu'), dict(Cc=768, G=4, Fq=4, T=501, act='glu'),
+                                dict(Cc=12, G=1, Fq=64, T=501, act='snake', per_row=True),
+                                dict(Cc=768, G=1, Fq=4, T=501, act='glu_ls_res', per_row=True),
+                                dict(Cc=96, G=4, Fq=22, T=501, act='gelu', trim=3), dict(Cc=2, G=1, Fq=3, T=20, act='snake', per_row=True)])
+def test_groupnorm(lib, kw):
+    oc.case_groupnorm(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(H=48, R=16, T=501), dict(H=96, R=8, T=501), dict(H=8, R=3, T=251), dict(H=48, R=5, T=150)])
+def test_blstm(lib, kw):
+    oc.case_blstm(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=48, heads=4, R=16, T=501), dict(Cc=96, heads=4, R=8, T=501), dict(Cc=4, heads=4, R=3, T=33)])
+def test_localstate(lib, kw):
+    oc.case_localstate(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Fq=256, Cc=48, T=501, B=1), dict(Fq=64, Cc=48, T=501), dict(Fq=8, Cc=192, T=501), dict(Fq=4, Cc=4, T=9, B=1)])
+def test_freqfc(lib, kw):
+    oc.case_freqfc(lib, DEV, **kw)
