@@ -1,0 +1,40 @@
+"""CPU: the gfx950 C-ABI library loads and exports every symbol include/aero_hip.h declares (no compute)."""
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'aero_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(aero_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_are_exported_by_the_gfx950_library():
+    import __graft_entry__ as g
+    from aero_amd import _lib
+    if not os.path.exists(_lib.DEFAULT_LIB):
+        g.build()
+    lib = _lib.load()
+    assert 'gfx950' in lib.version
+    names = _declared()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib.cdll, n), f'{n} declared in include/aero_hip.h but not exported'
+    assert set(_lib.EXPORTS) == set(names)
+
+
+def test_argument_errors_are_reported_not_thrown():
+    """Error convention: negative return code + thread-local message; no compute, no GPU needed."""
+    import ctypes as C
+    from aero_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    rc = lib.cdll.aero_conv_fwd(C.byref(d), None)
+    assert rc == -1 and b'conv' in lib.cdll.aero_last_error()
+    rc = lib.cdll.aero_stft_fwd(None, 1, 10, 10, 512, 16, None, 256, None, 1, None, 1, None)
+    assert rc < 0 and b'stft' in lib.cdll.aero_last_error()
+    mp, kp = C.c_int32(), C.c_int32()
+    assert lib.cdll.aero_lstm_geometry(96, C.byref(mp), C.byref(kp)) == 0 and (mp.value, kp.value) == (384, 96)
+    assert lib.cdll.aero_lstm_geometry(200, C.byref(mp), C.byref(kp)) == -3

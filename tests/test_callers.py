@@ -1,0 +1,100 @@
+"""CPU: caller-side rows of the hot-path table: predict.py chunking / concat /
+write normalisation, match_signal, wav I/O, config loader.  Integer paths are checked exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from aero_amd import _lib, audio_io, enhance
+from aero_amd.config import load_config
+from aero_amd.engine import HipEngine
+from conftest import ROOT, build_model
+from oracle import aero_oracle as O
+
+
+@pytest.mark.parametrize('n', [8000, 40000, 40001, 85000, 1])
+def test_chunk_ranges_exact(n):
+    r = enhance.chunk_ranges(n, 4000)
+    assert r == O.predict_chunks(n, 4000)
+    assert r[0][0] == 0 and r[-1][1] == n and all(a2 == b1 for (_, b1), (a2, _) in zip(r, r[1:]))
+    assert all(b - a == 40000 for a, b in r[:-1])
+
+
+def test_integer_index_paths():
+    assert O.derive_geometry(512, 64, 4000, 16000) == (4.0, 16, 128)
+    assert O.derive_geometry(512, 64, 8000, 24000) == (3.0, 21, 170)         # non-integer-friendly scale (Appendix C)
+    assert O.spec_pad_amount(8000, 16) == 0 and O.spec_pad_amount(7999, 16) == 1
+    assert O.unfold_geometry(501, 200, 100) == (6, 700)
+    sm = O.stitch_map(501, 200, 100, 6)
+    assert len(sm) == 501 and sm[0] == (0, 0) and sm[149] == (0, 149) and sm[150] == (1, 50) and sm[500] == (4, 100)
+    assert O.output_length(7999, 4.0) == 31996
+
+
+def test_wav_roundtrip_and_write_normalisation(tmp_path):
+    w = torch.randn(2, 1000) * 0.3
+    p = str(tmp_path / 'a.wav')
+    audio_io.save(p, w, 16000)
+    r, sr = audio_io.load(p)
+    assert sr == 16000 and torch.equal(r, w)
+    loud = torch.tensor([[0.5, -2.0, 1.0]])
+    enhance.write(loud, p, 16000)                       # enhance.py:20: divide by max(|w|max, 1)
+    r, _ = audio_io.load(p)
+    assert torch.allclose(r, loud / 2.0)
+    quiet = torch.tensor([[0.5, -0.25]])
+    enhance.write(quiet, p, 16000)
+    assert torch.equal(audio_io.load(p)[0], quiet)      # not amplified
+
+
+def test_match_signal():
+    x = torch.arange(10.)[None]
+    assert enhance.match_signal(x, 12).shape[-1] == 12 and enhance.match_signal(x, 7).shape[-1] == 7
+    assert torch.equal(enhance.match_signal(x, 12)[..., :10], x)
+
+
+def test_config_loader_resolves_the_experiment_group():
+    c = load_config(os.path.join(ROOT, 'conf'), ['experiment=aero_4-16_512_64', 'dset=4-16', '+filename=a.wav', 'lr=1e-4'])
+    assert c.experiment.name == 'aero-nfft=512-hl=64' and c.experiment.aero.nfft == 512 and c.filename == 'a.wav'
+    assert c.experiment.aero.dconv_init == 1e-3 and c.lr == 1e-4 and c.ddp_backend == 'nccl'
+    from aero_amd import Aero
+    m = Aero(**c.experiment.aero)
+    assert (m.scale, m.hop_length, m.win_length) == (4.0, 16, 128) and len(m.state_dict()) == 331
+    c4 = load_config(os.path.join(ROOT, 'conf'), ['experiment=aero_12-48_1024_256'])
+    assert (c4.experiment.aero.lr_sr, c4.experiment.aero.hr_sr, c4.experiment.aero.nfft) == (12000, 48000, 1024)
+
+
+def test_predict_signal_equals_per_chunk_forward(meta):
+    """predict.py:61-85 on the emulated kernels: batched full chunks + short tail == chunk-by-chunk forward."""
+    from emu.build_emu import build
+    m = build_model(meta, 'tiny')
+    object.__setattr__(m, '_engine', HipEngine(m, lib=_lib.load(build())))
+    sr = 40                                              # "10 s" chunk = 400 samples keeps the emulator fast
+    sig = torch.randn(1, 2 * 400 + 123, generator=torch.Generator().manual_seed(8))
+    pr = enhance.predict_signal(m, sig, sr, device='cpu')
+    assert pr.shape == (1, 4 * sig.shape[-1])
+    with torch.no_grad():
+        ref = torch.cat([m(sig[:, a:b].unsqueeze(0)).squeeze(0) for a, b in enhance.chunk_ranges(sig.shape[-1], sr)], -1)
+    assert torch.equal(pr, ref)
+
+
+def test_src_import_paths_and_checkpoint_format(tmp_path, meta):
+    """Reference checkpoints pickle the class path src.models.aero.Aero (model_serializer.py:22)."""
+    import pickle
+    from src.models.aero import Aero
+    from src.models.modelFactory import get_model
+    c = load_config(os.path.join(ROOT, 'conf'), ['experiment=aero_4-16_512_64'])
+    c.experiment.aero.channels = 4
+    c.experiment.aero.nfft = 128
+    c.experiment.aero.hop_length = 16
+    g = get_model(c)['generator']
+    assert isinstance(g, Aero) and g._init_args_kwargs[1]['channels'] == 4
+    blob = pickle.dumps({'class': g.__class__, 'args': g._init_args_kwargs[0], 'kwargs': g._init_args_kwargs[1]})
+    back = pickle.loads(blob)
+    assert back['class'] is Aero
+    pkg = {'models': {'generator': {'class': g.__class__, 'args': (), 'kwargs': dict(g._init_args_kwargs[1]),
+                                    'state': g.state_dict()}}}
+    p = str(tmp_path / 'checkpoint.th')
+    torch.save(pkg, p)
+    c.checkpoint_file = p
+    m2 = enhance.load_generator(c, device='cpu')
+    assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), g.state_dict().values()))
