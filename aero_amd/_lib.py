@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
 class NormDesc(C.Structure):
     _fields_ = [('src', vp), ('s_b', i64), ('s_f', i64), ('s_t', i64),
                 ('B', i32), ('F', i32), ('T', i32), ('C', i32), ('G', i32), ('per_row', i32),
-                ('eps', C.c_float), ('stats', fp), ('gamma', fp), ('beta', fp),
+                ('eps', C.c_float), ('stats', dp), ('stat_count', C.c_double), ('gamma', fp), ('beta', fp),
                 ('act', i32), ('snake_a', fp), ('layer_scale', fp),
                 ('res', vp), ('r_b', i64), ('r_f', i64), ('r_t', i64),
                 ('dst', vp), ('d_b', i64), ('d_f', i64), ('d_t', i64)]

@@ -18,7 +18,7 @@
 
 struct AeroConvK {
     aero_conv_desc d;
-    int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec_out;
+    int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec_out, staged;
 };
 
 template <int MF, int WM>
@@ -28,8 +28,13 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
     constexpr int BM = 16 * MF * WM;
     constexpr int BN = 128;
     constexpr int AV = (BM * 4 + 255) / 256;
-    __shared__ AERO_LDS_ALIGN h16 As[BM * 32];
-    __shared__ AERO_LDS_ALIGN h16 Bs[BN * 32];
+    // one LDS buffer: [A tile | B tile] during the K loop, then a [64][BM+8] fp16 output half-tile in the epilogue
+    constexpr int CS = BM + 8;                       // padded row (16 B) -> 2-way ds_write conflicts at most
+    constexpr int SMEM = (BM + BN) * 32 > 64 * CS ? (BM + BN) * 32 : 64 * CS;
+    __shared__ AERO_LDS_ALIGN h16 smem[SMEM];
+    h16* As = smem;
+    h16* Bs = smem + BM * 32;
+    h16* Cs = smem;
 
     const aero_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -149,6 +154,8 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
     }
 
     // ---------------- epilogue: D[m = (lane>>4)*4 + r][n = lane&15] per fragment ----------------
+    // Staged form (fp16 output, 8-channel aligned): the tile is transposed through LDS in two passes of 64
+    // positions so that every global store is a full 16-byte channel vector (256-byte runs per position).
     const int M = d.M;
     const bool glu = d.act == AERO_ACT_GLU;
     const int Mout = glu ? (M >> 1) : M;
@@ -158,67 +165,92 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
     const h16* res = (const h16*)d.res;
     const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
     const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
+    constexpr int NH = NF / 2;                      // n-fragments per wave per pass
+    constexpr int PH = NH * 16;                     // positions per wave per pass
 #pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int mbase = m0 + (wm * MF + i) * 16 + (lane >> 4) * 4;
-        if (mbase >= M) continue;
-        float bv[4];
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = (d.bias && mbase + r < M) ? d.bias[mbase + r] : 0.f;
+        for (int i = 0; i < MF; ++i) {
+            const int mbase = m0 + (wm * MF + i) * 16 + (lane >> 4) * 4;
+            if (mbase >= M) continue;
+            float bv[4];
 #pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const int t = t0 + (wn * NF + n) * 16 + (lane & 15);
-            if (t >= T) continue;
-            float o[4];
+            for (int r = 0; r < 4; ++r) bv[r] = (d.bias && mbase + r < M) ? d.bias[mbase + r] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = acc[i][n][r] + bv[r];
-            int cbase = mbase;
-            if (glu) {
-                o[0] = o[0] * aero_sigmoid(o[1]);
-                o[1] = o[2] * aero_sigmoid(o[3]);
-                cbase = mbase >> 1;
-            } else if (d.act == AERO_ACT_RELU) {
+            for (int nn = 0; nn < NH; ++nn) {
+                const int n = pass * NH + nn;
+                const int t = t0 + (wn * NF + n) * 16 + (lane & 15);
+                if (t >= T) continue;
+                float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
-            } else if (d.act == AERO_ACT_GELU) {
+                for (int r = 0; r < 4; ++r) o[r] = acc[i][n][r] + bv[r];
+                int cbase = mbase;
+                if (glu) {
+                    o[0] = o[0] * aero_sigmoid(o[1]);
+                    o[1] = o[2] * aero_sigmoid(o[3]);
+                    cbase = mbase >> 1;
+                } else if (d.act == AERO_ACT_RELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = aero_gelu(o[r]);
-            }
-            const int64_t doff = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * d.d_t + cbase;
-            const int64_t roff = (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + (int64_t)t * d.r_t + cbase;
+                    for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+                } else if (d.act == AERO_ACT_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r >= nout || cbase + r >= Mout) continue;
-                float x = o[r];
-                if (res) x += (float)res[roff + r];
-                if (d.post_add) x += d.post_add[(int64_t)fo * Mout + cbase + r];
-                o[r] = x * bsc + bsh;
-            }
-            if (p.vec_out && cbase + nout <= Mout) {
-                if (d.dst_f32) {
-                    if (glu) *(f32x2*)(dst32 + doff) = (f32x2){o[0], o[1]};
-                    else *(f32x4*)(dst32 + doff) = (f32x4){o[0], o[1], o[2], o[3]};
-                } else {
-                    if (glu) *(h16x2*)(dst16 + doff) = (h16x2){(h16)o[0], (h16)o[1]};
-                    else *(h16x4*)(dst16 + doff) = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+                    for (int r = 0; r < 4; ++r) o[r] = aero_gelu(o[r]);
                 }
-            } else {
+                const int64_t doff = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * d.d_t + cbase;
+                const int64_t roff = (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + (int64_t)t * d.r_t + cbase;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (r >= nout || cbase + r >= Mout) continue;
-                    if (d.dst_f32) dst32[doff + r] = o[r];
-                    else dst16[doff + r] = (h16)o[r];
+                    float x = o[r];
+                    if (res) x += (float)res[roff + r];
+                    if (d.post_add) x += d.post_add[(int64_t)fo * Mout + cbase + r];
+                    o[r] = x * bsc + bsh;
+                }
+                if (p.staged) {
+                    const int pc = wn * PH + nn * 16 + (lane & 15);
+                    const int cl = cbase - (glu ? (m0 >> 1) : m0);
+                    if (glu) *(h16x2*)&Cs[pc * CS + cl] = (h16x2){(h16)o[0], (h16)o[1]};
+                    else *(h16x4*)&Cs[pc * CS + cl] = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+                } else if (p.vec_out && cbase + nout <= Mout) {
+                    if (d.dst_f32) {
+                        if (glu) *(f32x2*)(dst32 + doff) = (f32x2){o[0], o[1]};
+                        else *(f32x4*)(dst32 + doff) = (f32x4){o[0], o[1], o[2], o[3]};
+                    } else {
+                        if (glu) *(h16x2*)(dst16 + doff) = (h16x2){(h16)o[0], (h16)o[1]};
+                        else *(h16x4*)(dst16 + doff) = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (r >= nout || cbase + r >= Mout) continue;
+                        if (d.dst_f32) dst32[doff + r] = o[r];
+                        else dst16[doff + r] = (h16)o[r];
+                    }
                 }
             }
+        }
+        if (p.staged) {
+            __syncthreads();
+            const int BMo = glu ? (BM >> 1) : BM;
+            const int nvec = BMo >> 3;
+            const int m0o = glu ? (m0 >> 1) : m0;
+            h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
+            for (int idx = tid; idx < 64 * nvec; idx += 256) {
+                const int pc = idx / nvec, cv = idx - pc * nvec;
+                const int wq = pc / PH, rr = pc - wq * PH;
+                const int t = t0 + (wq * NF + pass * NH + (rr >> 4)) * 16 + (rr & 15);
+                if (t < T && m0o + cv * 8 < Mout) *(h16x8*)(drow + (int64_t)t * d.d_t + cv * 8) = *(const h16x8*)&Cs[pc * CS + cv * 8];
+            }
+            __syncthreads();
         }
     }
 }
 
 static int aero_conv_pick_bm(int M, int Mpad) {
-    const int cand[5] = {128, 64, 48, 32, 16};
+    const int cand[6] = {128, 96, 64, 48, 32, 16};
     int best = 128;
     long best_cost = -1;
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 6; ++i) {
         const int bm = cand[i];
         const int tiles = (M + bm - 1) / bm;
         if (tiles * bm > Mpad) continue;
@@ -259,11 +291,15 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     const int esz = d->dst_f32 ? 4 : 2;
     p.vec_out = (Mout % nout == 0) && (d->d_b % nout == 0) && (d->d_f % nout == 0) && (d->d_t % nout == 0) &&
                 (((uintptr_t)d->dst % (uintptr_t)(esz * nout)) == 0);
+    // LDS-staged (transposed) epilogue: fp16 output whose rows can take aligned 16-byte channel vectors
+    p.staged = !d->dst_f32 && (Mout % 8 == 0) && (d->d_b % 8 == 0) && (d->d_f % 8 == 0) && (d->d_t % 8 == 0) &&
+               (((uintptr_t)d->dst & 15) == 0) && (bm % 16 == 0);
     const long nwg = (long)d->B * d->Fout * p.ntt * p.nmt;
     if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);
     switch (bm) {
         case 128: AERO_LAUNCH((aero_conv_kernel<4, 2>), grid, block, stream, p); break;
+        case 96: AERO_LAUNCH((aero_conv_kernel<3, 2>), grid, block, stream, p); break;
         case 64: AERO_LAUNCH((aero_conv_kernel<4, 1>), grid, block, stream, p); break;
         case 48: AERO_LAUNCH((aero_conv_kernel<3, 1>), grid, block, stream, p); break;
         case 32: AERO_LAUNCH((aero_conv_kernel<2, 1>), grid, block, stream, p); break;

@@ -1,151 +1,181 @@
 // k_norm.h -- GroupNorm statistics + fused normalise/activation (HBM-bound elementwise work).
 //
 // Replaces nn.GroupNorm + F.gelu / F.glu / Snake / LayerScale / residual add of the reference
-// (aero.py:127,133,198,206-214; modules.py:230-244; snake.py:67).  Statistics are reduced per
-// (item, group) in fp32 per thread and fp64 across threads; the apply pass reads each fp16 value
-// once and writes the activated result once.  Algorithmic bytes: stats 2 B/element read;
-// apply 2 B read + 2 B write per output element (GLU reads 4 B per output) -- DESIGN.md section 4.
+// (aero.py:127,133,198,206-214; modules.py:230-244; snake.py:67).
+//   aero_norm_stats : per (item, group) sum and sum of squares, fp32 per thread, fp64 across threads, many
+//                     blocks per group combined with fp64 atomics (caller zeroes the 2-double accumulators).
+//   aero_norm_apply : mean/rstd are derived from the accumulators in the block preamble and folded with
+//                     gamma/beta into one per-channel FMA held in registers; each thread owns a FIXED vector of
+//                     8 channels and walks time, so the inner loop is 16-byte load -> 8 FMA -> activation ->
+//                     16-byte store with no index arithmetic (no integer division: v1 spent its time there).
+// Algorithmic bytes: stats 2 B/element read; apply 2 B read + 2 B write per output element (GLU reads 4 B per
+// output; +2 B for a residual) -- DESIGN.md section 4.
 #pragma once
 #include "aero_common.h"
 
-// one block per (item, group); item = b (per_row == 0) or b*F + f (per_row == 1)
 template <int VEC>
-__global__ __launch_bounds__(256) void aero_norm_stats_kernel(aero_norm_desc d) {
+struct AeroVecT;
+template <>
+struct AeroVecT<8> { typedef h16x8 type; };
+template <>
+struct AeroVecT<4> { typedef h16x4 type; };
+template <>
+struct AeroVecT<1> { typedef h16 type; };
+
+template <int VEC>
+static __device__ __forceinline__ void aero_load_vec(const h16* p, float* out) {
+    if (VEC == 8) {
+        const h16x8 v = *(const h16x8*)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+    } else if (VEC == 4) {
+        const h16x4 v = *(const h16x4*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = (float)v[i];
+    } else {
+        out[0] = (float)p[0];
+    }
+}
+
+template <int VEC>
+static __device__ __forceinline__ void aero_store_vec(h16* p, const float* in) {
+    if (VEC == 8) {
+        h16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (h16)in[i];
+        *(h16x8*)p = v;
+    } else if (VEC == 4) {
+        h16x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (h16)in[i];
+        *(h16x4*)p = v;
+    } else {
+        p[0] = (h16)in[0];
+    }
+}
+
+// grid (t-chunks, nf, items*G), nf = F for per_row == 0 else 1.  Thread (v, ty): channel vector v of the group,
+// time phase ty; walks t = t0+ty, t0+ty+TY, ...
+template <int VEC>
+__global__ __launch_bounds__(256) void aero_norm_stats_kernel(aero_norm_desc d, int tchunk) {
     __shared__ double red[2][4];
     const int gs = d.C / d.G;
-    const int item = blockIdx.x / d.G, g = blockIdx.x % d.G;
+    const int item = blockIdx.z / d.G, g = blockIdx.z % d.G;
     const int b = d.per_row ? item / d.F : item;
-    const int f0 = d.per_row ? item % d.F : 0;
-    const int nf = d.per_row ? 1 : d.F;
-    const h16* base = (const h16*)d.src + (int64_t)b * d.s_b + (int64_t)g * gs;
-    const int vpp = gs / VEC;                       // vectors per position
-    const int64_t total = (int64_t)nf * d.T * vpp;
+    const int f = d.per_row ? item % d.F : blockIdx.y;
+    const int vpp = gs / VEC;
+    const int tid = threadIdx.x;
+    const bool wide = vpp > 256;
+    const int TY = wide ? 1 : 256 / vpp;
+    const int v = wide ? tid : tid % vpp;
+    const int ty = wide ? 0 : tid / vpp;
+    const int vstep = wide ? 256 : vpp;
+    const h16* base = (const h16*)d.src + (int64_t)b * d.s_b + (int64_t)f * d.s_f + (int64_t)g * gs;
+    const int t0 = blockIdx.x * tchunk;
+    const int t1 = (t0 + tchunk < d.T) ? t0 + tchunk : d.T;
     float s = 0.f, ss = 0.f;
-    for (int64_t e = threadIdx.x; e < total; e += 256) {
-        const int v = (int)(e % vpp);
-        const int64_t pos = e / vpp;
-        const int t = (int)(pos % d.T);
-        const int f = f0 + (int)(pos / d.T);
-        const h16* p = base + (int64_t)f * d.s_f + (int64_t)t * d.s_t + v * VEC;
-        if (VEC == 8) {
-            const h16x8 x = *(const h16x8*)p;
+    if (ty < TY) {
+        for (int t = t0 + ty; t < t1; t += TY) {
+            const h16* row = base + (int64_t)t * d.s_t;
+            for (int vv = v; vv < vpp; vv += vstep) {
+                float x[VEC];
+                aero_load_vec<VEC>(row + vv * VEC, x);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const float y = (float)x[i]; s += y; ss += y * y; }
-        } else if (VEC == 4) {
-            const h16x4 x = *(const h16x4*)p;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { const float y = (float)x[i]; s += y; ss += y * y; }
-        } else {
-            const float y = (float)p[0];
-            s += y;
-            ss += y * y;
+                for (int i = 0; i < VEC; ++i) { s += x[i]; ss += x[i] * x[i]; }
+            }
         }
     }
     double ds = aero_wave_sum((double)s), dss = aero_wave_sum((double)ss);
     if (aero_lane() == 0) { red[0][aero_wave()] = ds; red[1][aero_wave()] = dss; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        ds = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        dss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        const double n = (double)nf * d.T * gs;
-        const double mean = ds / n;
-        double var = dss / n - mean * mean;         // biased variance, as nn.GroupNorm
-        if (var < 0) var = 0;
-        d.stats[(int64_t)blockIdx.x * 2 + 0] = (float)mean;
-        d.stats[(int64_t)blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)d.eps));
+    if (tid == 0) {
+        atomicAdd(d.stats + (int64_t)blockIdx.z * 2 + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(d.stats + (int64_t)blockIdx.z * 2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
 }
 
-// each thread produces VEC consecutive output channels of one position
+// grid (t-chunks, F, B); thread (v, ty) owns output channels [v*VEC, v*VEC+VEC) for all its time steps.
 template <int VEC>
-__global__ __launch_bounds__(256) void aero_norm_apply_kernel(aero_norm_desc d, int64_t total) {
+__global__ __launch_bounds__(256) void aero_norm_apply_kernel(aero_norm_desc d, int tchunk) {
     const bool glu = d.act == AERO_ACT_GLU;
     const int Cout = glu ? d.C / 2 : d.C;
     const int vpp = Cout / VEC;
+    const int TY = 256 / vpp;
+    const int tid = threadIdx.x;
+    const int v = tid % vpp, ty = tid / vpp;
+    if (ty >= TY) return;
+    const int b = blockIdx.z, f = blockIdx.y;
+    const int item = d.per_row ? b * d.F + f : b;
     const int gs = d.C / d.G;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(e % vpp) * VEC;
-        int64_t pos = e / vpp;
-        const int t = (int)(pos % d.T);
-        pos /= d.T;
-        const int f = (int)(pos % d.F);
-        const int b = (int)(pos / d.F);
-        const int item = d.per_row ? b * d.F + f : b;
-        const h16* src = (const h16*)d.src + (int64_t)b * d.s_b + (int64_t)f * d.s_f + (int64_t)t * d.s_t;
-        float xa[VEC], xb[VEC];
-        if (VEC == 8) {
-            const h16x8 v = *(const h16x8*)(src + c0);
+    const int c0 = v * VEC;
+    // y = x*A + Bc  (normalisation and affine folded), per owned channel; second half for GLU gates
+    float A[VEC], Bc[VEC], A2[VEC], B2[VEC], ls[VEC];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) xa[i] = (float)v[i];
-            if (glu) {
-                const h16x8 w = *(const h16x8*)(src + c0 + Cout);
+    for (int i = 0; i < VEC; ++i) {
+        const int c = c0 + i;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) xb[i] = (float)w[i];
-            }
-        } else if (VEC == 4) {
-            const h16x4 v = *(const h16x4*)(src + c0);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) xa[i] = (float)v[i];
-            if (glu) {
-                const h16x4 w = *(const h16x4*)(src + c0 + Cout);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) xb[i] = (float)w[i];
-            }
-        } else {
-            xa[0] = (float)src[c0];
-            if (glu) xb[0] = (float)src[c0 + Cout];
-        }
-        float snake_a = 0.f, snake_ia = 0.f;
-        if (d.act == AERO_ACT_SNAKE) { snake_a = d.snake_a[f]; snake_ia = 1.0f / snake_a; }
-        float o[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const int c = c0 + i;
-            float y = xa[i];
-            if (d.stats) {
-                const float* st = d.stats + ((int64_t)item * d.G + c / gs) * 2;
-                y = (y - st[0]) * st[1];
-            }
-            if (d.gamma) y = y * d.gamma[c] + d.beta[c];
-            if (glu) {
-                const int c2 = c + Cout;
-                float z = xb[i];
+        for (int half = 0; half < 2; ++half) {
+            const int cc = c + half * Cout;
+            float a = 1.f, bb = 0.f;
+            if (half == 0 || glu) {
                 if (d.stats) {
-                    const float* st = d.stats + ((int64_t)item * d.G + c2 / gs) * 2;
-                    z = (z - st[0]) * st[1];
+                    const double* st = d.stats + ((int64_t)item * d.G + cc / gs) * 2;
+                    const double mean = st[0] / d.stat_count;
+                    double var = st[1] / d.stat_count - mean * mean;      // biased variance, as nn.GroupNorm
+                    if (var < 0) var = 0;
+                    const float rstd = (float)(1.0 / sqrt(var + (double)d.eps));
+                    a = rstd;
+                    bb = -(float)mean * rstd;
                 }
-                if (d.gamma) z = z * d.gamma[c2] + d.beta[c2];
-                y = y * aero_sigmoid(z);
-                if (d.layer_scale) y *= d.layer_scale[c];
-            } else if (d.act == AERO_ACT_GELU) {
-                y = aero_gelu(y);
-            } else if (d.act == AERO_ACT_RELU) {
-                y = fmaxf(y, 0.f);
-            } else if (d.act == AERO_ACT_SNAKE) {
-                const float sn = sinf(y * snake_a);
-                y = y + snake_ia * sn * sn;
+                if (d.gamma) {
+                    const float gm = d.gamma[cc], bt = d.beta[cc];
+                    a *= gm;
+                    bb = bb * gm + bt;
+                }
             }
-            o[i] = y;
+            if (half == 0) { A[i] = a; Bc[i] = bb; } else { A2[i] = a; B2[i] = bb; }
         }
-        if (d.res) {
-            const h16* r = (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)f * d.r_f + (int64_t)t * d.r_t + c0;
+        ls[i] = (glu && d.layer_scale) ? d.layer_scale[c] : 1.f;
+    }
+    float snake_a = 0.f, snake_ia = 0.f;
+    if (d.act == AERO_ACT_SNAKE) { snake_a = d.snake_a[f]; snake_ia = 1.0f / snake_a; }
+    const h16* src = (const h16*)d.src + (int64_t)b * d.s_b + (int64_t)f * d.s_f + c0;
+    const h16* res = d.res ? (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)f * d.r_f + c0 : nullptr;
+    h16* dst = (h16*)d.dst + (int64_t)b * d.d_b + (int64_t)f * d.d_f + c0;
+    const int t0 = blockIdx.x * tchunk;
+    const int t1 = (t0 + tchunk < d.T) ? t0 + tchunk : d.T;
+    for (int t = t0 + ty; t < t1; t += TY) {
+        float x[VEC], o[VEC];
+        aero_load_vec<VEC>(src + (int64_t)t * d.s_t, x);
+        if (glu) {
+            float z[VEC];
+            aero_load_vec<VEC>(src + (int64_t)t * d.s_t + Cout, z);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) o[i] += (float)r[i];
-        }
-        h16* dst = (h16*)d.dst + (int64_t)b * d.d_b + (int64_t)f * d.d_f + (int64_t)t * d.d_t + c0;
-        if (VEC == 8) {
-            h16x8 v;
+            for (int i = 0; i < VEC; ++i) o[i] = (x[i] * A[i] + Bc[i]) * aero_sigmoid(z[i] * A2[i] + B2[i]) * ls[i];
+        } else if (d.act == AERO_ACT_GELU) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (h16)o[i];
-            *(h16x8*)dst = v;
-        } else if (VEC == 4) {
-            h16x4 v;
+            for (int i = 0; i < VEC; ++i) o[i] = aero_gelu(x[i] * A[i] + Bc[i]);
+        } else if (d.act == AERO_ACT_RELU) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (h16)o[i];
-            *(h16x4*)dst = v;
+            for (int i = 0; i < VEC; ++i) o[i] = fmaxf(x[i] * A[i] + Bc[i], 0.f);
+        } else if (d.act == AERO_ACT_SNAKE) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float y = x[i] * A[i] + Bc[i];
+                const float sn = aero_fast_sin(y * snake_a);
+                o[i] = y + snake_ia * sn * sn;
+            }
         } else {
-            dst[0] = (h16)o[0];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) o[i] = x[i] * A[i] + Bc[i];
         }
+        if (res) {
+            float r[VEC];
+            aero_load_vec<VEC>(res + (int64_t)t * d.r_t, r);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) o[i] += r[i];
+        }
+        aero_store_vec<VEC>(dst + (int64_t)t * d.d_t, o);
     }
 }
 
@@ -165,7 +195,19 @@ static int aero_norm_pick_vec(int n, const void* p0, const void* p1, const void*
 static int aero_norm_check(const aero_norm_desc* d, const char** err) {
     if (!d || !d->src) { *err = "norm: null src"; return AERO_ERR_ARG; }
     if (d->B < 1 || d->F < 1 || d->T < 1 || d->C < 1 || d->G < 1 || d->C % d->G) { *err = "norm: bad geometry"; return AERO_ERR_ARG; }
+    if (d->B > 65535 || d->F > 65535) { *err = "norm: B and F must be <= 65535"; return AERO_ERR_ARG; }
     return AERO_OK;
+}
+
+// time steps per block: enough blocks to fill 256 CUs several times over, at least 2 passes per thread
+static int aero_norm_tchunk(int T, int TY, int64_t rows) {
+    int chunks = (int)((4096 + rows - 1) / rows);
+    if (chunks < 1) chunks = 1;
+    int tchunk = (T + chunks - 1) / chunks;
+    const int min_chunk = TY * 4;
+    if (tchunk < min_chunk) tchunk = min_chunk;
+    if (tchunk > T) tchunk = T;
+    return tchunk;
 }
 
 static int aero_norm_stats_launch(const aero_norm_desc* d, hipStream_t stream, const char** err) {
@@ -175,10 +217,15 @@ static int aero_norm_stats_launch(const aero_norm_desc* d, hipStream_t stream, c
     const int gs = d->C / d->G;
     const int vec = aero_norm_pick_vec(gs, d->src, nullptr, nullptr, d->s_b, d->s_f, d->s_t, 0, 0, 0, 0, 0, 0);
     const int64_t items = d->per_row ? (int64_t)d->B * d->F : d->B;
-    dim3 grid((unsigned)(items * d->G)), block(256);
-    if (vec == 8) AERO_LAUNCH((aero_norm_stats_kernel<8>), grid, block, stream, *d);
-    else if (vec == 4) AERO_LAUNCH((aero_norm_stats_kernel<4>), grid, block, stream, *d);
-    else AERO_LAUNCH((aero_norm_stats_kernel<1>), grid, block, stream, *d);
+    if (items * d->G > 65535) { *err = "norm_stats: more than 65535 (item, group) pairs in one launch"; return AERO_ERR_ARG; }
+    const int nf = d->per_row ? 1 : d->F;
+    const int vpp = gs / vec;
+    const int TY = vpp > 256 ? 1 : 256 / vpp;
+    const int tchunk = aero_norm_tchunk(d->T, TY, items * d->G * nf);
+    dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)nf, (unsigned)(items * d->G)), block(256);
+    if (vec == 8) AERO_LAUNCH((aero_norm_stats_kernel<8>), grid, block, stream, *d, tchunk);
+    else if (vec == 4) AERO_LAUNCH((aero_norm_stats_kernel<4>), grid, block, stream, *d, tchunk);
+    else AERO_LAUNCH((aero_norm_stats_kernel<1>), grid, block, stream, *d, tchunk);
     return AERO_OK;
 }
 
@@ -189,15 +236,17 @@ static int aero_norm_apply_launch(const aero_norm_desc* d, hipStream_t stream, c
     if (d->act == AERO_ACT_GLU && (d->C & 1)) { *err = "norm_apply: GLU needs even C"; return AERO_ERR_ARG; }
     if (d->act == AERO_ACT_SNAKE && !d->snake_a) { *err = "norm_apply: snake needs a"; return AERO_ERR_ARG; }
     if ((d->gamma == nullptr) != (d->beta == nullptr)) { *err = "norm_apply: gamma/beta"; return AERO_ERR_ARG; }
+    if (d->stats && !(d->stat_count >= 1.0)) { *err = "norm_apply: stat_count"; return AERO_ERR_ARG; }
     const int Cout = d->act == AERO_ACT_GLU ? d->C / 2 : d->C;
     const int vec = aero_norm_pick_vec(Cout, d->src, d->dst, d->res, d->s_b, d->s_f, d->s_t, d->d_b, d->d_f, d->d_t,
                                        d->res ? d->r_b : 0, d->res ? d->r_f : 0, d->res ? d->r_t : 0);
-    const int64_t total = (int64_t)d->B * d->F * d->T * (Cout / vec);
-    int64_t nb = (total + 255) / 256;
-    if (nb > 256 * 16) nb = 256 * 16;
-    dim3 grid((unsigned)nb), block(256);
-    if (vec == 8) AERO_LAUNCH((aero_norm_apply_kernel<8>), grid, block, stream, *d, total);
-    else if (vec == 4) AERO_LAUNCH((aero_norm_apply_kernel<4>), grid, block, stream, *d, total);
-    else AERO_LAUNCH((aero_norm_apply_kernel<1>), grid, block, stream, *d, total);
+    const int vpp = Cout / vec;
+    if (vpp > 256) { *err = "norm_apply: more than 256 channel vectors per position (C too large)"; return AERO_ERR_UNSUPPORTED; }
+    const int TY = 256 / vpp;
+    const int tchunk = aero_norm_tchunk(d->T, TY, (int64_t)d->B * d->F);
+    dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)d->F, (unsigned)d->B), block(256);
+    if (vec == 8) AERO_LAUNCH((aero_norm_apply_kernel<8>), grid, block, stream, *d, tchunk);
+    else if (vec == 4) AERO_LAUNCH((aero_norm_apply_kernel<4>), grid, block, stream, *d, tchunk);
+    else AERO_LAUNCH((aero_norm_apply_kernel<1>), grid, block, stream, *d, tchunk);
     return AERO_OK;
 }

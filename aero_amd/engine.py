@@ -116,7 +116,7 @@ class Ops:
             self.lib.call('aero_conv_fwd', C.byref(d), self.stream(dst))
         else:
             bm = self.lib.cdll.aero_conv_tile_m(spec.M)
-            kname = {128: 'aero_conv_kernel<4,2>', 64: 'aero_conv_kernel<4,1>', 48: 'aero_conv_kernel<3,1>',
+            kname = {128: 'aero_conv_kernel<4,2>', 96: 'aero_conv_kernel<3,2>', 64: 'aero_conv_kernel<4,1>', 48: 'aero_conv_kernel<3,1>',
                      32: 'aero_conv_kernel<2,1>', 16: 'aero_conv_kernel<1,1>'}[bm]
             pos = B * dst_F * T
             cin_exec = spec.C1 + (spec.C0 if src0 is not None else 0)
@@ -137,8 +137,9 @@ class Ops:
         stats = None
         if normalize:
             items = B * F if per_row else B
-            stats = torch.empty(items * G, 2, dtype=torch.float32, device=x.device)
+            stats = torch.zeros(items * G, 2, dtype=torch.float64, device=x.device)
             d.stats = _ptr(stats)
+            d.stat_count = float((1 if per_row else F) * T * (Cc // G))
             self._call('aero_norm_stats', 'aero_norm_stats_kernel', 0, x.numel() * 2, C.byref(d), self.stream(x))
         f_cnt = F if f_cnt is None else f_cnt
         assert not (per_row and (f_lo or f_cnt != F))

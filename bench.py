@@ -31,28 +31,56 @@ PEAK_MFMA_F16_TFLOPS = 2500.0      # dense fp16 MFMA peak, MI355X_MICROARCH.md "
 PEAK_HBM_GBS = 8000.0              # HBM3E spec peak, same table
 
 
-def cpu_baseline(batch, seconds_per_clip, lr_sr, reps):
-    """The oracle (a port of the reference's CPU path) timed on this box's host cores: bounded sample."""
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:                                                    # cgroup v2 CPU quota, if any
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline_worker(seconds_per_clip, lr_sr, budget_s=20.0):
+    """The oracle (a port of the reference's CPU path) timed on this box's host cores: a bounded sample.
+    Runs in a child process (see cpu_baseline) so that a slow host cannot stall the benchmark."""
     from oracle import aero_oracle as O
     from aero_amd import Aero
     torch.manual_seed(2036)
     model = Aero(**FULL_CFG).eval()
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
-    x = torch.randn(batch, 1, int(seconds_per_clip * lr_sr), generator=torch.Generator().manual_seed(0))
-    with torch.no_grad():
-        O.aero_forward(sd, FULL_CFG, x, fast=True)                     # warm-up
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
+    threads = min(_usable_cores(), 64)                      # more threads than that only adds sync overhead here
+    torch.set_num_threads(threads)
+    L = int(seconds_per_clip * lr_sr)
+
+    def run(batch):
+        x = torch.randn(batch, 1, L, generator=torch.Generator().manual_seed(0))
+        t0 = time.perf_counter()
+        with torch.no_grad():
             O.aero_forward(sd, FULL_CFG, x, fast=True)
-            ts.append(time.perf_counter() - t0)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    return {'value': round(batch * seconds_per_clip / med, 3), 'unit': 'audio-sec/wall-sec', 'cores': torch.get_num_threads(),
-            'kind': 'port',
-            'sample': f'oracle/aero_oracle.py fp32, batch {batch} x {seconds_per_clip:g} s clips, median of {reps} after 1 warm-up'}
+        return time.perf_counter() - t0
+    run(1)                                                  # warm-up
+    t1 = run(1)
+    batch = int(max(1, min(8, budget_s / 3.0 / max(t1, 1e-3))))
+    ts = sorted(run(batch) for _ in range(3))
+    med = ts[1]
+    return {'value': round(batch * seconds_per_clip / med, 3), 'unit': 'audio-sec/wall-sec', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle/aero_oracle.py (fp32 CPU port of the reference path), batch {batch} x {seconds_per_clip:g} s clips, '
+                      f'median of 3 after warm-up, {threads} threads of {_usable_cores()} usable cores'}
+
+
+def cpu_baseline(seconds_per_clip, lr_sr, timeout_s=150):
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker'], capture_output=True,
+                             text=True, timeout=timeout_s, env={**os.environ, 'HIP_VISIBLE_DEVICES': ''})
+        for line in out.stdout.splitlines():
+            if line.startswith('{'):
+                return json.loads(line)
+        return {'value': None, 'kind': 'port', 'sample': 'cpu baseline worker failed: ' + out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'kind': 'port', 'sample': f'cpu baseline worker exceeded {timeout_s} s and was stopped'}
 
 
 def main():
@@ -62,8 +90,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU (BASELINE config 2: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP-event pass')
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        print(json.dumps(cpu_baseline_worker(2.0, FULL_CFG['lr_sr'])))
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -141,7 +173,7 @@ def main():
         return
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(batch=8, seconds_per_clip=secs, lr_sr=FULL_CFG['lr_sr'], reps=3)
+        cpu = cpu_baseline(secs, FULL_CFG['lr_sr'])
     audio_s = world * B * secs * args.steps
     out = {
         'metric': 'real-time-factor (audio-sec/wall-sec), Aero.forward STFT+U-Net+iSTFT, 4->16kHz nfft=512 hop=64 batch=64 per GPU',

@@ -95,14 +95,16 @@ int aero_conv_tile_m(int32_t M);
  * +residual) / Snake (aero.py:127,133,198,214; modules.py:141,232-236,244; snake.py:67).
  * per_row == 0: statistics per (b, group) over (f, t, c in group)   [GroupNorm on B,C,F,T]
  * per_row == 1: statistics per (b, f) row and group                 [GroupNorm on B*F,C,T]
- * aero_norm_stats writes stats[(item*G+g)*2 + {0,1}] = mean, rstd; aero_norm_apply computes
+ * aero_norm_stats ADDS sum and sum of squares to stats[(item*G+g)*2 + {0,1}] (fp64; the caller zeroes them);
+ * aero_norm_apply derives mean / biased variance from them with stat_count = elements per (item, group)
+ * (lets the statistics cover more rows than are output: the trim of aero.py:206-209) and computes
  *   y = act((x-mean)*rstd*gamma[c]+beta[c]); GLU: y[c] = a[c]*sigmoid(a[c+C/2]) * layer_scale[c];
  *   Snake: y + sin^2(a_f y)/a_f;  then + res.  stats == NULL in apply means identity norm. */
 typedef struct {
     const void* src; int64_t s_b, s_f, s_t;
     int32_t B, F, T, C, G, per_row;
     float eps;
-    float* stats;
+    double* stats; double stat_count;
     const float* gamma; const float* beta;
     int32_t act;
     const float* snake_a;
