@@ -11,9 +11,11 @@
 #ifdef AERO_EMU
 #include "hip_emu.h"
 #define aero_fast_exp(x) expf(x)
+#define aero_rcp(x) (1.0f / (x))
 #define aero_fast_sin(x) sinf(x)
 #else
 #define aero_fast_exp(x) __expf(x)
+#define aero_rcp(x) __builtin_amdgcn_rcpf(x)
 #define aero_fast_sin(x) __sinf(x)
 #include <hip/hip_runtime.h>
 #define AERO_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
@@ -42,18 +44,18 @@ static __device__ __forceinline__ int aero_xcd_swizzle(int bid, int nwg) {
     return base + idx;
 }
 
-static __device__ __forceinline__ float aero_sigmoid(float x) { return 1.0f / (1.0f + aero_fast_exp(-x)); }
+static __device__ __forceinline__ float aero_sigmoid(float x) { return aero_rcp(1.0f + aero_fast_exp(-x)); }
 static __device__ __forceinline__ float aero_tanh(float x) {
     // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
     float e = aero_fast_exp(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
+    return 1.0f - 2.0f * aero_rcp(e + 1.0f);
 }
 // exact-erf GELU (F.gelu default).  erf by Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 (far below fp16 output
 // rounding), ~3x cheaper than erff on the vector ALU -- the norm/activation kernels are HBM-bound only if the
 // per-element instruction count stays small.
 static __device__ __forceinline__ float aero_erf(float x) {
     const float ax = fabsf(x);
-    const float t = 1.0f / (1.0f + 0.3275911f * ax);
+    const float t = aero_rcp(1.0f + 0.3275911f * ax);
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     const float r = 1.0f - poly * aero_fast_exp(-ax * ax);
     return x < 0.f ? -r : r;

@@ -73,6 +73,12 @@ int aero_conv_fwd(const aero_conv_desc* d, void* stream) {
 
 int aero_conv_tile_m(int32_t M) { return aero_conv_pick_bm(M, (M + 127) / 128 * 128); }
 
+int aero_conv_kernel_id(const aero_conv_desc* d) {
+    int mf = 0, kt = 0;
+    if (d && aero_pw_pick(d, &mf, &kt)) return 2000 + mf * 10 + kt;
+    return d ? 1000 + aero_conv_tile_m(d->M) : 0;
+}
+
 int aero_norm_stats(const aero_norm_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_norm_stats_launch(d, (hipStream_t)stream, &err);
@@ -86,9 +92,9 @@ int aero_norm_apply(const aero_norm_desc* d, void* stream) {
 }
 
 int aero_lstm_geometry(int32_t H, int32_t* MP, int32_t* KP) {
-    int tpw, kt;
-    if (aero_lstm_pick(H, &tpw, &kt)) return aero_fail(AERO_ERR_UNSUPPORTED, "lstm: hidden size > 128 unsupported");
-    if (MP) *MP = 64 * tpw;
+    int nw, tpw, kt;
+    if (aero_lstm_pick(H, &nw, &tpw, &kt)) return aero_fail(AERO_ERR_UNSUPPORTED, "lstm: hidden size > 128 unsupported");
+    if (MP) *MP = 16 * nw * tpw;
     if (KP) *KP = 32 * kt;
     return AERO_OK;
 }

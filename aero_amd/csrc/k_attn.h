@@ -1,83 +1,135 @@
-// k_attn.h -- LocalState attention core (reference modules.py:101-124), flash-style: the T x T
-// score matrix is never materialised.  One thread owns one query s of one (row, head); keys/values
-// stream through LDS in tiles of 128 with an online softmax.  The learned distance-decay bias
-// (modules.py:112-117) collapses analytically: sum_f -(f+1)|t-s|/sqrt(nd) * sigmoid(d_fs)/2
-//   = -|t-s| * D_s,  D_s = sum_f (f+1) sigmoid(d_fs) / (2 sqrt(nd)),
-// one scalar per query.  v1 runs the dot products on the vector ALU in fp32 (head dims are 12/24;
-// the op is ~1.4 % of the model's FLOPs); DESIGN.md lists the MFMA version as follow-up.
+// k_attn.h -- LocalState attention core (reference modules.py:101-124) as a flash-style MFMA kernel: the
+// T x T score matrix is never materialised.
+//
+//   S[t][s] = K_t . Q_s / sqrt(dh) - |t-s| * D_s,  S[s][s] = -100,  W = softmax over keys t,  O[:,s] = sum_t W[t][s] V_t
+// The learned distance-decay bias (modules.py:112-117) collapses analytically to one slope per query:
+//   sum_f -(f+1)|t-s|/sqrt(nd) * sigmoid(d_fs)/2 = -|t-s| * D_s,   D_s = sum_f (f+1) sigmoid(d_fs) / (2 sqrt(nd)).
+//
+// One block = 128 queries of one (row, head), 8 waves x 16 queries.  Keys are processed 32 at a time:
+//   two v_mfma_f32_16x16x32_f16 give S for keys [tb, tb+16) and [tb+16, tb+32): D[i = key][j = query], so a lane
+//   holds 4+4 keys of ONE query -> the online softmax is lane-local plus two cross-lane max shuffles, and the
+//   exponentials ARE the B fragment of the second MFMA (O += V^T P) after an fp16 pack: P never leaves registers.
+//   (The k-slot order of that MFMA is permuted -- slot (g, e) <-> key tb + 16*(e/4) + 4g + e%4 -- identically for
+//   the V^T A-fragment, which is legal because a contraction does not care about the order of k.)
+// K rows (zero padded to 32 channels) and V^T live in LDS, staged per 256-key chunk.  fp16 operands, fp32
+// accumulate/softmax.  Roofline: MFMA-side FLOPs are tiny (4 T^2 C per row); the kernel is bound by the exp/VALU work
+// of the softmax and LDS staging -- DESIGN.md section 4.4.
 #pragma once
 #include "aero_common.h"
 
-template <int DH>
-__global__ __launch_bounds__(256) void aero_attn_kernel(aero_attn_desc d) {
-    constexpr int KT = 128;
-    __shared__ AERO_LDS_ALIGN float Ks[KT * DH];
-    __shared__ AERO_LDS_ALIGN float Vs[KT * DH];
-    const int tid = threadIdx.x;
-    const int s = blockIdx.x * 256 + tid;
-    const int h = blockIdx.y;
-    const int row = blockIdx.z;
+#define AERO_ATTN_KC 256                 /* keys per LDS chunk */
+#define AERO_ATTN_VS (AERO_ATTN_KC + 4)  /* V^T row pitch (halfs): +8 B breaks the ds_read_b64 bank pattern */
+
+template <int DT>  // number of 16-row output tiles: head dim <= 16*DT
+__global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
+    __shared__ AERO_LDS_ALIGN h16 Ks[AERO_ATTN_KC * 32];
+    __shared__ AERO_LDS_ALIGN h16 Vt[DT * 16 * AERO_ATTN_VS];
+    __shared__ AERO_LDS_ALIGN h16 Qs[128 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, col = lane & 15;
+    const int h = blockIdx.y, row = blockIdx.z;
     const int C = d.C, T = d.T;
+    const int dh = C / d.heads;
+    const int s_blk = blockIdx.x * 128;
     const h16* base = (const h16*)d.qkvd + (int64_t)row * T * d.ld;
-    const bool live = s < T;
-    float qv[DH], acc[DH];
+    const float qscale = 1.0f / sqrtf((float)dh);
+
+    // ---- queries of this block: [128][32], pre-scaled by 1/sqrt(dh), zero padded
+    for (int idx = tid; idx < 128 * 32; idx += 512) {
+        const int sl = idx >> 5, c = idx & 31;
+        const int s = s_blk + sl;
+        float v = 0.f;
+        if (s < T && c < dh) v = (float)base[(int64_t)s * d.ld + h * dh + c] * qscale;
+        Qs[aero_tile_off(sl, c >> 3) + (c & 7)] = (h16)v;
+    }
+    // this lane's query and its decay slope
+    const int s = s_blk + wave * 16 + col;
     float Dq = 0.f;
-    const float qscale = 1.0f / sqrtf((float)DH);
-#pragma unroll
-    for (int e = 0; e < DH; ++e) { qv[e] = 0.f; acc[e] = 0.f; }
-    if (live) {
-        const h16* qp = base + (int64_t)s * d.ld + h * DH;
-#pragma unroll
-        for (int e = 0; e < DH; ++e) qv[e] = (float)qp[e] * qscale;
+    if (s < T) {
         const h16* dp = base + (int64_t)s * d.ld + 3 * C + h * d.ndecay;
         for (int f = 0; f < d.ndecay; ++f) Dq += (float)(f + 1) * aero_sigmoid((float)dp[f]);
-        Dq *= 0.5f / sqrtf((float)d.ndecay);
+        Dq *= 0.5f / sqrtf((float)(d.ndecay > 0 ? d.ndecay : 1));
     }
     float m = -1e30f, l = 0.f;
-    for (int k0 = 0; k0 < T; k0 += KT) {
-        __syncthreads();
-        for (int idx = tid; idx < KT * DH; idx += 256) {
-            const int kk = idx / DH, e = idx % DH;
-            const int t = k0 + kk;
-            float kv = 0.f, vv = 0.f;
-            if (t < T) {
-                const h16* kp = base + (int64_t)t * d.ld + C + h * DH + e;
-                kv = (float)kp[0];
-                vv = (float)kp[C];
-            }
-            Ks[idx] = kv;
-            Vs[idx] = vv;
+    f32x4 O[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) O[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    h16x8 qf = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int kc0 = 0; kc0 < T; kc0 += AERO_ATTN_KC) {
+        __syncthreads();                                   // previous chunk fully consumed (and Qs written)
+        const int kn = (T - kc0) < AERO_ATTN_KC ? (T - kc0) : AERO_ATTN_KC;
+        const int kn32 = (kn + 31) & ~31;
+        for (int idx = tid; idx < kn32 * 32; idx += 512) {
+            const int tl = idx >> 5, c = idx & 31;
+            h16 v = (h16)0;
+            if (tl < kn && c < dh) v = base[(int64_t)(kc0 + tl) * d.ld + C + h * dh + c];
+            Ks[aero_tile_off(tl, c >> 3) + (c & 7)] = v;
+        }
+        for (int idx = tid; idx < kn32 * DT * 16; idx += 512) {
+            const int tl = idx / (DT * 16), dd = idx - tl * (DT * 16);
+            h16 v = (h16)0;
+            if (tl < kn && dd < dh) v = base[(int64_t)(kc0 + tl) * d.ld + 2 * C + h * dh + dd];
+            Vt[dd * AERO_ATTN_VS + tl] = v;
         }
         __syncthreads();
-        const int kn = (T - k0) < KT ? (T - k0) : KT;
-        if (live) {
-            for (int kk = 0; kk < kn; ++kk) {
-                const int t = k0 + kk;
-                float sc = 0.f;
+        if (kc0 == 0) qf = *(const h16x8*)&Qs[aero_tile_off(wave * 16 + col, g)];
+        for (int tb = 0; tb < kn32; tb += 32) {
+            const h16x8 k0 = *(const h16x8*)&Ks[aero_tile_off(tb + col, g)];
+            const h16x8 k1 = *(const h16x8*)&Ks[aero_tile_off(tb + 16 + col, g)];
+            const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf, z4, 0, 0, 0);
+            const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf, z4, 0, 0, 0);
+            float sc[8];
+            float cmax = -1e30f;
 #pragma unroll
-                for (int e = 0; e < DH; ++e) sc += qv[e] * Ks[kk * DH + e];
+            for (int e = 0; e < 8; ++e) {
+                const int t = kc0 + tb + ((e >> 2) << 4) + g * 4 + (e & 3);
+                float v = (e < 4) ? s0[e & 3] : s1[e & 3];
                 const int dist = t > s ? t - s : s - t;
-                sc -= (float)dist * Dq;
-                if (t == s) sc = -100.f;                      // modules.py:120 "kill self reference"
-                if (sc > m) {
-                    const float a = aero_fast_exp(m - sc);
-                    l *= a;
+                v -= (float)dist * Dq;
+                if (t == s) v = -100.f;                    // modules.py:120 "kill self reference"
+                if (t >= T) v = -1e30f;
+                sc[e] = v;
+                cmax = fmaxf(cmax, v);
+            }
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const float mn = fmaxf(m, cmax);
+            const float alpha = aero_fast_exp(m - mn);
+            m = mn;
+            float psum = 0.f;
+            h16x8 pf;
 #pragma unroll
-                    for (int e = 0; e < DH; ++e) acc[e] *= a;
-                    m = sc;
-                }
-                const float pw = aero_fast_exp(sc - m);
-                l += pw;
+            for (int e = 0; e < 8; ++e) {
+                const float pw = aero_fast_exp(sc[e] - mn);
+                psum += pw;
+                pf[e] = (h16)pw;
+            }
+            l = l * alpha + psum;
 #pragma unroll
-                for (int e = 0; e < DH; ++e) acc[e] += pw * Vs[kk * DH + e];
+            for (int i = 0; i < DT; ++i) {
+                const h16* vr = &Vt[(i * 16 + col) * AERO_ATTN_VS + tb + g * 4];
+                const h16x4 va = *(const h16x4*)vr;
+                const h16x4 vb = *(const h16x4*)(vr + 16);
+                const h16x8 vf = (h16x8){va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                O[i] = O[i] * alpha;
+                O[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, O[i], 0, 0, 0);
             }
         }
     }
-    if (live) {
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (s < T) {
         const float inv = 1.0f / l;
-        h16* op = (h16*)d.out + ((int64_t)row * T + s) * C + h * DH;
+        h16* op = (h16*)d.out + ((int64_t)row * T + s) * C + h * dh;
 #pragma unroll
-        for (int e = 0; e < DH; ++e) op[e] = (h16)(acc[e] * inv);
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int dd = i * 16 + g * 4 + r;
+                if (dd < dh) op[dd] = (h16)(O[i][r] * inv);
+            }
     }
 }
 
@@ -85,19 +137,11 @@ static int aero_attn_launch(const aero_attn_desc* d, hipStream_t stream, const c
     if (!d || !d->qkvd || !d->out) { *err = "localstate: null pointer"; return AERO_ERR_ARG; }
     if (d->R < 1 || d->T < 1 || d->C < 1 || d->heads < 1 || d->C % d->heads || d->ndecay < 0) { *err = "localstate: bad geometry"; return AERO_ERR_ARG; }
     if (d->ld < 3 * d->C + d->heads * d->ndecay) { *err = "localstate: ld too small"; return AERO_ERR_ARG; }
-    if (d->R > 65535) { *err = "localstate: too many rows for one launch"; return AERO_ERR_ARG; }
+    if (d->R > 65535 || d->heads > 65535) { *err = "localstate: too many rows/heads for one launch"; return AERO_ERR_ARG; }
     const int dh = d->C / d->heads;
-    dim3 grid((unsigned)((d->T + 255) / 256), (unsigned)d->heads, (unsigned)d->R), block(256);
-    switch (dh) {
-        case 1: AERO_LAUNCH((aero_attn_kernel<1>), grid, block, stream, *d); break;
-        case 2: AERO_LAUNCH((aero_attn_kernel<2>), grid, block, stream, *d); break;
-        case 4: AERO_LAUNCH((aero_attn_kernel<4>), grid, block, stream, *d); break;
-        case 8: AERO_LAUNCH((aero_attn_kernel<8>), grid, block, stream, *d); break;
-        case 12: AERO_LAUNCH((aero_attn_kernel<12>), grid, block, stream, *d); break;
-        case 16: AERO_LAUNCH((aero_attn_kernel<16>), grid, block, stream, *d); break;
-        case 24: AERO_LAUNCH((aero_attn_kernel<24>), grid, block, stream, *d); break;
-        case 32: AERO_LAUNCH((aero_attn_kernel<32>), grid, block, stream, *d); break;
-        default: *err = "localstate: head dim not in {1,2,4,8,12,16,24,32}"; return AERO_ERR_UNSUPPORTED;
-    }
+    if (dh > 32) { *err = "localstate: head dim > 32 unsupported"; return AERO_ERR_UNSUPPORTED; }
+    dim3 grid((unsigned)((d->T + 127) / 128), (unsigned)d->heads, (unsigned)d->R), block(512);
+    if (dh <= 16) AERO_LAUNCH((aero_attn_kernel<1>), grid, block, stream, *d);
+    else AERO_LAUNCH((aero_attn_kernel<2>), grid, block, stream, *d);
     return AERO_OK;
 }

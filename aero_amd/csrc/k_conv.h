@@ -15,6 +15,7 @@
 // next K-chunk prefetched into VGPRs while the current one feeds the MFMAs.
 #pragma once
 #include "aero_common.h"
+#include "k_pw.h"
 
 struct AeroConvK {
     aero_conv_desc d;
@@ -272,6 +273,10 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     if (d->fstride < 1 || d->B < 1 || d->Fout < 1 || d->T < 1) { *err = "conv: bad geometry"; return AERO_ERR_ARG; }
     if (d->act == AERO_ACT_GLU && (d->M & 1)) { *err = "conv: GLU needs even M"; return AERO_ERR_ARG; }
     if (d->act < 0 || d->act > AERO_ACT_GLU) { *err = "conv: unsupported act"; return AERO_ERR_UNSUPPORTED; }
+    {   // short-K 1x1 contractions take the weight-stationary streaming kernel (k_pw.h)
+        int mf = 0, kt = 0;
+        if (aero_pw_pick(d, &mf, &kt)) return aero_pw_launch(d, mf, kt, stream, err);
+    }
     AeroConvK p;
     p.d = *d;
     p.Cp = (d->C0 + d->C1 + 31) / 32 * 32;

@@ -115,9 +115,12 @@ class Ops:
         if self.prof is None:
             self.lib.call('aero_conv_fwd', C.byref(d), self.stream(dst))
         else:
-            bm = self.lib.cdll.aero_conv_tile_m(spec.M)
-            kname = {128: 'aero_conv_kernel<4,2>', 96: 'aero_conv_kernel<3,2>', 64: 'aero_conv_kernel<4,1>', 48: 'aero_conv_kernel<3,1>',
-                     32: 'aero_conv_kernel<2,1>', 16: 'aero_conv_kernel<1,1>'}[bm]
+            kid = self.lib.cdll.aero_conv_kernel_id(C.byref(d))
+            if kid >= 2000:
+                kname = f'aero_pw_kernel<{(kid - 2000) // 10},{(kid - 2000) % 10}>'
+            else:
+                kname = {128: 'aero_conv_kernel<4,2>', 96: 'aero_conv_kernel<3,2>', 64: 'aero_conv_kernel<4,1>',
+                         48: 'aero_conv_kernel<3,1>', 32: 'aero_conv_kernel<2,1>', 16: 'aero_conv_kernel<1,1>'}[kid - 1000]
             pos = B * dst_F * T
             cin_exec = spec.C1 + (spec.C0 if src0 is not None else 0)
             flops = 2.0 * pos * spec.M * len(spec.df) * cin_exec       # executed (NULL source skipped)

@@ -37,6 +37,13 @@ def test_istft(emu, geom):
     dict(Cin=96, Cout=192, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=2, T=33, split=48),              # 48+48 chunks
     dict(Cin=12, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=4, T=45, residual=True),
     dict(Cin=4, Cout=2, kF=4, kT=1, stride=2, padF=1, padT=0, Fin=4, T=20),                    # tiny-model shapes
+    # weight-stationary pointwise kernel (k_pw.h): short-K 1x1, flat tensors
+    dict(Cin=96, Cout=384, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=3, T=50),                 # LSTM projection shape
+    dict(Cin=96, Cout=48, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=5, T=77, split=48, act='relu'),   # FTB conv2
+    dict(Cin=24, Cout=160, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=2, T=131),                # q|k|v|decay, BM=96 x2
+    dict(Cin=192, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=2, T=40, residual=True),  # LSTM linear + skip, KT=6
+    dict(Cin=48, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=4, T=45, act='glu'),       # encoder rewrite + GLU
+    dict(Cin=128, Cout=304, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=1, T=200, B=3),
 ])
 def test_conv2d(emu, kw):
     oc.case_conv2d(emu, DEV, **kw)
