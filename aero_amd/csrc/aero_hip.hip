@@ -74,9 +74,11 @@ int aero_conv_fwd(const aero_conv_desc* d, void* stream) {
 int aero_conv_tile_m(int32_t M) { return aero_conv_pick_bm(M, (M + 127) / 128 * 128); }
 
 int aero_conv_kernel_id(const aero_conv_desc* d) {
-    int mf = 0, kt = 0;
-    if (d && aero_pw_pick(d, &mf, &kt)) return 2000 + mf * 10 + kt;
-    return d ? 1000 + aero_conv_tile_m(d->M) : 0;
+    if (!d) return 0;
+    const int bm = aero_conv_tile_m(d->M);
+    const bool vin = (d->C0 % 8 == 0) && (d->C1 % 8 == 0);
+    if (bm == 128 && vin && aero_conv_is_3x3(d)) return 3000;
+    return 1000 + bm;
 }
 
 int aero_norm_stats(const aero_norm_desc* d, void* stream) {

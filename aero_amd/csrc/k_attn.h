@@ -34,13 +34,29 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
     const h16* base = (const h16*)d.qkvd + (int64_t)row * T * d.ld;
     const float qscale = 1.0f / sqrtf((float)dh);
 
+    // staging moves 4 channels (8 bytes) per step when the head slices are 8-byte aligned, else scalars
+    const bool vec4 = (dh % 4 == 0) && (d.ld % 4 == 0) && (C % 4 == 0) && (((uintptr_t)d.qkvd & 7) == 0);
     // ---- queries of this block: [128][32], pre-scaled by 1/sqrt(dh), zero padded
-    for (int idx = tid; idx < 128 * 32; idx += 512) {
-        const int sl = idx >> 5, c = idx & 31;
-        const int s = s_blk + sl;
-        float v = 0.f;
-        if (s < T && c < dh) v = (float)base[(int64_t)s * d.ld + h * dh + c] * qscale;
-        Qs[aero_tile_off(sl, c >> 3) + (c & 7)] = (h16)v;
+    if (vec4) {
+        for (int idx = tid; idx < 128 * 8; idx += 512) {
+            const int sl = idx >> 3, c4 = idx & 7;
+            const int s = s_blk + sl;
+            h16x4 v = (h16x4){0, 0, 0, 0};
+            if (s < T && c4 * 4 < dh) {
+                const h16x4 x = *(const h16x4*)(base + (int64_t)s * d.ld + h * dh + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (h16)((float)x[e] * qscale);
+            }
+            *(h16x4*)&Qs[aero_tile_off(sl, c4 >> 1) + (c4 & 1) * 4] = v;
+        }
+    } else {
+        for (int idx = tid; idx < 128 * 32; idx += 512) {
+            const int sl = idx >> 5, c = idx & 31;
+            const int s = s_blk + sl;
+            float v = 0.f;
+            if (s < T && c < dh) v = (float)base[(int64_t)s * d.ld + h * dh + c] * qscale;
+            Qs[aero_tile_off(sl, c >> 3) + (c & 7)] = (h16)v;
+        }
     }
     // this lane's query and its decay slope
     const int s = s_blk + wave * 16 + col;
@@ -60,17 +76,33 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
         __syncthreads();                                   // previous chunk fully consumed (and Qs written)
         const int kn = (T - kc0) < AERO_ATTN_KC ? (T - kc0) : AERO_ATTN_KC;
         const int kn32 = (kn + 31) & ~31;
-        for (int idx = tid; idx < kn32 * 32; idx += 512) {
-            const int tl = idx >> 5, c = idx & 31;
-            h16 v = (h16)0;
-            if (tl < kn && c < dh) v = base[(int64_t)(kc0 + tl) * d.ld + C + h * dh + c];
-            Ks[aero_tile_off(tl, c >> 3) + (c & 7)] = v;
-        }
-        for (int idx = tid; idx < kn32 * DT * 16; idx += 512) {
-            const int tl = idx / (DT * 16), dd = idx - tl * (DT * 16);
-            h16 v = (h16)0;
-            if (tl < kn && dd < dh) v = base[(int64_t)(kc0 + tl) * d.ld + 2 * C + h * dh + dd];
-            Vt[dd * AERO_ATTN_VS + tl] = v;
+        if (vec4) {
+            for (int idx = tid; idx < kn32 * 8; idx += 512) {
+                const int tl = idx >> 3, c4 = idx & 7;
+                h16x4 v = (h16x4){0, 0, 0, 0};
+                if (tl < kn && c4 * 4 < dh) v = *(const h16x4*)(base + (int64_t)(kc0 + tl) * d.ld + C + h * dh + c4 * 4);
+                *(h16x4*)&Ks[aero_tile_off(tl, c4 >> 1) + (c4 & 1) * 4] = v;
+            }
+            for (int idx = tid; idx < kn32 * DT * 4; idx += 512) {
+                const int tl = idx / (DT * 4), d4 = idx - tl * (DT * 4);
+                h16x4 v = (h16x4){0, 0, 0, 0};
+                if (tl < kn && d4 * 4 < dh) v = *(const h16x4*)(base + (int64_t)(kc0 + tl) * d.ld + 2 * C + h * dh + d4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Vt[(d4 * 4 + e) * AERO_ATTN_VS + tl] = v[e];
+            }
+        } else {
+            for (int idx = tid; idx < kn32 * 32; idx += 512) {
+                const int tl = idx >> 5, c = idx & 31;
+                h16 v = (h16)0;
+                if (tl < kn && c < dh) v = base[(int64_t)(kc0 + tl) * d.ld + C + h * dh + c];
+                Ks[aero_tile_off(tl, c >> 3) + (c & 7)] = v;
+            }
+            for (int idx = tid; idx < kn32 * DT * 16; idx += 512) {
+                const int tl = idx / (DT * 16), dd = idx - tl * (DT * 16);
+                h16 v = (h16)0;
+                if (tl < kn && dd < dh) v = base[(int64_t)(kc0 + tl) * d.ld + 2 * C + h * dh + dd];
+                Vt[dd * AERO_ATTN_VS + tl] = v;
+            }
         }
         __syncthreads();
         if (kc0 == 0) qf = *(const h16x8*)&Qs[aero_tile_off(wave * 16 + col, g)];

@@ -15,12 +15,115 @@
 // next K-chunk prefetched into VGPRs while the current one feeds the MFMAs.
 #pragma once
 #include "aero_common.h"
-#include "k_pw.h"
 
 struct AeroConvK {
     aero_conv_desc d;
     int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec_out, staged;
 };
+
+// Shared epilogue of the tiled kernels: D[m = (lane>>4)*4 + r][n = lane&15] per fragment.
+template <int MF, int WM>
+static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f32x4 (&acc)[MF][8 / (4 / WM)], h16* Cs, int b, int fo,
+                                                          int fdst, int m0, int t0) {
+    constexpr int WN = 4 / WM;
+    constexpr int NF = 8 / WN;
+    constexpr int BM = 16 * MF * WM;
+    constexpr int CS = BM + 8;
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int T = d.T;
+    // Staged form (fp16 output, 8-channel aligned): the tile is transposed through LDS in two passes of 64
+    // positions so that every global store is a full 16-byte channel vector (256-byte runs per position).
+    const int M = d.M;
+    const bool glu = d.act == AERO_ACT_GLU;
+    const int Mout = glu ? (M >> 1) : M;
+    const int nout = glu ? 2 : 4;
+    h16* dst16 = (h16*)d.dst;
+    float* dst32 = (float*)d.dst;
+    const h16* res = (const h16*)d.res;
+    const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
+    const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
+    constexpr int NH = NF / 2;                      // n-fragments per wave per pass
+    constexpr int PH = NH * 16;                     // positions per wave per pass
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int mbase = m0 + (wm * MF + i) * 16 + (lane >> 4) * 4;
+            if (mbase >= M) continue;
+            float bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (d.bias && mbase + r < M) ? d.bias[mbase + r] : 0.f;
+#pragma unroll
+            for (int nn = 0; nn < NH; ++nn) {
+                const int n = pass * NH + nn;
+                const int t = t0 + (wn * NF + n) * 16 + (lane & 15);
+                if (t >= T) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[i][n][r] + bv[r];
+                int cbase = mbase;
+                if (glu) {
+                    o[0] = o[0] * aero_sigmoid(o[1]);
+                    o[1] = o[2] * aero_sigmoid(o[3]);
+                    cbase = mbase >> 1;
+                } else if (d.act == AERO_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+                } else if (d.act == AERO_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = aero_gelu(o[r]);
+                }
+                const int64_t doff = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * d.d_t + cbase;
+                const int64_t roff = (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + (int64_t)t * d.r_t + cbase;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r >= nout || cbase + r >= Mout) continue;
+                    float x = o[r];
+                    if (res) x += (float)res[roff + r];
+                    if (d.post_add) x += d.post_add[(int64_t)fo * Mout + cbase + r];
+                    o[r] = x * bsc + bsh;
+                }
+                if (p.staged) {
+                    const int pc = wn * PH + nn * 16 + (lane & 15);
+                    const int cl = cbase - (glu ? (m0 >> 1) : m0);
+                    if (glu) *(h16x2*)&Cs[pc * CS + cl] = (h16x2){(h16)o[0], (h16)o[1]};
+                    else *(h16x4*)&Cs[pc * CS + cl] = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+                } else if (p.vec_out && cbase + nout <= Mout) {
+                    if (d.dst_f32) {
+                        if (glu) *(f32x2*)(dst32 + doff) = (f32x2){o[0], o[1]};
+                        else *(f32x4*)(dst32 + doff) = (f32x4){o[0], o[1], o[2], o[3]};
+                    } else {
+                        if (glu) *(h16x2*)(dst16 + doff) = (h16x2){(h16)o[0], (h16)o[1]};
+                        else *(h16x4*)(dst16 + doff) = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (r >= nout || cbase + r >= Mout) continue;
+                        if (d.dst_f32) dst32[doff + r] = o[r];
+                        else dst16[doff + r] = (h16)o[r];
+                    }
+                }
+            }
+        }
+        if (p.staged) {
+            __syncthreads();
+            const int BMo = glu ? (BM >> 1) : BM;
+            const int nvec = BMo >> 3;
+            const int m0o = glu ? (m0 >> 1) : m0;
+            h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
+            for (int idx = tid; idx < 64 * nvec; idx += 256) {
+                const int pc = idx / nvec, cv = idx - pc * nvec;
+                const int wq = pc / PH, rr = pc - wq * PH;
+                const int t = t0 + (wq * NF + pass * NH + (rr >> 4)) * 16 + (rr & 15);
+                if (t < T && m0o + cv * 8 < Mout) *(h16x8*)(drow + (int64_t)t * d.d_t + cv * 8) = *(const h16x8*)&Cs[pc * CS + cv * 8];
+            }
+            __syncthreads();
+        }
+    }
+}
 
 template <int MF, int WM>
 __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
@@ -154,97 +257,129 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
         __syncthreads();
     }
 
-    // ---------------- epilogue: D[m = (lane>>4)*4 + r][n = lane&15] per fragment ----------------
-    // Staged form (fp16 output, 8-channel aligned): the tile is transposed through LDS in two passes of 64
-    // positions so that every global store is a full 16-byte channel vector (256-byte runs per position).
-    const int M = d.M;
-    const bool glu = d.act == AERO_ACT_GLU;
-    const int Mout = glu ? (M >> 1) : M;
-    const int nout = glu ? 2 : 4;
-    h16* dst16 = (h16*)d.dst;
-    float* dst32 = (float*)d.dst;
-    const h16* res = (const h16*)d.res;
-    const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
-    const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
-    constexpr int NH = NF / 2;                      // n-fragments per wave per pass
-    constexpr int PH = NH * 16;                     // positions per wave per pass
+    aero_conv_epilogue<MF, WM>(p, acc, Cs, b, fo, fdst, m0, t0);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 3x3 (time-context) specialisation -- the decoder "rewrite" convs, 68 % of the model's FLOPs.
+// Same tiling as above (128 channels x 128 steps of one row), but a pipeline stage is (frequency tap df, 32-channel
+// chunk) and carries all THREE time taps: the activation slab [t0-1, t0+129) x 32ch is staged once and read at row
+// offsets 0/1/2, with three weight tiles.  Per barrier pair: 48 MFMAs per wave instead of 16, and activations are
+// fetched from HBM/L2 once instead of three times.
+__global__ __launch_bounds__(256) void aero_conv3x3_kernel(AeroConvK p) {
+    constexpr int MF = 4, WM = 2, WN = 2, NF = 4, BM = 128, BN = 128;
+    constexpr int SLAB = 136;                                   // >= BN + 2 rows
+    constexpr int CS = BM + 8;
+    constexpr int SMEM = 3 * BM * 32 + SLAB * 32 > 64 * CS ? 3 * BM * 32 + SLAB * 32 : 64 * CS;
+    __shared__ AERO_LDS_ALIGN h16 smem[SMEM];
+    h16* As = smem;                                             // [3][BM][32]
+    h16* Bs = smem + 3 * BM * 32;                               // [SLAB][32]
+    h16* Cs = smem;
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const int mt = id % p.nmt;
+    id /= p.nmt;
+    const int tt = id % p.ntt;
+    const int row = id / p.ntt;
+    const int b = row / d.Fout, fo = row % d.Fout;
+    const int fdst = fo - d.dst_f_off;
+    if (fdst < 0 || fdst >= d.dst_F) return;
+    const int m0 = mt * BM, t0 = tt * BN;
+    const h16* Wp = (const h16*)d.weight + (int64_t)m0 * p.Ktot;
+    const h16* s0 = (const h16*)d.src0;
+    const h16* s1 = (const h16*)d.src1;
+    const int C0 = d.C0, C1 = d.C1, T = d.T;
+
+    f32x4 acc[MF][NF];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int mbase = m0 + (wm * MF + i) * 16 + (lane >> 4) * 4;
-            if (mbase >= M) continue;
-            float bv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (d.bias && mbase + r < M) ? d.bias[mbase + r] : 0.f;
-#pragma unroll
-            for (int nn = 0; nn < NH; ++nn) {
-                const int n = pass * NH + nn;
-                const int t = t0 + (wn * NF + n) * 16 + (lane & 15);
-                if (t >= T) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[i][n][r] + bv[r];
-                int cbase = mbase;
-                if (glu) {
-                    o[0] = o[0] * aero_sigmoid(o[1]);
-                    o[1] = o[2] * aero_sigmoid(o[3]);
-                    cbase = mbase >> 1;
-                } else if (d.act == AERO_ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
-                } else if (d.act == AERO_ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = aero_gelu(o[r]);
-                }
-                const int64_t doff = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * d.d_t + cbase;
-                const int64_t roff = (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + (int64_t)t * d.r_t + cbase;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (r >= nout || cbase + r >= Mout) continue;
-                    float x = o[r];
-                    if (res) x += (float)res[roff + r];
-                    if (d.post_add) x += d.post_add[(int64_t)fo * Mout + cbase + r];
-                    o[r] = x * bsc + bsh;
-                }
-                if (p.staged) {
-                    const int pc = wn * PH + nn * 16 + (lane & 15);
-                    const int cl = cbase - (glu ? (m0 >> 1) : m0);
-                    if (glu) *(h16x2*)&Cs[pc * CS + cl] = (h16x2){(h16)o[0], (h16)o[1]};
-                    else *(h16x4*)&Cs[pc * CS + cl] = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
-                } else if (p.vec_out && cbase + nout <= Mout) {
-                    if (d.dst_f32) {
-                        if (glu) *(f32x2*)(dst32 + doff) = (f32x2){o[0], o[1]};
-                        else *(f32x4*)(dst32 + doff) = (f32x4){o[0], o[1], o[2], o[3]};
-                    } else {
-                        if (glu) *(h16x2*)(dst16 + doff) = (h16x2){(h16)o[0], (h16)o[1]};
-                        else *(h16x4*)(dst16 + doff) = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (r >= nout || cbase + r >= Mout) continue;
-                        if (d.dst_f32) dst32[doff + r] = o[r];
-                        else dst16[doff + r] = (h16)o[r];
-                    }
+        for (int n = 0; n < NF; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    h16x8 ra[6], rb[3];
+    int jf = -1, cc = p.cpt - 1, fi = 0;                        // stage iterator: frequency tap jf (df = jf-1), chunk cc
+    auto next_stage = [&]() -> bool {
+        for (;;) {
+            ++cc;
+            if (cc == p.cpt) {
+                cc = 0;
+                ++jf;
+                while (jf < 3) {
+                    fi = fo + jf - 1;
+                    if (fi >= 0 && fi < d.Fin) break;
+                    ++jf;
                 }
             }
+            if (jf >= 3) return false;
+            if (s0 == nullptr && (cc + 1) * 32 <= C0) continue;
+            return true;
         }
-        if (p.staged) {
-            __syncthreads();
-            const int BMo = glu ? (BM >> 1) : BM;
-            const int nvec = BMo >> 3;
-            const int m0o = glu ? (m0 >> 1) : m0;
-            h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
-            for (int idx = tid; idx < 64 * nvec; idx += 256) {
-                const int pc = idx / nvec, cv = idx - pc * nvec;
-                const int wq = pc / PH, rr = pc - wq * PH;
-                const int t = t0 + (wq * NF + pass * NH + (rr >> 4)) * 16 + (rr & 15);
-                if (t < T && m0o + cv * 8 < Mout) *(h16x8*)(drow + (int64_t)t * d.d_t + cv * 8) = *(const h16x8*)&Cs[pc * CS + cv * 8];
+    };
+    auto load_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                           // 3 taps x 128 rows x 4 vectors = 1536 = 6 per thread
+            const int v = tid + 256 * i;
+            const int dtj = v >> 9, rem = v & 511;
+            ra[i] = *(const h16x8*)(Wp + (int64_t)(rem >> 2) * p.Ktot + (jf * 3 + dtj) * p.Cp + cc * 32 + (rem & 3) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                           // slab: 130 rows x 4 vectors
+            const int v = tid + 256 * i;
+            h16x8 z = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            const int t = t0 - 1 + (v >> 2);
+            const int c = cc * 32 + (v & 3) * 8;
+            if (v < (BN + 2) * 4 && t >= 0 && t < T) {
+                if (c < C0) {
+                    if (s0) z = *(const h16x8*)(s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)t * d.s0_t + c);
+                } else if (c - C0 < C1) {
+                    z = *(const h16x8*)(s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)t * d.s1_t + (c - C0));
+                }
             }
-            __syncthreads();
+            rb[i] = z;
         }
+    };
+
+    bool have = next_stage();
+    if (have) load_stage();
+    while (have) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int v = tid + 256 * i;
+            const int dtj = v >> 9, rem = v & 511;
+            *(h16x8*)&As[dtj * BM * 32 + aero_tile_off(rem >> 2, rem & 3)] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int v = tid + 256 * i;
+            if (v < SLAB * 4) *(h16x8*)&Bs[aero_tile_off(v >> 2, v & 3)] = rb[i];
+        }
+        __syncthreads();
+        have = next_stage();
+        if (have) load_stage();
+#pragma unroll
+        for (int dtj = 0; dtj < 3; ++dtj) {
+            h16x8 af[MF], bf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const h16x8*)&As[dtj * BM * 32 + aero_tile_off((wm * MF + i) * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+            for (int n = 0; n < NF; ++n) bf[n] = *(const h16x8*)&Bs[aero_tile_off((wn * NF + n) * 16 + (lane & 15) + dtj, lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[n], acc[i][n], 0, 0, 0);
+        }
+        __syncthreads();
     }
+    aero_conv_epilogue<MF, WM>(p, acc, Cs, b, fo, fdst, m0, t0);
+}
+
+static bool aero_conv_is_3x3(const aero_conv_desc* d) {
+    if (d->ntaps != 9 || d->transposed || d->fstride != 1) return false;
+    for (int j = 0; j < 9; ++j)
+        if (d->df[j] != j / 3 - 1 || d->dt[j] != j % 3 - 1) return false;
+    return true;
 }
 
 static int aero_conv_pick_bm(int M, int Mpad) {
@@ -273,10 +408,6 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     if (d->fstride < 1 || d->B < 1 || d->Fout < 1 || d->T < 1) { *err = "conv: bad geometry"; return AERO_ERR_ARG; }
     if (d->act == AERO_ACT_GLU && (d->M & 1)) { *err = "conv: GLU needs even M"; return AERO_ERR_ARG; }
     if (d->act < 0 || d->act > AERO_ACT_GLU) { *err = "conv: unsupported act"; return AERO_ERR_UNSUPPORTED; }
-    {   // short-K 1x1 contractions take the weight-stationary streaming kernel (k_pw.h)
-        int mf = 0, kt = 0;
-        if (aero_pw_pick(d, &mf, &kt)) return aero_pw_launch(d, mf, kt, stream, err);
-    }
     AeroConvK p;
     p.d = *d;
     p.Cp = (d->C0 + d->C1 + 31) / 32 * 32;
@@ -302,6 +433,10 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     const long nwg = (long)d->B * d->Fout * p.ntt * p.nmt;
     if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);
+    if (bm == 128 && p.vec_in && aero_conv_is_3x3(d)) {
+        AERO_LAUNCH(aero_conv3x3_kernel, grid, block, stream, p);
+        return AERO_OK;
+    }
     switch (bm) {
         case 128: AERO_LAUNCH((aero_conv_kernel<4, 2>), grid, block, stream, p); break;
         case 96: AERO_LAUNCH((aero_conv_kernel<3, 2>), grid, block, stream, p); break;

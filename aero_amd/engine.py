@@ -116,8 +116,8 @@ class Ops:
             self.lib.call('aero_conv_fwd', C.byref(d), self.stream(dst))
         else:
             kid = self.lib.cdll.aero_conv_kernel_id(C.byref(d))
-            if kid >= 2000:
-                kname = f'aero_pw_kernel<{(kid - 2000) // 10},{(kid - 2000) % 10}>'
+            if kid == 3000:
+                kname = 'aero_conv3x3_kernel'
             else:
                 kname = {128: 'aero_conv_kernel<4,2>', 96: 'aero_conv_kernel<3,2>', 64: 'aero_conv_kernel<4,1>',
                          48: 'aero_conv_kernel<3,1>', 32: 'aero_conv_kernel<2,1>', 16: 'aero_conv_kernel<1,1>'}[kid - 1000]

@@ -91,7 +91,7 @@ int aero_conv_fwd(const aero_conv_desc* d, void* stream);
 /* rows per block (16/32/48/64/128) of the kernel instantiation aero_conv_fwd picks for M output channels */
 int aero_conv_tile_m(int32_t M);
 /* which kernel aero_conv_fwd will launch for this descriptor: 1000+BM = tiled implicit GEMM (k_conv.h),
- * 2000+10*MF+KT = weight-stationary pointwise streaming kernel (k_pw.h); used for profiling labels only */
+ * 3000 = 3x3 time-context specialisation; used for profiling labels only */
 int aero_conv_kernel_id(const aero_conv_desc* d);
 
 /* K7+K8 -- nn.GroupNorm (aero.py:56,148; modules.py:189) followed by GELU / GLU(+LayerScale

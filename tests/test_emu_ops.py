@@ -37,7 +37,11 @@ def test_istft(emu, geom):
     dict(Cin=96, Cout=192, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=2, T=33, split=48),              # 48+48 chunks
     dict(Cin=12, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=4, T=45, residual=True),
     dict(Cin=4, Cout=2, kF=4, kT=1, stride=2, padF=1, padT=0, Fin=4, T=20),                    # tiny-model shapes
-    # weight-stationary pointwise kernel (k_pw.h): short-K 1x1, flat tensors
+    # 3x3 specialisation (aero_conv3x3_kernel): BM = 128 tiles, slab reuse across the three time taps
+    dict(Cin=96, Cout=128, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=3, T=140, split=48),             # chunk spans both sources
+    dict(Cin=64, Cout=256, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=2, T=129, split=32, act='glu'),
+    dict(Cin=32, Cout=128, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=1, T=37),                        # single source, one row
+    # short-K 1x1 shapes of the path
     dict(Cin=96, Cout=384, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=3, T=50),                 # LSTM projection shape
     dict(Cin=96, Cout=48, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=5, T=77, split=48, act='relu'),   # FTB conv2
     dict(Cin=24, Cout=160, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=2, T=131),                # q|k|v|decay, BM=96 x2
