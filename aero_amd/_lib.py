@@ -54,6 +54,12 @@ class FreqFcDesc(C.Structure):
                 ('B', i32), ('F', i32), ('T', i32), ('C', i32)]
 
 
+class FtbFirstDesc(C.Structure):
+    _fields_ = [('xn', vp), ('u', vp), ('gate', vp), ('w2a', vp),
+                ('p0', fp), ('p1', fp), ('pb', fp), ('rs', fp), ('a_re', fp), ('a_im', fp), ('bias', fp),
+                ('dst', vp), ('B', i32), ('F', i32), ('T', i32), ('C', i32)]
+
+
 _PROTOS = {
     'aero_version': (C.c_char_p, []),
     'aero_last_error': (C.c_char_p, []),
@@ -69,6 +75,7 @@ _PROTOS = {
     'aero_lstm_geometry': (i32, [i32, C.POINTER(i32), C.POINTER(i32)]),
     'aero_localstate_fwd': (i32, [C.POINTER(AttnDesc), vp]),
     'aero_freqfc_fwd': (i32, [C.POINTER(FreqFcDesc), vp]),
+    'aero_ftb_first_fwd': (i32, [C.POINTER(FtbFirstDesc), vp]),
 }
 
 EXPORTS = tuple(_PROTOS)

@@ -119,4 +119,10 @@ int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream) {
     return aero_finish(rc, err);
 }
 
+int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_ftb_first_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 }  // extern "C"

@@ -119,3 +119,137 @@ static int aero_freqfc_launch(const aero_freqfc_desc* d, hipStream_t stream, con
     AERO_LAUNCH(aero_freqfc_kernel, grid, block, stream, p);
     return AERO_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------
+// First-layer FTB, algebraically collapsed (reference aero.py:119-123 + modules.py:304-325 for encoder 0).
+// At layer 0 the FTB input is x0 = pre_conv(v), a LINEAR map of the 2-channel normalised spectrogram v = (re, im)
+// (aero.py:89,120; no activation in between).  Everything in the FTB that is linear in x0 therefore collapses onto
+// the 2 channels of v instead of 48:
+//   freq_fc(gate * x0)[c]  = gate[c] * (p0[c]*U_re + p1[c]*U_im + pb[c]*rs[f]),   U = freq_fc applied to v (2 ch),
+//                                                                               rs[f] = row sums of W_fc
+//   conv2(cat[att, x0])[m] = sum_c W2a[m][c]*att[c] + a_re[m]*re + a_im[m]*im + bias[m]      (BatchNorm folded)
+// so the 48-channel tensors x0 and att are never written to HBM: per position this kernel reads 4 B of v, 4 B of U
+// and the (L2-resident) gate row, builds att in registers as the MFMA B operand, and writes the 2C-byte output once.
+// HBM-bound: algorithmic bytes per position = 8 + 2*C (+ gate reuse).
+struct AeroFtbFirstK {
+    aero_ftb_first_desc d;
+    int Kp;
+};
+
+template <int MF>
+__global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
+    constexpr int BM = MF * 16, BN = 128, KT = 2;              // C <= 64: two k-steps of 32 channels
+    constexpr int CS = BM + 8;
+    constexpr int SMEM = KT * (BM + BN) * 32 > BN * CS ? KT * (BM + BN) * 32 : BN * CS;
+    __shared__ AERO_LDS_ALIGN h16 smem[SMEM];
+    h16* As = smem;                       // [KT][BM][32]
+    h16* Bs = smem + KT * BM * 32;        // [KT][BN][32]
+    h16* Cs = smem;                       // [BN][CS] output staging (after the MFMAs)
+    const aero_ftb_first_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = d.C, T = d.T;
+    int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const int ntt = (T + BN - 1) / BN;
+    const int tt = id % ntt;
+    const int row = id / ntt;
+    const int b = row / d.F, f = row % d.F;
+    const int t0 = tt * BN;
+    // weights -> LDS
+    for (int v = tid; v < KT * BM * 4; v += 256) {
+        const int kt = v / (BM * 4), rem = v - kt * (BM * 4);
+        const int r = rem >> 2, q = rem & 3;
+        h16x8 w = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (kt * 32 < p.Kp) w = *(const h16x8*)((const h16*)d.w2a + (int64_t)r * p.Kp + kt * 32 + q * 8);
+        *(h16x8*)&As[kt * BM * 32 + aero_tile_off(r, q)] = w;
+    }
+    // attention-branch operand att[pos][c] built on the fly
+    const h16* xn = (const h16*)d.xn + ((int64_t)row * T) * 2;
+    const h16* un = (const h16*)d.u + ((int64_t)row * T) * 2;
+    const h16* gate = (const h16*)d.gate + (int64_t)b * T * C;
+    const float rsf = d.rs[f];
+    for (int v = tid; v < KT * BN * 4; v += 256) {
+        const int kt = v / (BN * 4), rem = v - kt * (BN * 4);
+        const int pos = rem >> 2, q = rem & 3;
+        const int t = t0 + pos, c = kt * 32 + q * 8;
+        h16x8 o = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < T && c < C) {
+            const h16x2 uu = *(const h16x2*)(un + (int64_t)t * 2);
+            const float ur = (float)uu[0], ui = (float)uu[1];
+            const h16x8 g8 = *(const h16x8*)(gate + (int64_t)t * C + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o[e] = (h16)((float)g8[e] * (d.p0[c + e] * ur + d.p1[c + e] * ui + d.pb[c + e] * rsf));
+        }
+        *(h16x8*)&Bs[kt * BN * 32 + aero_tile_off(pos, q)] = o;
+    }
+    __syncthreads();
+    f32x4 acc[MF][2];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        h16x8 bf[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[n] = *(const h16x8*)&Bs[kt * BN * 32 + aero_tile_off((wave * 2 + n) * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const h16x8 a = *(const h16x8*)&As[kt * BM * 32 + aero_tile_off(i * 16 + (lane & 15), lane >> 4)];
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[1], acc[i][1], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                           // operands consumed: smem becomes the output tile
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int pos = (wave * 2 + n) * 16 + (lane & 15);
+        const int t = t0 + pos;
+        float re = 0.f, im = 0.f;
+        if (t < T) {
+            const h16x2 vv = *(const h16x2*)(xn + (int64_t)t * 2);
+            re = (float)vv[0];
+            im = (float)vv[1];
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = i * 16 + (lane >> 4) * 4;
+            h16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = 0.f;
+                if (m + r < C) x = fmaxf(acc[i][n][r] + d.a_re[m + r] * re + d.a_im[m + r] * im + d.bias[m + r], 0.f);
+                o[r] = (h16)x;
+            }
+            *(h16x4*)&Cs[pos * CS + m] = o;
+        }
+    }
+    __syncthreads();
+    const int nvec = C >> 3;
+    h16* drow = (h16*)d.dst + ((int64_t)row * T) * C;
+    for (int idx = tid; idx < BN * nvec; idx += 256) {
+        const int pos = idx / nvec, cv = idx - pos * nvec;
+        const int t = t0 + pos;
+        if (t < T) *(h16x8*)(drow + (int64_t)t * C + cv * 8) = *(const h16x8*)&Cs[pos * CS + cv * 8];
+    }
+}
+
+static int aero_ftb_first_launch(const aero_ftb_first_desc* d, hipStream_t stream, const char** err) {
+    if (!d || !d->xn || !d->u || !d->gate || !d->w2a || !d->p0 || !d->p1 || !d->pb || !d->rs || !d->a_re || !d->a_im ||
+        !d->bias || !d->dst) { *err = "ftb_first: null pointer"; return AERO_ERR_ARG; }
+    if (d->B < 1 || d->F < 1 || d->T < 1 || d->C < 8 || d->C > 64 || d->C % 8) { *err = "ftb_first: C must be a multiple of 8 in [8,64]"; return AERO_ERR_UNSUPPORTED; }
+    AeroFtbFirstK p;
+    p.d = *d;
+    p.Kp = (d->C + 31) / 32 * 32;
+    const long nwg = (long)d->B * d->F * ((d->T + 127) / 128);
+    if (nwg > 0x7fffffffL) { *err = "ftb_first: grid too large"; return AERO_ERR_ARG; }
+    dim3 grid((unsigned)nwg), block(256);
+    const int mf = (d->C + 15) / 16;
+    if (mf == 1) AERO_LAUNCH((aero_ftb_first_kernel<1>), grid, block, stream, p);
+    else if (mf == 2) AERO_LAUNCH((aero_ftb_first_kernel<2>), grid, block, stream, p);
+    else if (mf == 3) AERO_LAUNCH((aero_ftb_first_kernel<3>), grid, block, stream, p);
+    else AERO_LAUNCH((aero_ftb_first_kernel<4>), grid, block, stream, p);
+    return AERO_OK;
+}

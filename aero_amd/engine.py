@@ -192,6 +192,24 @@ class Ops:
         return out
 
 
+def _ftb_first(self, xn, u, gate, P):
+    B, F, T, _ = xn.shape
+    Cc = P['C']
+    out = torch.empty(B, F, T, Cc, dtype=torch.float16, device=xn.device)
+    d = _lib.FtbFirstDesc()
+    d.xn, d.u, d.gate, d.w2a = _ptr(xn), _ptr(u), _ptr(gate), _ptr(P['w2a'])
+    d.p0, d.p1, d.pb, d.rs = _ptr(P['p0']), _ptr(P['p1']), _ptr(P['pb']), _ptr(P['rs'])
+    d.a_re, d.a_im, d.bias = _ptr(P['a_re']), _ptr(P['a_im']), _ptr(P['bias'])
+    d.dst = _ptr(out)
+    d.B, d.F, d.T, d.C = B, F, T, Cc
+    self._call('aero_ftb_first_fwd', 'aero_ftb_first_kernel', 2.0 * B * F * T * Cc * Cc, B * F * T * (8 + 2 * Cc),
+               C.byref(d), self.stream(out))
+    return out
+
+
+Ops.ftb_first = _ftb_first
+
+
 def _hann_padded(win_length, n_fft, device):
     w = torch.zeros(n_fft, dtype=torch.float32)
     left = (n_fft - win_length) // 2
@@ -206,6 +224,7 @@ class HipEngine:
         self.ops = Ops(self.lib)
         self._key = None
         self._tables = {}
+        self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
 
     # ------------------------------------------------------------------ weights
     def _weights_key(self, device):
@@ -254,6 +273,25 @@ class HipEngine:
                                     sd[f'{q}.conv2.1.bias'], sd[f'{q}.conv2.1.running_mean'], sd[f'{q}.conv2.1.running_var'])
                 w, df, dt = pack.conv2d_taps(w, 0, 0)
                 L['ftb_c2'] = mk(w, b, Cc, Cc, df, dt, device, act=ACT_RELU)
+                if enc.is_first and Cc % 8 == 0 and Cc <= 64:
+                    # encoder 0: pre_conv feeds the FTB linearly -> collapse onto the 2 input channels (k_ftb.h)
+                    Wp = sd[f'{p}.pre_conv.weight'][:, :, 0, 0]                    # [C, 2]
+                    bp = sd[f'{p}.pre_conv.bias']
+                    w1, b1 = pack.bn_fold(sd[f'{q}.conv1.0.weight'], sd[f'{q}.conv1.0.bias'], sd[f'{q}.conv1.1.weight'],
+                                          sd[f'{q}.conv1.1.bias'], sd[f'{q}.conv1.1.running_mean'], sd[f'{q}.conv1.1.running_var'])
+                    w1 = w1[:, :, 0, 0]                                            # [r, C]
+                    L['ftb0_c1'] = mk((w1 @ Wp)[None, :, None, :], w1 @ bp + b1, Wp.shape[1], 0, [0], [0], device, act=ACT_RELU)
+                    w2, b2 = pack.bn_fold(sd[f'{q}.conv2.0.weight'], sd[f'{q}.conv2.0.bias'], sd[f'{q}.conv2.1.weight'],
+                                          sd[f'{q}.conv2.1.bias'], sd[f'{q}.conv2.1.running_mean'], sd[f'{q}.conv2.1.running_var'])
+                    w2 = w2[:, :, 0, 0]                                            # [C, 2C]: [attention branch | direct]
+                    w2a, w2b = w2[:, :Cc], w2[:, Cc:]
+                    img = torch.zeros(128, pack._round_up(Cc, 32))
+                    img[:Cc, :Cc] = w2a
+                    A = w2b @ Wp
+                    f32 = lambda t: t.float().to(device).contiguous()             # noqa: E731
+                    L['ftb0'] = dict(C=Cc, w2a=img.to(device=device, dtype=torch.float16).contiguous(),
+                                     p0=f32(Wp[:, 0]), p1=f32(Wp[:, 1]), pb=f32(bp), rs=f32(wfc.sum(1)),
+                                     a_re=f32(A[:, 0]), a_im=f32(A[:, 1]), bias=f32(w2b @ bp + b2))
             w, df, dt = pack.conv2d_taps(sd[f'{p}.conv.weight'], enc.pad, 0)
             L['conv'] = mk(w, sd[f'{p}.conv.bias'], w.shape[-1], 0, df, dt, device, fstride=enc.stride,
                            act=ACT_NONE if enc.norm else ACT_GELU)
@@ -416,6 +454,21 @@ class HipEngine:
 
     def _encode(self, i, enc, L, x, B, Fq, T):
         ops = self.ops
+        if 'ftb0' in L and self.collapse_first_ftb:
+            Cc, rp = L['ftb0']['C'], L['ftb_rp']
+            c1 = torch.zeros(B, T, Fq * rp, dtype=torch.float16, device=x.device)
+            ops.conv(L['ftb0_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
+            gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)      # [B,1,T,Cc]
+            ones = self._tables.setdefault(('ones', B, T, str(x.device)),
+                                           torch.ones(B, T, 2, dtype=torch.float16, device=x.device))
+            u = ops.freqfc(x, L['ftb_fc'], ones)                                           # freq_fc on (re, im) only
+            x = ops.ftb_first(x, u, gate.view(B, T, Cc), L['ftb0'])
+        elif 'ftb_c1' in L or 'pre' in L:
+            x = self._encode_head_unfused(L, x, B, Fq, T)
+        return self._encode_tail(i, enc, L, x, B, Fq, T)
+
+    def _encode_head_unfused(self, L, x, B, Fq, T):
+        ops = self.ops
         if 'pre' in L:
             x = ops.conv(L['pre'], x, None, B, Fq, Fq, T)
         if 'ftb_c1' in L:
@@ -425,6 +478,10 @@ class HipEngine:
             gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)      # [B,1,T,Cc]
             fc = ops.freqfc(x, L['ftb_fc'], gate.view(B, T, Cc))
             x = ops.conv(L['ftb_c2'], fc, x, B, Fq, Fq, T)
+        return x
+
+    def _encode_tail(self, i, enc, L, x, B, Fq, T):
+        ops = self.ops
         Fo = (Fq + 2 * enc.pad - enc.kernel_size) // enc.stride + 1
         y = ops.conv(L['conv'], x, None, B, Fq, Fo, T)
         if enc.norm:

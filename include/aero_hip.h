@@ -157,6 +157,21 @@ typedef struct {
 } aero_freqfc_desc;
 int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream);
 
+/* K3+K12 fused for encoder 0 -- pre_conv (aero.py:89,120) followed by the FTB (modules.py:304-325) with eval-mode
+ * BatchNorm, algebraically collapsed onto the 2-channel normalised spectrogram xn (see aero_amd/csrc/k_ftb.h):
+ *   att[c] = gate[b,t,c] * (p0[c]*u_re + p1[c]*u_im + pb[c]*rs[f]),      u = freq_fc applied to xn (aero_freqfc_fwd)
+ *   dst[m] = relu( sum_c w2a[m][c]*att[c] + a_re[m]*re + a_im[m]*im + bias[m] )
+ * xn, u fp16 [B][F][T][2]; gate fp16 [B][T][C]; w2a fp16 [>=roundup(C,16)][roundup(C,32)] zero padded;
+ * p0,p1,pb,a_re,a_im,bias fp32 [C]; rs fp32 [F]; dst fp16 [B][F][T][C].  C multiple of 8, <= 64. */
+typedef struct {
+    const void* xn; const void* u; const void* gate; const void* w2a;
+    const float* p0; const float* p1; const float* pb; const float* rs;
+    const float* a_re; const float* a_im; const float* bias;
+    void* dst;
+    int32_t B, F, T, C;
+} aero_ftb_first_desc;
+int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

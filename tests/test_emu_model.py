@@ -33,6 +33,21 @@ def test_tiny_model_golden(emu, meta, L):
     assert rel_l2(y, io[f'y_{L}']) < 5e-3
 
 
+@pytest.mark.parametrize('collapse', [True, False])
+def test_small_model_golden_first_layer_ftb_paths(emu, meta, collapse):
+    """channels=16 model: encoder 0's FTB runs collapsed onto the 2-channel spectrogram (aero_ftb_first_fwd) or layer by
+    layer (pre_conv + aero_freqfc_fwd + convs); both must match the reference's golden output."""
+    m = build_model(meta, 'small')
+    eng = HipEngine(m, lib=emu)
+    eng.collapse_first_ftb = collapse
+    object.__setattr__(m, '_engine', eng)
+    io = load_npz('small_io.npz')
+    with torch.no_grad():
+        y, s = m(torch.from_numpy(io['x_800']), return_spec=True)
+    assert rel_l2(s, io['spec_800']) < 1e-3
+    assert rel_l2(y, io['y_800']) < 5e-3
+
+
 def test_spec_ispec_api(emu, meta):
     """Aero._spec / _spec(scale=True) / _ispec (used by evaluate.py:67, solver.py:374) against the oracle."""
     from oracle import aero_oracle as O
