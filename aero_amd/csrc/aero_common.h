@@ -32,6 +32,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define AERO_LDS_ALIGN __attribute__((aligned(16)))
 
+// 64 zero bytes+: source of masked lanes of the direct global->LDS copies (padding, out-of-range rows/channels)
+static __device__ h16 aero_zero_page[64];
+
+// Direct global -> LDS copy of 16 bytes per lane (gfx950 `global_load_lds_dwordx4`): no VGPR round trip and no
+// ds_write issue cost.  The LDS destination is WAVE-UNIFORM base + lane*16 (linear); a swizzled image is obtained by
+// permuting the per-lane SOURCE address.  Completion is tracked by vmcnt; __syncthreads() drains it.
+static __device__ __forceinline__ void aero_glds16(const h16* gsrc, h16* lds_wave_base) {
+#ifdef AERO_EMU
+    memcpy(lds_wave_base + (threadIdx.x & 63) * 8, gsrc, 16);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
 static __device__ __forceinline__ int aero_lane() { return threadIdx.x & 63; }
 static __device__ __forceinline__ int aero_wave() { return threadIdx.x >> 6; }
 

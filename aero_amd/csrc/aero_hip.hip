@@ -77,7 +77,8 @@ int aero_conv_kernel_id(const aero_conv_desc* d) {
     if (!d) return 0;
     const int bm = aero_conv_tile_m(d->M);
     const bool vin = (d->C0 % 8 == 0) && (d->C1 % 8 == 0);
-    if (bm == 128 && vin && aero_conv_is_3x3(d)) return 3000;
+    if (bm == 128 && vin && !aero_conv_use_glds() && aero_conv_is_3x3(d)) return 3000;
+    if (vin && aero_conv_use_glds()) return 4000 + bm;
     return 1000 + bm;
 }
 

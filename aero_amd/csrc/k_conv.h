@@ -14,11 +14,13 @@
 // position.  v1 pipeline: register-staged global->LDS, one LDS buffer,
 // next K-chunk prefetched into VGPRs while the current one feeds the MFMAs.
 #pragma once
+#include <stdlib.h>
+
 #include "aero_common.h"
 
 struct AeroConvK {
     aero_conv_desc d;
-    int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec_out, staged;
+    int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec_out, staged, glds;
 };
 
 // Shared epilogue of the tiled kernels: D[m = (lane>>4)*4 + r][n = lane&15] per fragment.
@@ -261,6 +263,123 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Direct-to-LDS pipeline (vector-aligned sources): operands go HBM/L2 -> LDS with `global_load_lds_dwordx4`, two LDS
+// stages, ONE barrier per K-chunk; the next chunk's copies are in flight while the current one feeds the MFMAs.  No
+// staging VGPRs, no ds_write.  Padding / out-of-range lanes read a zero page.  The LDS image keeps the XOR swizzle
+// of aero_tile_off(): the destination is lane-linear, so the permutation is applied to the SOURCE address.
+template <int MF, int WM>
+__global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
+    constexpr int WN = 4 / WM;
+    constexpr int NF = 8 / WN;
+    constexpr int BM = 16 * MF * WM;
+    constexpr int BN = 128;
+    constexpr int STAGE = (BM + BN) * 32;
+    constexpr int CS = BM + 8;
+    constexpr int SMEM = 2 * STAGE > 64 * CS ? 2 * STAGE : 64 * CS;
+    __shared__ AERO_LDS_ALIGN h16 smem[SMEM];
+    h16* Cs = smem;
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const int mt = id % p.nmt;
+    id /= p.nmt;
+    const int tt = id % p.ntt;
+    const int row = id / p.ntt;
+    const int b = row / d.Fout, fo = row % d.Fout;
+    const int fdst = fo - d.dst_f_off;
+    if (fdst < 0 || fdst >= d.dst_F) return;
+    const int m0 = mt * BM, t0 = tt * BN;
+    const int wset = d.transposed ? (fo % d.fstride) : 0;
+    const int fbase = d.transposed ? (fo / d.fstride) : (fo * d.fstride);
+    const h16* Wp = (const h16*)d.weight + ((int64_t)wset * p.Mpad + m0) * p.Ktot;
+    const h16* s0 = (const h16*)d.src0;
+    const h16* s1 = (const h16*)d.src1;
+    const int C0 = d.C0, C1 = d.C1, T = d.T;
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int j = -1, cc = p.cpt - 1, fi = 0;
+    auto next_chunk = [&]() -> bool {
+        for (;;) {
+            ++cc;
+            if (cc == p.cpt) {
+                cc = 0;
+                ++j;
+                while (j < d.ntaps) {
+                    fi = fbase + d.df[j];
+                    if (fi >= 0 && fi < d.Fin) break;
+                    ++j;
+                }
+            }
+            if (j >= d.ntaps) return false;
+            if (s0 == nullptr && (cc + 1) * 32 <= C0) continue;
+            return true;
+        }
+    };
+    // lane l of wave-instruction ii owns 16-byte LDS slot s = ii*64 + l  ->  tile row s>>2, swizzled slot s&3
+    auto issue = [&](int buf) {
+        h16* As = smem + buf * STAGE;
+        h16* Bs = As + BM * 32;
+        const int kofs = j * p.Cp + cc * 32;
+#pragma unroll
+        for (int i = 0; i < (BM / 16 + 3) / 4; ++i) {
+            const int ii = wave + 4 * i;
+            if (ii < BM / 16) {
+                const int s = ii * 64 + lane;
+                const int r = s >> 2, q = (s & 3) ^ ((0 - (r >> 2)) & 3);
+                aero_glds16(Wp + (int64_t)r * p.Ktot + kofs + q * 8, As + ii * 512);
+            }
+        }
+        const int dtj = d.dt[j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ii = wave + 4 * i;
+            const int s = ii * 64 + lane;
+            const int pos = s >> 2, q = (s & 3) ^ ((0 - (pos >> 2)) & 3);
+            const int t = t0 + pos + dtj;
+            const int c = cc * 32 + q * 8;
+            const h16* src = aero_zero_page;
+            if (t >= 0 && t < T) {
+                if (c < C0) {
+                    if (s0) src = s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)t * d.s0_t + c;
+                } else if (c - C0 < C1) {
+                    src = s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)t * d.s1_t + (c - C0);
+                }
+            }
+            aero_glds16(src, Bs + ii * 512);
+        }
+    };
+
+    bool have = next_chunk();
+    if (have) issue(0);
+    int buf = 0;
+    while (have) {
+        __syncthreads();                       // stage `buf` has landed (vmcnt drained) and stage buf^1 is free again
+        have = next_chunk();
+        if (have) issue(buf ^ 1);
+        const h16* As = smem + buf * STAGE;
+        const h16* Bs = As + BM * 32;
+        h16x8 af[MF], bf[NF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af[i] = *(const h16x8*)&As[aero_tile_off((wm * MF + i) * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+        for (int n = 0; n < NF; ++n) bf[n] = *(const h16x8*)&Bs[aero_tile_off((wn * NF + n) * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[n], acc[i][n], 0, 0, 0);
+        buf ^= 1;
+    }
+    __syncthreads();                           // all waves done with the operand stages: smem becomes the output tile
+    aero_conv_epilogue<MF, WM>(p, acc, Cs, b, fo, fdst, m0, t0);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // 3x3 (time-context) specialisation -- the decoder "rewrite" convs, 68 % of the model's FLOPs.
 // Same tiling as above (128 channels x 128 steps of one row), but a pipeline stage is (frequency tap df, 32-channel
 // chunk) and carries all THREE time taps: the activation slab [t0-1, t0+129) x 32ch is staged once and read at row
@@ -382,6 +501,16 @@ static bool aero_conv_is_3x3(const aero_conv_desc* d) {
     return true;
 }
 
+// AERO_CONV_GLDS=0 in the environment selects the register-staged pipeline (A/B experiments, bisecting)
+static int aero_conv_use_glds() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AERO_CONV_GLDS");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
 static int aero_conv_pick_bm(int M, int Mpad) {
     const int cand[6] = {128, 96, 64, 48, 32, 16};
     int best = 128;
@@ -422,6 +551,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     if (d->src0) vin = vin && al8(d->s0_b) && al8(d->s0_f) && al8(d->s0_t) && (((uintptr_t)d->src0 & 15) == 0);
     if (d->src1) vin = vin && al8(d->s1_b) && al8(d->s1_f) && al8(d->s1_t) && (((uintptr_t)d->src1 & 15) == 0);
     p.vec_in = vin;
+    p.glds = aero_conv_use_glds();
     const int Mout = d->act == AERO_ACT_GLU ? d->M / 2 : d->M;
     const int nout = d->act == AERO_ACT_GLU ? 2 : 4;
     const int esz = d->dst_f32 ? 4 : 2;
@@ -433,8 +563,19 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     const long nwg = (long)d->B * d->Fout * p.ntt * p.nmt;
     if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);
-    if (bm == 128 && p.vec_in && aero_conv_is_3x3(d)) {
+    if (bm == 128 && p.vec_in && !p.glds && aero_conv_is_3x3(d)) {
         AERO_LAUNCH(aero_conv3x3_kernel, grid, block, stream, p);
+        return AERO_OK;
+    }
+    if (p.vec_in && p.glds) {
+        switch (bm) {
+            case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2>), grid, block, stream, p); break;
+            case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2>), grid, block, stream, p); break;
+            case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1>), grid, block, stream, p); break;
+            case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1>), grid, block, stream, p); break;
+            case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1>), grid, block, stream, p); break;
+            default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1>), grid, block, stream, p); break;
+        }
         return AERO_OK;
     }
     switch (bm) {
