@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
     const h16* s0 = (const h16*)d.src0;
     const h16* s1 = (const h16*)d.src1;
     const int C0 = d.C0, C1 = d.C1, T = d.T;
+    const int64_t st0_b = d.s0_b, st0_f = d.s0_f, st0_t = d.s0_t, st1_b = d.s1_b, st1_f = d.s1_f, st1_t = d.s1_t;
 
     f32x4 acc[MF][NF];
 #pragma unroll
@@ -336,6 +337,11 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
             }
         }
         const int dtj = d.dt[j];
+        // block-uniform row bases of both sources; the per-lane part is t*stride + channel.  Both candidate
+        // addresses are formed arithmetically and SELECTED (a per-lane select of descriptor fields would make
+        // hipcc fetch them with vector loads, whose vmcnt(0) wait drains the in-flight LDS copies).
+        const h16* base0 = s0 ? s0 + (int64_t)b * st0_b + (int64_t)fi * st0_f : aero_zero_page;
+        const h16* base1 = s1 ? s1 + (int64_t)b * st1_b + (int64_t)fi * st1_f : aero_zero_page;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ii = wave + 4 * i;
@@ -343,14 +349,12 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
             const int pos = s >> 2, q = (s & 3) ^ ((0 - (pos >> 2)) & 3);
             const int t = t0 + pos + dtj;
             const int c = cc * 32 + q * 8;
-            const h16* src = aero_zero_page;
-            if (t >= 0 && t < T) {
-                if (c < C0) {
-                    if (s0) src = s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)t * d.s0_t + c;
-                } else if (c - C0 < C1) {
-                    src = s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)t * d.s1_t + (c - C0);
-                }
-            }
+            const bool tin = t >= 0 && t < T;
+            const h16* a0 = base0 + (int64_t)t * st0_t + c;
+            const h16* a1 = base1 + (int64_t)t * st1_t + (c - C0);
+            const bool use0 = tin && c < C0 && s0 != nullptr;
+            const bool use1 = tin && c >= C0 && (c - C0) < C1;
+            const h16* src = use0 ? a0 : (use1 ? a1 : (const h16*)aero_zero_page);
             aero_glds16(src, Bs + ii * 512);
         }
     };
