@@ -21,6 +21,7 @@
 struct AeroConvK {
     aero_conv_desc d;
     int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec_out, staged, glds;
+    int nT, f_lo, f_step, t_lo, t_step;      // regular tap grid: df = f_lo + (j / nT) * f_step, dt = t_lo + (j % nT) * t_step
 };
 
 // Shared epilogue of the tiled kernels: D[m = (lane>>4)*4 + r][n = lane&15] per fragment.
@@ -263,19 +264,37 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Direct-to-LDS pipeline (vector-aligned sources): operands go HBM/L2 -> LDS with `global_load_lds_dwordx4`, two LDS
-// stages, ONE barrier per K-chunk; the next chunk's copies are in flight while the current one feeds the MFMAs.  No
-// staging VGPRs, no ds_write.  Padding / out-of-range lanes read a zero page.  The LDS image keeps the XOR swizzle
-// of aero_tile_off(): the destination is lane-linear, so the permutation is applied to the SOURCE address.
-template <int MF, int WM>
+// Direct-to-LDS pipeline (vector-aligned sources, regular tap grids): operands go HBM/L2 -> LDS with
+// `global_load_lds_dwordx4`, two LDS stages, ONE barrier per K-chunk of KC channels; the next chunk's copies are in
+// flight while the current one feeds the MFMAs.  No staging VGPRs, no ds_write.  Padding / out-of-range lanes read a
+// zero page.  The LDS image keeps an XOR swizzle (conflict-free ds_read_b128); the destination of the copy is
+// lane-linear, so the permutation is applied to the SOURCE address.
+// PMC on the first version showed the loop was ISSUE-bound by integer overhead (~200 scalar/vector instructions per
+// 16 MFMAs), not by LDS or HBM: everything lane-dependent is therefore hoisted out of the loop (per-lane pointers and
+// 32-bit offsets), the per-chunk part is a handful of block-uniform scalars, and KC = 64 halves what is left.
+template <int KC>
+static __device__ __forceinline__ int aero_tile_off_kc(int row, int slot) {
+    if (KC == 32) return row * 32 + ((slot ^ ((0 - (row >> 2)) & 3)) << 3);
+    return row * 64 + ((slot ^ ((row >> 1) & 7)) << 3);
+}
+template <int KC>
+static __device__ __forceinline__ int aero_tile_swz(int row) {
+    return KC == 32 ? ((0 - (row >> 2)) & 3) : ((row >> 1) & 7);
+}
+
+template <int MF, int WM, int KC>
 __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
     constexpr int WN = 4 / WM;
     constexpr int NF = 8 / WN;
     constexpr int BM = 16 * MF * WM;
     constexpr int BN = 128;
-    constexpr int STAGE = (BM + BN) * 32;
+    constexpr int SLOTS = KC / 8;                   // 16-byte slots per tile row
+    constexpr int KS = KC / 32;                     // MFMA k-steps per chunk
+    constexpr int STAGE = (BM + BN) * KC;
     constexpr int CS = BM + 8;
     constexpr int SMEM = 2 * STAGE > 64 * CS ? 2 * STAGE : 64 * CS;
+    constexpr int NIA = (BM * SLOTS / 64 + 3) / 4;  // A copy instructions per wave
+    constexpr int NIB = BN * SLOTS / 64 / 4;        // B copy instructions per wave
     __shared__ AERO_LDS_ALIGN h16 smem[SMEM];
     h16* Cs = smem;
     const aero_conv_desc& d = p.d;
@@ -291,12 +310,35 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
     if (fdst < 0 || fdst >= d.dst_F) return;
     const int m0 = mt * BM, t0 = tt * BN;
     const int wset = d.transposed ? (fo % d.fstride) : 0;
-    const int fbase = d.transposed ? (fo / d.fstride) : (fo * d.fstride);
+    const int fbase = (d.transposed ? (fo / d.fstride) : (fo * d.fstride)) + p.f_lo;
     const h16* Wp = (const h16*)d.weight + ((int64_t)wset * p.Mpad + m0) * p.Ktot;
     const h16* s0 = (const h16*)d.src0;
     const h16* s1 = (const h16*)d.src1;
-    const int C0 = d.C0, C1 = d.C1, T = d.T;
-    const int64_t st0_b = d.s0_b, st0_f = d.s0_f, st0_t = d.s0_t, st1_b = d.s1_b, st1_f = d.s1_f, st1_t = d.s1_t;
+    const h16* zp = aero_zero_page;
+    const int C0 = d.C0, C01 = d.C0 + d.C1, T = d.T;
+    const int st0 = (int)d.s0_t, st1 = (int)d.s1_t;
+    const int cpt = p.Cp / KC;
+    const int cc_lo = (s0 == nullptr && C0 % KC == 0) ? C0 / KC : 0;
+    const int nF = d.ntaps / p.nT;
+
+    // ---- lane-invariant parts of the copy addresses
+    const h16* a_ptr[NIA];
+    int b_pos[NIB], b_q8[NIB], b_off0[NIB], b_off1[NIB];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int s = (wave + 4 * i) * 64 + lane;
+        const int r = s / SLOTS, q = (s % SLOTS) ^ aero_tile_swz<KC>(r);
+        a_ptr[i] = Wp + (int64_t)r * p.Ktot + q * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int s = (wave + 4 * i) * 64 + lane;
+        const int pos = s / SLOTS, q = (s % SLOTS) ^ aero_tile_swz<KC>(pos);
+        b_pos[i] = pos;
+        b_q8[i] = q * 8;
+        b_off0[i] = pos * st0 + q * 8;
+        b_off1[i] = pos * st1 + q * 8;
+    }
 
     f32x4 acc[MF][NF];
 #pragma unroll
@@ -304,58 +346,40 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
 #pragma unroll
         for (int n = 0; n < NF; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int j = -1, cc = p.cpt - 1, fi = 0;
+    // ---- chunk iterator over (frequency tap jf, time tap jt, channel chunk cc); all state block-uniform
+    int jf = -1, jt = p.nT - 1, cc = cpt - 1, fi = 0;
     auto next_chunk = [&]() -> bool {
+        if (++cc < cpt) return true;
+        cc = cc_lo;
+        if (++jt < p.nT) return true;
+        jt = 0;
         for (;;) {
-            ++cc;
-            if (cc == p.cpt) {
-                cc = 0;
-                ++j;
-                while (j < d.ntaps) {
-                    fi = fbase + d.df[j];
-                    if (fi >= 0 && fi < d.Fin) break;
-                    ++j;
-                }
-            }
-            if (j >= d.ntaps) return false;
-            if (s0 == nullptr && (cc + 1) * 32 <= C0) continue;
-            return true;
+            if (++jf >= nF) return false;
+            fi = fbase + jf * p.f_step;
+            if (fi >= 0 && fi < d.Fin) return true;
         }
     };
-    // lane l of wave-instruction ii owns 16-byte LDS slot s = ii*64 + l  ->  tile row s>>2, swizzled slot s&3
     auto issue = [&](int buf) {
         h16* As = smem + buf * STAGE;
-        h16* Bs = As + BM * 32;
-        const int kofs = j * p.Cp + cc * 32;
+        h16* Bs = As + BM * KC;
+        const int kofs = (jf * p.nT + jt) * p.Cp + cc * KC;
 #pragma unroll
-        for (int i = 0; i < (BM / 16 + 3) / 4; ++i) {
-            const int ii = wave + 4 * i;
-            if (ii < BM / 16) {
-                const int s = ii * 64 + lane;
-                const int r = s >> 2, q = (s & 3) ^ ((0 - (r >> 2)) & 3);
-                aero_glds16(Wp + (int64_t)r * p.Ktot + kofs + q * 8, As + ii * 512);
-            }
-        }
-        const int dtj = d.dt[j];
-        // block-uniform row bases of both sources; the per-lane part is t*stride + channel.  Both candidate
-        // addresses are formed arithmetically and SELECTED (a per-lane select of descriptor fields would make
-        // hipcc fetch them with vector loads, whose vmcnt(0) wait drains the in-flight LDS copies).
-        const h16* base0 = s0 ? s0 + (int64_t)b * st0_b + (int64_t)fi * st0_f : aero_zero_page;
-        const h16* base1 = s1 ? s1 + (int64_t)b * st1_b + (int64_t)fi * st1_f : aero_zero_page;
+        for (int i = 0; i < NIA; ++i)
+            if (wave + 4 * i < BM * SLOTS / 64) aero_glds16(a_ptr[i] + kofs, As + (wave + 4 * i) * 512);
+        const int tsh = t0 + p.t_lo + jt * p.t_step;          // source time of position 0
+        const int c_lo = cc * KC;
+        const h16* rb0 = s0 ? s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)tsh * st0 + c_lo : zp;
+        const h16* rb1 = s1 ? s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)tsh * st1 + (c_lo - C0) : zp;
+        const int lim0 = C0 - c_lo, lim1 = C01 - c_lo;        // channel q8 comes from src0 if q8 < lim0, src1 if q8 < lim1
+        const bool has0 = s0 != nullptr;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ii = wave + 4 * i;
-            const int s = ii * 64 + lane;
-            const int pos = s >> 2, q = (s & 3) ^ ((0 - (pos >> 2)) & 3);
-            const int t = t0 + pos + dtj;
-            const int c = cc * 32 + q * 8;
-            const bool tin = t >= 0 && t < T;
-            const h16* a0 = base0 + (int64_t)t * st0_t + c;
-            const h16* a1 = base1 + (int64_t)t * st1_t + (c - C0);
-            const bool use0 = tin && c < C0 && s0 != nullptr;
-            const bool use1 = tin && c >= C0 && (c - C0) < C1;
-            const h16* src = use0 ? a0 : (use1 ? a1 : (const h16*)aero_zero_page);
-            aero_glds16(src, Bs + ii * 512);
+        for (int i = 0; i < NIB; ++i) {
+            const int tpos = b_pos[i] + tsh;
+            const bool tin = tpos >= 0 && tpos < T;
+            const bool u0 = b_q8[i] < lim0;
+            const bool ok = tin && (u0 ? has0 : (b_q8[i] < lim1));
+            const h16* ptr = (u0 ? rb0 : rb1) + (u0 ? b_off0[i] : b_off1[i]);
+            aero_glds16(ok ? ptr : zp, Bs + (wave + 4 * i) * 512);
         }
     };
 
@@ -367,16 +391,19 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
         have = next_chunk();
         if (have) issue(buf ^ 1);
         const h16* As = smem + buf * STAGE;
-        const h16* Bs = As + BM * 32;
-        h16x8 af[MF], bf[NF];
+        const h16* Bs = As + BM * KC;
 #pragma unroll
-        for (int i = 0; i < MF; ++i) af[i] = *(const h16x8*)&As[aero_tile_off((wm * MF + i) * 16 + (lane & 15), lane >> 4)];
+        for (int ks = 0; ks < KS; ++ks) {
+            h16x8 af[MF], bf[NF];
 #pragma unroll
-        for (int n = 0; n < NF; ++n) bf[n] = *(const h16x8*)&Bs[aero_tile_off((wn * NF + n) * 16 + (lane & 15), lane >> 4)];
+            for (int i = 0; i < MF; ++i) af[i] = *(const h16x8*)&As[aero_tile_off_kc<KC>((wm * MF + i) * 16 + (lane & 15), ks * 4 + (lane >> 4))];
 #pragma unroll
-        for (int i = 0; i < MF; ++i)
+            for (int n = 0; n < NF; ++n) bf[n] = *(const h16x8*)&Bs[aero_tile_off_kc<KC>((wn * NF + n) * 16 + (lane & 15), ks * 4 + (lane >> 4))];
 #pragma unroll
-            for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[n], acc[i][n], 0, 0, 0);
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[n], acc[i][n], 0, 0, 0);
+        }
         buf ^= 1;
     }
     __syncthreads();                           // all waves done with the operand stages: smem becomes the output tile
@@ -498,6 +525,26 @@ __global__ __launch_bounds__(256) void aero_conv3x3_kernel(AeroConvK p) {
     aero_conv_epilogue<MF, WM>(p, acc, Cs, b, fo, fdst, m0, t0);
 }
 
+// taps on a regular (frequency x time) grid?  fills the grid parameters of AeroConvK
+static bool aero_conv_regular_taps(const aero_conv_desc* d, AeroConvK* p) {
+    const int n = d->ntaps;
+    int nT = 1;
+    while (nT < n && d->df[nT] == d->df[0]) ++nT;
+    if (n % nT) return false;
+    const int nF = n / nT;
+    const int f_step = nF > 1 ? d->df[nT] - d->df[0] : 0;
+    const int t_step = nT > 1 ? d->dt[1] - d->dt[0] : 0;
+    for (int j = 0; j < n; ++j)
+        if (d->df[j] != d->df[0] + (j / nT) * f_step || d->dt[j] != d->dt[0] + (j % nT) * t_step) return false;
+    if (d->s0_t > 0x3fffff || d->s1_t > 0x3fffff) return false;       // 32-bit in-row offsets
+    p->nT = nT;
+    p->f_lo = d->df[0];
+    p->f_step = f_step;
+    p->t_lo = d->dt[0];
+    p->t_step = t_step;
+    return true;
+}
+
 static bool aero_conv_is_3x3(const aero_conv_desc* d) {
     if (d->ntaps != 9 || d->transposed || d->fstride != 1) return false;
     for (int j = 0; j < 9; ++j)
@@ -556,6 +603,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     if (d->src1) vin = vin && al8(d->s1_b) && al8(d->s1_f) && al8(d->s1_t) && (((uintptr_t)d->src1 & 15) == 0);
     p.vec_in = vin;
     p.glds = aero_conv_use_glds();
+    p.nT = 1; p.f_lo = p.f_step = p.t_lo = p.t_step = 0;
     const int Mout = d->act == AERO_ACT_GLU ? d->M / 2 : d->M;
     const int nout = d->act == AERO_ACT_GLU ? 2 : 4;
     const int esz = d->dst_f32 ? 4 : 2;
@@ -571,14 +619,26 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         AERO_LAUNCH(aero_conv3x3_kernel, grid, block, stream, p);
         return AERO_OK;
     }
-    if (p.vec_in && p.glds) {
-        switch (bm) {
-            case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2>), grid, block, stream, p); break;
-            case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2>), grid, block, stream, p); break;
-            case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1>), grid, block, stream, p); break;
-            case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1>), grid, block, stream, p); break;
-            case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1>), grid, block, stream, p); break;
-            default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1>), grid, block, stream, p); break;
+    if (p.vec_in && p.glds && aero_conv_regular_taps(d, &p)) {
+        const bool k64 = (p.Cp % 64 == 0) && (bm * 2 + 256) * 64 * 2 <= 65536;     // two 64-channel stages must fit 64 KiB
+        if (k64) {
+            switch (bm) {
+                case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2, 64>), grid, block, stream, p); break;
+                case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2, 64>), grid, block, stream, p); break;
+                case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1, 64>), grid, block, stream, p); break;
+                case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1, 64>), grid, block, stream, p); break;
+                case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1, 64>), grid, block, stream, p); break;
+                default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1, 64>), grid, block, stream, p); break;
+            }
+        } else {
+            switch (bm) {
+                case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2, 32>), grid, block, stream, p); break;
+                case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2, 32>), grid, block, stream, p); break;
+                case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1, 32>), grid, block, stream, p); break;
+                case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1, 32>), grid, block, stream, p); break;
+                case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1, 32>), grid, block, stream, p); break;
+                default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1, 32>), grid, block, stream, p); break;
+            }
         }
         return AERO_OK;
     }
