@@ -47,20 +47,6 @@ static __device__ __forceinline__ void aero_glds16(const h16* gsrc, h16* lds_wav
 #endif
 }
 
-// Counted wait on outstanding vector-memory operations (incl. LDS copies) and a raw workgroup barrier that does NOT
-// drain them: lets direct-to-LDS copies stay in flight across barriers (deep software pipelines).
-#ifdef AERO_EMU
-#define AERO_WAIT_VMCNT(n) do { } while (0)
-static __device__ __forceinline__ void aero_raw_barrier() { __syncthreads(); }
-#else
-#define AERO_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-static __device__ __forceinline__ void aero_raw_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-#endif
-
 static __device__ __forceinline__ int aero_lane() { return threadIdx.x & 63; }
 static __device__ __forceinline__ int aero_wave() { return threadIdx.x >> 6; }
 

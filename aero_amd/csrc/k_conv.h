@@ -282,7 +282,7 @@ static __device__ __forceinline__ int aero_tile_swz(int row) {
     return KC == 32 ? ((0 - (row >> 2)) & 3) : ((row >> 1) & 7);
 }
 
-template <int MF, int WM, int KC, int NST>
+template <int MF, int WM, int KC>
 __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
     constexpr int WN = 4 / WM;
     constexpr int NF = 8 / WN;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
     constexpr int KS = KC / 32;                     // MFMA k-steps per chunk
     constexpr int STAGE = (BM + BN) * KC;
     constexpr int CS = BM + 8;
-    constexpr int SMEM = NST * STAGE > 64 * CS ? NST * STAGE : 64 * CS;
+    constexpr int SMEM = 2 * STAGE > 64 * CS ? 2 * STAGE : 64 * CS;
     constexpr int NIA = (BM * SLOTS / 64 + 3) / 4;  // A copy instructions per wave
     constexpr int NIB = BN * SLOTS / 64 / 4;        // B copy instructions per wave
     __shared__ AERO_LDS_ALIGN h16 smem[SMEM];
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
                 for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[n], acc[i][n], 0, 0, 0);
         }
     };
-    if constexpr (NST == 2) {
+    {
         bool have = next_chunk();
         if (have) issue(0);
         int buf = 0;
@@ -409,32 +409,6 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
             if (have) issue(buf ^ 1);
             compute(buf);
             buf ^= 1;
-        }
-    } else {
-        // 4 stages, copies issued THREE chunks ahead; every wave issues exactly LPC copies per chunk, so
-        // "chunk k has landed for this wave" == at most 2*LPC of its copies are still outstanding (counted vmcnt).
-        // The raw barrier publishes that to the other waves and proves chunk k-1 was consumed by everyone, which
-        // frees stage (k+3)%4 for the next copy -- the copies themselves are never drained inside the loop.
-        constexpr int LPC = NIA + NIB;
-        static_assert(NST == 2 || BM * SLOTS / 64 % 4 == 0, "deep pipeline needs the same copy count on every wave");
-        int issued = 0, done = 0;
-        bool more = true;
-        for (int i = 0; i < 3 && more; ++i) {
-            more = next_chunk();
-            if (more) { issue(issued & 3); ++issued; }
-        }
-        while (done < issued) {
-            const int infl = issued - done - 1;            // chunks allowed to remain in flight behind chunk `done`
-            if (infl >= 2) AERO_WAIT_VMCNT(2 * LPC);
-            else if (infl == 1) AERO_WAIT_VMCNT(LPC);
-            else AERO_WAIT_VMCNT(0);
-            aero_raw_barrier();
-            if (more) {
-                more = next_chunk();
-                if (more) { issue(issued & 3); ++issued; }
-            }
-            compute(done & 3);
-            ++done;
         }
     }
     __syncthreads();                           // all waves done with the operand stages: smem becomes the output tile
@@ -593,7 +567,7 @@ static int aero_conv_use_glds() {
     return v;
 }
 
-// AERO_CONV_MODE=1/2/3 forces a glds pipeline flavour (A/B experiments); default 0 = automatic
+// AERO_CONV_MODE=1/2 forces 32-/64-channel K-chunks in the glds pipeline (A/B experiments); default 0 = automatic
 static int aero_conv_glds_mode() {
     static int v = -1;
     if (v < 0) {
@@ -661,33 +635,28 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         return AERO_OK;
     }
     if (p.vec_in && p.glds && aero_conv_regular_taps(d, &p)) {
-        const int mode = aero_conv_glds_mode();               // 0 auto, 1 = 2-stage KC=32, 2 = 2-stage KC=64, 3 = 4-stage KC=32
-        const bool deep_ok = (bm == 128 || bm == 64);
+        // 64-channel chunks pay off only for the big compute-bound contractions (measured: +5 % on the decoder 3x3
+        // convs, -2 % on the whole model if used everywhere because two 64-KiB stages halve the blocks per CU)
+        const int mode = aero_conv_glds_mode();               // 0 auto, 1 = KC 32, 2 = KC 64 where legal
         const bool k64_ok = (p.Cp % 64 == 0);
-        int use = mode;
-        if (use == 0) use = deep_ok ? 3 : (k64_ok ? 2 : 1);
-        if (use == 3 && !deep_ok) use = k64_ok ? 2 : 1;
-        if (use == 2 && !k64_ok) use = 1;
-        if (use == 3) {
-            if (bm == 128) AERO_LAUNCH((aero_conv_glds_kernel<4, 2, 32, 4>), grid, block, stream, p);
-            else AERO_LAUNCH((aero_conv_glds_kernel<4, 1, 32, 4>), grid, block, stream, p);
-        } else if (use == 2) {
+        const bool k64 = mode == 2 ? k64_ok : (mode == 1 ? false : (k64_ok && bm >= 96 && p.Ktot >= 1024));
+        if (k64) {
             switch (bm) {
-                case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2, 64, 2>), grid, block, stream, p); break;
-                case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2, 64, 2>), grid, block, stream, p); break;
-                case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1, 64, 2>), grid, block, stream, p); break;
-                case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1, 64, 2>), grid, block, stream, p); break;
-                case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1, 64, 2>), grid, block, stream, p); break;
-                default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1, 64, 2>), grid, block, stream, p); break;
+                case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2, 64>), grid, block, stream, p); break;
+                case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2, 64>), grid, block, stream, p); break;
+                case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1, 64>), grid, block, stream, p); break;
+                case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1, 64>), grid, block, stream, p); break;
+                case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1, 64>), grid, block, stream, p); break;
+                default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1, 64>), grid, block, stream, p); break;
             }
         } else {
             switch (bm) {
-                case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2, 32, 2>), grid, block, stream, p); break;
-                case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2, 32, 2>), grid, block, stream, p); break;
-                case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1, 32, 2>), grid, block, stream, p); break;
-                case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1, 32, 2>), grid, block, stream, p); break;
-                case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1, 32, 2>), grid, block, stream, p); break;
-                default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1, 32, 2>), grid, block, stream, p); break;
+                case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2, 32>), grid, block, stream, p); break;
+                case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2, 32>), grid, block, stream, p); break;
+                case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1, 32>), grid, block, stream, p); break;
+                case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1, 32>), grid, block, stream, p); break;
+                case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1, 32>), grid, block, stream, p); break;
+                default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1, 32>), grid, block, stream, p); break;
             }
         }
         return AERO_OK;

@@ -11,6 +11,7 @@ The complex spectrograms handed back to the caller are exactly the reference's c
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -227,6 +228,7 @@ class HipEngine:
         self.ops = Ops(self.lib)
         self._key = None
         self._tables = {}
+        self.streams = int(os.environ.get('AERO_STREAMS', '1'))   # sub-batches in flight on separate HIP streams
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
 
     # ------------------------------------------------------------------ weights
@@ -420,6 +422,37 @@ class HipEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, mix, want_spec=False, want_lr_spec=False):
+        """Clips are independent units: with `self.streams` > 1 the batch is cut into that many sub-batches whose
+        kernel sequences are enqueued on separate HIP streams, so latency-bound launches of one sub-batch (the
+        recurrent LSTM kernel: one block per CU, 200 dependent steps) overlap with bandwidth/MFMA-bound launches of
+        the others.  Results are identical to the single-stream order (per-clip arithmetic does not change)."""
+        ns = min(self.streams, mix.shape[0]) if mix.is_cuda else 1
+        if ns <= 1 or self.ops.prof is not None:
+            return self._forward_one(mix, want_spec, want_lr_spec)
+        cur = torch.cuda.current_stream(mix.device)
+        key = ('streams', ns, str(mix.device))
+        if key not in self._tables:
+            self._tables[key] = [torch.cuda.Stream(device=mix.device) for _ in range(ns)]
+        outs = []
+        self._prepare(mix.device)                       # weights packed once, on the caller's stream
+        for st, part in zip(self._tables[key], mix.chunk(ns, dim=0)):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self._forward_one(part, want_spec, want_lr_spec))
+        for st in self._tables[key]:
+            cur.wait_stream(st)
+        res = []
+        for k in range(3):
+            parts = [o[k] for o in outs]
+            if parts[0] is None:
+                res.append(None)
+                continue
+            for t in parts:
+                t.record_stream(cur)
+            res.append(torch.cat(parts, 0))
+        return tuple(res)
+
+    def _forward_one(self, mix, want_spec=False, want_lr_spec=False):
         m, ops, P = self.model, self.ops, None
         self._check_input(mix)
         if m.in_channels != 1 or m.out_channels != 1:
