@@ -60,6 +60,11 @@ class FtbFirstDesc(C.Structure):
                 ('dst', vp), ('B', i32), ('F', i32), ('T', i32), ('C', i32)]
 
 
+class DconvTailDesc(C.Structure):
+    _fields_ = [('h', vp), ('weight', vp), ('bias', fp), ('gamma', fp), ('beta', fp), ('layer_scale', fp),
+                ('res', vp), ('dst', vp), ('R', i32), ('T', i32), ('C', i32), ('h_pitch', i32), ('eps', C.c_float)]
+
+
 _PROTOS = {
     'aero_version': (C.c_char_p, []),
     'aero_last_error': (C.c_char_p, []),
@@ -76,6 +81,7 @@ _PROTOS = {
     'aero_localstate_fwd': (i32, [C.POINTER(AttnDesc), vp]),
     'aero_freqfc_fwd': (i32, [C.POINTER(FreqFcDesc), vp]),
     'aero_ftb_first_fwd': (i32, [C.POINTER(FtbFirstDesc), vp]),
+    'aero_dconv_tail_fwd': (i32, [C.POINTER(DconvTailDesc), vp]),
 }
 
 EXPORTS = tuple(_PROTOS)

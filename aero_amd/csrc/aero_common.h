@@ -19,6 +19,18 @@
 #define aero_fast_sin(x) __sinf(x)
 #include <hip/hip_runtime.h>
 #define AERO_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
+// dynamic LDS (up to the full 160 KiB of a CU): one extern array per translation unit
+extern __shared__ __attribute__((aligned(16))) char aero_dyn_smem_[];
+#define AERO_DYN_SMEM aero_dyn_smem_
+#define AERO_LAUNCH_DYN(kern, grid, block, dyn_bytes, stream, ...)                                                   \
+    do {                                                                                                              \
+        static size_t aero_max_dyn_ = 0;                                                                              \
+        if ((size_t)(dyn_bytes) > aero_max_dyn_) {                                                                    \
+            (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dyn_bytes)); \
+            aero_max_dyn_ = (size_t)(dyn_bytes);                                                                      \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, grid, block, dyn_bytes, stream, __VA_ARGS__);                                        \
+    } while (0)
 #endif
 
 #include "../../include/aero_hip.h"

@@ -134,7 +134,7 @@ class Ops:
 
     # -- GroupNorm + activation ----------------------------------------------------------------
     def norm_act(self, x, G, per_row, gamma, beta, act, snake_a=None, layer_scale=None, res=None, normalize=True,
-                 f_lo=0, f_cnt=None, eps=1e-5):
+                 f_lo=0, f_cnt=None, eps=1e-5, dst=None):
         """x [B,F,T,C] fp16.  Statistics over all F rows; output only rows [f_lo, f_lo+f_cnt)."""
         B, F, T, Cc = x.shape
         d = _lib.NormDesc()
@@ -151,7 +151,8 @@ class Ops:
         f_cnt = F if f_cnt is None else f_cnt
         assert not (per_row and (f_lo or f_cnt != F))
         Cout = Cc // 2 if act == ACT_GLU else Cc
-        out = torch.empty(B, f_cnt, T, Cout, dtype=torch.float16, device=x.device)
+        out = dst if dst is not None else torch.empty(B, f_cnt, T, Cout, dtype=torch.float16, device=x.device)
+        assert out.shape == (B, f_cnt, T, Cout)
         d.src = x.data_ptr() + f_lo * x.stride(1) * x.element_size()
         d.F = f_cnt
         d.gamma, d.beta = _ptr(gamma), _ptr(beta)
@@ -214,6 +215,23 @@ def _ftb_first(self, xn, u, gate, P):
 Ops.ftb_first = _ftb_first
 
 
+def _dconv_tail(self, h, P, res, R, T, eps=1e-5):
+    """h fp16 [R, T, h_pitch] -> res + layer_scale * GLU(GN(conv1x1(h)))  (aero_dconv_tail_fwd)."""
+    Cc = P['C']
+    out = torch.empty(R, T, Cc, dtype=torch.float16, device=h.device)
+    d = _lib.DconvTailDesc()
+    d.h, d.weight, d.bias = _ptr(h), _ptr(P['weight']), _ptr(P['bias'])
+    d.gamma, d.beta, d.layer_scale = _ptr(P['gamma']), _ptr(P['beta']), _ptr(P['scale'])
+    d.res, d.dst = _ptr(res), _ptr(out)
+    d.R, d.T, d.C, d.h_pitch, d.eps = R, T, Cc, h.shape[-1], eps
+    self._call('aero_dconv_tail_fwd', 'aero_dconv_tail_kernel', 2 * 2.0 * R * T * 2 * Cc * h.shape[-1],
+               R * T * (h.shape[-1] * 2 + 4 * Cc), C.byref(d), self.stream(out))
+    return out
+
+
+Ops.dconv_tail = _dconv_tail
+
+
 def _hann_padded(win_length, n_fft, device):
     w = torch.zeros(n_fft, dtype=torch.float32)
     left = (n_fft - win_length) // 2
@@ -229,6 +247,7 @@ class HipEngine:
         self._key = None
         self._tables = {}
         self.streams = int(os.environ.get('AERO_STREAMS', '1'))   # sub-batches in flight on separate HIP streams
+        self.fuse_dconv_tail = True        # DConv conv2+GroupNorm+GLU+LayerScale+skip in one kernel (k_dconv.h)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
 
     # ------------------------------------------------------------------ weights
@@ -365,6 +384,19 @@ class HipEngine:
             L['conv2'] = mk(w, sd[f'{q}.conv2.0.bias'], w.shape[-1], 0, df, dt, device)
             L['gn2'] = (sd[f'{q}.conv2.1.weight'].to(device), sd[f'{q}.conv2.1.bias'].to(device)) if dc.norm else None
             L['scale'] = sd[f'{q}.conv2.3.scale'].to(device).contiguous()
+            # fused tail (aero_dconv_tail_fwd): conv2 + GroupNorm(1) + GLU + LayerScale + residual in one kernel
+            hid, Cc = dc.hidden, dc.channels
+            hp = pack._round_up(hid, 8)
+            if (2 * Cc) % 32 == 0 and hp <= 128:
+                w2 = pack.glu_interleave(sd[f'{q}.conv2.0.weight'][:, :, 0])                 # [2C, hid]
+                img = torch.zeros(pack._round_up(2 * Cc, 128), pack._round_up(hp, 32))
+                img[:2 * Cc, :hid] = w2
+                f32 = lambda t: t.float().to(device).contiguous()                        # noqa: E731
+                L['tail'] = dict(C=Cc, h_pitch=hp, weight=img.to(device=device, dtype=torch.float16).contiguous(),
+                                 bias=f32(pack.glu_interleave(sd[f'{q}.conv2.0.bias'])),
+                                 gamma=f32(pack.glu_interleave(sd[f'{q}.conv2.1.weight'])) if dc.norm else None,
+                                 beta=f32(pack.glu_interleave(sd[f'{q}.conv2.1.bias'])) if dc.norm else None,
+                                 scale=L['scale'])
             out.append(L)
         return out
 
@@ -543,8 +575,17 @@ class HipEngine:
         for L in layers:
             h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T)
             g1 = L['gn1']
+            fused_tail = 'tail' in L and self.fuse_dconv_tail and x.is_contiguous()
+            hdst = hfull = None
+            if fused_tail and L['tail']['h_pitch'] != h.shape[-1] and 'lstm' not in L and 'attn_qkvd' not in L:
+                # hidden size not a multiple of 8 (12 at encoder 0): write the activation straight into a zero-padded
+                # 16-byte-pitch buffer so the fused tail can stream it with aligned 16-byte copies
+                hfull = torch.zeros(B, Fo, T, L['tail']['h_pitch'], dtype=torch.float16, device=h.device)
+                hdst = hfull[..., :h.shape[-1]]
             h = ops.norm_act(h, 1, True, g1[0] if g1 else None, g1[1] if g1 else None, act,
-                             snake_a=L.get('snake_a'), normalize=g1 is not None)
+                             snake_a=L.get('snake_a'), normalize=g1 is not None, dst=hdst)
+            if hfull is not None:
+                h = hfull
             if 'lstm' in L:
                 h = self._blstm(dc, L, h, B, Fo, T)
             if 'attn_qkvd' in L:
@@ -552,6 +593,15 @@ class HipEngine:
                 qkvd = ops.conv(L['attn_qkvd'], h, None, B, Fo, Fo, T)
                 att = ops.localstate(qkvd, B * Fo, T, dc.hidden, heads, ndecay)
                 h = ops.conv(L['attn_proj'], att.view(B, Fo, T, dc.hidden), None, B, Fo, Fo, T, res=h)
+            if fused_tail:
+                tp = L['tail']
+                if h.shape[-1] != tp['h_pitch']:                     # hidden size not a multiple of 8: zero-padded copy
+                    hpad = torch.zeros(B, Fo, T, tp['h_pitch'], dtype=torch.float16, device=h.device)
+                    hpad[..., :h.shape[-1]] = h
+                    h = hpad
+                x = ops.dconv_tail(h.contiguous().view(B * Fo, T, tp['h_pitch']), tp, x.view(B * Fo, T, -1),
+                                   B * Fo, T).view(B, Fo, T, -1)
+                continue
             g = ops.conv(L['conv2'], h, None, B, Fo, Fo, T)
             g2 = L['gn2']
             x = ops.norm_act(g, 1, True, g2[0] if g2 else None, g2[1] if g2 else None, ACT_GLU,

@@ -172,6 +172,21 @@ typedef struct {
 } aero_ftb_first_desc;
 int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream);
 
+/* K9+K7+K8 fused -- tail of a DConv residual layer (modules.py:209-210,141,243-244):
+ *   dst = res + layer_scale * GLU( GroupNorm(1, 2C)( conv1x1(h) ) )     statistics per (b, f) row over (2C, T)
+ * h fp16 [R][T][h_pitch] (h_pitch multiple of 8; channels beyond the hidden size must be zero), weight fp16
+ * [roundup(2C,128)][roundup(h_pitch,32)] with GLU-interleaved rows (2u = value u, 2u+1 = gate u) zero padded; bias,
+ * gamma, beta fp32 [2C] in the same interleaved order (gamma == NULL: no normalisation); layer_scale fp32 [C];
+ * res, dst fp16 [R][T][C].  The 2C-channel intermediate never reaches HBM (two-pass recompute, k_dconv.h). */
+typedef struct {
+    const void* h; const void* weight;
+    const float* bias; const float* gamma; const float* beta; const float* layer_scale;
+    const void* res; void* dst;
+    int32_t R, T, C, h_pitch;
+    float eps;
+} aero_dconv_tail_desc;
+int aero_dconv_tail_fwd(const aero_dconv_tail_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,7 +65,7 @@ static void run_block(BlockCtx& b, std::vector<char*>& stacks) {
     g_blk = nullptr;
 }
 
-void launch(Dim3 grid, Dim3 block, const std::function<void()>& body) {
+void launch(Dim3 grid, Dim3 block, const std::function<void()>& body, size_t dyn_bytes) {
     long nblocks = (long)grid.x * grid.y * grid.z;
     if (nblocks <= 0) return;
     int nthreads = block.x * block.y * block.z;
@@ -76,6 +76,7 @@ void launch(Dim3 grid, Dim3 block, const std::function<void()>& body) {
     std::atomic<long> next(0);
     auto worker = [&]() {
         std::vector<char*> stacks;
+        char* dyn = dyn_bytes ? (char*)aligned_alloc(64, (dyn_bytes + 63) / 64 * 64) : nullptr;
         for (;;) {
             long i = next.fetch_add(1);
             if (i >= nblocks) break;
@@ -87,9 +88,11 @@ void launch(Dim3 grid, Dim3 block, const std::function<void()>& body) {
             b.bid.y = (i / grid.x) % grid.y;
             b.bid.z = i / ((long)grid.x * grid.y);
             b.body = &body;
+            b.dyn_smem = dyn;
             run_block(b, stacks);
         }
         for (char* s : stacks) free(s);
+        free(dyn);
     };
     if (nworkers == 1) {
         worker();

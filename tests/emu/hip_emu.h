@@ -67,6 +67,7 @@ struct BlockCtx {
     std::vector<WaveCtx> waves;
     ucontext_t main_ctx;
     const std::function<void()>* body;
+    char* dyn_smem;              // dynamic LDS of this block (emulated)
 };
 
 extern thread_local BlockCtx* g_blk;
@@ -115,7 +116,7 @@ static inline T shfl_idx(T v, int src) {
     return out;
 }
 
-void launch(Dim3 grid, Dim3 block, const std::function<void()>& body);
+void launch(Dim3 grid, Dim3 block, const std::function<void()>& body, size_t dyn_bytes = 0);
 
 template <class T>
 static inline T atomic_add_cas(T* addr, T val) {
@@ -175,3 +176,6 @@ static inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu::eh8 a, emu::eh8
 
 #define AERO_LAUNCH(kern, grid, block, stream, ...) \
     emu::launch(grid, block, [=]() { kern(__VA_ARGS__); })
+#define AERO_LAUNCH_DYN(kern, grid, block, dyn_bytes, stream, ...) \
+    emu::launch(grid, block, [=]() { kern(__VA_ARGS__); }, dyn_bytes)
+#define AERO_DYN_SMEM (emu::g_blk->dyn_smem)

@@ -33,6 +33,20 @@ def test_tiny_model_golden(emu, meta, L):
     assert rel_l2(y, io[f'y_{L}']) < 5e-3
 
 
+@pytest.mark.parametrize('fuse', [True, False])
+def test_small_model_golden_dconv_tail_paths(emu, meta, fuse):
+    """DConv conv2 + GroupNorm + GLU + LayerScale + skip as ONE kernel (aero_dconv_tail_fwd) or as conv / stats / apply."""
+    m = build_model(meta, 'small')
+    eng = HipEngine(m, lib=emu)
+    eng.fuse_dconv_tail = fuse
+    object.__setattr__(m, '_engine', eng)
+    io = load_npz('small_io.npz')
+    with torch.no_grad():
+        y, s = m(torch.from_numpy(io['x_2003']), return_spec=True)
+    assert rel_l2(s, io['spec_2003']) < 1e-3
+    assert rel_l2(y, io['y_2003']) < 5e-3
+
+
 @pytest.mark.parametrize('collapse', [True, False])
 def test_small_model_golden_first_layer_ftb_paths(emu, meta, collapse):
     """channels=16 model: encoder 0's FTB runs collapsed onto the 2-channel spectrogram (aero_ftb_first_fwd) or layer by
