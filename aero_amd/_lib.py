@@ -26,7 +26,10 @@ class ConvDesc(C.Structure):
                 ('ntaps', i32), ('df', i32 * 9), ('dt', i32 * 9),
                 ('act', i32),
                 ('res', vp), ('r_b', i64), ('r_f', i64), ('r_t', i64),
-                ('post_add', fp), ('batch_scale', fp), ('batch_shift', fp)]
+                ('post_add', fp), ('batch_scale', fp), ('batch_shift', fp),
+                ('stats', dp), ('stat_count', C.c_double),
+                ('stat_mode', i32), ('stat_G', i32), ('stat_per_row', i32), ('stat_eps', C.c_float),
+                ('gamma', fp), ('beta', fp), ('layer_scale', fp)]
 
 
 class NormDesc(C.Structure):
@@ -60,11 +63,6 @@ class FtbFirstDesc(C.Structure):
                 ('dst', vp), ('B', i32), ('F', i32), ('T', i32), ('C', i32)]
 
 
-class DconvTailDesc(C.Structure):
-    _fields_ = [('h', vp), ('weight', vp), ('bias', fp), ('gamma', fp), ('beta', fp), ('layer_scale', fp),
-                ('res', vp), ('dst', vp), ('R', i32), ('T', i32), ('C', i32), ('h_pitch', i32), ('eps', C.c_float)]
-
-
 _PROTOS = {
     'aero_version': (C.c_char_p, []),
     'aero_last_error': (C.c_char_p, []),
@@ -81,7 +79,6 @@ _PROTOS = {
     'aero_localstate_fwd': (i32, [C.POINTER(AttnDesc), vp]),
     'aero_freqfc_fwd': (i32, [C.POINTER(FreqFcDesc), vp]),
     'aero_ftb_first_fwd': (i32, [C.POINTER(FtbFirstDesc), vp]),
-    'aero_dconv_tail_fwd': (i32, [C.POINTER(DconvTailDesc), vp]),
 }
 
 EXPORTS = tuple(_PROTOS)

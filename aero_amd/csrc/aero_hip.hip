@@ -6,7 +6,6 @@
 #include "aero_common.h"
 #include "k_attn.h"
 #include "k_conv.h"
-#include "k_dconv.h"
 #include "k_ftb.h"
 #include "k_lstm.h"
 #include "k_norm.h"
@@ -124,12 +123,6 @@ int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream) {
 int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_ftb_first_launch(d, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_dconv_tail_fwd(const aero_dconv_tail_desc* d, void* stream) {
-    const char* err = "";
-    int rc = aero_dconv_tail_launch(d, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 

@@ -25,6 +25,14 @@ struct AeroConvK {
 };
 
 // Shared epilogue of the tiled kernels: D[m = (lane>>4)*4 + r][n = lane&15] per fragment.
+//   v = acc + bias
+//   stat_mode 1/2: GroupNorm statistics of v are accumulated here (fp32 per thread, fp64 shuffles, one fp64 atomic
+//                  pair per (wave, group)) -- the separate statistics pass over the stored tensor disappears;
+//                  mode 2 stores nothing (first half of a recompute pair whose wide intermediate never reaches HBM)
+//   stat_mode 3:   v = (v - mean) * rstd * gamma + beta from previously accumulated statistics
+//   then act (GLU pairs rows 2u,2u+1; optional LayerScale), residual, frequency embedding, per-item affine, store.
+// Staged form (fp16 output, 8-channel aligned): the tile is transposed through LDS in two passes of 64 positions so
+// that every global store (and residual load) is a full 16-byte channel vector (256-byte runs per position).
 template <int MF, int WM>
 static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f32x4 (&acc)[MF][8 / (4 / WM)], h16* Cs, int b, int fo,
                                                           int fdst, int m0, int t0) {
@@ -36,8 +44,6 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int T = d.T;
-    // Staged form (fp16 output, 8-channel aligned): the tile is transposed through LDS in two passes of 64
-    // positions so that every global store is a full 16-byte channel vector (256-byte runs per position).
     const int M = d.M;
     const bool glu = d.act == AERO_ACT_GLU;
     const int Mout = glu ? (M >> 1) : M;
@@ -45,8 +51,28 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
     h16* dst16 = (h16*)d.dst;
     float* dst32 = (float*)d.dst;
     const h16* res = (const h16*)d.res;
+    const bool res_in_copy = p.staged && res != nullptr;       // residual added with coalesced 16-byte loads
     const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
     const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
+    const int smode = d.stat_mode;
+    const int gs = smode ? M / d.stat_G : M;                    // rows per statistics group
+    const int64_t sitem = smode ? (int64_t)(d.stat_per_row ? b * d.Fout + fo : b) * d.stat_G : 0;
+    float st_mean[MF], st_rstd[MF], st_s1[MF], st_s2[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        st_mean[i] = 0.f; st_rstd[i] = 1.f; st_s1[i] = 0.f; st_s2[i] = 0.f;
+        if (smode == 3) {
+            const int grp = (m0 + (wm * MF + i) * 16) / gs;
+            if (grp < d.stat_G) {
+                const double* sp = d.stats + (sitem + grp) * 2;
+                const double mu = sp[0] / d.stat_count;
+                double var = sp[1] / d.stat_count - mu * mu;
+                if (var < 0) var = 0;
+                st_mean[i] = (float)mu;
+                st_rstd[i] = (float)(1.0 / sqrt(var + (double)d.stat_eps));
+            }
+        }
+    }
     constexpr int NH = NF / 2;                      // n-fragments per wave per pass
     constexpr int PH = NH * 16;                     // positions per wave per pass
 #pragma unroll
@@ -55,9 +81,14 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
         for (int i = 0; i < MF; ++i) {
             const int mbase = m0 + (wm * MF + i) * 16 + (lane >> 4) * 4;
             if (mbase >= M) continue;
-            float bv[4];
+            float bv[4], gm[4], bt[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (d.bias && mbase + r < M) ? d.bias[mbase + r] : 0.f;
+            for (int r = 0; r < 4; ++r) {
+                const bool in = mbase + r < M;
+                bv[r] = (d.bias && in) ? d.bias[mbase + r] : 0.f;
+                gm[r] = (smode == 3 && d.gamma && in) ? d.gamma[mbase + r] * st_rstd[i] : st_rstd[i];
+                bt[r] = (smode == 3 && d.gamma && in) ? d.beta[mbase + r] : 0.f;
+            }
 #pragma unroll
             for (int nn = 0; nn < NH; ++nn) {
                 const int n = pass * NH + nn;
@@ -66,11 +97,24 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = acc[i][n][r] + bv[r];
+                if (smode == 1 || smode == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (mbase + r < M) { st_s1[i] += o[r]; st_s2[i] += o[r] * o[r]; }
+                    if (smode == 2) continue;
+                } else if (smode == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (o[r] - st_mean[i]) * gm[r] + bt[r];
+                }
                 int cbase = mbase;
                 if (glu) {
                     o[0] = o[0] * aero_sigmoid(o[1]);
                     o[1] = o[2] * aero_sigmoid(o[3]);
                     cbase = mbase >> 1;
+                    if (d.layer_scale) {
+                        o[0] *= d.layer_scale[cbase];
+                        if (cbase + 1 < Mout) o[1] *= d.layer_scale[cbase + 1];
+                    }
                 } else if (d.act == AERO_ACT_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
@@ -84,7 +128,7 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
                 for (int r = 0; r < 4; ++r) {
                     if (r >= nout || cbase + r >= Mout) continue;
                     float x = o[r];
-                    if (res) x += (float)res[roff + r];
+                    if (res && !res_in_copy) x += (float)res[roff + r];
                     if (d.post_add) x += d.post_add[(int64_t)fo * Mout + cbase + r];
                     o[r] = x * bsc + bsh;
                 }
@@ -111,19 +155,48 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
                 }
             }
         }
-        if (p.staged) {
+        if (p.staged && smode != 2) {
             __syncthreads();
             const int BMo = glu ? (BM >> 1) : BM;
             const int nvec = BMo >> 3;
             const int m0o = glu ? (m0 >> 1) : m0;
             h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
+            const h16* rrow = res_in_copy ? res + (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + m0o : nullptr;
             for (int idx = tid; idx < 64 * nvec; idx += 256) {
                 const int pc = idx / nvec, cv = idx - pc * nvec;
                 const int wq = pc / PH, rr = pc - wq * PH;
                 const int t = t0 + (wq * NF + pass * NH + (rr >> 4)) * 16 + (rr & 15);
-                if (t < T && m0o + cv * 8 < Mout) *(h16x8*)(drow + (int64_t)t * d.d_t + cv * 8) = *(const h16x8*)&Cs[pc * CS + cv * 8];
+                if (t < T && m0o + cv * 8 < Mout) {
+                    h16x8 v = *(const h16x8*)&Cs[pc * CS + cv * 8];
+                    if (rrow) {
+                        const h16x8 r8 = *(const h16x8*)(rrow + (int64_t)t * d.r_t + cv * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + (float)r8[e]);
+                    }
+                    *(h16x8*)(drow + (int64_t)t * d.d_t + cv * 8) = v;
+                }
             }
             __syncthreads();
+        }
+    }
+    if (smode == 1 || smode == 2) {
+        // fold fragment rows of one group, reduce across the wave in fp64, one atomic pair per (wave, group)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int base_i = m0 + (wm * MF + i) * 16;
+            const int grp = base_i / gs;
+            if (i + 1 < MF && (base_i + 16) / gs == grp && base_i + 16 < M) {
+                st_s1[i + 1] += st_s1[i];
+                st_s2[i + 1] += st_s2[i];
+                continue;
+            }
+            if (base_i >= M) continue;
+            const double a = aero_wave_sum((double)st_s1[i]);
+            const double c = aero_wave_sum((double)st_s2[i]);
+            if (lane == 0) {
+                atomicAdd(d.stats + (sitem + grp) * 2, a);
+                atomicAdd(d.stats + (sitem + grp) * 2 + 1, c);
+            }
         }
     }
 }
@@ -595,7 +668,7 @@ static int aero_conv_pick_bm(int M, int Mpad) {
 }
 
 static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const char** err) {
-    if (!d || !d->weight || !d->dst) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
+    if (!d || !d->weight || (!d->dst && d->stat_mode != 2)) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
     if (d->ntaps < 1 || d->ntaps > 9) { *err = "conv: ntaps must be 1..9"; return AERO_ERR_ARG; }
     if (d->C0 < 0 || d->C1 < 0 || d->C0 + d->C1 <= 0 || d->M <= 0) { *err = "conv: bad channel counts"; return AERO_ERR_ARG; }
     if (d->C1 > 0 && !d->src1) { *err = "conv: src1 NULL with C1>0"; return AERO_ERR_ARG; }
@@ -603,6 +676,15 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     if (d->fstride < 1 || d->B < 1 || d->Fout < 1 || d->T < 1) { *err = "conv: bad geometry"; return AERO_ERR_ARG; }
     if (d->act == AERO_ACT_GLU && (d->M & 1)) { *err = "conv: GLU needs even M"; return AERO_ERR_ARG; }
     if (d->act < 0 || d->act > AERO_ACT_GLU) { *err = "conv: unsupported act"; return AERO_ERR_UNSUPPORTED; }
+    if (d->stat_mode < 0 || d->stat_mode > 3) { *err = "conv: bad stat_mode"; return AERO_ERR_ARG; }
+    if (d->stat_mode) {
+        if (!d->stats || d->stat_G < 1 || d->M % d->stat_G) { *err = "conv: statistics need stats, stat_G | M"; return AERO_ERR_ARG; }
+        if (d->stat_G > 1 && ((d->M / d->stat_G) % 16 || d->act == AERO_ACT_GLU)) { *err = "conv: grouped statistics need 16-row aligned groups and un-interleaved rows"; return AERO_ERR_UNSUPPORTED; }
+        if ((d->stat_mode == 1 || d->stat_mode == 2) && d->act != AERO_ACT_NONE) { *err = "conv: statistics are taken before the activation (act must be NONE)"; return AERO_ERR_ARG; }
+        if (d->stat_mode == 3 && !(d->stat_count >= 1.0)) { *err = "conv: stat_count"; return AERO_ERR_ARG; }
+        if (d->stat_mode == 3 && ((d->gamma == nullptr) != (d->beta == nullptr))) { *err = "conv: gamma/beta"; return AERO_ERR_ARG; }
+        if (d->dst_f_off != 0 || d->dst_F != d->Fout) { *err = "conv: statistics and frequency trim do not combine"; return AERO_ERR_UNSUPPORTED; }
+    }
     AeroConvK p;
     p.d = *d;
     p.Cp = (d->C0 + d->C1 + 31) / 32 * 32;
@@ -627,6 +709,8 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     // LDS-staged (transposed) epilogue: fp16 output whose rows can take aligned 16-byte channel vectors
     p.staged = !d->dst_f32 && (Mout % 8 == 0) && (d->d_b % 8 == 0) && (d->d_f % 8 == 0) && (d->d_t % 8 == 0) &&
                (((uintptr_t)d->dst & 15) == 0) && (bm % 16 == 0);
+    if (d->res && ((d->r_b % 8) || (d->r_f % 8) || (d->r_t % 8) || ((uintptr_t)d->res & 15))) p.staged = 0;
+    if (d->stat_mode == 2) p.staged = 0;
     const long nwg = (long)d->B * d->Fout * p.ntt * p.nmt;
     if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);

@@ -79,13 +79,15 @@ class Ops:
 
     # -- convolution family --------------------------------------------------------------------
     def conv(self, spec, src0, src1, B, Fin, Fout, T, dst=None, dst_f32=False, dst_f_off=0, dst_F=None, res=None,
-             post_add=None, batch_scale=None, batch_shift=None, act=None, dst_strides=None, src0_strides=None):
+             post_add=None, batch_scale=None, batch_shift=None, act=None, dst_strides=None, src0_strides=None,
+             stat=None):
         """src0/src1: channels-last [B,Fin,T,C] tensors (src0 may be None = zeros).  Returns dst."""
         dev = spec.weight.device
         act = spec.act if act is None else act
         Mout = spec.M // 2 if act == ACT_GLU else spec.M
         dst_F = Fout if dst_F is None else dst_F
-        if dst is None:
+        no_store = stat is not None and stat['mode'] == 2
+        if dst is None and not no_store:
             dst = torch.empty(B, dst_F, T, Mout, dtype=torch.float32 if dst_f32 else torch.float16, device=dev)
         d = _lib.ConvDesc()
         d.src0 = _ptr(src0)
@@ -99,8 +101,13 @@ class Ops:
         d.weight = _ptr(spec.weight)
         d.bias = _ptr(spec.bias)
         d.dst = _ptr(dst)
-        d.d_b, d.d_f, d.d_t = dst_strides if dst_strides else _strides4(dst)
-        d.dst_f32 = int(dst.dtype == torch.float32)
+        if dst is not None:
+            d.d_b, d.d_f, d.d_t = dst_strides if dst_strides else _strides4(dst)
+        d.dst_f32 = int(dst is not None and dst.dtype == torch.float32)
+        if stat is not None:
+            d.stats, d.stat_count = _ptr(stat['stats']), float(stat.get('count', 0.0))
+            d.stat_mode, d.stat_G, d.stat_per_row, d.stat_eps = stat['mode'], stat['G'], int(stat['per_row']), stat.get('eps', 1e-5)
+            d.gamma, d.beta, d.layer_scale = _ptr(stat.get('gamma')), _ptr(stat.get('beta')), _ptr(stat.get('layer_scale'))
         d.dst_f_off, d.dst_F = dst_f_off, dst_F
         d.B, d.Fin, d.Fout, d.T, d.M = B, Fin, Fout, T, spec.M
         d.transposed, d.fstride = spec.transposed, spec.fstride
@@ -113,8 +120,9 @@ class Ops:
             d.r_b, d.r_f, d.r_t = _strides4(res)
         d.post_add = _ptr(post_add)
         d.batch_scale, d.batch_shift = _ptr(batch_scale), _ptr(batch_shift)
+        ref_t = dst if dst is not None else spec.weight
         if self.prof is None:
-            self.lib.call('aero_conv_fwd', C.byref(d), self.stream(dst))
+            self.lib.call('aero_conv_fwd', C.byref(d), self.stream(ref_t))
         else:
             kid = self.lib.cdll.aero_conv_kernel_id(C.byref(d))
             tiles = {128: '4,2', 96: '3,2', 64: '4,1', 48: '3,1', 32: '2,1', 16: '1,1'}
@@ -128,26 +136,35 @@ class Ops:
             pos = B * dst_F * T
             cin_exec = spec.C1 + (spec.C0 if src0 is not None else 0)
             flops = 2.0 * pos * spec.M * len(spec.df) * cin_exec       # executed (NULL source skipped)
-            nbytes = pos * (Mout * dst.element_size()) + B * Fin * T * cin_exec * 2
-            self._call('aero_conv_fwd', kname, flops, nbytes, C.byref(d), self.stream(dst))
+            nbytes = pos * (Mout * (dst.element_size() if dst is not None else 0)) + B * Fin * T * cin_exec * 2
+            self._call('aero_conv_fwd', kname, flops, nbytes, C.byref(d), self.stream(ref_t))
         return dst
+
+    @staticmethod
+    def new_stats(B, F, G, per_row, device):
+        return torch.zeros((B * F if per_row else B) * G, 2, dtype=torch.float64, device=device)
+
+    @staticmethod
+    def can_fuse_stats(M, G):
+        """the conv epilogue can accumulate GroupNorm statistics when a group is 16-row aligned (or there is one group)"""
+        return G == 1 or (M % G == 0 and (M // G) % 16 == 0)
 
     # -- GroupNorm + activation ----------------------------------------------------------------
     def norm_act(self, x, G, per_row, gamma, beta, act, snake_a=None, layer_scale=None, res=None, normalize=True,
-                 f_lo=0, f_cnt=None, eps=1e-5, dst=None):
+                 f_lo=0, f_cnt=None, eps=1e-5, dst=None, stats=None):
         """x [B,F,T,C] fp16.  Statistics over all F rows; output only rows [f_lo, f_lo+f_cnt)."""
         B, F, T, Cc = x.shape
         d = _lib.NormDesc()
         d.src = _ptr(x)
         d.s_b, d.s_f, d.s_t = _strides4(x)
         d.B, d.F, d.T, d.C, d.G, d.per_row, d.eps = B, F, T, Cc, G, int(per_row), eps
-        stats = None
         if normalize:
-            items = B * F if per_row else B
-            stats = torch.zeros(items * G, 2, dtype=torch.float64, device=x.device)
-            d.stats = _ptr(stats)
             d.stat_count = float((1 if per_row else F) * T * (Cc // G))
-            self._call('aero_norm_stats', 'aero_norm_stats_kernel', 0, x.numel() * 2, C.byref(d), self.stream(x))
+            if stats is None:                       # not already accumulated by the producing conv's epilogue
+                stats = self.new_stats(B, F, G, per_row, x.device)
+                d.stats = _ptr(stats)
+                self._call('aero_norm_stats', 'aero_norm_stats_kernel', 0, x.numel() * 2, C.byref(d), self.stream(x))
+            d.stats = _ptr(stats)
         f_cnt = F if f_cnt is None else f_cnt
         assert not (per_row and (f_lo or f_cnt != F))
         Cout = Cc // 2 if act == ACT_GLU else Cc
@@ -215,23 +232,6 @@ def _ftb_first(self, xn, u, gate, P):
 Ops.ftb_first = _ftb_first
 
 
-def _dconv_tail(self, h, P, res, R, T, eps=1e-5):
-    """h fp16 [R, T, h_pitch] -> res + layer_scale * GLU(GN(conv1x1(h)))  (aero_dconv_tail_fwd)."""
-    Cc = P['C']
-    out = torch.empty(R, T, Cc, dtype=torch.float16, device=h.device)
-    d = _lib.DconvTailDesc()
-    d.h, d.weight, d.bias = _ptr(h), _ptr(P['weight']), _ptr(P['bias'])
-    d.gamma, d.beta, d.layer_scale = _ptr(P['gamma']), _ptr(P['beta']), _ptr(P['scale'])
-    d.res, d.dst = _ptr(res), _ptr(out)
-    d.R, d.T, d.C, d.h_pitch, d.eps = R, T, Cc, h.shape[-1], eps
-    self._call('aero_dconv_tail_fwd', 'aero_dconv_tail_kernel', 2 * 2.0 * R * T * 2 * Cc * h.shape[-1],
-               R * T * (h.shape[-1] * 2 + 4 * Cc), C.byref(d), self.stream(out))
-    return out
-
-
-Ops.dconv_tail = _dconv_tail
-
-
 def _hann_padded(win_length, n_fft, device):
     w = torch.zeros(n_fft, dtype=torch.float32)
     left = (n_fft - win_length) // 2
@@ -247,7 +247,8 @@ class HipEngine:
         self._key = None
         self._tables = {}
         self.streams = int(os.environ.get('AERO_STREAMS', '1'))   # sub-batches in flight on separate HIP streams
-        self.fuse_dconv_tail = True        # DConv conv2+GroupNorm+GLU+LayerScale+skip in one kernel (k_dconv.h)
+        self.fuse_dconv_tail = True        # DConv tail as a recompute pair of conv launches: the 2C-channel tensor never reaches HBM
+        self.fuse_stats = True             # GroupNorm statistics accumulated in the producing conv's epilogue
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
 
     # ------------------------------------------------------------------ weights
@@ -384,19 +385,12 @@ class HipEngine:
             L['conv2'] = mk(w, sd[f'{q}.conv2.0.bias'], w.shape[-1], 0, df, dt, device)
             L['gn2'] = (sd[f'{q}.conv2.1.weight'].to(device), sd[f'{q}.conv2.1.bias'].to(device)) if dc.norm else None
             L['scale'] = sd[f'{q}.conv2.3.scale'].to(device).contiguous()
-            # fused tail (aero_dconv_tail_fwd): conv2 + GroupNorm(1) + GLU + LayerScale + residual in one kernel
-            hid, Cc = dc.hidden, dc.channels
-            hp = pack._round_up(hid, 8)
-            if (2 * Cc) % 32 == 0 and hp <= 128:
-                w2 = pack.glu_interleave(sd[f'{q}.conv2.0.weight'][:, :, 0])                 # [2C, hid]
-                img = torch.zeros(pack._round_up(2 * Cc, 128), pack._round_up(hp, 32))
-                img[:2 * Cc, :hid] = w2
-                f32 = lambda t: t.float().to(device).contiguous()                        # noqa: E731
-                L['tail'] = dict(C=Cc, h_pitch=hp, weight=img.to(device=device, dtype=torch.float16).contiguous(),
-                                 bias=f32(pack.glu_interleave(sd[f'{q}.conv2.0.bias'])),
-                                 gamma=f32(pack.glu_interleave(sd[f'{q}.conv2.1.weight'])) if dc.norm else None,
-                                 beta=f32(pack.glu_interleave(sd[f'{q}.conv2.1.bias'])) if dc.norm else None,
-                                 scale=L['scale'])
+            # recompute pair for the tail (conv2 -> GroupNorm(1) -> GLU -> LayerScale -> +skip): rows GLU-interleaved
+            w, df, dt = pack.conv1d_taps(sd[f'{q}.conv2.0.weight'], 1, 0)
+            L['conv2_glu'] = mk(w, sd[f'{q}.conv2.0.bias'], w.shape[-1], 0, df, dt, device, act=ACT_GLU)
+            if dc.norm:
+                L['gn2_glu'] = (pack.glu_interleave(sd[f'{q}.conv2.1.weight']).to(device).contiguous(),
+                                pack.glu_interleave(sd[f'{q}.conv2.1.bias']).to(device).contiguous())
             out.append(L)
         return out
 
@@ -551,9 +545,12 @@ class HipEngine:
     def _encode_tail(self, i, enc, L, x, B, Fq, T):
         ops = self.ops
         Fo = (Fq + 2 * enc.pad - enc.kernel_size) // enc.stride + 1
-        y = ops.conv(L['conv'], x, None, B, Fq, Fo, T)
         if enc.norm:
-            y = ops.norm_act(y, enc.norm_groups, False, L['norm1'][0], L['norm1'][1], ACT_GELU)
+            st = self._stats_for(L['conv'].M, enc.norm_groups, B, Fo, x.device)
+            y = ops.conv(L['conv'], x, None, B, Fq, Fo, T, stat=self._acc(st, enc.norm_groups))
+            y = ops.norm_act(y, enc.norm_groups, False, L['norm1'][0], L['norm1'][1], ACT_GELU, stats=st)
+        else:
+            y = ops.conv(L['conv'], x, None, B, Fq, Fo, T)
         if 'dconv' in L:
             y = self._dconv(enc.dconv, L['dconv'], y, B, Fo, T)
         if 'rewrite' in L:
@@ -561,8 +558,9 @@ class HipEngine:
             if enc.norm:
                 if emb is not None:
                     raise NotImplementedError('GroupNorm on encoder 0 together with the frequency embedding')
-                r = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T)
-                y = ops.norm_act(r, enc.norm_groups, False, L['norm2'][0], L['norm2'][1], ACT_GLU)
+                st = self._stats_for(L['rewrite'].M, enc.norm_groups, B, Fo, y.device)
+                r = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, stat=self._acc(st, enc.norm_groups))
+                y = ops.norm_act(r, enc.norm_groups, False, L['norm2'][0], L['norm2'][1], ACT_GLU, stats=st)
             else:
                 y = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, post_add=emb)
         elif i == 0 and 'freq_emb' in self.P:
@@ -573,19 +571,15 @@ class HipEngine:
         ops = self.ops
         act = {'snake': ACT_SNAKE, 'gelu': ACT_GELU}.get(dc.act_func, ACT_RELU)
         for L in layers:
-            h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T)
             g1 = L['gn1']
-            fused_tail = 'tail' in L and self.fuse_dconv_tail and x.is_contiguous()
-            hdst = hfull = None
-            if fused_tail and L['tail']['h_pitch'] != h.shape[-1] and 'lstm' not in L and 'attn_qkvd' not in L:
-                # hidden size not a multiple of 8 (12 at encoder 0): write the activation straight into a zero-padded
-                # 16-byte-pitch buffer so the fused tail can stream it with aligned 16-byte copies
-                hfull = torch.zeros(B, Fo, T, L['tail']['h_pitch'], dtype=torch.float16, device=h.device)
-                hdst = hfull[..., :h.shape[-1]]
+            st1 = None
+            if g1 is not None and self.fuse_stats:
+                st1 = ops.new_stats(B, Fo, 1, True, x.device)
+                h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T, stat=dict(mode=1, stats=st1, G=1, per_row=True))
+            else:
+                h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T)
             h = ops.norm_act(h, 1, True, g1[0] if g1 else None, g1[1] if g1 else None, act,
-                             snake_a=L.get('snake_a'), normalize=g1 is not None, dst=hdst)
-            if hfull is not None:
-                h = hfull
+                             snake_a=L.get('snake_a'), normalize=g1 is not None, stats=st1)
             if 'lstm' in L:
                 h = self._blstm(dc, L, h, B, Fo, T)
             if 'attn_qkvd' in L:
@@ -593,20 +587,30 @@ class HipEngine:
                 qkvd = ops.conv(L['attn_qkvd'], h, None, B, Fo, Fo, T)
                 att = ops.localstate(qkvd, B * Fo, T, dc.hidden, heads, ndecay)
                 h = ops.conv(L['attn_proj'], att.view(B, Fo, T, dc.hidden), None, B, Fo, Fo, T, res=h)
-            if fused_tail:
-                tp = L['tail']
-                if h.shape[-1] != tp['h_pitch']:                     # hidden size not a multiple of 8: zero-padded copy
-                    hpad = torch.zeros(B, Fo, T, tp['h_pitch'], dtype=torch.float16, device=h.device)
-                    hpad[..., :h.shape[-1]] = h
-                    h = hpad
-                x = ops.dconv_tail(h.contiguous().view(B * Fo, T, tp['h_pitch']), tp, x.view(B * Fo, T, -1),
-                                   B * Fo, T).view(B, Fo, T, -1)
+            g2 = L['gn2']
+            if g2 is not None and self.fuse_dconv_tail:
+                # pass 0: statistics of conv2(h) only (nothing stored); pass 1: recompute, normalise, GLU, scale, + skip
+                st2 = ops.new_stats(B, Fo, 1, True, x.device)
+                c2 = L['conv2_glu']
+                ops.conv(c2, h, None, B, Fo, Fo, T, act=ACT_NONE, stat=dict(mode=2, stats=st2, G=1, per_row=True))
+                x = ops.conv(c2, h, None, B, Fo, Fo, T, res=x,
+                             stat=dict(mode=3, stats=st2, G=1, per_row=True, count=float(T * c2.M),
+                                       gamma=L['gn2_glu'][0], beta=L['gn2_glu'][1], layer_scale=L['scale']))
                 continue
             g = ops.conv(L['conv2'], h, None, B, Fo, Fo, T)
-            g2 = L['gn2']
             x = ops.norm_act(g, 1, True, g2[0] if g2 else None, g2[1] if g2 else None, ACT_GLU,
                              layer_scale=L['scale'], res=x, normalize=g2 is not None)
         return x
+
+    def _stats_for(self, M, G, B, F, device):
+        """fp64 accumulators for a GroupNorm over [B, M, F, T] if the conv epilogue can fill them, else None"""
+        if self.fuse_stats and self.ops.can_fuse_stats(M, G):
+            return self.ops.new_stats(B, F, G, False, device)
+        return None
+
+    @staticmethod
+    def _acc(st, G):
+        return None if st is None else dict(mode=1, stats=st, G=G, per_row=False)
 
     def _blstm(self, dc, L, h, B, Fo, T):
         """BLSTM (modules.py:32-65): framing and stitching are index arithmetic inside the LSTM kernel."""
@@ -633,11 +637,12 @@ class HipEngine:
     def _decode(self, j, dec, L, x, skip, B, Fq, T, mean, std):
         ops = self.ops
         if 'rewrite' in L:
-            r = ops.conv(L['rewrite'], x, skip, B, Fq, Fq, T)
             if dec.norm:
-                y = ops.norm_act(r, dec.norm_groups, False, L['norm1'][0], L['norm1'][1], ACT_GLU)
+                st = self._stats_for(L['rewrite'].M, dec.norm_groups, B, Fq, skip.device)
+                r = ops.conv(L['rewrite'], x, skip, B, Fq, Fq, T, stat=self._acc(st, dec.norm_groups))
+                y = ops.norm_act(r, dec.norm_groups, False, L['norm1'][0], L['norm1'][1], ACT_GLU, stats=st)
             else:
-                y = r
+                y = ops.conv(L['rewrite'], x, skip, B, Fq, Fq, T)
         else:
             raise NotImplementedError('decoder without rewrite conv')
         Fu = (Fq - 1) * dec.stride + dec.kernel_size          # untrimmed rows of the transposed conv
@@ -645,9 +650,10 @@ class HipEngine:
         if dec.norm:
             if dec.last:
                 raise NotImplementedError('GroupNorm on the last decoder layer (norm_starts = 0)')
-            z = ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T)
+            st = self._stats_for(L['conv_tr'].M, dec.norm_groups, B, Fu, y.device)
+            z = ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T, stat=self._acc(st, dec.norm_groups))
             return ops.norm_act(z, dec.norm_groups, False, L['norm2'][0], L['norm2'][1],
-                                ACT_NONE if dec.last else ACT_GELU, f_lo=dec.pad, f_cnt=Ft)
+                                ACT_NONE if dec.last else ACT_GELU, f_lo=dec.pad, f_cnt=Ft, stats=st)
         if dec.last:
             # aero.py:497-498: x*std + mean fused into the last epilogue; fp32 [B,F0,T,2] == complex64 [B,1,F0,T]
             return ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T, dst_f32=True, dst_f_off=dec.pad, dst_F=Ft,

@@ -69,7 +69,7 @@ int aero_istft_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_
  *                     rewritten as fstride interleaved ordinary convolutions).
  * weight: fp16 [nwset][Mpad][ntaps*Cp], Cp = roundup(C0+C1,32), Mpad = roundup(M,128), zero padded.
  * src0 == NULL with C0 > 0 means "C0 channels of zeros" (first decoder input, aero.py:484).
- * Epilogue order: +bias, act (GLU pairs rows 2u,2u+1 -> channel u, Mout = M/2), +res, +post_add[fo][.],
+ * Epilogue order: +bias, [GroupNorm, see stat_mode], act (GLU pairs rows 2u,2u+1 -> channel u, Mout = M/2), +res, +post_add[fo][.],
  * per-b affine v*batch_scale[b]+batch_shift[b]; store fp16 or fp32 at row f = fo - dst_f_off when
  * 0 <= f < dst_F (the trim of aero.py:207-209). */
 typedef struct {
@@ -86,6 +86,15 @@ typedef struct {
     const void* res; int64_t r_b, r_f, r_t;
     const float* post_add;
     const float* batch_scale; const float* batch_shift;
+    /* GroupNorm fused into the epilogue (all optional; stat_mode 0 = off).  Statistics of v = conv + bias per
+     * (item, group): item = b (stat_per_row 0) or the (b, fo) row (1); group = m / (M/stat_G).  stats: fp64
+     * [items*stat_G][2] sum / sum of squares, same format as aero_norm_stats (caller zeroes it).
+     *   1: accumulate, then the usual epilogue/store      2: accumulate only, nothing is stored
+     *   3: v <- (v-mean)*rstd*gamma[m]+beta[m] from stats / stat_count, then act; GLU output u is multiplied by
+     *      layer_scale[u] when given (DConv tail: modules.py:209-210,141,244 via a recompute pair of launches). */
+    double* stats; double stat_count;
+    int32_t stat_mode, stat_G, stat_per_row; float stat_eps;
+    const float* gamma; const float* beta; const float* layer_scale;
 } aero_conv_desc;
 int aero_conv_fwd(const aero_conv_desc* d, void* stream);
 /* rows per block (16/32/48/64/128) of the kernel instantiation aero_conv_fwd picks for M output channels */
@@ -171,21 +180,6 @@ typedef struct {
     int32_t B, F, T, C;
 } aero_ftb_first_desc;
 int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream);
-
-/* K9+K7+K8 fused -- tail of a DConv residual layer (modules.py:209-210,141,243-244):
- *   dst = res + layer_scale * GLU( GroupNorm(1, 2C)( conv1x1(h) ) )     statistics per (b, f) row over (2C, T)
- * h fp16 [R][T][h_pitch] (h_pitch multiple of 8; channels beyond the hidden size must be zero), weight fp16
- * [roundup(2C,128)][roundup(h_pitch,32)] with GLU-interleaved rows (2u = value u, 2u+1 = gate u) zero padded; bias,
- * gamma, beta fp32 [2C] in the same interleaved order (gamma == NULL: no normalisation); layer_scale fp32 [C];
- * res, dst fp16 [R][T][C].  The 2C-channel intermediate never reaches HBM (two-pass recompute, k_dconv.h). */
-typedef struct {
-    const void* h; const void* weight;
-    const float* bias; const float* gamma; const float* beta; const float* layer_scale;
-    const void* res; void* dst;
-    int32_t R, T, C, h_pitch;
-    float eps;
-} aero_dconv_tail_desc;
-int aero_dconv_tail_fwd(const aero_dconv_tail_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

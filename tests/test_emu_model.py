@@ -33,12 +33,14 @@ def test_tiny_model_golden(emu, meta, L):
     assert rel_l2(y, io[f'y_{L}']) < 5e-3
 
 
-@pytest.mark.parametrize('fuse', [True, False])
-def test_small_model_golden_dconv_tail_paths(emu, meta, fuse):
-    """DConv conv2 + GroupNorm + GLU + LayerScale + skip as ONE kernel (aero_dconv_tail_fwd) or as conv / stats / apply."""
+@pytest.mark.parametrize('fuse', [(True, True), (False, True), (False, False)])
+def test_small_model_golden_groupnorm_fusion_paths(emu, meta, fuse):
+    """GroupNorm statistics accumulated in the conv epilogue (stat_mode 1) and the DConv tail as a recompute pair
+    (stat_mode 2 + 3: conv2 -> GN -> GLU -> LayerScale -> +skip without materialising the 2C-channel tensor) versus the
+    separate aero_norm_stats / aero_norm_apply kernels: all must reproduce the reference's golden output."""
     m = build_model(meta, 'small')
     eng = HipEngine(m, lib=emu)
-    eng.fuse_dconv_tail = fuse
+    eng.fuse_dconv_tail, eng.fuse_stats = fuse
     object.__setattr__(m, '_engine', eng)
     io = load_npz('small_io.npz')
     with torch.no_grad():
