@@ -33,7 +33,7 @@ struct AeroConvK {
 //   then act (GLU pairs rows 2u,2u+1; optional LayerScale), residual, frequency embedding, per-item affine, store.
 // Staged form (fp16 output, 8-channel aligned): the tile is transposed through LDS in two passes of 64 positions so
 // that every global store (and residual load) is a full 16-byte channel vector (256-byte runs per position).
-template <int MF, int WM>
+template <int MF, int WM, bool STATS>
 static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f32x4 (&acc)[MF][8 / (4 / WM)], h16* Cs, int b, int fo,
                                                           int fdst, int m0, int t0) {
     constexpr int WN = 4 / WM;
@@ -54,7 +54,7 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
     const bool res_in_copy = p.staged && res != nullptr;       // residual added with coalesced 16-byte loads
     const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
     const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
-    const int smode = d.stat_mode;
+    const int smode = STATS ? d.stat_mode : 0;               // compile-time off: no register/code cost for plain convs
     const int gs = smode ? M / d.stat_G : M;                    // rows per statistics group
     const int64_t sitem = smode ? (int64_t)(d.stat_per_row ? b * d.Fout + fo : b) * d.stat_G : 0;
     float st_mean[MF], st_rstd[MF], st_s1[MF], st_s2[MF];
@@ -201,7 +201,7 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
     }
 }
 
-template <int MF, int WM>
+template <int MF, int WM, bool STATS>
 __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
     constexpr int WN = 4 / WM;
     constexpr int NF = 8 / WN;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
         __syncthreads();
     }
 
-    aero_conv_epilogue<MF, WM>(p, acc, Cs, b, fo, fdst, m0, t0);
+    aero_conv_epilogue<MF, WM, STATS>(p, acc, Cs, b, fo, fdst, m0, t0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -355,7 +355,7 @@ static __device__ __forceinline__ int aero_tile_swz(int row) {
     return KC == 32 ? ((0 - (row >> 2)) & 3) : ((row >> 1) & 7);
 }
 
-template <int MF, int WM, int KC>
+template <int MF, int WM, int KC, bool STATS>
 __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
     constexpr int WN = 4 / WM;
     constexpr int NF = 8 / WN;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
         }
     }
     __syncthreads();                           // all waves done with the operand stages: smem becomes the output tile
-    aero_conv_epilogue<MF, WM>(p, acc, Cs, b, fo, fdst, m0, t0);
+    aero_conv_epilogue<MF, WM, STATS>(p, acc, Cs, b, fo, fdst, m0, t0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void aero_conv3x3_kernel(AeroConvK p) {
         }
         __syncthreads();
     }
-    aero_conv_epilogue<MF, WM>(p, acc, Cs, b, fo, fdst, m0, t0);
+    aero_conv_epilogue<MF, WM, false>(p, acc, Cs, b, fo, fdst, m0, t0);
 }
 
 // taps on a regular (frequency x time) grid?  fills the grid parameters of AeroConvK
@@ -667,6 +667,17 @@ static int aero_conv_pick_bm(int M, int Mpad) {
     return best;
 }
 
+#define AERO_CONV_GO(K, A, B, C_)                                                          \
+    do {                                                                                   \
+        if (d->stat_mode) AERO_LAUNCH((K<A, B, C_, true>), grid, block, stream, p);        \
+        else AERO_LAUNCH((K<A, B, C_, false>), grid, block, stream, p);                    \
+    } while (0)
+#define AERO_CONV_GO2(K, A, B)                                                             \
+    do {                                                                                   \
+        if (d->stat_mode) AERO_LAUNCH((K<A, B, true>), grid, block, stream, p);            \
+        else AERO_LAUNCH((K<A, B, false>), grid, block, stream, p);                        \
+    } while (0)
+
 static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const char** err) {
     if (!d || !d->weight || (!d->dst && d->stat_mode != 2)) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
     if (d->ntaps < 1 || d->ntaps > 9) { *err = "conv: ntaps must be 1..9"; return AERO_ERR_ARG; }
@@ -714,7 +725,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     const long nwg = (long)d->B * d->Fout * p.ntt * p.nmt;
     if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);
-    if (bm == 128 && p.vec_in && !p.glds && aero_conv_is_3x3(d)) {
+    if (bm == 128 && p.vec_in && !p.glds && !d->stat_mode && aero_conv_is_3x3(d)) {
         AERO_LAUNCH(aero_conv3x3_kernel, grid, block, stream, p);
         return AERO_OK;
     }
@@ -726,32 +737,32 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         const bool k64 = mode == 2 ? k64_ok : (mode == 1 ? false : (k64_ok && bm >= 96 && p.Ktot >= 1024));
         if (k64) {
             switch (bm) {
-                case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2, 64>), grid, block, stream, p); break;
-                case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2, 64>), grid, block, stream, p); break;
-                case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1, 64>), grid, block, stream, p); break;
-                case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1, 64>), grid, block, stream, p); break;
-                case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1, 64>), grid, block, stream, p); break;
-                default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1, 64>), grid, block, stream, p); break;
+                case 128: AERO_CONV_GO(aero_conv_glds_kernel, 4, 2, 64); break;
+                case 96: AERO_CONV_GO(aero_conv_glds_kernel, 3, 2, 64); break;
+                case 64: AERO_CONV_GO(aero_conv_glds_kernel, 4, 1, 64); break;
+                case 48: AERO_CONV_GO(aero_conv_glds_kernel, 3, 1, 64); break;
+                case 32: AERO_CONV_GO(aero_conv_glds_kernel, 2, 1, 64); break;
+                default: AERO_CONV_GO(aero_conv_glds_kernel, 1, 1, 64); break;
             }
         } else {
             switch (bm) {
-                case 128: AERO_LAUNCH((aero_conv_glds_kernel<4, 2, 32>), grid, block, stream, p); break;
-                case 96: AERO_LAUNCH((aero_conv_glds_kernel<3, 2, 32>), grid, block, stream, p); break;
-                case 64: AERO_LAUNCH((aero_conv_glds_kernel<4, 1, 32>), grid, block, stream, p); break;
-                case 48: AERO_LAUNCH((aero_conv_glds_kernel<3, 1, 32>), grid, block, stream, p); break;
-                case 32: AERO_LAUNCH((aero_conv_glds_kernel<2, 1, 32>), grid, block, stream, p); break;
-                default: AERO_LAUNCH((aero_conv_glds_kernel<1, 1, 32>), grid, block, stream, p); break;
+                case 128: AERO_CONV_GO(aero_conv_glds_kernel, 4, 2, 32); break;
+                case 96: AERO_CONV_GO(aero_conv_glds_kernel, 3, 2, 32); break;
+                case 64: AERO_CONV_GO(aero_conv_glds_kernel, 4, 1, 32); break;
+                case 48: AERO_CONV_GO(aero_conv_glds_kernel, 3, 1, 32); break;
+                case 32: AERO_CONV_GO(aero_conv_glds_kernel, 2, 1, 32); break;
+                default: AERO_CONV_GO(aero_conv_glds_kernel, 1, 1, 32); break;
             }
         }
         return AERO_OK;
     }
     switch (bm) {
-        case 128: AERO_LAUNCH((aero_conv_kernel<4, 2>), grid, block, stream, p); break;
-        case 96: AERO_LAUNCH((aero_conv_kernel<3, 2>), grid, block, stream, p); break;
-        case 64: AERO_LAUNCH((aero_conv_kernel<4, 1>), grid, block, stream, p); break;
-        case 48: AERO_LAUNCH((aero_conv_kernel<3, 1>), grid, block, stream, p); break;
-        case 32: AERO_LAUNCH((aero_conv_kernel<2, 1>), grid, block, stream, p); break;
-        default: AERO_LAUNCH((aero_conv_kernel<1, 1>), grid, block, stream, p); break;
+        case 128: AERO_CONV_GO2(aero_conv_kernel, 4, 2); break;
+        case 96: AERO_CONV_GO2(aero_conv_kernel, 3, 2); break;
+        case 64: AERO_CONV_GO2(aero_conv_kernel, 4, 1); break;
+        case 48: AERO_CONV_GO2(aero_conv_kernel, 3, 1); break;
+        case 32: AERO_CONV_GO2(aero_conv_kernel, 2, 1); break;
+        default: AERO_CONV_GO2(aero_conv_kernel, 1, 1); break;
     }
     return AERO_OK;
 }

