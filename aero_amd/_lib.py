@@ -44,7 +44,8 @@ class NormDesc(C.Structure):
 class LstmDesc(C.Structure):
     _fields_ = [('xproj', vp), ('xbias', vp), ('whh', vp), ('out', vp),
                 ('H', i32), ('nseq', i32), ('W', i32), ('in_mode', i32), ('out_mode', i32),
-                ('nframes', i32), ('S', i32), ('T', i32)]
+                ('nframes', i32), ('S', i32), ('T', i32),
+                ('x', vp), ('wih', vp), ('bias', fp), ('in_ch', i32), ('x_pitch', i32)]
 
 
 class AttnDesc(C.Structure):
@@ -76,6 +77,7 @@ _PROTOS = {
     'aero_norm_apply': (i32, [C.POINTER(NormDesc), vp]),
     'aero_lstm_fwd': (i32, [C.POINTER(LstmDesc), vp]),
     'aero_lstm_geometry': (i32, [i32, C.POINTER(i32), C.POINTER(i32)]),
+    'aero_lstm_geometry_in': (i32, [i32, i32, C.POINTER(i32)]),
     'aero_localstate_fwd': (i32, [C.POINTER(AttnDesc), vp]),
     'aero_freqfc_fwd': (i32, [C.POINTER(FreqFcDesc), vp]),
     'aero_ftb_first_fwd': (i32, [C.POINTER(FtbFirstDesc), vp]),
@@ -114,6 +116,12 @@ class Lib:
 
     def call(self, name, *args):
         self.check(getattr(self.cdll, name)(*args), name)
+
+    def lstm_geometry_in(self, H, in_ch):
+        """padded W_ih column count for the fused input projection, or None if (H, in_ch) has no instantiation"""
+        kpi = i32(0)
+        rc = self.cdll.aero_lstm_geometry_in(H, in_ch, C.byref(kpi))
+        return kpi.value if rc == 0 else None
 
     def lstm_geometry(self, H):
         mp, kp = i32(0), i32(0)

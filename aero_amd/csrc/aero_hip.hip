@@ -102,6 +102,13 @@ int aero_lstm_geometry(int32_t H, int32_t* MP, int32_t* KP) {
     return AERO_OK;
 }
 
+int aero_lstm_geometry_in(int32_t H, int32_t in_ch, int32_t* KPI) {
+    const int kti = aero_lstm_kti(H, in_ch);
+    if (kti <= 0) return aero_fail(AERO_ERR_UNSUPPORTED, "lstm: no fused-projection instantiation for this (H, in_ch)");
+    if (KPI) *KPI = 32 * kti;
+    return AERO_OK;
+}
+
 int aero_lstm_fwd(const aero_lstm_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_lstm_launch(d, (hipStream_t)stream, &err);

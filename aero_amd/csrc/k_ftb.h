@@ -168,20 +168,34 @@ __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
     const h16* un = (const h16*)d.u + ((int64_t)row * T) * 2;
     const h16* gate = (const h16*)d.gate + (int64_t)b * T * C;
     const float rsf = d.rs[f];
-    for (int v = tid; v < KT * BN * 4; v += 256) {
-        const int kt = v / (BN * 4), rem = v - kt * (BN * 4);
-        const int pos = rem >> 2, q = rem & 3;
-        const int t = t0 + pos, c = kt * 32 + q * 8;
-        h16x8 o = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (t < T && c < C) {
-            const h16x2 uu = *(const h16x2*)(un + (int64_t)t * 2);
-            const float ur = (float)uu[0], ui = (float)uu[1];
-            const h16x8 g8 = *(const h16x8*)(gate + (int64_t)t * C + c);
+    // thread tid always builds the same 8-channel slot (q = tid & 3) of k-step kt = i: its per-channel coefficients
+    // (pre_conv weights / bias) are loaded once into registers, the per-position work is 3 FMA + 1 MUL per channel
+    const int qf = tid & 3;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                o[e] = (h16)((float)g8[e] * (d.p0[c + e] * ur + d.p1[c + e] * ui + d.pb[c + e] * rsf));
+    for (int kt = 0; kt < KT; ++kt) {
+        const int c = kt * 32 + qf * 8;
+        float k0[8], k1[8], kb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool in = c + e < C;
+            k0[e] = in ? d.p0[c + e] : 0.f;
+            k1[e] = in ? d.p1[c + e] : 0.f;
+            kb[e] = in ? d.pb[c + e] * rsf : 0.f;
         }
-        *(h16x8*)&Bs[kt * BN * 32 + aero_tile_off(pos, q)] = o;
+#pragma unroll
+        for (int i = 0; i < BN * 4 / 256; ++i) {
+            const int pos = (tid + 256 * i) >> 2;
+            const int t = t0 + pos;
+            h16x8 o = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (t < T && c < C) {
+                const h16x2 uu = *(const h16x2*)(un + (int64_t)t * 2);
+                const float ur = (float)uu[0], ui = (float)uu[1];
+                const h16x8 g8 = *(const h16x8*)(gate + (int64_t)t * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (h16)((float)g8[e] * (k0[e] * ur + k1[e] * ui + kb[e]));
+            }
+            *(h16x8*)&Bs[kt * BN * 32 + aero_tile_off(pos, qf)] = o;
+        }
     }
     __syncthreads();
     f32x4 acc[MF][2];
@@ -203,26 +217,34 @@ __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
         }
     }
     __syncthreads();                                           // operands consumed: smem becomes the output tile
+    float re[2], im[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int pos = (wave * 2 + n) * 16 + (lane & 15);
-        const int t = t0 + pos;
-        float re = 0.f, im = 0.f;
+        const int t = t0 + (wave * 2 + n) * 16 + (lane & 15);
+        re[n] = im[n] = 0.f;
         if (t < T) {
             const h16x2 vv = *(const h16x2*)(xn + (int64_t)t * 2);
-            re = (float)vv[0];
-            im = (float)vv[1];
+            re[n] = (float)vv[0];
+            im[n] = (float)vv[1];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = i * 16 + (lane >> 4) * 4;
+        float ar[4], ai[4], bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool in = m + r < C;
+            ar[r] = in ? d.a_re[m + r] : 0.f;
+            ai[r] = in ? d.a_im[m + r] : 0.f;
+            bb[r] = in ? d.bias[m + r] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int m = i * 16 + (lane >> 4) * 4;
+        for (int n = 0; n < 2; ++n) {
+            const int pos = (wave * 2 + n) * 16 + (lane & 15);
             h16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = 0.f;
-                if (m + r < C) x = fmaxf(acc[i][n][r] + d.a_re[m + r] * re + d.a_im[m + r] * im + d.bias[m + r], 0.f);
-                o[r] = (h16)x;
-            }
+            for (int r = 0; r < 4; ++r) o[r] = (h16)fmaxf(acc[i][n][r] + ar[r] * re[n] + ai[r] * im[n] + bb[r], 0.f);
             *(h16x4*)&Cs[pos * CS + m] = o;
         }
     }

@@ -33,7 +33,24 @@ static inline int aero_lstm_pick(int H, int* nw, int* tpw, int* kt) {
     return -1;
 }
 
-template <int NW, int TPW, int KT>
+// KTI = 0: the input projection arrives precomputed (xproj).  KTI > 0: the projection W_ih x_t is FUSED: W_ih lives in
+// VGPRs next to W_hh, x_t is loaded straight into MFMA B-fragments (16-byte loads, one step ahead) and the KTI extra
+// MFMAs per gate tile are issued before the barrier of the previous step -- the 8H-channel pre-activation tensor
+// (4x the size of x for layer 2) never exists in HBM and the separate projection launch disappears.
+// k-steps of the fused input projection for (H, in_ch), or -1 if that combination is not instantiated
+static inline int aero_lstm_kti(int H, int in_ch) {
+    int nw, tpw, kt;
+    if (aero_lstm_pick(H, &nw, &tpw, &kt)) return -1;
+    const int need = (in_ch + 31) / 32;
+    if (nw == 4 && tpw == 1) return need <= 1 ? 1 : -1;
+    if (nw == 4 && tpw == 2) return need <= 1 ? 1 : (need <= 2 ? 2 : -1);
+    if (nw == 6) return need <= 2 ? 2 : (need <= 3 ? 3 : -1);
+    if (tpw == 2) return need <= 2 ? 2 : (need <= 4 ? 4 : -1);
+    if (tpw == 3) return need <= 3 ? 3 : (need <= 6 ? 6 : -1);
+    return -1;
+}
+
+template <int NW, int TPW, int KT, int KTI>
 __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
     constexpr int KP = KT * 32;
     constexpr int MP = NW * TPW * 16;
@@ -56,6 +73,22 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
             wf[i][kt] = *(const h16x8*)(whh + (int64_t)((wave * TPW + i) * 16 + col) * KP + kt * 32 + q * 8);
+
+    constexpr int KI = KTI > 0 ? KTI : 1;
+    h16x8 wi[TPW][KI];
+    f32x4 bias4[TPW];
+    if (KTI > 0) {
+        const h16* wih = (const h16*)d.wih + (int64_t)dir * MP * (KTI * 32);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+#pragma unroll
+            for (int kt = 0; kt < KI; ++kt)
+                wi[i][kt] = *(const h16x8*)(wih + (int64_t)((wave * TPW + i) * 16 + col) * (KTI * 32) + kt * 32 + q * 8);
+            const int rr = (wave * TPW + i) * 16 + q * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[i][r] = (rr + r < H4) ? d.bias[dir * H4 + rr + r] : 0.f;
+        }
+    }
 
     for (int idx = tid; idx < 2 * 16 * KP; idx += NT) (&hbuf[0][0])[idx] = (h16)0;
 
@@ -85,6 +118,37 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
             if (seq_ok && rr < H4) v = *(const h16x4*)(rowp + dir * H4 + rr);
             xp[i] = v;
         }
+    };
+
+    // fused mode: x_tau as MFMA B-fragments (lane: sequence col, channels kt*32 + q*8 .. +7)
+    const h16* xin = (const h16*)d.x;
+    const bool xvec = (d.in_ch % 8 == 0) && (d.x_pitch % 8 == 0);
+    auto load_x = [&](int tau, h16x8* xb) {
+        const bool pad = ((d.in_mode == 1) && (t_first + tau >= d.T)) || !seq_ok;
+        const h16* rowp = xin + (in_base + tau) * d.x_pitch;
+#pragma unroll
+        for (int kt = 0; kt < KI; ++kt) {
+            const int c = kt * 32 + q * 8;
+            h16x8 v = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (!pad && c < d.in_ch) {
+                if (xvec) {
+                    v = *(const h16x8*)(rowp + c);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (c + e < d.in_ch) v[e] = rowp[c + e];
+                }
+            }
+            xb[kt] = v;
+        }
+    };
+    auto project = [&](const h16x8* xb, f32x4* ax) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) ax[i] = bias4[i];
+#pragma unroll
+        for (int kt = 0; kt < KI; ++kt)
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) ax[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wi[i][kt], xb[kt], ax[i], 0, 0, 0);
     };
 
     // per-thread slots of the cooperative output store: slot idx -> (local sequence sl, element e)
@@ -119,19 +183,29 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
     }
 
     h16x4 xp_cur[TPW], xp_nxt[TPW];
-    load_xp(dir ? W - 1 : 0, xp_cur);
+    h16x8 xb[KI];
+    f32x4 accx[TPW];                               // fused mode: bias + W_ih x_tau for the step about to run
+    if (KTI > 0) {
+        load_x(dir ? W - 1 : 0, xb);
+        project(xb, accx);
+        if (W > 1) load_x(dir ? W - 2 : 1, xb);
+    } else {
+        load_xp(dir ? W - 1 : 0, xp_cur);
+    }
     __syncthreads();
     int cur = 0;
     for (int step = 0; step < W; ++step) {
         const int tau = dir ? W - 1 - step : step;
-        if (step + 1 < W) load_xp(dir ? tau - 1 : tau + 1, xp_nxt);
+        if (KTI == 0 && step + 1 < W) load_xp(dir ? tau - 1 : tau + 1, xp_nxt);
         h16x8 bf[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) bf[kt] = *(const h16x8*)&hbuf[cur][col * KP + kt * 32 + q * 8];
         f32x4 accs[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
-            accs[i] = (f32x4){(float)xp_cur[i][0], (float)xp_cur[i][1], (float)xp_cur[i][2], (float)xp_cur[i][3]};
+        for (int i = 0; i < TPW; ++i) {
+            if (KTI > 0) accs[i] = accx[i];
+            else accs[i] = (f32x4){(float)xp_cur[i][0], (float)xp_cur[i][1], (float)xp_cur[i][2], (float)xp_cur[i][3]};
+        }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)       // k outer: TPW independent accumulator chains interleave on the matrix pipe
 #pragma unroll
@@ -145,6 +219,11 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
             c[i] = fg * c[i] + ig * gg;
             const float h = og * aero_tanh(c[i]);
             if (j < H) hbuf[cur ^ 1][col * KP + j] = (h16)h;
+        }
+        if (KTI > 0 && step + 1 < W) {
+            // projection of the NEXT step (independent of h): fills the matrix pipe while other waves reach the barrier
+            project(xb, accx);
+            if (step + 2 < W) load_x(dir ? tau - 2 : tau + 2, xb);
         }
         __syncthreads();
         // cooperative, coalesced store of h_tau for the block's 16 sequences (addresses precomputed above)
@@ -162,14 +241,23 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
             if (vecs) *(h16x8*)(out + opos * H2 + dir * H + st_e[it] * 8) = *(const h16x8*)&hbuf[cur ^ 1][st_sl[it] * KP + st_e[it] * 8];
             else out[opos * H2 + dir * H + st_e[it]] = hbuf[cur ^ 1][st_sl[it] * KP + st_e[it]];
         }
+        if (KTI == 0) {
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) xp_cur[i] = xp_nxt[i];
+            for (int i = 0; i < TPW; ++i) xp_cur[i] = xp_nxt[i];
+        }
         cur ^= 1;
     }
 }
 
 static int aero_lstm_launch(const aero_lstm_desc* d, hipStream_t stream, const char** err) {
-    if (!d || !d->xproj || !d->xbias || !d->whh || !d->out) { *err = "lstm: null pointer"; return AERO_ERR_ARG; }
+    if (!d || !d->whh || !d->out) { *err = "lstm: null pointer"; return AERO_ERR_ARG; }
+    const bool fused = d->wih != nullptr;
+    if (fused) {
+        if (!d->x || !d->bias || d->in_ch < 1 || d->x_pitch < d->in_ch) { *err = "lstm: fused projection needs x, bias, in_ch, x_pitch"; return AERO_ERR_ARG; }
+    } else if (!d->xproj || !d->xbias) {
+        *err = "lstm: null xproj/xbias";
+        return AERO_ERR_ARG;
+    }
     if (d->H < 1 || d->nseq < 1 || d->W < 1) { *err = "lstm: bad geometry"; return AERO_ERR_ARG; }
     if ((d->in_mode == 1 || d->out_mode == 1) && (d->nframes < 1 || d->S < 1 || d->T < 1 || d->nseq % d->nframes)) {
         *err = "lstm: bad framing";
@@ -177,16 +265,20 @@ static int aero_lstm_launch(const aero_lstm_desc* d, hipStream_t stream, const c
     }
     int nw, tpw, kt;
     if (aero_lstm_pick(d->H, &nw, &tpw, &kt)) { *err = "lstm: hidden size > 128 unsupported"; return AERO_ERR_UNSUPPORTED; }
+    const int kti = fused ? aero_lstm_kti(d->H, d->in_ch) : 0;
+    if (fused && kti <= 0) { *err = "lstm: no fused-projection instantiation for this (H, in_ch)"; return AERO_ERR_UNSUPPORTED; }
     AeroLstmK p;
     p.d = *d;
     p.MP = 16 * nw * tpw;
     p.KP = 32 * kt;
     dim3 grid((unsigned)((d->nseq + 15) / 16), 2), block((unsigned)(nw * 64));
-    if (nw == 4 && tpw == 1) AERO_LAUNCH((aero_lstm_kernel<4, 1, 1>), grid, block, stream, p);
-    else if (nw == 4 && tpw == 2) AERO_LAUNCH((aero_lstm_kernel<4, 2, 1>), grid, block, stream, p);
-    else if (nw == 6) AERO_LAUNCH((aero_lstm_kernel<6, 2, 2>), grid, block, stream, p);
-    else if (tpw == 2) AERO_LAUNCH((aero_lstm_kernel<8, 2, 2>), grid, block, stream, p);
-    else if (tpw == 3) AERO_LAUNCH((aero_lstm_kernel<8, 3, 3>), grid, block, stream, p);
-    else AERO_LAUNCH((aero_lstm_kernel<8, 4, 4>), grid, block, stream, p);
+#define AERO_LSTM_GO(NW_, TPW_, KT_, KTI_) AERO_LAUNCH((aero_lstm_kernel<NW_, TPW_, KT_, KTI_>), grid, block, stream, p)
+    if (nw == 4 && tpw == 1) { if (kti == 0) AERO_LSTM_GO(4, 1, 1, 0); else AERO_LSTM_GO(4, 1, 1, 1); }
+    else if (nw == 4 && tpw == 2) { if (kti == 0) AERO_LSTM_GO(4, 2, 1, 0); else if (kti == 1) AERO_LSTM_GO(4, 2, 1, 1); else AERO_LSTM_GO(4, 2, 1, 2); }
+    else if (nw == 6) { if (kti == 0) AERO_LSTM_GO(6, 2, 2, 0); else if (kti == 2) AERO_LSTM_GO(6, 2, 2, 2); else AERO_LSTM_GO(6, 2, 2, 3); }
+    else if (tpw == 2) { if (kti == 0) AERO_LSTM_GO(8, 2, 2, 0); else if (kti == 2) AERO_LSTM_GO(8, 2, 2, 2); else AERO_LSTM_GO(8, 2, 2, 4); }
+    else if (tpw == 3) { if (kti == 0) AERO_LSTM_GO(8, 3, 3, 0); else if (kti == 3) AERO_LSTM_GO(8, 3, 3, 3); else AERO_LSTM_GO(8, 3, 3, 6); }
+    else AERO_LSTM_GO(8, 4, 4, 0);
+#undef AERO_LSTM_GO
     return AERO_OK;
 }

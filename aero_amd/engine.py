@@ -185,12 +185,21 @@ class Ops:
         return out
 
     # -- LSTM / attention / FTB ----------------------------------------------------------------
-    def lstm(self, xproj, xbias, whh, H, nseq, W, in_mode, out_mode, nframes, S, T, out):
+    def lstm(self, xproj, xbias, whh, H, nseq, W, in_mode, out_mode, nframes, S, T, out, x=None, fused=None):
+        """one bidirectional layer.  Either (xproj, xbias) = precomputed input projection, or (x, fused=(wih, bias, in_ch)):
+        the projection is computed inside the recurrent kernel from the raw input rows x [npos, in_ch]."""
         d = _lib.LstmDesc()
         d.xproj, d.xbias, d.whh, d.out = _ptr(xproj), _ptr(xbias), _ptr(whh), _ptr(out)
         d.H, d.nseq, d.W, d.in_mode, d.out_mode, d.nframes, d.S, d.T = H, nseq, W, in_mode, out_mode, nframes, S, T
-        self._call('aero_lstm_fwd', 'aero_lstm_kernel', 2.0 * nseq * W * 2 * 4 * H * H, xproj.numel() * 2 + out.numel() * 2,
-                   C.byref(d), self.stream(out))
+        flops, nbytes = 2.0 * nseq * W * 2 * 4 * H * H, out.numel() * 2
+        if fused is not None:
+            wih, bias, in_ch = fused
+            d.x, d.wih, d.bias, d.in_ch, d.x_pitch = _ptr(x), _ptr(wih), _ptr(bias), in_ch, x.shape[-1]
+            flops += 2.0 * nseq * W * 2 * 4 * H * in_ch
+            nbytes += nseq * W * in_ch * 2
+        else:
+            nbytes += xproj.numel() * 2
+        self._call('aero_lstm_fwd', 'aero_lstm_kernel', flops, nbytes, C.byref(d), self.stream(out))
         return out
 
     def localstate(self, qkvd, R, T, Cc, heads, ndecay):
@@ -247,8 +256,12 @@ class HipEngine:
         self._key = None
         self._tables = {}
         self.streams = int(os.environ.get('AERO_STREAMS', '1'))   # sub-batches in flight on separate HIP streams
-        self.fuse_dconv_tail = True        # DConv tail as a recompute pair of conv launches: the 2C-channel tensor never reaches HBM
-        self.fuse_stats = True             # GroupNorm statistics accumulated in the producing conv's epilogue
+        # GroupNorm fused into conv epilogues (stat_mode 1-3 of aero_conv_fwd).  Both are correct (tested against golden)
+        # but measured SLOWER on MI355X than the separate statistics/apply kernels (24.1 vs 22.8 ms per step: the wider
+        # epilogue costs registers and the recompute pass re-pays the tile latency), so they are off by default.
+        self.fuse_dconv_tail = False       # DConv tail as a recompute pair of conv launches (2C-channel tensor never stored)
+        self.fuse_stats = False            # GroupNorm statistics accumulated in the producing conv's epilogue
+        self.fuse_lstm_proj = True         # W_ih x_t inside the recurrent kernel (no 8H-channel pre-activation tensor in HBM)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
 
     # ------------------------------------------------------------------ weights
@@ -275,7 +288,7 @@ class HipEngine:
             if enc.freq_attn:
                 q = f'{p}.freq_attn_block'
                 Fd, Cc, r = enc.freq_attn_block.input_dim, enc.freq_attn_block.in_channel, enc.freq_attn_block.r_channel
-                rp = 8 * ((r + 7) // 8)
+                rp = r if (Fd * r) % 8 == 0 else 8 * ((r + 7) // 8)    # channel pitch per frequency bin in the [B,T,F*rp] image
                 w, b = pack.bn_fold(sd[f'{q}.conv1.0.weight'], sd[f'{q}.conv1.0.bias'], sd[f'{q}.conv1.1.weight'],
                                     sd[f'{q}.conv1.1.bias'], sd[f'{q}.conv1.1.running_mean'], sd[f'{q}.conv1.1.running_var'])
                 w, df, dt = pack.conv2d_taps(w, 0, 0)
@@ -625,13 +638,19 @@ class HipEngine:
         else:
             W, S, nframes = T, 1, 1
         nseq = R * nframes
-        (pj0, xb0, whh0), (pj1, xb1, whh1) = L['lstm']
-        xp0 = ops.conv(pj0, h, None, B, Fo, Fo, T)                                  # [B,Fo,T,8H]
+        (pj0, xb0, whh0, fz0), (pj1, xb1, whh1, fz1) = L['lstm']
         out0 = torch.empty(nseq, W, 2 * H, dtype=torch.float16, device=h.device)
-        ops.lstm(xp0, xb0, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0)
-        xp1 = ops.conv(pj1, out0.view(nseq, 1, W, 2 * H), None, nseq, 1, 1, W)      # [nseq,1,W,8H]
+        if fz0 is not None and self.fuse_lstm_proj and h.is_contiguous():
+            ops.lstm(None, None, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0, x=h.view(R, T, H), fused=fz0)
+        else:
+            xp0 = ops.conv(pj0, h, None, B, Fo, Fo, T)                              # [B,Fo,T,8H], per position not per frame
+            ops.lstm(xp0, xb0, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0)
         out1 = torch.empty(R, T, 2 * H, dtype=torch.float16, device=h.device)
-        ops.lstm(xp1, xb1, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1)
+        if fz1 is not None and self.fuse_lstm_proj:
+            ops.lstm(None, None, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1, x=out0, fused=fz1)
+        else:
+            xp1 = ops.conv(pj1, out0.view(nseq, 1, W, 2 * H), None, nseq, 1, 1, W)  # [nseq,1,W,8H]
+            ops.lstm(xp1, xb1, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1)
         return ops.conv(L['lstm_lin'], out1.view(B, Fo, T, 2 * H), None, B, Fo, Fo, T, res=h)
 
     def _decode(self, j, dec, L, x, skip, B, Fq, T, mean, std):

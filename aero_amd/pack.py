@@ -119,5 +119,13 @@ def pack_lstm_layer(lib, sd, prefix, layer, H, device):
     whh = torch.zeros(2, MP, KP)
     for dr in range(2):
         whh[dr, :4 * H, :H] = w_hh[dr]
+    fused = None
+    in_ch = w_ih.shape[1]
+    KPI = lib.lstm_geometry_in(H, in_ch)
+    if KPI is not None:                                          # W_ih x_t computed inside the recurrent kernel
+        wih = torch.zeros(2, MP, KPI)
+        for dr in range(2):
+            wih[dr, :4 * H, :in_ch] = w_ih[dr * 4 * H:(dr + 1) * 4 * H]
+        fused = (wih.to(device=device, dtype=torch.float16).contiguous(), b.float().to(device).contiguous(), in_ch)
     return spec, b.to(device=device, dtype=torch.float16).contiguous(), \
-        whh.to(device=device, dtype=torch.float16).contiguous()
+        whh.to(device=device, dtype=torch.float16).contiguous(), fused

@@ -141,10 +141,17 @@ int aero_norm_apply(const aero_norm_desc* d, void* stream);
 typedef struct {
     const void* xproj; const void* xbias; const void* whh; void* out;
     int32_t H, nseq, W, in_mode, out_mode, nframes, S, T;
+    /* fused input projection (wih != NULL; xproj/xbias unused): x fp16 [npos][x_pitch] holds the in_ch input channels of
+     * every position (same position indexing as xproj; padded steps are zero inputs), wih fp16 [2][MP][KPI] rows 4*j+gate
+     * zero padded (KPI from aero_lstm_geometry_in), bias fp32 [2][4H] = b_ih + b_hh in the same row order. */
+    const void* x; const void* wih; const float* bias;
+    int32_t in_ch, x_pitch;
 } aero_lstm_desc;
 int aero_lstm_fwd(const aero_lstm_desc* d, void* stream);
 /* padded W_hh geometry the kernel instantiation for hidden size H expects: MP rows, KP columns */
 int aero_lstm_geometry(int32_t H, int32_t* MP, int32_t* KP);
+/* padded column count KPI of wih for the fused projection of in_ch inputs, or a negative code if not supported */
+int aero_lstm_geometry_in(int32_t H, int32_t in_ch, int32_t* KPI);
 
 /* K11 -- LocalState attention core (modules.py:101-124).  qkvd fp16 [R][T][ld] holds per position
  * query | key | content (C each) | decay logits (heads*ndecay), produced by one aero_conv_fwd.

@@ -209,8 +209,9 @@ def _lstm_sd(H, seed):
     return sd
 
 
-def case_blstm(lib, dev, H, R, T, seed=60):
-    """Whole BLSTM block (projection convs + 2 recurrent layers + linear + skip) against the oracle."""
+def case_blstm(lib, dev, H, R, T, seed=60, fuse=True):
+    """Whole BLSTM block (input projections fused in the recurrent kernel or as separate convs, 2 recurrent layers,
+    linear + skip) against the oracle."""
     from aero_amd.engine import HipEngine
 
     class _DC:
@@ -220,6 +221,7 @@ def case_blstm(lib, dev, H, R, T, seed=60):
     ref = O.blstm(sd, 'b', q16(x))
     eng = HipEngine.__new__(HipEngine)
     eng.lib, eng.ops = lib, Ops(lib)
+    eng.fuse_lstm_proj = fuse
     L = {'lstm': [pack.pack_lstm_layer(lib, sd, 'b.lstm', l, H, dev) for l in range(2)]}
     w = sd['b.linear.weight']
     L['lstm_lin'] = pack.make_conv_spec(w[None, :, None, :], sd['b.linear.bias'], 2 * H, 0, [0], [0], dev)

@@ -80,7 +80,8 @@ def test_groupnorm(emu, kw):
     oc.case_groupnorm(emu, DEV, **kw)
 
 
-@pytest.mark.parametrize('kw', [dict(H=4, R=3, T=50), dict(H=8, R=2, T=251), dict(H=48, R=2, T=40), dict(H=24, R=18, T=30)])
+@pytest.mark.parametrize('kw', [dict(H=4, R=3, T=50), dict(H=8, R=2, T=251), dict(H=48, R=2, T=40), dict(H=24, R=18, T=30),
+                                dict(H=8, R=2, T=251, fuse=False), dict(H=48, R=2, T=40, fuse=False), dict(H=96, R=1, T=33)])
 def test_blstm(emu, kw):
     oc.case_blstm(emu, DEV, **kw)
 

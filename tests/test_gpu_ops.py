@@ -72,7 +72,8 @@ def test_groupnorm(lib, kw):
     oc.case_groupnorm(lib, DEV, **kw)
 
 
-@pytest.mark.parametrize('kw', [dict(H=48, R=16, T=501), dict(H=96, R=8, T=501), dict(H=8, R=3, T=251), dict(H=48, R=5, T=150)])
+@pytest.mark.parametrize('kw', [dict(H=48, R=16, T=501), dict(H=96, R=8, T=501), dict(H=8, R=3, T=251), dict(H=48, R=5, T=150),
+                                dict(H=48, R=16, T=501, fuse=False), dict(H=96, R=8, T=501, fuse=False)])
 def test_blstm(lib, kw):
     oc.case_blstm(lib, DEV, **kw)
 
