@@ -72,7 +72,7 @@ _PROTOS = {
     'aero_istft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, fp, fp, i32, vp]),
     'aero_conv_fwd': (i32, [C.POINTER(ConvDesc), vp]),
     'aero_conv_tile_m': (i32, [i32]),
-    'aero_conv_kernel_id': (i32, [C.POINTER(ConvDesc)]),
+    'aero_conv_kernel_name': (i32, [C.POINTER(ConvDesc), C.c_char_p, i32]),
     'aero_norm_stats': (i32, [C.POINTER(NormDesc), vp]),
     'aero_norm_apply': (i32, [C.POINTER(NormDesc), vp]),
     'aero_lstm_fwd': (i32, [C.POINTER(LstmDesc), vp]),

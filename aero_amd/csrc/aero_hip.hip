@@ -73,13 +73,12 @@ int aero_conv_fwd(const aero_conv_desc* d, void* stream) {
 
 int aero_conv_tile_m(int32_t M) { return aero_conv_pick_bm(M, (M + 127) / 128 * 128); }
 
-int aero_conv_kernel_id(const aero_conv_desc* d) {
-    if (!d) return 0;
-    const int bm = aero_conv_tile_m(d->M);
-    const bool vin = (d->C0 % 8 == 0) && (d->C1 % 8 == 0);
-    if (bm == 128 && vin && !aero_conv_use_glds() && aero_conv_is_3x3(d)) return 3000;
-    if (vin && aero_conv_use_glds()) return 4000 + bm;
-    return 1000 + bm;
+int aero_conv_kernel_name(const aero_conv_desc* d, char* name, int32_t cap) {
+    if (!name || cap < 96) return aero_fail(AERO_ERR_ARG, "conv_kernel_name: buffer of >= 96 bytes required");
+    const char* err = "";
+    name[0] = 0;
+    int rc = aero_conv_launch(d, nullptr, &err, name);
+    return rc == AERO_OK ? AERO_OK : aero_fail(rc, err);
 }
 
 int aero_norm_stats(const aero_norm_desc* d, void* stream) {

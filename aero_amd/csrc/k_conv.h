@@ -14,6 +14,7 @@
 // position.  v1 pipeline: register-staged global->LDS, one LDS buffer,
 // next K-chunk prefetched into VGPRs while the current one feeds the MFMAs.
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "aero_common.h"
@@ -667,18 +668,21 @@ static int aero_conv_pick_bm(int M, int Mpad) {
     return best;
 }
 
-#define AERO_CONV_GO(K, A, B, C_)                                                          \
-    do {                                                                                   \
-        if (d->stat_mode) AERO_LAUNCH((K<A, B, C_, true>), grid, block, stream, p);        \
-        else AERO_LAUNCH((K<A, B, C_, false>), grid, block, stream, p);                    \
+// `name` != NULL: dry run -- only report which kernel instantiation would run (profiling labels that match rocprofv3)
+#define AERO_CONV_GO(K, A, B, C_)                                                                              \
+    do {                                                                                                       \
+        if (name) snprintf(name, 96, #K "<" #A ", " #B ", " #C_ ", %s>", d->stat_mode ? "true" : "false");    \
+        else if (d->stat_mode) AERO_LAUNCH((K<A, B, C_, true>), grid, block, stream, p);                       \
+        else AERO_LAUNCH((K<A, B, C_, false>), grid, block, stream, p);                                        \
     } while (0)
-#define AERO_CONV_GO2(K, A, B)                                                             \
-    do {                                                                                   \
-        if (d->stat_mode) AERO_LAUNCH((K<A, B, true>), grid, block, stream, p);            \
-        else AERO_LAUNCH((K<A, B, false>), grid, block, stream, p);                        \
+#define AERO_CONV_GO2(K, A, B)                                                                                 \
+    do {                                                                                                       \
+        if (name) snprintf(name, 96, #K "<" #A ", " #B ", %s>", d->stat_mode ? "true" : "false");             \
+        else if (d->stat_mode) AERO_LAUNCH((K<A, B, true>), grid, block, stream, p);                           \
+        else AERO_LAUNCH((K<A, B, false>), grid, block, stream, p);                                            \
     } while (0)
 
-static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const char** err) {
+static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const char** err, char* name = nullptr) {
     if (!d || !d->weight || (!d->dst && d->stat_mode != 2)) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
     if (d->ntaps < 1 || d->ntaps > 9) { *err = "conv: ntaps must be 1..9"; return AERO_ERR_ARG; }
     if (d->C0 < 0 || d->C1 < 0 || d->C0 + d->C1 <= 0 || d->M <= 0) { *err = "conv: bad channel counts"; return AERO_ERR_ARG; }
@@ -726,7 +730,8 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);
     if (bm == 128 && p.vec_in && !p.glds && !d->stat_mode && aero_conv_is_3x3(d)) {
-        AERO_LAUNCH(aero_conv3x3_kernel, grid, block, stream, p);
+        if (name) snprintf(name, 96, "aero_conv3x3_kernel");
+        else AERO_LAUNCH(aero_conv3x3_kernel, grid, block, stream, p);
         return AERO_OK;
     }
     if (p.vec_in && p.glds && aero_conv_regular_taps(d, &p)) {

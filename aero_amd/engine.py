@@ -124,15 +124,9 @@ class Ops:
         if self.prof is None:
             self.lib.call('aero_conv_fwd', C.byref(d), self.stream(ref_t))
         else:
-            kid = self.lib.cdll.aero_conv_kernel_id(C.byref(d))
-            tiles = {128: '4,2', 96: '3,2', 64: '4,1', 48: '3,1', 32: '2,1', 16: '1,1'}
-            if kid == 3000:
-                kname = 'aero_conv3x3_kernel'
-            elif kid >= 4000:
-                kname = f'aero_conv_glds_kernel<{tiles[kid - 4000]}>'
-            else:
-                kname = {128: 'aero_conv_kernel<4,2>', 96: 'aero_conv_kernel<3,2>', 64: 'aero_conv_kernel<4,1>',
-                         48: 'aero_conv_kernel<3,1>', 32: 'aero_conv_kernel<2,1>', 16: 'aero_conv_kernel<1,1>'}[kid - 1000]
+            buf = C.create_string_buffer(128)
+            self.lib.check(self.lib.cdll.aero_conv_kernel_name(C.byref(d), buf, 128), 'aero_conv_kernel_name')
+            kname = buf.value.decode()
             pos = B * dst_F * T
             cin_exec = spec.C1 + (spec.C0 if src0 is not None else 0)
             flops = 2.0 * pos * spec.M * len(spec.df) * cin_exec       # executed (NULL source skipped)

@@ -99,9 +99,9 @@ typedef struct {
 int aero_conv_fwd(const aero_conv_desc* d, void* stream);
 /* rows per block (16/32/48/64/128) of the kernel instantiation aero_conv_fwd picks for M output channels */
 int aero_conv_tile_m(int32_t M);
-/* which kernel aero_conv_fwd will launch for this descriptor: 1000+BM = tiled implicit GEMM (k_conv.h),
- * 3000 = 3x3 time-context specialisation; used for profiling labels only */
-int aero_conv_kernel_id(const aero_conv_desc* d);
+/* the kernel instantiation aero_conv_fwd would launch for this descriptor, as rocprofv3 prints it (e.g.
+ * "aero_conv_glds_kernel<4, 2, 64, false>"); nothing is launched.  name must hold >= 96 bytes.  Profiling labels only. */
+int aero_conv_kernel_name(const aero_conv_desc* d, char* name, int32_t cap);
 
 /* K7+K8 -- nn.GroupNorm (aero.py:56,148; modules.py:189) followed by GELU / GLU(+LayerScale
  * +residual) / Snake (aero.py:127,133,198,214; modules.py:141,232-236,244; snake.py:67).
