@@ -153,7 +153,8 @@ def main():
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom)
+                ent = json.load(open(pmc)).get(dom)
+                traffic = ent['bytes'] if ent else None       # HBM-side bytes per launch (rocprofv3 --pmc, see tools/pmc_traffic.py)
             except Exception:
                 traffic = None
         if k['flops'] > 0:
