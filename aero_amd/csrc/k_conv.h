@@ -34,10 +34,10 @@ struct AeroConvK {
 //   then act (GLU pairs rows 2u,2u+1; optional LayerScale), residual, frequency embedding, per-item affine, store.
 // Staged form (fp16 output, 8-channel aligned): the tile is transposed through LDS in two passes of 64 positions so
 // that every global store (and residual load) is a full 16-byte channel vector (256-byte runs per position).
-template <int MF, int WM, bool STATS>
-static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f32x4 (&acc)[MF][8 / (4 / WM)], h16* Cs, int b, int fo,
+template <int MF, int WM, bool STATS, int NWV = 4>
+static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f32x4 (&acc)[MF][8 / (NWV / WM)], h16* Cs, int b, int fo,
                                                           int fdst, int m0, int t0) {
-    constexpr int WN = 4 / WM;
+    constexpr int WN = NWV / WM;
     constexpr int NF = 8 / WN;
     constexpr int BM = 16 * MF * WM;
     constexpr int CS = BM + 8;
@@ -163,7 +163,7 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
             const int m0o = glu ? (m0 >> 1) : m0;
             h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
             const h16* rrow = res_in_copy ? res + (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + m0o : nullptr;
-            for (int idx = tid; idx < 64 * nvec; idx += 256) {
+            for (int idx = tid; idx < 64 * nvec; idx += NWV * 64) {
                 const int pc = idx / nvec, cv = idx - pc * nvec;
                 const int wq = pc / PH, rr = pc - wq * PH;
                 const int t = t0 + (wq * NF + pass * NH + (rr >> 4)) * 16 + (rr & 15);
@@ -356,20 +356,25 @@ static __device__ __forceinline__ int aero_tile_swz(int row) {
     return KC == 32 ? ((0 - (row >> 2)) & 3) : ((row >> 1) & 7);
 }
 
-template <int MF, int WM, int KC, bool STATS>
-__global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
-    constexpr int WN = 4 / WM;
+template <int MF, int WM, int KC, int NWV>
+struct AeroGldsGeom {
+    static constexpr int BM = 16 * MF * WM;
+    static constexpr int STAGE = (BM + 128) * KC;
+    static constexpr int CS = BM + 8;
+    static constexpr int SMEM = 2 * STAGE > 64 * CS ? 2 * STAGE : 64 * CS;    // h16 elements
+};
+
+template <int MF, int WM, int KC, bool STATS, int NWV>
+static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h16* smem) {
+    constexpr int WN = NWV / WM;
     constexpr int NF = 8 / WN;
     constexpr int BM = 16 * MF * WM;
     constexpr int BN = 128;
     constexpr int SLOTS = KC / 8;                   // 16-byte slots per tile row
     constexpr int KS = KC / 32;                     // MFMA k-steps per chunk
     constexpr int STAGE = (BM + BN) * KC;
-    constexpr int CS = BM + 8;
-    constexpr int SMEM = 2 * STAGE > 64 * CS ? 2 * STAGE : 64 * CS;
-    constexpr int NIA = (BM * SLOTS / 64 + 3) / 4;  // A copy instructions per wave
-    constexpr int NIB = BN * SLOTS / 64 / 4;        // B copy instructions per wave
-    __shared__ AERO_LDS_ALIGN h16 smem[SMEM];
+    constexpr int NIA = (BM * SLOTS / 64 + NWV - 1) / NWV;  // A copy instructions per wave
+    constexpr int NIB = BN * SLOTS / 64 / NWV;              // B copy instructions per wave
     h16* Cs = smem;
     const aero_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -400,13 +405,13 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
     int b_pos[NIB], b_q8[NIB], b_off0[NIB], b_off1[NIB];
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
-        const int s = (wave + 4 * i) * 64 + lane;
+        const int s = (wave + NWV * i) * 64 + lane;
         const int r = s / SLOTS, q = (s % SLOTS) ^ aero_tile_swz<KC>(r);
         a_ptr[i] = Wp + (int64_t)r * p.Ktot + q * 8;
     }
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
-        const int s = (wave + 4 * i) * 64 + lane;
+        const int s = (wave + NWV * i) * 64 + lane;
         const int pos = s / SLOTS, q = (s % SLOTS) ^ aero_tile_swz<KC>(pos);
         b_pos[i] = pos;
         b_q8[i] = q * 8;
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
         const int kofs = (jf * p.nT + jt) * p.Cp + cc * KC;
 #pragma unroll
         for (int i = 0; i < NIA; ++i)
-            if (wave + 4 * i < BM * SLOTS / 64) aero_glds16(a_ptr[i] + kofs, As + (wave + 4 * i) * 512);
+            if (wave + NWV * i < BM * SLOTS / 64) aero_glds16(a_ptr[i] + kofs, As + (wave + NWV * i) * 512);
         const int tsh = t0 + p.t_lo + jt * p.t_step;          // source time of position 0
         const int c_lo = cc * KC;
         const h16* rb0 = s0 ? s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)tsh * st0 + c_lo : zp;
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
             const bool u0 = b_q8[i] < lim0;
             const bool ok = tin && (u0 ? has0 : (b_q8[i] < lim1));
             const h16* ptr = (u0 ? rb0 : rb1) + (u0 ? b_off0[i] : b_off1[i]);
-            aero_glds16(ok ? ptr : zp, Bs + (wave + 4 * i) * 512);
+            aero_glds16(ok ? ptr : zp, Bs + (wave + NWV * i) * 512);
         }
     };
 
@@ -486,7 +491,21 @@ __global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
         }
     }
     __syncthreads();                           // all waves done with the operand stages: smem becomes the output tile
-    aero_conv_epilogue<MF, WM, STATS>(p, acc, Cs, b, fo, fdst, m0, t0);
+    aero_conv_epilogue<MF, WM, STATS, NWV>(p, acc, Cs, b, fo, fdst, m0, t0);
+}
+
+template <int MF, int WM, int KC, bool STATS>
+__global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
+    __shared__ AERO_LDS_ALIGN h16 smem[AeroGldsGeom<MF, WM, KC, 4>::SMEM];
+    aero_conv_glds_body<MF, WM, KC, STATS, 4>(p, smem);
+}
+
+// 256 output channels x 128 steps with EIGHT waves (4 x 2, each 64 x 64 as above): the activation tile is shared by
+// twice as many output rows, so the global->LDS traffic per MFMA drops by a quarter and each wave issues 3 copy
+// instructions per 32-channel chunk instead of 4.  Dynamic LDS (48 KiB with KC 32).
+template <int MF, int KC, bool STATS>
+__global__ __launch_bounds__(512) void aero_conv_glds8_kernel(AeroConvK p) {
+    aero_conv_glds_body<MF, 4, KC, STATS, 8>(p, (h16*)AERO_DYN_SMEM);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -740,6 +759,30 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         const int mode = aero_conv_glds_mode();               // 0 auto, 1 = KC 32, 2 = KC 64 where legal
         const bool k64_ok = (p.Cp % 64 == 0);
         const bool k64 = mode == 2 ? k64_ok : (mode == 1 ? false : (k64_ok && bm >= 96 && p.Ktot >= 1024));
+        // 256-/192-row tiles (8 waves) for the wide compute-bound contractions; AERO_CONV_BM256=0 disables (A/B),
+        // =1 only the 256-row tile.  KC 32 here: two 48-KiB blocks (16 waves) per CU measured 937 TF/s on the first
+        // decoder layer vs 872 with one 96-KiB KC-64 block and 860 for the 128-row KC-64 tile.
+        static int wide = -1;
+        if (wide < 0) { const char* e = getenv("AERO_CONV_BM256"); wide = e ? atoi(e) : 2; }
+        const int wbm = (wide >= 1 && d->M % 256 == 0 && p.Ktot >= 1024) ? 256
+                        : (wide >= 2 && d->M % 192 == 0 && p.Ktot >= 768) ? 192 : 0;
+        if (wbm) {
+            p.nmt = d->M / wbm;
+            grid = dim3((unsigned)((long)d->B * d->Fout * p.ntt * p.nmt));
+            block = dim3(512);
+            const bool st = d->stat_mode != 0;
+            if (name) snprintf(name, 96, "aero_conv_glds8_kernel<%d, 32, %s>", wbm / 64, st ? "true" : "false");
+            else if (wbm == 256) {
+                const size_t dyn = AeroGldsGeom<4, 4, 32, 8>::SMEM * sizeof(h16);
+                if (st) AERO_LAUNCH_DYN((aero_conv_glds8_kernel<4, 32, true>), grid, block, dyn, stream, p);
+                else AERO_LAUNCH_DYN((aero_conv_glds8_kernel<4, 32, false>), grid, block, dyn, stream, p);
+            } else {
+                const size_t dyn = AeroGldsGeom<3, 4, 32, 8>::SMEM * sizeof(h16);
+                if (st) AERO_LAUNCH_DYN((aero_conv_glds8_kernel<3, 32, true>), grid, block, dyn, stream, p);
+                else AERO_LAUNCH_DYN((aero_conv_glds8_kernel<3, 32, false>), grid, block, dyn, stream, p);
+            }
+            return AERO_OK;
+        }
         if (k64) {
             switch (bm) {
                 case 128: AERO_CONV_GO(aero_conv_glds_kernel, 4, 2, 64); break;

@@ -48,6 +48,12 @@ def test_istft(emu, geom):
     dict(Cin=192, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=2, T=40, residual=True),  # LSTM linear + skip, KT=6
     dict(Cin=48, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=4, T=45, act='glu'),       # encoder rewrite + GLU
     dict(Cin=128, Cout=304, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=1, T=200, B=3),
+    # 256-row / 8-wave tiles (aero_conv_glds8_kernel): KC 64 and KC 32, two sources, GLU, ragged time tile
+    dict(Cin=128, Cout=256, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=2, T=137, split=64, B=1),
+    dict(Cin=160, Cout=512, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=2, T=70, split=96, act='glu', B=1),
+    dict(Cin=1024, Cout=256, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=1, T=90, residual=True, B=2),
+    dict(Cin=96, Cout=192, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=3, T=150, split=48, act='glu', B=1),   # 192-row tile
+    dict(Cin=64, Cout=384, kF=8, kT=1, stride=2, padF=3, padT=0, Fin=6, T=66, B=1, act='gelu'),
 ])
 def test_conv2d(emu, kw):
     oc.case_conv2d(emu, DEV, **kw)
@@ -62,7 +68,8 @@ def test_conv1d(emu, kw):
 @pytest.mark.parametrize('kw', [dict(Cin=32, Cout=16, K=8, stride=2, Fin=4, T=40), dict(Cin=16, Cout=8, K=8, stride=4, Fin=5, T=33),
                                 dict(Cin=16, Cout=2, K=8, stride=4, Fin=6, T=70, f32_affine=True),
                                 dict(Cin=8, Cout=4, K=4, stride=2, Fin=3, T=20), dict(Cin=8, Cout=4, K=2, stride=2, Fin=2, T=20),
-                                dict(Cin=16, Cout=8, K=8, stride=2, Fin=4, T=30, trim=False)])
+                                dict(Cin=16, Cout=8, K=8, stride=2, Fin=4, T=30, trim=False),
+                                dict(Cin=256, Cout=192, K=8, stride=2, Fin=3, T=70)])     # 192-row 8-wave tile, weight sets
 def test_convtr(emu, kw):
     oc.case_convtr(emu, DEV, **kw)
 
