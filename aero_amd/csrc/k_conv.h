@@ -509,6 +509,105 @@ __global__ __launch_bounds__(512) void aero_conv_glds8_kernel(AeroConvK p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Skinny outputs (M <= 16: the FTB 5-channel squeeze, the last decoder's 2-channel transposed conv): HBM-bound
+// streaming, not GEMMs.  A 128-step tile kernel spends its time in per-block set-up for two or three K-chunks; here a
+// block owns 256 steps of one row, the whole 16 x Ktot weight slab sits in LDS, and each wave streams its 64 steps
+// straight from global memory into MFMA B-fragments (lane = (step, 8 channels): one 16-byte load, no LDS, no barrier
+// in the loop).  Roofline: HBM, algorithmic bytes = source row + output row.
+#define AERO_SKINNY_KMAX 512
+__global__ __launch_bounds__(256) void aero_conv_skinny_kernel(AeroConvK p) {
+    __shared__ AERO_LDS_ALIGN h16 Ws[16 * (AERO_SKINNY_KMAX + 8)];
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const int tt = id % p.ntt;
+    const int row = id / p.ntt;
+    const int b = row / d.Fout, fo = row % d.Fout;
+    const int fdst = fo - d.dst_f_off;
+    if (fdst < 0 || fdst >= d.dst_F) return;
+    const int wset = d.transposed ? (fo % d.fstride) : 0;
+    const int fbase = d.transposed ? (fo / d.fstride) : (fo * d.fstride);
+    const h16* Wp = (const h16*)d.weight + (int64_t)wset * p.Mpad * p.Ktot;
+    const int WS = p.Ktot + 8;                                  // padded LDS row: conflict-free fragment reads
+    const int kv = p.Ktot >> 3;
+    for (int v = tid; v < 16 * kv; v += 256) {
+        const int r = v / kv, q = v - r * kv;
+        *(h16x8*)&Ws[r * WS + q * 8] = *(const h16x8*)(Wp + (int64_t)r * p.Ktot + q * 8);
+    }
+    __syncthreads();
+    const h16* s0 = (const h16*)d.src0;
+    const h16* s1 = (const h16*)d.src1;
+    const int C0 = d.C0, C01 = d.C0 + d.C1, T = d.T;
+    const bool has0 = s0 != nullptr;
+    const int tw = tt * 256 + wave * 64 + (lane & 15);          // step of group 0
+    const int cl = (lane >> 4) * 8;
+    const h16x8 zero8 = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < d.ntaps; ++j) {
+        const int fi = fbase + d.df[j];
+        if (fi < 0 || fi >= d.Fin) continue;
+        const int dtj = d.dt[j];
+        const h16* rb0 = has0 ? s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f : aero_zero_page;
+        const h16* rb1 = s1 ? s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f : aero_zero_page;
+        for (int cc = 0; cc < p.cpt; ++cc) {
+            if (!has0 && (cc + 1) * 32 <= C0) continue;
+            const int c = cc * 32 + cl;
+            const bool u0 = c < C0;
+            const bool cok = u0 ? has0 : (c < C01);
+            const h16* base = u0 ? rb0 + c : rb1 + (c - C0);
+            const int64_t st = u0 ? d.s0_t : d.s1_t;
+            h16x8 bf[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int t = tw + g * 16 + dtj;
+                bf[g] = (cok && t >= 0 && t < T) ? *(const h16x8*)(base + (int64_t)t * st) : zero8;
+            }
+            const h16x8 af = *(const h16x8*)&Ws[(lane & 15) * WS + j * p.Cp + c];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[g], acc[g], 0, 0, 0);
+        }
+    }
+    // epilogue: rows m = (lane>>4)*4 + r of step tw + g*16
+    const int M = d.M;
+    const int mbase = (lane >> 4) * 4;
+    if (mbase >= M) return;
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (d.bias && mbase + r < M) ? d.bias[mbase + r] : 0.f;
+    const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
+    const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
+    h16* dst16 = (h16*)d.dst;
+    float* dst32 = (float*)d.dst;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int t = tw + g * 16;
+        if (t >= T) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = acc[g][r] + bv[r];
+            if (d.act == AERO_ACT_RELU) x = fmaxf(x, 0.f);
+            else if (d.act == AERO_ACT_GELU) x = aero_gelu(x);
+            o[r] = x * bsc + bsh;
+        }
+        const int64_t doff = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * d.d_t + mbase;
+        if (p.vec_out && mbase + 4 <= M) {
+            if (d.dst_f32) *(f32x4*)(dst32 + doff) = (f32x4){o[0], o[1], o[2], o[3]};
+            else *(h16x4*)(dst16 + doff) = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (mbase + r >= M) continue;
+                if (d.dst_f32) dst32[doff + r] = o[r];
+                else dst16[doff + r] = (h16)o[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // 3x3 (time-context) specialisation -- the decoder "rewrite" convs, 68 % of the model's FLOPs.
 // Same tiling as above (128 channels x 128 steps of one row), but a pipeline stage is (frequency tap df, 32-channel
 // chunk) and carries all THREE time taps: the activation slab [t0-1, t0+129) x 32ch is staged once and read at row
@@ -748,6 +847,16 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     const long nwg = (long)d->B * d->Fout * p.ntt * p.nmt;
     if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);
+    static int skinny = -1;
+    if (skinny < 0) { const char* e = getenv("AERO_CONV_SKINNY"); skinny = (e && e[0] == '0') ? 0 : 1; }
+    if (skinny && d->M <= 16 && p.vec_in && p.Ktot <= AERO_SKINNY_KMAX && d->act != AERO_ACT_GLU && !d->res && !d->post_add &&
+        !d->stat_mode) {
+        p.ntt = (d->T + 255) / 256;
+        const long nb = (long)d->B * d->Fout * p.ntt;
+        if (name) snprintf(name, 96, "aero_conv_skinny_kernel");
+        else AERO_LAUNCH(aero_conv_skinny_kernel, dim3((unsigned)nb), block, stream, p);
+        return AERO_OK;
+    }
     if (bm == 128 && p.vec_in && !p.glds && !d->stat_mode && aero_conv_is_3x3(d)) {
         if (name) snprintf(name, 96, "aero_conv3x3_kernel");
         else AERO_LAUNCH(aero_conv3x3_kernel, grid, block, stream, p);

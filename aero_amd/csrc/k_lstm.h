@@ -10,6 +10,8 @@
 // (fp16) and seeds the accumulator; the next step's slice is prefetched during the current step.
 // Latency-bound by construction (W dependent steps); MFMA is used for the 4H x H x 16 step GEMM.
 #pragma once
+#include <stdlib.h>
+
 #include "aero_common.h"
 
 struct AeroLstmK {
@@ -249,6 +251,195 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Ring form of the fused kernel (the one the engine runs).  The ISA of the kernel above showed why a step cost
+// 1.1-2.5 us against a ~0.5 us arithmetic floor: x_t was fetched one step ahead and h_t stored every step, and because
+// the stores are conditional the compiler can only wait with `s_waitcnt vmcnt(0)` -- every step paid a full HBM round
+// trip (load latency AND the previous step's store acknowledgements).  Here all global traffic moves in GROUPS of G
+// steps through LDS rings:
+//   * x for group g+1 is loaded into a few VGPRs at the start of group g and parked in LDS at its end (G steps of
+//     latency cover); the step reads it back as MFMA B-fragments with one ds_read_b128 per k-step;
+//   * h_t goes to a 2G-slot LDS ring (it is the recurrence operand anyway); group g-1 is written to HBM in one
+//     coalesced burst at the start of group g;
+//   * so vmcnt is waited for ONCE per group, G steps after the traffic was issued, and the step loop itself contains
+//     only LDS reads, MFMAs, gate math, one ds_write and one barrier.
+// (global_load_lds was tried for the x copy: the compiler then waits vmcnt(0) before every barrier.)
+// Rows of both rings are padded by 16 bytes: conflict-free ds_read_b128 for every KP/KPI used.
+// Gate math: 5 exp + 3 rcp per (unit, sequence) instead of 5 + 5 (shared reciprocals, clamped arguments).
+// The gate tiles may be spread over up to 12 waves (3 per SIMD): shorter per-wave chains, and W_ih fits in VGPRs.
+
+template <int KT, int KTI, int G>
+struct AeroLstmRingGeom {
+    static constexpr int HS = KT * 32 + 8, XS = KTI * 32 + 8;
+    static constexpr size_t BYTES = (size_t)(2 * G * 16 * HS + 2 * G * 16 * XS) * sizeof(h16);
+};
+
+template <int NW, int TPW, int KT, int KTI, int G>
+__global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
+    constexpr int R = 2 * G;
+    constexpr int KP = KT * 32, HS = KP + 8, KPI = KTI * 32, XS = KPI + 8, SPR = KTI * 4, NT = NW * 64;
+    constexpr int NXV = (G * 16 * SPR + NT - 1) / NT;              // x vectors per thread per group
+    h16* hring = (h16*)AERO_DYN_SMEM;                              // [R][16][HS]
+    h16* xring = hring + R * 16 * HS;                              // [2][G][16][XS]
+    const aero_lstm_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y;
+    const int seq0 = blockIdx.x * 16;
+    const int H = d.H, W = d.W, H4 = 4 * d.H, H2 = 2 * d.H;
+    const int q = lane >> 4, col = lane & 15;
+    const h16* whh = (const h16*)d.whh + (int64_t)dir * (NW * TPW * 16) * KP;
+    const h16* wih = (const h16*)d.wih + (int64_t)dir * (NW * TPW * 16) * KPI;
+    const h16* xin = (const h16*)d.x;
+    h16* out = (h16*)d.out;
+
+    h16x8 wf[TPW][KT], wi[TPW][KTI];
+    f32x4 bias4[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int wrow = (wave * TPW + i) * 16 + col;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) wf[i][kt] = *(const h16x8*)(whh + (int64_t)wrow * KP + kt * 32 + q * 8);
+#pragma unroll
+        for (int kt = 0; kt < KTI; ++kt) wi[i][kt] = *(const h16x8*)(wih + (int64_t)wrow * KPI + kt * 32 + q * 8);
+        const int rr = (wave * TPW + i) * 16 + q * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[i][r] = (rr + r < H4) ? d.bias[dir * H4 + rr + r] : 0.f;
+    }
+    for (int idx = tid; idx < R * 16 * HS / 8; idx += NT) ((h16x8*)hring)[idx] = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+
+    // cooperative x copy: vector L = tid + v*NT -> (step-in-group, sequence row, 8-channel slot); the addressing is
+    // recomputed per group (a handful of integer ops every G steps) rather than held in VGPRs
+    const bool xvec = (d.in_ch % 8 == 0) && (d.x_pitch % 8 == 0) && (((uintptr_t)xin & 15) == 0);
+    h16x8 xr[NXV];
+    auto load_x = [&](int g) {          // global -> VGPR for group g (steps beyond W, padded frames, bad rows: zeros)
+#pragma unroll
+        for (int v = 0; v < NXV; ++v) {
+            const int L = tid + v * NT;
+            const int i = L / (16 * SPR), rem = L - i * (16 * SPR);
+            const int row = rem / SPR, c = (rem - row * SPR) * 8;
+            const int seq = seq0 + row;
+            const int step = g * G + i;
+            const int tau = dir ? W - 1 - step : step;
+            bool ok = L < G * 16 * SPR && step < W && seq < d.nseq && c < d.in_ch;
+            int64_t pos;
+            if (d.in_mode == 1) {
+                const int r = seq / d.nframes, k = seq - r * d.nframes;
+                ok = ok && (k * d.S + tau < d.T);
+                pos = (int64_t)r * d.T + k * d.S + tau;
+            } else {
+                pos = (int64_t)seq * W + tau;
+            }
+            h16x8 z = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) {
+                const h16* sp = xin + pos * d.x_pitch + c;
+                if (xvec) {
+                    z = *(const h16x8*)sp;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (c + e < d.in_ch) z[e] = sp[e];
+                }
+            }
+            xr[v] = z;
+        }
+    };
+    auto park_x = [&](int buf) {        // VGPR -> LDS ring buffer
+#pragma unroll
+        for (int v = 0; v < NXV; ++v) {
+            const int L = tid + v * NT;
+            const int i = L / (16 * SPR), rem = L - i * (16 * SPR);
+            const int row = rem / SPR, slot = rem - row * SPR;
+            if (L < G * 16 * SPR) *(h16x8*)(xring + buf * (G * 16 * XS) + (i * 16 + row) * XS + slot * 8) = xr[v];
+        }
+    };
+    // write the h rows of group g (LDS ring slots) to the stitched output
+    const int vecs = (H % 8 == 0 && (((uintptr_t)out & 15) == 0)) ? H / 8 : 0;
+    const int per = vecs ? vecs : H;
+    auto store_group = [&](int g) {
+        const int s_base = g * G;
+        const int nst = W - s_base < G ? W - s_base : G;
+        for (int idx = tid; idx < nst * 16 * per; idx += NT) {
+            const int i = idx / (16 * per), rem = idx - i * (16 * per);
+            const int sl = rem / per, e = rem - sl * per;
+            const int s2 = seq0 + sl;
+            if (s2 >= d.nseq) continue;
+            const int step = s_base + i;
+            const int tau = dir ? W - 1 - step : step;
+            int64_t opos;
+            if (d.out_mode == 1) {
+                const int r = s2 / d.nframes, k = s2 - r * d.nframes;
+                const int lim = d.S / 2;
+                const int lo = (k == 0) ? 0 : lim;
+                const int hi = (k == d.nframes - 1 && k != 0) ? W : W - lim;
+                const int t = k * d.S + tau;
+                if (tau < lo || tau >= hi || t >= d.T) continue;
+                opos = (int64_t)r * d.T + t;
+            } else {
+                opos = (int64_t)s2 * W + tau;
+            }
+            const h16* hp = hring + ((step & (R - 1)) * 16 + sl) * HS;
+            if (vecs) *(h16x8*)(out + opos * H2 + dir * H + e * 8) = *(const h16x8*)(hp + e * 8);
+            else out[opos * H2 + dir * H + e] = hp[e];
+        }
+    };
+
+    float c[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) c[i] = 0.f;
+    const int ngroups = (W + G - 1) / G;
+    load_x(0);
+    park_x(0);
+    __syncthreads();
+    for (int g = 0; g < ngroups; ++g) {
+        if (g + 1 < ngroups) load_x(g + 1);
+        if (g > 0) store_group(g - 1);
+        const int nst = W - g * G < G ? W - g * G : G;
+        for (int i = 0; i < nst; ++i) {
+            const int s = g * G + i;
+            const h16* hprev = hring + (((s + R - 1) & (R - 1)) * 16 + col) * HS;
+            h16* hnext = hring + ((s & (R - 1)) * 16 + col) * HS;
+            const h16* xs = xring + (((g & 1) * G + i) * 16 + col) * XS;
+            h16x8 xf[KTI], bf[KT];
+#pragma unroll
+            for (int kt = 0; kt < KTI; ++kt) xf[kt] = *(const h16x8*)(xs + kt * 32 + q * 8);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) bf[kt] = *(const h16x8*)(hprev + kt * 32 + q * 8);
+            f32x4 accs[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) accs[t] = bias4[t];
+#pragma unroll
+            for (int kt = 0; kt < KTI; ++kt)       // input projection first: independent of h_{t-1}
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wi[t][kt], xf[kt], accs[t], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][kt], bf[kt], accs[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const f32x4 a = accs[t];
+                const int j = (wave * TPW + t) * 4 + q;
+                // exponents pre-scaled by log2(e) and clamped (|x| <= 30, tanh arguments |x| <= 15): bare v_exp_f32
+                constexpr float L2E = 1.4426950408889634f, LIM = 43.28f;
+                const float ei = aero_exp2(aero_med3(a[0] * -L2E, -LIM, LIM));
+                const float ef = aero_exp2(aero_med3(a[1] * -L2E, -LIM, LIM));
+                const float eg = aero_exp2(aero_med3(a[2] * (2.f * L2E), -LIM, LIM));
+                const float eo = aero_exp2(aero_med3(a[3] * -L2E, -LIM, LIM));
+                const float r1 = aero_rcp((1.f + ei) * (eg + 1.f));
+                const float igg = fmaf(eg, r1, -r1);                                    // sigmoid(i) * tanh(g)
+                c[t] = fmaf(aero_rcp(1.f + ef), c[t], igg);
+                const float ec = aero_exp2(aero_med3(c[t] * (2.f * L2E), -LIM, LIM));
+                const float r2 = aero_rcp((1.f + eo) * (ec + 1.f));
+                const float h = fmaf(ec, r2, -r2);                                      // sigmoid(o) * tanh(c)
+                if (j < H) hnext[j] = (h16)h;
+            }
+            if (i == nst - 1 && g + 1 < ngroups) park_x((g + 1) & 1);   // loads issued G steps ago
+            __syncthreads();
+        }
+    }
+    store_group(ngroups - 1);
+}
+
 static int aero_lstm_launch(const aero_lstm_desc* d, hipStream_t stream, const char** err) {
     if (!d || !d->whh || !d->out) { *err = "lstm: null pointer"; return AERO_ERR_ARG; }
     const bool fused = d->wih != nullptr;
@@ -272,6 +463,31 @@ static int aero_lstm_launch(const aero_lstm_desc* d, hipStream_t stream, const c
     p.MP = 16 * nw * tpw;
     p.KP = 32 * kt;
     dim3 grid((unsigned)((d->nseq + 15) / 16), 2), block((unsigned)(nw * 64));
+    // AERO_LSTM_RING=0: step-wise kernel above (A/B);  AERO_LSTM_WIDE=0: keep the tiles on 6/8 waves instead of 12
+    static int ring = -1, wide = -1;
+    if (ring < 0) { const char* e = getenv("AERO_LSTM_RING"); ring = (e && e[0] == '0') ? 0 : 1; }
+    if (wide < 0) { const char* e = getenv("AERO_LSTM_WIDE"); wide = (e && e[0] == '0') ? 0 : 1; }
+#define AERO_LSTM_RING_GO(NW_, TPW_, KT_, KTI_, G_)                                                                     \
+    do {                                                                                                                \
+        block = dim3(NW_ * 64);                                                                                         \
+        AERO_LAUNCH_DYN((aero_lstm_ring_kernel<NW_, TPW_, KT_, KTI_, G_>), grid, block,                                 \
+                        (AeroLstmRingGeom<KT_, KTI_, G_>::BYTES), stream, p);                                           \
+    } while (0)
+    if (fused && ring) {
+        if (nw == 4 && tpw == 1) AERO_LSTM_RING_GO(4, 1, 1, 1, 4);
+        else if (nw == 4 && tpw == 2) { if (kti == 1) AERO_LSTM_RING_GO(4, 2, 1, 1, 4); else AERO_LSTM_RING_GO(4, 2, 1, 2, 4); }
+        else if (nw == 6) {
+            if (wide) { if (kti == 2) AERO_LSTM_RING_GO(12, 1, 2, 2, 4); else AERO_LSTM_RING_GO(12, 1, 2, 3, 4); }
+            else { if (kti == 2) AERO_LSTM_RING_GO(6, 2, 2, 2, 4); else AERO_LSTM_RING_GO(6, 2, 2, 3, 4); }
+        }
+        else if (tpw == 2) { if (kti == 2) AERO_LSTM_RING_GO(8, 2, 2, 2, 4); else AERO_LSTM_RING_GO(8, 2, 2, 4, 4); }
+        else {
+            if (wide) { if (kti == 3) AERO_LSTM_RING_GO(12, 2, 3, 3, 8); else AERO_LSTM_RING_GO(12, 2, 3, 6, 4); }
+            else { if (kti == 3) AERO_LSTM_RING_GO(8, 3, 3, 3, 8); else AERO_LSTM_RING_GO(8, 3, 3, 6, 4); }
+        }
+        return AERO_OK;
+    }
+#undef AERO_LSTM_RING_GO
 #define AERO_LSTM_GO(NW_, TPW_, KT_, KTI_) AERO_LAUNCH((aero_lstm_kernel<NW_, TPW_, KT_, KTI_>), grid, block, stream, p)
     if (nw == 4 && tpw == 1) { if (kti == 0) AERO_LSTM_GO(4, 1, 1, 0); else AERO_LSTM_GO(4, 1, 1, 1); }
     else if (nw == 4 && tpw == 2) { if (kti == 0) AERO_LSTM_GO(4, 2, 1, 0); else if (kti == 1) AERO_LSTM_GO(4, 2, 1, 1); else AERO_LSTM_GO(4, 2, 1, 2); }

@@ -54,6 +54,9 @@ def test_istft(emu, geom):
     dict(Cin=1024, Cout=256, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=1, T=90, residual=True, B=2),
     dict(Cin=96, Cout=192, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=3, T=150, split=48, act='glu', B=1),   # 192-row tile
     dict(Cin=64, Cout=384, kF=8, kT=1, stride=2, padF=3, padT=0, Fin=6, T=66, B=1, act='gelu'),
+    # skinny-M streaming kernel (aero_conv_skinny_kernel): two sources, chunk spanning both, NULL first source
+    dict(Cin=80, Cout=7, kF=1, kT=3, stride=1, padF=0, padT=1, Fin=3, T=300, split=24, act='gelu'),
+    dict(Cin=64, Cout=16, kF=3, kT=1, stride=1, padF=1, padT=0, Fin=4, T=77, split=32, null0=True),
 ])
 def test_conv2d(emu, kw):
     oc.case_conv2d(emu, DEV, **kw)
