@@ -63,6 +63,27 @@ static __device__ __forceinline__ void aero_glds16(const h16* gsrc, h16* lds_wav
 #endif
 }
 
+// Mark a value the whole wave agrees on as scalar.  Indexing a kernel-argument array (tap tables) with an index the
+// compiler cannot prove uniform turns into a VECTOR load from the kernarg segment followed by `s_waitcnt vmcnt(0)`,
+// which drains every global load in flight; with a readfirstlane'd index it is an s_load.
+static __device__ __forceinline__ int aero_uniform(int x) {
+#ifdef AERO_EMU
+    return x;
+#else
+    return __builtin_amdgcn_readfirstlane(x);
+#endif
+}
+
+// wave-level rendezvous between an LDS write and a read of other lanes' data by the SAME wave: hardware executes a
+// wave's LDS instructions in order, so this is only a compiler scheduling fence (and a fiber rendezvous in the emulator)
+static __device__ __forceinline__ void aero_wave_sync() {
+#ifdef AERO_EMU
+    emu::wave_barrier();
+#else
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
 static __device__ __forceinline__ int aero_lane() { return threadIdx.x & 63; }
 static __device__ __forceinline__ int aero_wave() { return threadIdx.x >> 6; }
 

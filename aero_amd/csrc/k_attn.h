@@ -25,7 +25,7 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
     __shared__ AERO_LDS_ALIGN h16 Ks[AERO_ATTN_KC * 32];
     __shared__ AERO_LDS_ALIGN h16 Vt[DT * 16 * AERO_ATTN_VS];
     __shared__ AERO_LDS_ALIGN h16 Qs[128 * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int g = lane >> 4, col = lane & 15;
     const int h = blockIdx.y, row = blockIdx.z;
     const int C = d.C, T = d.T;

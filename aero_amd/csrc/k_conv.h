@@ -34,6 +34,95 @@ struct AeroConvK {
 //   then act (GLU pairs rows 2u,2u+1; optional LayerScale), residual, frequency embedding, per-item affine, store.
 // Staged form (fp16 output, 8-channel aligned): the tile is transposed through LDS in two passes of 64 positions so
 // that every global store (and residual load) is a full 16-byte channel vector (256-byte runs per position).
+// Lean epilogue for the common case (fp16 output through the LDS transpose, no statistics / frequency embedding /
+// per-item affine): the activation is a TEMPLATE parameter and nothing is decided per element.  PMC on the pointwise
+// convs showed why this matters: the generic epilogue below executes ~3600 scalar+vector instructions per wave for
+// 48 MFMAs (every runtime option re-evaluated inside the unrolled fragment loops) and those kernels ran issue-bound at
+// 1.5 TB/s.  Rows >= M carry zero weights and are masked at the copy-out, so no fragment is skipped here.
+template <int MF, int WM, int NWV, int ACT>
+static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& p, f32x4 (&acc)[MF][8 / (NWV / WM)], h16* Cs, int b,
+                                                               int fdst, int m0, int t0) {
+    constexpr int WN = NWV / WM;
+    constexpr int NF = 8 / WN;
+    constexpr int BM = 16 * MF * WM;
+    constexpr int CS = BM + 8;
+    constexpr int NH = NF / 2, PH = NH * 16;
+    constexpr bool GLU = ACT == AERO_ACT_GLU;
+    constexpr int BMo = GLU ? BM / 2 : BM;
+    constexpr int NVEC = BMo / 8;
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int T = d.T, M = d.M;
+    const int Mout = GLU ? (M >> 1) : M;
+    const int m0o = GLU ? (m0 >> 1) : m0;
+    float bv[MF][4], ls[MF][2];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int mbase = m0 + (wm * MF + i) * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mi = mbase + r < M ? mbase + r : M - 1;
+            bv[i][r] = d.bias ? d.bias[mi] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ci = (mbase >> 1) + r < Mout ? (mbase >> 1) + r : Mout - 1;
+            ls[i][r] = (GLU && d.layer_scale) ? d.layer_scale[ci] : 1.f;
+        }
+    }
+    h16* dst16 = (h16*)d.dst;
+    h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
+    const h16* rrow = d.res ? (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + m0o : nullptr;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int cl = (wm * MF + i) * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int nn = 0; nn < NH; ++nn) {
+                const int n = pass * NH + nn;
+                const int pc = wn * PH + nn * 16 + (lane & 15);
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[i][n][r] + bv[i][r];
+                if (GLU) {
+                    const float g0 = o[0] * aero_sigmoid(o[1]) * ls[i][0];
+                    const float g1 = o[2] * aero_sigmoid(o[3]) * ls[i][1];
+                    *(h16x2*)&Cs[pc * CS + (cl >> 1)] = (h16x2){(h16)g0, (h16)g1};
+                } else {
+                    if (ACT == AERO_ACT_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+                    } else if (ACT == AERO_ACT_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = aero_gelu(o[r]);
+                    }
+                    *(h16x4*)&Cs[pc * CS + cl] = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (64 * NVEC + NWV * 64 - 1) / (NWV * 64); ++it) {
+            const int idx = tid + it * NWV * 64;
+            const int pc = idx / NVEC, cv = idx - pc * NVEC;
+            const int wq = pc / PH, rr = pc - wq * PH;
+            const int t = t0 + (wq * NF + pass * NH + (rr >> 4)) * 16 + (rr & 15);
+            if (idx < 64 * NVEC && t < T && m0o + cv * 8 < Mout) {
+                h16x8 v = *(const h16x8*)&Cs[pc * CS + cv * 8];
+                if (rrow) {
+                    const h16x8 r8 = *(const h16x8*)(rrow + (int64_t)t * d.r_t + cv * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + (float)r8[e]);
+                }
+                *(h16x8*)(drow + (int64_t)t * d.d_t + cv * 8) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int MF, int WM, bool STATS, int NWV = 4>
 static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f32x4 (&acc)[MF][8 / (NWV / WM)], h16* Cs, int b, int fo,
                                                           int fdst, int m0, int t0) {
@@ -42,7 +131,16 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
     constexpr int BM = 16 * MF * WM;
     constexpr int CS = BM + 8;
     const aero_conv_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.staged && !d.post_add && !d.batch_scale && (!STATS || d.stat_mode == 0)) {
+        switch (d.act) {
+            case AERO_ACT_NONE: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_NONE>(p, acc, Cs, b, fdst, m0, t0); break;
+            case AERO_ACT_RELU: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_RELU>(p, acc, Cs, b, fdst, m0, t0); break;
+            case AERO_ACT_GELU: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GELU>(p, acc, Cs, b, fdst, m0, t0); break;
+            default: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GLU>(p, acc, Cs, b, fdst, m0, t0); break;
+        }
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int T = d.T;
     const int M = d.M;
@@ -218,7 +316,7 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
     h16* Cs = smem;
 
     const aero_conv_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const int mt = id % p.nmt;
@@ -252,7 +350,7 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
                 cc = 0;
                 ++j;
                 while (j < d.ntaps) {
-                    fi = fbase + d.df[j];
+                    fi = fbase + d.df[aero_uniform(j)];
                     if (fi >= 0 && fi < d.Fin) break;
                     ++j;
                 }
@@ -298,7 +396,7 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
             const int v = tid + 256 * i;
             if (v < BM * 4) ra[i] = *(const h16x8*)(Wp + (int64_t)(v >> 2) * p.Ktot + kofs + (v & 3) * 8);
         }
-        const int dtj = d.dt[j];
+        const int dtj = d.dt[aero_uniform(j)];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int v = tid + 256 * i;
@@ -377,7 +475,7 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
     constexpr int NIB = BN * SLOTS / 64 / NWV;              // B copy instructions per wave
     h16* Cs = smem;
     const aero_conv_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const int mt = id % p.nmt;
@@ -509,99 +607,228 @@ __global__ __launch_bounds__(512) void aero_conv_glds8_kernel(AeroConvK p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Skinny outputs (M <= 16: the FTB 5-channel squeeze, the last decoder's 2-channel transposed conv): HBM-bound
-// streaming, not GEMMs.  A 128-step tile kernel spends its time in per-block set-up for two or three K-chunks; here a
-// block owns 256 steps of one row, the whole 16 x Ktot weight slab sits in LDS, and each wave streams its 64 steps
-// straight from global memory into MFMA B-fragments (lane = (step, 8 channels): one 16-byte load, no LDS, no barrier
-// in the loop).  Roofline: HBM, algorithmic bytes = source row + output row.
-#define AERO_SKINNY_KMAX 512
+// Skinny outputs (M <= 16: the FTB 5-channel squeeze, the 12-channel DConv squeeze of the first layer, the last
+// decoder's 2-channel transposed conv): HBM-bound streaming, not GEMMs.  A 128-step tile kernel spends its time in
+// per-block set-up for two or three K-chunks; here the blocks are PERSISTENT: the 16 x Ktot weight slab of every
+// weight set is staged in LDS once, then each WAVE walks over (row, group of 64-step segments) items on its own:
+//   * the loads of up to SIX (segment, 32-channel chunk) slots are issued back to back -- coalesced 16-byte loads,
+//     4 adjacent lanes = the 64 bytes of one step -- so an item costs ONE memory latency, not one per chunk;
+//   * each slot is transposed through a private 4-KiB LDS tile into MFMA B-fragment order (no block barrier: LDS is
+//     in-order per wave) and multiplied against the LDS-resident weights;
+//   * the outputs of a segment (64 steps x M channels: one contiguous byte range when the destination is dense) go
+//     back through the same LDS tile and leave as full-width coalesced dword stores.
+// Earlier forms, measured: fragment-order global loads (adjacent lanes 96+ B apart: 1.4 TB/s); one chunk in flight
+// per wave and per-channel 2-byte stores (every chunk waited for the previous item's partial-line store acks: 1.8 TB/s).
+// Roofline: HBM, algorithmic bytes = source rows + output rows.
+#define AERO_SKINNY_WMAX 832                        /* halves per weight row, all sets together (incl. 8 of padding each) */
+#define AERO_SKINNY_SLOTS 6
+// VW = halves per load piece (8: one 16-byte load per lane and step; 4/2/1 for channel counts or strides that are
+// only 8-/4-/2-byte aligned).  Every load is unconditional (masked lanes read the zero page): no branches between the
+// loads of a batch, so the compiler keeps them all in flight instead of waiting after each one.
+template <int VW>
 __global__ __launch_bounds__(256) void aero_conv_skinny_kernel(AeroConvK p) {
-    __shared__ AERO_LDS_ALIGN h16 Ws[16 * (AERO_SKINNY_KMAX + 8)];
+    __shared__ AERO_LDS_ALIGN h16 Ws[16 * AERO_SKINNY_WMAX];
+    __shared__ AERO_LDS_ALIGN h16 Xs[4][64 * 32];
+    typedef h16 hvw __attribute__((ext_vector_type(VW > 1 ? VW : 2)));
+    constexpr int NS = AERO_SKINNY_SLOTS;
     const aero_conv_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
-    const int tt = id % p.ntt;
-    const int row = id / p.ntt;
-    const int b = row / d.Fout, fo = row % d.Fout;
-    const int fdst = fo - d.dst_f_off;
-    if (fdst < 0 || fdst >= d.dst_F) return;
-    const int wset = d.transposed ? (fo % d.fstride) : 0;
-    const int fbase = d.transposed ? (fo / d.fstride) : (fo * d.fstride);
-    const h16* Wp = (const h16*)d.weight + (int64_t)wset * p.Mpad * p.Ktot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int WS = p.Ktot + 8;                                  // padded LDS row: conflict-free fragment reads
+    const int nws = d.transposed ? d.fstride : 1;
     const int kv = p.Ktot >> 3;
-    for (int v = tid; v < 16 * kv; v += 256) {
-        const int r = v / kv, q = v - r * kv;
-        *(h16x8*)&Ws[r * WS + q * 8] = *(const h16x8*)(Wp + (int64_t)r * p.Ktot + q * 8);
+    for (int v = tid; v < nws * 16 * kv; v += 256) {
+        const int ws = v / (16 * kv), rem = v - ws * (16 * kv);
+        const int r = rem / kv, q = rem - r * kv;
+        *(h16x8*)&Ws[(ws * 16 + r) * WS + q * 8] = *(const h16x8*)((const h16*)d.weight + ((int64_t)ws * p.Mpad + r) * p.Ktot + q * 8);
     }
     __syncthreads();
     const h16* s0 = (const h16*)d.src0;
     const h16* s1 = (const h16*)d.src1;
-    const int C0 = d.C0, C01 = d.C0 + d.C1, T = d.T;
+    const int C0 = d.C0, C01 = d.C0 + d.C1, T = d.T, M = d.M;
     const bool has0 = s0 != nullptr;
-    const int tw = tt * 256 + wave * 64 + (lane & 15);          // step of group 0
-    const int cl = (lane >> 4) * 8;
-    const h16x8 zero8 = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    f32x4 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < d.ntaps; ++j) {
-        const int fi = fbase + d.df[j];
-        if (fi < 0 || fi >= d.Fin) continue;
-        const int dtj = d.dt[j];
-        const h16* rb0 = has0 ? s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f : aero_zero_page;
-        const h16* rb1 = s1 ? s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f : aero_zero_page;
-        for (int cc = 0; cc < p.cpt; ++cc) {
-            if (!has0 && (cc + 1) * 32 <= C0) continue;
-            const int c = cc * 32 + cl;
-            const bool u0 = c < C0;
-            const bool cok = u0 ? has0 : (c < C01);
-            const h16* base = u0 ? rb0 + c : rb1 + (c - C0);
-            const int64_t st = u0 ? d.s0_t : d.s1_t;
-            h16x8 bf[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int t = tw + g * 16 + dtj;
-                bf[g] = (cok && t >= 0 && t < T) ? *(const h16x8*)(base + (int64_t)t * st) : zero8;
-            }
-            const h16x8 af = *(const h16x8*)&Ws[(lane & 15) * WS + j * p.Cp + c];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[g], acc[g], 0, 0, 0);
-        }
-    }
-    // epilogue: rows m = (lane>>4)*4 + r of step tw + g*16
-    const int M = d.M;
+    h16* Xw = Xs[wave];
+    const int lp = lane >> 2, lq = lane & 3;                    // load role: step lp (+16 i), 8-channel slice lq
     const int mbase = (lane >> 4) * 4;
-    if (mbase >= M) return;
+    const h16x8 zero8 = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
     float bv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = (d.bias && mbase + r < M) ? d.bias[mbase + r] : 0.f;
-    const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
-    const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
     h16* dst16 = (h16*)d.dst;
     float* dst32 = (float*)d.dst;
+    const bool dense = (d.d_t == M) && (((uintptr_t)d.dst & 3) == 0);
+    const int nseg = (T + 63) >> 6;
+    const int SG = p.nmt;                                       // segments per item (host: 6 / worst-case chunks per segment)
+    const int ngrp = (nseg + SG - 1) / SG;
+    const long nitems = (long)d.B * d.Fout * ngrp;
+    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+        const int grp = (int)(item % ngrp);
+        const int row = (int)(item / ngrp);
+        const int b = row / d.Fout, fo = row - b * d.Fout;
+        const int fdst = fo - d.dst_f_off;
+        if (fdst < 0 || fdst >= d.dst_F) continue;
+        const int wset = d.transposed ? (fo % d.fstride) : 0;
+        const int fbase = d.transposed ? (fo / d.fstride) : (fo * d.fstride);
+        const h16* Wl = Ws + (wset * 16 + (lane & 15)) * WS + (lane >> 4) * 8;
+        const int seg_end = (grp + 1) * SG < nseg ? (grp + 1) * SG : nseg;
+        // (segment, tap j, 32-channel chunk cc) iterator, wave-uniform; a segment without any valid chunk yields one
+        // empty slot (kofs < 0) so that its bias-only output is still written
+        int it_seg = grp * SG, it_j = -1, it_cc = p.cpt - 1, it_fi = 0, it_n = 0;
+        auto advance = [&]() -> bool {                          // -> false: item exhausted
+            for (;;) {
+                bool found = false;
+                for (;;) {
+                    if (++it_cc == p.cpt) {
+                        it_cc = 0;
+                        for (++it_j; it_j < d.ntaps; ++it_j) {
+                            it_fi = fbase + d.df[aero_uniform(it_j)];
+                            if (it_fi >= 0 && it_fi < d.Fin) break;
+                        }
+                    }
+                    if (it_j >= d.ntaps) break;
+                    if (!has0 && (it_cc + 1) * 32 <= C0) continue;   // chunk inside the structurally-zero first source
+                    found = true;
+                    break;
+                }
+                if (found) { ++it_n; return true; }
+                if (it_n == 0) { it_n = 1; it_j = d.ntaps; it_cc = -1; return true; }     // empty segment
+                if (++it_seg >= seg_end) return false;
+                it_j = -1; it_cc = p.cpt - 1; it_n = 0;
+            }
+        };
+        auto load = [&](h16x8* nb, int seg, int jj, int cc, int fi) {     // global -> registers, coalesced
+            const int c = cc * 32 + lq * 8;
+            const h16* rb0 = has0 ? s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f : aero_zero_page;
+            const h16* rb1 = s1 ? s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f : aero_zero_page;
+            const int t0 = seg * 64 + lp + d.dt[aero_uniform(jj)];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int t = tw + g * 16;
-        if (t >= T) continue;
-        float o[4];
+            for (int i = 0; i < 4; ++i) {
+                const int t = t0 + i * 16;
+                const bool tok = t >= 0 && t < T;
+                h16x8 z;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float x = acc[g][r] + bv[r];
-            if (d.act == AERO_ACT_RELU) x = fmaxf(x, 0.f);
-            else if (d.act == AERO_ACT_GELU) x = aero_gelu(x);
-            o[r] = x * bsc + bsh;
-        }
-        const int64_t doff = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * d.d_t + mbase;
-        if (p.vec_out && mbase + 4 <= M) {
-            if (d.dst_f32) *(f32x4*)(dst32 + doff) = (f32x4){o[0], o[1], o[2], o[3]};
-            else *(h16x4*)(dst16 + doff) = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
-        } else {
+                for (int pc = 0; pc < 8 / VW; ++pc) {
+                    const int ce = c + pc * VW;
+                    const bool u0 = ce < C0;
+                    const bool ok = tok && (u0 ? has0 : (ce < C01));
+                    const h16* sp = u0 ? rb0 + (int64_t)t * d.s0_t + ce : rb1 + (int64_t)t * d.s1_t + (ce - C0);
+                    sp = ok ? sp : (const h16*)aero_zero_page;
+                    if (VW == 1) {
+                        z[pc] = *sp;
+                    } else {
+                        const hvw v = *(const hvw*)sp;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (mbase + r >= M) continue;
-                if (d.dst_f32) dst32[doff + r] = o[r];
-                else dst16[doff + r] = (h16)o[r];
+                        for (int e = 0; e < VW; ++e) z[pc * VW + e] = v[e];
+                    }
+                }
+                nb[i] = z;
+            }
+        };
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto mma = [&](const h16x8* nb, int kofs) {             // registers -> private LDS tile -> fragments -> MFMA
+            aero_wave_sync();                                   // earlier readers of the tile are done
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(h16x8*)&Xw[aero_tile_off(i * 16 + lp, lq)] = nb[i];
+            aero_wave_sync();
+            const h16x8 af = *(const h16x8*)(Wl + kofs);
+            h16x8 bf[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bf[g] = *(const h16x8*)&Xw[aero_tile_off(g * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[g], acc[g], 0, 0, 0);
+        };
+        auto epilogue = [&](int seg) {
+            const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
+            const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
+            const int tw = seg * 64 + (lane & 15);
+            if (dense) aero_wave_sync();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int t = tw + g * 16;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[g][r] + bv[r];
+                    if (d.act == AERO_ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (d.act == AERO_ACT_GELU) x = aero_gelu(x);
+                    o[r] = x * bsc + bsh;
+                    acc[g][r] = 0.f;
+                }
+                if (t >= T || mbase >= M) continue;
+                if (dense) {                                    // stage [step][channel]: the memory order of the segment
+                    const int li = (g * 16 + (lane & 15)) * M + mbase;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mbase + r >= M) continue;
+                        if (d.dst_f32) ((float*)Xw)[li + r] = o[r];
+                        else Xw[li + r] = (h16)o[r];
+                    }
+                    continue;
+                }
+                const int64_t doff = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * d.d_t + mbase;
+                if (p.vec_out && mbase + 4 <= M) {
+                    if (d.dst_f32) *(f32x4*)(dst32 + doff) = (f32x4){o[0], o[1], o[2], o[3]};
+                    else *(h16x4*)(dst16 + doff) = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mbase + r >= M) continue;
+                        if (d.dst_f32) dst32[doff + r] = o[r];
+                        else dst16[doff + r] = (h16)o[r];
+                    }
+                }
+            }
+            if (dense) {
+                aero_wave_sync();
+                const int npos = T - seg * 64 < 64 ? T - seg * 64 : 64;
+                const int N = npos * M;
+                const int64_t E0 = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)seg * 64 * M;
+                if (d.dst_f32) {
+                    for (int idx = lane; idx < N; idx += 64) dst32[E0 + idx] = ((const float*)Xw)[idx];
+                } else {
+                    const int a = (int)(E0 & 1);                // halves between the dword boundary and the segment start
+                    const int ndw = (a + N + 1) >> 1;
+                    uint32_t* gw = (uint32_t*)(dst16 + (E0 - a));
+                    for (int w = lane; w < ndw; w += 64) {
+                        const int le = 2 * w - a;
+                        const bool lo = le >= 0, hi = le + 1 < N;
+                        if (lo && hi) {
+                            union { h16 h[2]; uint32_t u; } pk;
+                            pk.h[0] = Xw[le];
+                            pk.h[1] = Xw[le + 1];
+                            gw[w] = pk.u;
+                        } else if (lo) {
+                            dst16[E0 + le] = Xw[le];
+                        } else if (hi) {
+                            dst16[E0 + le + 1] = Xw[le + 1];
+                        }
+                    }
+                }
+            }
+        };
+        // batches of up to NS slots: all loads first, then transpose + MFMA slot by slot
+        bool more = advance();
+        while (more) {
+            h16x8 nb[NS][4];
+            int s_kofs[NS], s_seg[NS];
+            bool s_last[NS];
+            int ns = 0;
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                if (!more) continue;
+                s_seg[sl] = it_seg;
+                s_kofs[sl] = it_cc < 0 ? -1 : it_j * p.Cp + it_cc * 32;
+                if (it_cc >= 0) load(nb[sl], it_seg, it_j, it_cc, it_fi);
+                more = advance();
+                s_last[sl] = !more || it_seg != s_seg[sl];
+                ns = sl + 1;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                if (sl >= ns) continue;
+                if (s_kofs[sl] >= 0) mma(nb[sl], s_kofs[sl]);
+                if (s_last[sl]) epilogue(s_seg[sl]);
             }
         }
     }
@@ -623,7 +850,7 @@ __global__ __launch_bounds__(256) void aero_conv3x3_kernel(AeroConvK p) {
     h16* Bs = smem + 3 * BM * 32;                               // [SLAB][32]
     h16* Cs = smem;
     const aero_conv_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const int mt = id % p.nmt;
@@ -847,14 +1074,35 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     const long nwg = (long)d->B * d->Fout * p.ntt * p.nmt;
     if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("AERO_CONV_DEBUG") ? 1 : 0;
+    if (dbg && !name)
+        fprintf(stderr, "[aero_conv] M=%d C0=%d C1=%d ntaps=%d B=%d Fin=%d Fout=%d T=%d tr=%d fs=%d act=%d vec_in=%d f32=%d res=%d post=%d s0=%d\n",
+                d->M, d->C0, d->C1, d->ntaps, d->B, d->Fin, d->Fout, d->T, d->transposed, d->fstride, d->act, p.vec_in, d->dst_f32,
+                d->res != nullptr, d->post_add != nullptr, d->src0 != nullptr);
     static int skinny = -1;
     if (skinny < 0) { const char* e = getenv("AERO_CONV_SKINNY"); skinny = (e && e[0] == '0') ? 0 : 1; }
-    if (skinny && d->M <= 16 && p.vec_in && p.Ktot <= AERO_SKINNY_KMAX && d->act != AERO_ACT_GLU && !d->res && !d->post_add &&
-        !d->stat_mode) {
-        p.ntt = (d->T + 255) / 256;
-        const long nb = (long)d->B * d->Fout * p.ntt;
-        if (name) snprintf(name, 96, "aero_conv_skinny_kernel");
-        else AERO_LAUNCH(aero_conv_skinny_kernel, dim3((unsigned)nb), block, stream, p);
+    if (skinny && d->M <= 16 && (d->transposed ? d->fstride : 1) * (p.Ktot + 8) <= AERO_SKINNY_WMAX && d->act != AERO_ACT_GLU &&
+        !d->res && !d->post_add && !d->stat_mode) {
+        const int nkmax = d->ntaps * p.cpt;                    // worst-case K-chunks per 64-step segment
+        p.nmt = nkmax >= AERO_SKINNY_SLOTS ? 1 : AERO_SKINNY_SLOTS / nkmax;      // segments per wave item
+        const int nseg = (d->T + 63) / 64;
+        const long nitems = (long)d->B * d->Fout * ((nseg + p.nmt - 1) / p.nmt);
+        const long want = (nitems + 3) / 4;
+        const long nb = want < 256 * 2 ? want : 256 * 2;      // persistent: 2 blocks (8 waves x 24 KiB of loads in flight) per CU
+        int vw = 8;                                             // widest load piece the layout allows
+        auto fits = [&](int w) {
+            bool ok = (d->C0 % w == 0) && (d->C1 % w == 0);
+            if (d->src0) ok = ok && d->s0_b % w == 0 && d->s0_f % w == 0 && d->s0_t % w == 0 && ((uintptr_t)d->src0 % (2 * w)) == 0;
+            if (d->src1) ok = ok && d->s1_b % w == 0 && d->s1_f % w == 0 && d->s1_t % w == 0 && ((uintptr_t)d->src1 % (2 * w)) == 0;
+            return ok;
+        };
+        while (vw > 1 && !fits(vw)) vw >>= 1;
+        if (name) snprintf(name, 96, "aero_conv_skinny_kernel<%d>", vw);
+        else if (vw == 8) AERO_LAUNCH(aero_conv_skinny_kernel<8>, dim3((unsigned)nb), block, stream, p);
+        else if (vw == 4) AERO_LAUNCH(aero_conv_skinny_kernel<4>, dim3((unsigned)nb), block, stream, p);
+        else if (vw == 2) AERO_LAUNCH(aero_conv_skinny_kernel<2>, dim3((unsigned)nb), block, stream, p);
+        else AERO_LAUNCH(aero_conv_skinny_kernel<1>, dim3((unsigned)nb), block, stream, p);
         return AERO_OK;
     }
     if (bm == 128 && p.vec_in && !p.glds && !d->stat_mode && aero_conv_is_3x3(d)) {

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void aero_freqfc_kernel(AeroFreqFcK p) {
     __shared__ AERO_LDS_ALIGN h16 As[BM * 32];
     __shared__ AERO_LDS_ALIGN h16 Bs[BN * 32];
     const aero_freqfc_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const int mt = id % p.nmt;
     id /= p.nmt;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
     h16* Bs = smem + KT * BM * 32;        // [KT][BN][32]
     h16* Cs = smem;                       // [BN][CS] output staging (after the MFMAs)
     const aero_ftb_first_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int C = d.C, T = d.T;
     int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const int ntt = (T + BN - 1) / BN;

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
     constexpr int NT = NW * 64;
     __shared__ AERO_LDS_ALIGN h16 hbuf[2][16 * KP];
     const aero_lstm_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int dir = blockIdx.y;
     const int seq0 = blockIdx.x * 16;
     const int H = d.H, W = d.W, H4 = 4 * d.H, H8 = 8 * d.H, H2 = 2 * d.H;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
     h16* hring = (h16*)AERO_DYN_SMEM;                              // [R][16][HS]
     h16* xring = hring + R * 16 * HS;                              // [2][G][16][XS]
     const aero_lstm_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int dir = blockIdx.y;
     const int seq0 = blockIdx.x * 16;
     const int H = d.H, W = d.W, H4 = 4 * d.H, H2 = 2 * d.H;
@@ -386,6 +386,18 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
     float c[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) c[i] = 0.f;
+    f32x4 accx[TPW];                    // bias + W_ih x for the step about to run
+    auto project = [&](const h16* xs) {
+        h16x8 xf[KTI];
+#pragma unroll
+        for (int kt = 0; kt < KTI; ++kt) xf[kt] = *(const h16x8*)(xs + kt * 32 + q * 8);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) accx[t] = bias4[t];
+#pragma unroll
+        for (int kt = 0; kt < KTI; ++kt)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wi[t][kt], xf[kt], accx[t], 0, 0, 0);
+    };
     const int ngroups = (W + G - 1) / G;
     load_x(0);
     park_x(0);
@@ -398,19 +410,13 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
             const int s = g * G + i;
             const h16* hprev = hring + (((s + R - 1) & (R - 1)) * 16 + col) * HS;
             h16* hnext = hring + ((s & (R - 1)) * 16 + col) * HS;
-            const h16* xs = xring + (((g & 1) * G + i) * 16 + col) * XS;
-            h16x8 xf[KTI], bf[KT];
-#pragma unroll
-            for (int kt = 0; kt < KTI; ++kt) xf[kt] = *(const h16x8*)(xs + kt * 32 + q * 8);
+            if (i == 0) project(xring + (((g & 1) * G) * 16 + col) * XS);      // first step of a group: x just parked
+            h16x8 bf[KT];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) bf[kt] = *(const h16x8*)(hprev + kt * 32 + q * 8);
             f32x4 accs[TPW];
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) accs[t] = bias4[t];
-#pragma unroll
-            for (int kt = 0; kt < KTI; ++kt)       // input projection first: independent of h_{t-1}
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wi[t][kt], xf[kt], accs[t], 0, 0, 0);
+            for (int t = 0; t < TPW; ++t) accs[t] = accx[t];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -419,21 +425,26 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
             for (int t = 0; t < TPW; ++t) {
                 const f32x4 a = accs[t];
                 const int j = (wave * TPW + t) * 4 + q;
-                // exponents pre-scaled by log2(e) and clamped (|x| <= 30, tanh arguments |x| <= 15): bare v_exp_f32
-                constexpr float L2E = 1.4426950408889634f, LIM = 43.28f;
-                const float ei = aero_exp2(aero_med3(a[0] * -L2E, -LIM, LIM));
-                const float ef = aero_exp2(aero_med3(a[1] * -L2E, -LIM, LIM));
-                const float eg = aero_exp2(aero_med3(a[2] * (2.f * L2E), -LIM, LIM));
-                const float eo = aero_exp2(aero_med3(a[3] * -L2E, -LIM, LIM));
+                // exponents pre-scaled by log2(e): bare v_exp_f32.  Only the tanh-type exponents need a clamp (from above,
+                // 2x <= 60 in log2 units): an infinite e_i/e_f/e_o just drives its reciprocal to 0, which is the right limit,
+                // whereas e_g = inf would meet that 0 as inf * 0.
+                constexpr float L2E = 1.4426950408889634f, LIM = 60.f, NOLIM = -3.0e38f;
+                const float ei = aero_exp2(a[0] * -L2E);
+                const float ef = aero_exp2(a[1] * -L2E);
+                const float eg = aero_exp2(aero_med3(a[2] * (2.f * L2E), NOLIM, LIM));
+                const float eo = aero_exp2(a[3] * -L2E);
                 const float r1 = aero_rcp((1.f + ei) * (eg + 1.f));
                 const float igg = fmaf(eg, r1, -r1);                                    // sigmoid(i) * tanh(g)
                 c[t] = fmaf(aero_rcp(1.f + ef), c[t], igg);
-                const float ec = aero_exp2(aero_med3(c[t] * (2.f * L2E), -LIM, LIM));
+                const float ec = aero_exp2(aero_med3(c[t] * (2.f * L2E), NOLIM, LIM));
                 const float r2 = aero_rcp((1.f + eo) * (ec + 1.f));
                 const float h = fmaf(ec, r2, -r2);                                      // sigmoid(o) * tanh(c)
                 if (j < H) hnext[j] = (h16)h;
             }
-            if (i == nst - 1 && g + 1 < ngroups) park_x((g + 1) & 1);   // loads issued G steps ago
+            // input projection of the NEXT step (independent of h): issued before the barrier so its LDS reads and
+            // MFMAs fill the pipes while the other waves finish their gate math
+            if (i + 1 < nst) project(xring + (((g & 1) * G + i + 1) * 16 + col) * XS);
+            else if (g + 1 < ngroups) park_x((g + 1) & 1);              // loads issued G steps ago
             __syncthreads();
         }
     }

@@ -14,7 +14,9 @@ from aero_amd.engine import Ops  # noqa: E402
 LAYERS = {  # name: (Cx, Cskip, M, F, null_x, glu)
     'd0': (384, 384, 1536, 4, True, False), 'd1': (192, 192, 768, 8, False, False),
     'd2': (96, 96, 384, 16, False, True), 'd3': (48, 48, 192, 64, False, True),
-    'tr0': None,
+}
+PW = {  # pointwise (1x1) shapes of the path: name: (C, M, F)
+    'pw768': (96, 768, 4), 'pw384': (48, 384, 8), 'pw96': (48, 96, 64), 'pw192': (24, 192, 16), 'pw768k': (384, 768, 4),
 }
 
 
@@ -28,6 +30,26 @@ def main():
     dev = 'cuda'
     ops = Ops(_lib.load())
     for name in a.layers.split(','):
+        if name in PW:
+            C, M, F = PW[name]
+            w = torch.randn(M, C, 1, 1) * 0.05
+            taps, df, dt = pack.conv2d_taps(w, 0, 0)
+            spec = pack.make_conv_spec(taps, torch.zeros(M), C, 0, df, dt, dev)
+            x = torch.randn(a.batch, F, a.T, C, device=dev).half()
+            out = torch.empty(a.batch, F, a.T, M, device=dev, dtype=torch.float16)
+            for _ in range(3):
+                ops.conv(spec, x, None, a.batch, F, F, a.T, dst=out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                ops.conv(spec, x, None, a.batch, F, F, a.T, dst=out)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            nb = x.numel() * 2 + out.numel() * 2
+            print(f'{name}: {ms * 1e3:8.1f} us  {nb / ms / 1e9:6.2f} TB/s  (C={C} M={M} rows={a.batch * F}, {nb / 1e6:.0f} MB)', flush=True)
+            continue
         C0, C1, M, F, null0, glu = LAYERS[name]
         w = torch.randn(M, C0 + C1, 3, 3) * 0.02
         taps, df, dt = pack.conv2d_taps(w, 1, 1)
