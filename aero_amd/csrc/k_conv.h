@@ -498,14 +498,21 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
     const int cc_lo = (s0 == nullptr && C0 % KC == 0) ? C0 / KC : 0;
     const int nF = d.ntaps / p.nT;
 
-    // ---- lane-invariant parts of the copy addresses
+    // ---- lane-invariant parts of the copy addresses: full per-lane pointers (item, in-tile position and channel slice
+    // folded in), so that a K-chunk only adds ONE block-uniform 32-bit element offset per source.  PMC: the loop used
+    // to spend ~85 scalar + ~50 vector instructions per 16 MFMAs rebuilding 64-bit row addresses and re-loading spilled
+    // kernel arguments (and the zero-page address) every chunk.
     const h16* a_ptr[NIA];
-    int b_pos[NIB], b_q8[NIB], b_off0[NIB], b_off1[NIB];
+    const h16* pb0[NIB];
+    const h16* pb1[NIB];
+    int b_pos[NIB], b_q8[NIB];
+    const h16* base0 = s0 ? s0 + (int64_t)b * d.s0_b : zp;
+    const h16* base1 = s1 ? s1 + (int64_t)b * d.s1_b - C0 : zp;
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
         const int s = (wave + NWV * i) * 64 + lane;
         const int r = s / SLOTS, q = (s % SLOTS) ^ aero_tile_swz<KC>(r);
-        a_ptr[i] = Wp + (int64_t)r * p.Ktot + q * 8;
+        a_ptr[i] = Wp + (r * p.Ktot + q * 8);
     }
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
@@ -513,9 +520,14 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
         const int pos = s / SLOTS, q = (s % SLOTS) ^ aero_tile_swz<KC>(pos);
         b_pos[i] = pos;
         b_q8[i] = q * 8;
-        b_off0[i] = pos * st0 + q * 8;
-        b_off1[i] = pos * st1 + q * 8;
+        pb0[i] = base0 + (pos * st0 + q * 8);
+        pb1[i] = base1 + (pos * st1 + q * 8);
     }
+    // the zero page's address lives in a VGPR pair (opaque to the compiler: no GOT reload inside the loop)
+    const h16* zpv = zp;
+#ifndef AERO_EMU
+    asm volatile("" : "+v"(zpv));
+#endif
 
     f32x4 acc[MF][NF];
 #pragma unroll
@@ -523,40 +535,51 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
 #pragma unroll
         for (int n = 0; n < NF; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- chunk iterator over (frequency tap jf, time tap jt, channel chunk cc); all state block-uniform
-    int jf = -1, jt = p.nT - 1, cc = cpt - 1, fi = 0;
+    // ---- chunk iterator over (frequency tap jf, time tap jt, channel chunk cc); all state block-uniform.  It carries
+    // the weight offset `kofs`, the source time `tsh` of position 0 and the element offsets `off0/off1` of the chunk
+    // relative to the per-lane pointers; a plain cc step is three additions.
+    const int nT = p.nT, f_step = p.f_step, t_step = p.t_step, Cpk = p.Cp;
+    const int s0f = (int)d.s0_f, s1f = (int)d.s1_f;             // in-item row offsets fit 32 bits (checked on the host)
+    const int t_base = t0 + p.t_lo;
+    int jf = -1, jt = nT - 1, cc = cpt - 1, fi = 0;
+    int kofs = 0, tsh = 0, off0 = 0, off1 = 0;
     auto next_chunk = [&]() -> bool {
-        if (++cc < cpt) return true;
-        cc = cc_lo;
-        if (++jt < p.nT) return true;
-        jt = 0;
-        for (;;) {
-            if (++jf >= nF) return false;
-            fi = fbase + jf * p.f_step;
-            if (fi >= 0 && fi < d.Fin) return true;
+        if (++cc < cpt) {
+            kofs += KC; off0 += KC; off1 += KC;
+            return true;
         }
+        cc = cc_lo;
+        if (++jt >= nT) {
+            jt = 0;
+            for (;;) {
+                if (++jf >= nF) return false;
+                fi = fbase + jf * f_step;
+                if (fi >= 0 && fi < d.Fin) break;
+            }
+        }
+        kofs = (jf * nT + jt) * Cpk + cc_lo * KC;
+        tsh = t_base + jt * t_step;
+        off0 = fi * s0f + tsh * st0 + cc_lo * KC;
+        off1 = fi * s1f + tsh * st1 + cc_lo * KC;
+        return true;
     };
+    const bool has0 = s0 != nullptr;
     auto issue = [&](int buf) {
         h16* As = smem + buf * STAGE;
         h16* Bs = As + BM * KC;
-        const int kofs = (jf * p.nT + jt) * p.Cp + cc * KC;
 #pragma unroll
         for (int i = 0; i < NIA; ++i)
             if (wave + NWV * i < BM * SLOTS / 64) aero_glds16(a_ptr[i] + kofs, As + (wave + NWV * i) * 512);
-        const int tsh = t0 + p.t_lo + jt * p.t_step;          // source time of position 0
         const int c_lo = cc * KC;
-        const h16* rb0 = s0 ? s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)tsh * st0 + c_lo : zp;
-        const h16* rb1 = s1 ? s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)tsh * st1 + (c_lo - C0) : zp;
         const int lim0 = C0 - c_lo, lim1 = C01 - c_lo;        // channel q8 comes from src0 if q8 < lim0, src1 if q8 < lim1
-        const bool has0 = s0 != nullptr;
 #pragma unroll
         for (int i = 0; i < NIB; ++i) {
             const int tpos = b_pos[i] + tsh;
             const bool tin = tpos >= 0 && tpos < T;
             const bool u0 = b_q8[i] < lim0;
             const bool ok = tin && (u0 ? has0 : (b_q8[i] < lim1));
-            const h16* ptr = (u0 ? rb0 : rb1) + (u0 ? b_off0[i] : b_off1[i]);
-            aero_glds16(ok ? ptr : zp, Bs + (wave + NWV * i) * 512);
+            const h16* ptr = u0 ? pb0[i] + off0 : pb1[i] + off1;
+            aero_glds16(ok ? ptr : zpv, Bs + (wave + NWV * i) * 512);
         }
     };
 
@@ -592,8 +615,9 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
     aero_conv_epilogue<MF, WM, STATS, NWV>(p, acc, Cs, b, fo, fdst, m0, t0);
 }
 
+// (KC 32, 128-row tile: ask for 3 blocks per CU -- 168 registers -- instead of the 204 the allocator takes by default)
 template <int MF, int WM, int KC, bool STATS>
-__global__ __launch_bounds__(256) void aero_conv_glds_kernel(AeroConvK p) {
+__global__ __launch_bounds__(256, (KC == 32 && MF * WM == 8) ? 3 : 1) void aero_conv_glds_kernel(AeroConvK p) {
     __shared__ AERO_LDS_ALIGN h16 smem[AeroGldsGeom<MF, WM, KC, 4>::SMEM];
     aero_conv_glds_body<MF, WM, KC, STATS, 4>(p, smem);
 }
@@ -961,6 +985,9 @@ static bool aero_conv_regular_taps(const aero_conv_desc* d, AeroConvK* p) {
     for (int j = 0; j < n; ++j)
         if (d->df[j] != d->df[0] + (j / nT) * f_step || d->dt[j] != d->dt[0] + (j % nT) * t_step) return false;
     if (d->s0_t > 0x3fffff || d->s1_t > 0x3fffff) return false;       // 32-bit in-row offsets
+    // 32-bit element offsets inside one batch item (frequency row + time shift + channel chunk)
+    auto span = [&](int64_t sf, int64_t st) { return (int64_t)(d->Fin + 1) * (sf < 0 ? -sf : sf) + (int64_t)(d->T + 512) * st; };
+    if ((d->src0 && span(d->s0_f, d->s0_t) > 0x7ffffff0LL) || (d->src1 && span(d->s1_f, d->s1_t) > 0x7ffffff0LL)) return false;
     p->nT = nT;
     p->f_lo = d->df[0];
     p->f_step = f_step;

@@ -108,8 +108,28 @@ __global__ __launch_bounds__(256) void aero_norm_apply_kernel(aero_norm_desc d, 
     const int item = d.per_row ? b * d.F + f : b;
     const int gs = d.C / d.G;
     const int c0 = v * VEC;
-    // y = x*A + Bc  (normalisation and affine folded), per owned channel; second half for GLU gates
+    // y = x*A + Bc  (normalisation and affine folded), per owned channel; second half for GLU gates.
+    // The statistics are turned into (rstd, -mean*rstd) ONCE per group this thread touches: fp64 only for the
+    // cancellation-prone E[x^2] - mean^2, one reciprocal of the count, a float rsqrt with one Newton step.  (Doing a
+    // double division and a double sqrt per channel made this preamble ~2400 instructions per thread -- as much as the
+    // whole streaming loop -- and the kernel issue-bound at 3.5 TB/s.)
     float A[VEC], Bc[VEC], A2[VEC], B2[VEC], ls[VEC];
+    const double inv_count = d.stats ? 1.0 / d.stat_count : 0.0;
+    int g_prev = -1;
+    float g_a = 1.f, g_b = 0.f;
+    auto group_ab = [&](int g) {
+        if (g == g_prev) return;
+        g_prev = g;
+        const double* st = d.stats + ((int64_t)item * d.G + g) * 2;
+        const double mean = st[0] * inv_count;
+        double var = st[1] * inv_count - mean * mean;              // biased variance, as nn.GroupNorm
+        if (var < 0) var = 0;
+        const float vf = (float)var + d.eps;
+        float r = aero_rsqrt(vf);
+        r = r * (1.5f - 0.5f * vf * r * r);                        // Newton step: full fp32 accuracy
+        g_a = r;
+        g_b = -(float)mean * r;
+    };
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         const int c = c0 + i;
@@ -119,13 +139,9 @@ __global__ __launch_bounds__(256) void aero_norm_apply_kernel(aero_norm_desc d, 
             float a = 1.f, bb = 0.f;
             if (half == 0 || glu) {
                 if (d.stats) {
-                    const double* st = d.stats + ((int64_t)item * d.G + cc / gs) * 2;
-                    const double mean = st[0] / d.stat_count;
-                    double var = st[1] / d.stat_count - mean * mean;      // biased variance, as nn.GroupNorm
-                    if (var < 0) var = 0;
-                    const float rstd = (float)(1.0 / sqrt(var + (double)d.eps));
-                    a = rstd;
-                    bb = -(float)mean * rstd;
+                    group_ab(cc / gs);
+                    a = g_a;
+                    bb = g_b;
                 }
                 if (d.gamma) {
                     const float gm = d.gamma[cc], bt = d.beta[cc];
