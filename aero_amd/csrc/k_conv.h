@@ -525,8 +525,10 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
     }
     // the zero page's address lives in a VGPR pair (opaque to the compiler: no GOT reload inside the loop)
     const h16* zpv = zp;
+    int Tv = T;                                                 // likewise T: compared per lane, no SGPR (re)load in the loop
 #ifndef AERO_EMU
     asm volatile("" : "+v"(zpv));
+    asm volatile("" : "+v"(Tv));
 #endif
 
     f32x4 acc[MF][NF];
@@ -575,7 +577,7 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
 #pragma unroll
         for (int i = 0; i < NIB; ++i) {
             const int tpos = b_pos[i] + tsh;
-            const bool tin = tpos >= 0 && tpos < T;
+            const bool tin = tpos >= 0 && tpos < Tv;
             const bool u0 = b_q8[i] < lim0;
             const bool ok = tin && (u0 ? has0 : (b_q8[i] < lim1));
             const h16* ptr = u0 ? pb0[i] + off0 : pb1[i] + off1;
