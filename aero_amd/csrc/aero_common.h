@@ -115,6 +115,19 @@ static __device__ __forceinline__ float aero_erf(float x) {
     return x < 0.f ? -r : r;
 }
 static __device__ __forceinline__ float aero_gelu(float x) { return 0.5f * x * (1.0f + aero_erf(x * 0.70710678118654752f)); }
+// Two GELUs at once (packed fp32: the affine parts compile to v_pk_fma_f32 / v_pk_mul_f32).  Same A&S 7.1.26 erf,
+// rearranged so that no sign select is needed:  gelu(y) = max(y, 0) - |y| * (poly(t)/2) * exp(-y^2/2),
+// t = 1/(1 + p|y|/sqrt2);  the 1/2 and the 1/sqrt2 are folded into the constants, exp(-y^2/2) = exp2(-0.7213475 y^2).
+static __device__ __forceinline__ f32x2 aero_gelu2(f32x2 y) {
+    const f32x2 ay = {fabsf(y[0]), fabsf(y[1])};
+    const f32x2 u = ay * 0.23164189678f + 1.0f;
+    const f32x2 t = {aero_rcp(u[0]), aero_rcp(u[1])};
+    const f32x2 a = y * y * -0.72134752044f;
+    const f32x2 E = {aero_exp2(a[0]), aero_exp2(a[1])};
+    const f32x2 p = ((((0.5307027145f * t - 0.7265760135f) * t + 0.7107068705f) * t - 0.142248368f) * t + 0.127414796f) * t;
+    const f32x2 g = {fmaxf(y[0], 0.f), fmaxf(y[1], 0.f)};
+    return g - ay * (p * E);
+}
 
 template <class T>
 static __device__ __forceinline__ T aero_wave_sum(T v) {

@@ -21,7 +21,7 @@
 
 struct AeroConvK {
     aero_conv_desc d;
-    int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec_out, staged, glds;
+    int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec4, vec_out, staged, glds;
     int nT, f_lo, f_step, t_lo, t_step;      // regular tap grid: df = f_lo + (j / nT) * f_step, dt = t_lo + (j % nT) * t_step
 };
 
@@ -41,7 +41,7 @@ struct AeroConvK {
 // 1.5 TB/s.  Rows >= M carry zero weights and are masked at the copy-out, so no fragment is skipped here.
 template <int MF, int WM, int NWV, int ACT>
 static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& p, f32x4 (&acc)[MF][8 / (NWV / WM)], h16* Cs, int b,
-                                                               int fdst, int m0, int t0) {
+                                                               int fo, int fdst, int m0, int t0) {
     constexpr int WN = NWV / WM;
     constexpr int NF = 8 / WN;
     constexpr int BM = 16 * MF * WM;
@@ -74,6 +74,7 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
     h16* dst16 = (h16*)d.dst;
     h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
     const h16* rrow = d.res ? (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + m0o : nullptr;
+    const float* prow = d.post_add ? d.post_add + (int64_t)fo * Mout + m0o : nullptr;      // frequency embedding row
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -116,6 +117,10 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + (float)r8[e]);
                 }
+                if (prow) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + prow[cv * 8 + e]);
+                }
                 *(h16x8*)(drow + (int64_t)t * d.d_t + cv * 8) = v;
             }
         }
@@ -131,12 +136,12 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
     constexpr int BM = 16 * MF * WM;
     constexpr int CS = BM + 8;
     const aero_conv_desc& d = p.d;
-    if (p.staged && !d.post_add && !d.batch_scale && (!STATS || d.stat_mode == 0)) {
+    if (p.staged && !d.batch_scale && (!STATS || d.stat_mode == 0)) {
         switch (d.act) {
-            case AERO_ACT_NONE: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_NONE>(p, acc, Cs, b, fdst, m0, t0); break;
-            case AERO_ACT_RELU: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_RELU>(p, acc, Cs, b, fdst, m0, t0); break;
-            case AERO_ACT_GELU: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GELU>(p, acc, Cs, b, fdst, m0, t0); break;
-            default: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GLU>(p, acc, Cs, b, fdst, m0, t0); break;
+            case AERO_ACT_NONE: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_NONE>(p, acc, Cs, b, fo, fdst, m0, t0); break;
+            case AERO_ACT_RELU: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_RELU>(p, acc, Cs, b, fo, fdst, m0, t0); break;
+            case AERO_ACT_GELU: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GELU>(p, acc, Cs, b, fo, fdst, m0, t0); break;
+            default: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GLU>(p, acc, Cs, b, fo, fdst, m0, t0); break;
         }
         return;
     }
@@ -370,6 +375,19 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
                 if (s0) z = *(const h16x8*)(s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)t * d.s0_t + c);
             } else if (c - C0 < C1) {
                 z = *(const h16x8*)(s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)t * d.s1_t + (c - C0));
+            }
+        } else if (p.vec4) {                                    // channel counts / strides that are only 8-byte aligned (C = 12)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int ch = c + hf * 4;
+                h16x4 v = (h16x4){0, 0, 0, 0};
+                if (ch < C0) {
+                    if (s0) v = *(const h16x4*)(s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)t * d.s0_t + ch);
+                } else if (ch - C0 < C1) {
+                    v = *(const h16x4*)(s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)t * d.s1_t + (ch - C0));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[hf * 4 + e] = v[e];
             }
         } else {
             const h16* p0 = s0 ? s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)t * d.s0_t : nullptr;
@@ -1088,6 +1106,11 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     if (d->src0) vin = vin && al8(d->s0_b) && al8(d->s0_f) && al8(d->s0_t) && (((uintptr_t)d->src0 & 15) == 0);
     if (d->src1) vin = vin && al8(d->s1_b) && al8(d->s1_f) && al8(d->s1_t) && (((uintptr_t)d->src1 & 15) == 0);
     p.vec_in = vin;
+    auto al4 = [](int64_t v) { return (v & 3) == 0; };
+    int v4 = (d->C0 % 4 == 0) && (d->C1 % 4 == 0);
+    if (d->src0) v4 = v4 && al4(d->s0_b) && al4(d->s0_f) && al4(d->s0_t) && (((uintptr_t)d->src0 & 7) == 0);
+    if (d->src1) v4 = v4 && al4(d->s1_b) && al4(d->s1_f) && al4(d->s1_t) && (((uintptr_t)d->src1 & 7) == 0);
+    p.vec4 = v4 && !vin;
     p.glds = aero_conv_use_glds();
     p.nT = 1; p.f_lo = p.f_step = p.t_lo = p.t_step = 0;
     const int Mout = d->act == AERO_ACT_GLU ? d->M / 2 : d->M;

@@ -11,6 +11,8 @@
 // Algorithmic bytes: stats 2 B/element read; apply 2 B read + 2 B write per output element (GLU reads 4 B per
 // output; +2 B for a residual) -- DESIGN.md section 4.
 #pragma once
+#include <stdlib.h>
+
 #include "aero_common.h"
 
 template <int VEC>
@@ -34,6 +36,21 @@ static __device__ __forceinline__ void aero_load_vec(const h16* p, float* out) {
         for (int i = 0; i < 4; ++i) out[i] = (float)v[i];
     } else {
         out[0] = (float)p[0];
+    }
+}
+
+// raw (unconverted) vector load and its conversion, so that several loads can be issued before the first is used
+template <int VEC>
+static __device__ __forceinline__ typename AeroVecT<VEC>::type aero_load_raw(const h16* p) {
+    return *(const typename AeroVecT<VEC>::type*)p;
+}
+template <int VEC>
+static __device__ __forceinline__ void aero_cvt_vec(const typename AeroVecT<VEC>::type& v, float* out) {
+    if constexpr (VEC == 1) {
+        out[0] = (float)v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) out[i] = (float)v[i];
     }
 }
 
@@ -75,13 +92,37 @@ __global__ __launch_bounds__(256) void aero_norm_stats_kernel(aero_norm_desc d, 
     const int t1 = (t0 + tchunk < d.T) ? t0 + tchunk : d.T;
     float s = 0.f, ss = 0.f;
     if (ty < TY) {
-        for (int t = t0 + ty; t < t1; t += TY) {
-            const h16* row = base + (int64_t)t * d.s_t;
-            for (int vv = v; vv < vpp; vv += vstep) {
+        if (!wide) {
+            // four time steps per trip, all loads issued before the first use: one wave keeps 4 KiB in flight instead of 1
+            const h16* colp = base + v * VEC;
+            int t = t0 + ty;
+            for (; t + 3 * TY < t1; t += 4 * TY) {
+                typename AeroVecT<VEC>::type r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = aero_load_raw<VEC>(colp + (int64_t)(t + k * TY) * d.s_t);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float x[VEC];
+                    aero_cvt_vec<VEC>(r[k], x);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) { s += x[i]; ss += x[i] * x[i]; }
+                }
+            }
+            for (; t < t1; t += TY) {
                 float x[VEC];
-                aero_load_vec<VEC>(row + vv * VEC, x);
+                aero_load_vec<VEC>(colp + (int64_t)t * d.s_t, x);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { s += x[i]; ss += x[i] * x[i]; }
+            }
+        } else {
+            for (int t = t0 + ty; t < t1; t += TY) {
+                const h16* row = base + (int64_t)t * d.s_t;
+                for (int vv = v; vv < vpp; vv += vstep) {
+                    float x[VEC];
+                    aero_load_vec<VEC>(row + vv * VEC, x);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) { s += x[i]; ss += x[i] * x[i]; }
+                }
             }
         }
     }
@@ -160,37 +201,91 @@ __global__ __launch_bounds__(256) void aero_norm_apply_kernel(aero_norm_desc d, 
     h16* dst = (h16*)d.dst + (int64_t)b * d.d_b + (int64_t)f * d.d_f + c0;
     const int t0 = blockIdx.x * tchunk;
     const int t1 = (t0 + tchunk < d.T) ? t0 + tchunk : d.T;
-    for (int t = t0 + ty; t < t1; t += TY) {
-        float x[VEC], o[VEC];
-        aero_load_vec<VEC>(src + (int64_t)t * d.s_t, x);
-        if (glu) {
-            float z[VEC];
-            aero_load_vec<VEC>(src + (int64_t)t * d.s_t + Cout, z);
+    // Fold what can be folded into the per-channel FMA coefficients: LayerScale into (A, Bc); -log2(e) into the gate's
+    // (A2, B2) so that sigmoid(v) = rcp(1 + exp2(v')) needs no multiply.
+    if (glu) {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) o[i] = (x[i] * A[i] + Bc[i]) * aero_sigmoid(z[i] * A2[i] + B2[i]) * ls[i];
-        } else if (d.act == AERO_ACT_GELU) {
+        for (int i = 0; i < VEC; ++i) {
+            A[i] *= ls[i]; Bc[i] *= ls[i];
+            A2[i] *= -1.4426950408889634f; B2[i] *= -1.4426950408889634f;
+        }
+    }
+    // one time step: x (and the GLU gate z, the residual r) -> o.  The arithmetic runs on PAIRS of channels (f32x2): the
+    // affine part, the erf polynomial and the products compile to v_pk_fma/mul_f32, two elements per instruction; only
+    // exp2 / rcp / sin stay scalar.  (These kernels are VALU-bound, not HBM-bound: 16 B in -> ~100-200 instructions.)
+    auto step = [&](const float* x, const float* z, const float* r, float* o) {
+        if constexpr (VEC >= 2) {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) o[i] = aero_gelu(x[i] * A[i] + Bc[i]);
-        } else if (d.act == AERO_ACT_RELU) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) o[i] = fmaxf(x[i] * A[i] + Bc[i], 0.f);
-        } else if (d.act == AERO_ACT_SNAKE) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const float y = x[i] * A[i] + Bc[i];
-                const float sn = aero_fast_sin(y * snake_a);
-                o[i] = y + snake_ia * sn * sn;
+            for (int j = 0; j < VEC / 2; ++j) {
+                const f32x2 xp = {x[2 * j], x[2 * j + 1]};
+                const f32x2 Ap = {A[2 * j], A[2 * j + 1]}, Bp = {Bc[2 * j], Bc[2 * j + 1]};
+                const f32x2 y = xp * Ap + Bp;
+                f32x2 q;
+                if (glu) {
+                    const f32x2 zp = {z[2 * j], z[2 * j + 1]};
+                    const f32x2 A2p = {A2[2 * j], A2[2 * j + 1]}, B2p = {B2[2 * j], B2[2 * j + 1]};
+                    const f32x2 v = zp * A2p + B2p;
+                    const f32x2 e = {aero_exp2(v[0]), aero_exp2(v[1])};
+                    const f32x2 u = e + 1.0f;
+                    const f32x2 sg = {aero_rcp(u[0]), aero_rcp(u[1])};
+                    q = y * sg;
+                } else if (d.act == AERO_ACT_GELU) {
+                    q = aero_gelu2(y);
+                } else if (d.act == AERO_ACT_RELU) {
+                    q = (f32x2){fmaxf(y[0], 0.f), fmaxf(y[1], 0.f)};
+                } else if (d.act == AERO_ACT_SNAKE) {
+                    const f32x2 ya = y * snake_a;
+                    const f32x2 sn = {aero_fast_sin(ya[0]), aero_fast_sin(ya[1])};
+                    q = y + (sn * sn) * snake_ia;
+                } else {
+                    q = y;
+                }
+                if (res) q += (f32x2){r[2 * j], r[2 * j + 1]};
+                o[2 * j] = q[0];
+                o[2 * j + 1] = q[1];
             }
         } else {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) o[i] = x[i] * A[i] + Bc[i];
+            const float y = x[0] * A[0] + Bc[0];
+            float q;
+            if (glu) q = y * aero_rcp(1.0f + aero_exp2(z[0] * A2[0] + B2[0]));
+            else if (d.act == AERO_ACT_GELU) q = aero_gelu(y);
+            else if (d.act == AERO_ACT_RELU) q = fmaxf(y, 0.f);
+            else if (d.act == AERO_ACT_SNAKE) { const float sn = aero_fast_sin(y * snake_a); q = y + snake_ia * sn * sn; }
+            else q = y;
+            if (res) q += r[0];
+            o[0] = q;
         }
-        if (res) {
-            float r[VEC];
-            aero_load_vec<VEC>(res + (int64_t)t * d.r_t, r);
+    };
+    // UNR time steps per trip with every load issued before the first use (a wave keeps UNR KiB in flight; with one
+    // load per trip the kernel sat at 3.5 TB/s, latency-bound)
+    constexpr int UNR = 4;
+    typedef typename AeroVecT<VEC>::type raw_t;
+    int t = t0 + ty;
+    for (; t + (UNR - 1) * TY < t1; t += UNR * TY) {
+        raw_t rx[UNR], rz[UNR], rr[UNR];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) o[i] += r[i];
+        for (int k = 0; k < UNR; ++k) {
+            const int64_t tk = t + k * TY;
+            rx[k] = aero_load_raw<VEC>(src + tk * d.s_t);
+            if (glu) rz[k] = aero_load_raw<VEC>(src + tk * d.s_t + Cout);
+            if (res) rr[k] = aero_load_raw<VEC>(res + tk * d.r_t);
         }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            float x[VEC], z[VEC], r[VEC], o[VEC];
+            aero_cvt_vec<VEC>(rx[k], x);
+            if (glu) aero_cvt_vec<VEC>(rz[k], z);
+            if (res) aero_cvt_vec<VEC>(rr[k], r);
+            step(x, z, r, o);
+            aero_store_vec<VEC>(dst + (int64_t)(t + k * TY) * d.d_t, o);
+        }
+    }
+    for (; t < t1; t += TY) {
+        float x[VEC], z[VEC], r[VEC], o[VEC];
+        aero_load_vec<VEC>(src + (int64_t)t * d.s_t, x);
+        if (glu) aero_load_vec<VEC>(src + (int64_t)t * d.s_t + Cout, z);
+        if (res) aero_load_vec<VEC>(res + (int64_t)t * d.r_t, r);
+        step(x, z, r, o);
         aero_store_vec<VEC>(dst + (int64_t)t * d.d_t, o);
     }
 }
@@ -216,12 +311,22 @@ static int aero_norm_check(const aero_norm_desc* d, const char** err) {
 }
 
 // time steps per block: enough blocks to fill 256 CUs several times over, at least 2 passes per thread
-static int aero_norm_tchunk(int T, int TY, int64_t rows) {
+// Blocks are launched in memory order (t-chunks of a row fastest) and each takes a SHORT contiguous piece: the set of
+// blocks in flight then covers a few MB of adjacent addresses, like a plain streaming kernel.  (One block per 96-KiB
+// row meant ~1300 independent DRAM streams in flight and 3.5 TB/s.)  AERO_NORM_CHUNK_KB overrides the piece size.
+static int aero_norm_tchunk(int T, int TY, int64_t rows, int row_bytes_per_step) {
+    static int kb = -1;
+    if (kb < 0) { const char* e = getenv("AERO_NORM_CHUNK_KB"); kb = e ? atoi(e) : 0; }
     int chunks = (int)((4096 + rows - 1) / rows);
     if (chunks < 1) chunks = 1;
     int tchunk = (T + chunks - 1) / chunks;
-    const int min_chunk = TY * 4;
-    if (tchunk < min_chunk) tchunk = min_chunk;
+    const int unit = TY * 4;                                     // one unrolled trip of every thread
+    if (kb > 0) {
+        int want = (kb * 1024 + row_bytes_per_step - 1) / row_bytes_per_step;
+        want = (want + unit - 1) / unit * unit;
+        if (want < tchunk) tchunk = want;
+    }
+    if (tchunk < unit) tchunk = unit;
     if (tchunk > T) tchunk = T;
     return tchunk;
 }
@@ -237,7 +342,7 @@ static int aero_norm_stats_launch(const aero_norm_desc* d, hipStream_t stream, c
     const int nf = d->per_row ? 1 : d->F;
     const int vpp = gs / vec;
     const int TY = vpp > 256 ? 1 : 256 / vpp;
-    const int tchunk = aero_norm_tchunk(d->T, TY, items * d->G * nf);
+    const int tchunk = aero_norm_tchunk(d->T, TY, items * d->G * nf, gs * 2);
     dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)nf, (unsigned)(items * d->G)), block(256);
     if (vec == 8) AERO_LAUNCH((aero_norm_stats_kernel<8>), grid, block, stream, *d, tchunk);
     else if (vec == 4) AERO_LAUNCH((aero_norm_stats_kernel<4>), grid, block, stream, *d, tchunk);
@@ -259,7 +364,7 @@ static int aero_norm_apply_launch(const aero_norm_desc* d, hipStream_t stream, c
     const int vpp = Cout / vec;
     if (vpp > 256) { *err = "norm_apply: more than 256 channel vectors per position (C too large)"; return AERO_ERR_UNSUPPORTED; }
     const int TY = 256 / vpp;
-    const int tchunk = aero_norm_tchunk(d->T, TY, (int64_t)d->B * d->F);
+    const int tchunk = aero_norm_tchunk(d->T, TY, (int64_t)d->B * d->F, d->C * 2);
     dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)d->F, (unsigned)d->B), block(256);
     if (vec == 8) AERO_LAUNCH((aero_norm_apply_kernel<8>), grid, block, stream, *d, tchunk);
     else if (vec == 4) AERO_LAUNCH((aero_norm_apply_kernel<4>), grid, block, stream, *d, tchunk);
