@@ -879,6 +879,83 @@ __global__ __launch_bounds__(256) void aero_conv_skinny_kernel(AeroConvK p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Pointwise conv with a handful of channels on both sides and a FREQUENCY-major destination ([b][t][f][m], d_f = M,
+// d_t = F*M): the first FTB's 2 -> 5 squeeze, whose output feeds a conv1d over (f, m) (reference modules.py:287-289,
+// 309-311).  Per position that is C FMAs per output, so the MFMA tile machinery is pure overhead; what matters is
+// that both sides move in full lines although the layout is transposed between them: a block owns a 32-row x 64-step
+// tile, reads it along time (256-byte runs), converts in registers, parks the results in LDS as [step][row][m] and
+// writes every step's 32*M contiguous values as dwords.  Roofline: HBM, (C + M) * 2 bytes per position.
+#define AERO_TINY_TF 32
+#define AERO_TINY_TT 64
+__global__ __launch_bounds__(256) void aero_conv_tiny_kernel(AeroConvK p) {
+    __shared__ AERO_LDS_ALIGN h16 Os[AERO_TINY_TT * AERO_TINY_TF * 8];
+    __shared__ float Wt[8 * 8 + 8];
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x;
+    const int C = d.C0, M = d.M, T = d.T, F = d.Fout;
+    int id = (int)blockIdx.x;
+    const int tt = id % p.ntt;
+    id /= p.ntt;
+    const int ft = id % p.nmt;
+    const int b = id / p.nmt;
+    const int f0 = ft * AERO_TINY_TF, t0 = tt * AERO_TINY_TT;
+    if (tid < M * 8) {
+        const int m = tid >> 3, c = tid & 7;
+        Wt[tid] = c < C ? (float)((const h16*)d.weight)[(int64_t)m * p.Ktot + c] : 0.f;
+    }
+    if (tid < 8) Wt[64 + tid] = (d.bias && tid < M) ? d.bias[tid] : 0.f;
+    __syncthreads();
+    // phase 1: thread -> row fl, 8 consecutive steps
+    const int fl = tid >> 3, tl0 = (tid & 7) * 8;
+    const int f = f0 + fl;
+    const h16* src = (const h16*)d.src0 + (int64_t)b * d.s0_b + (int64_t)f * d.s0_f;
+    float w[8][8], bias[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        bias[m] = Wt[64 + m];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[m][c] = Wt[m * 8 + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int tl = tl0 + k, t = t0 + tl;
+        float x[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = (f < F && t < T && c < C) ? (float)src[(int64_t)t * d.s0_t + c] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (m >= M) continue;
+            float o = bias[m];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o += w[m][c] * x[c];
+            if (d.act == AERO_ACT_RELU) o = fmaxf(o, 0.f);
+            else if (d.act == AERO_ACT_GELU) o = aero_gelu(o);
+            Os[(tl * AERO_TINY_TF + fl) * M + m] = (h16)o;
+        }
+    }
+    __syncthreads();
+    // phase 2: every step's [rows][M] run is contiguous in LDS and in the destination
+    const int nf = F - f0 < AERO_TINY_TF ? F - f0 : AERO_TINY_TF;
+    const int run = nf * M;                                       // halves per step
+    const int ndw = (run + 1) >> 1;
+    h16* dbase = (h16*)d.dst + (int64_t)b * d.d_b + (int64_t)f0 * d.d_f;
+    const bool al = ((((uintptr_t)dbase) | (uintptr_t)(d.d_t * 2)) & 3) == 0 && (run & 1) == 0;
+    for (int idx = tid; idx < AERO_TINY_TT * ndw; idx += 256) {
+        const int tl = idx / ndw, wd = idx - tl * ndw;
+        const int t = t0 + tl;
+        if (t >= T) continue;
+        const h16* lp = Os + tl * AERO_TINY_TF * M + wd * 2;
+        h16* gp = dbase + (int64_t)t * d.d_t + wd * 2;
+        if (al) {
+            *(uint32_t*)gp = *(const uint32_t*)lp;
+        } else {
+            gp[0] = lp[0];
+            if (wd * 2 + 1 < run) gp[1] = lp[1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // 3x3 (time-context) specialisation -- the decoder "rewrite" convs, 68 % of the model's FLOPs.
 // Same tiling as above (128 channels x 128 steps of one row), but a pipeline stage is (frequency tap df, 32-channel
 // chunk) and carries all THREE time taps: the activation slab [t0-1, t0+129) x 32ch is staged once and read at row
@@ -1132,6 +1209,19 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         fprintf(stderr, "[aero_conv] M=%d C0=%d C1=%d ntaps=%d B=%d Fin=%d Fout=%d T=%d tr=%d fs=%d act=%d vec_in=%d f32=%d res=%d post=%d s0=%d\n",
                 d->M, d->C0, d->C1, d->ntaps, d->B, d->Fin, d->Fout, d->T, d->transposed, d->fstride, d->act, p.vec_in, d->dst_f32,
                 d->res != nullptr, d->post_add != nullptr, d->src0 != nullptr);
+    // few channels in, few out, frequency-major destination: the transposing pointwise kernel
+    if (d->ntaps == 1 && d->df[0] == 0 && d->dt[0] == 0 && !d->transposed && d->fstride == 1 && d->C1 == 0 && d->src0 && d->C0 <= 8 &&
+        d->M <= 8 && d->act != AERO_ACT_GLU && !d->res && !d->post_add && !d->batch_scale && !d->stat_mode && !d->dst_f32 &&
+        d->d_f == d->M && d->d_t == (int64_t)d->Fout * d->M && d->dst_f_off == 0 && d->dst_F == d->Fout && d->Fin == d->Fout &&
+        getenv("AERO_CONV_TINY_OFF") == nullptr) {
+        p.ntt = (d->T + AERO_TINY_TT - 1) / AERO_TINY_TT;
+        p.nmt = (d->Fout + AERO_TINY_TF - 1) / AERO_TINY_TF;
+        const long nb = (long)d->B * p.nmt * p.ntt;
+        if (nb > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
+        if (name) snprintf(name, 96, "aero_conv_tiny_kernel");
+        else AERO_LAUNCH(aero_conv_tiny_kernel, dim3((unsigned)nb), block, stream, p);
+        return AERO_OK;
+    }
     static int skinny = -1;
     if (skinny < 0) { const char* e = getenv("AERO_CONV_SKINNY"); skinny = (e && e[0] == '0') ? 0 : 1; }
     if (skinny && d->M <= 16 && (d->transposed ? d->fstride : 1) * (p.Ktot + 8) <= AERO_SKINNY_WMAX && d->act != AERO_ACT_GLU &&

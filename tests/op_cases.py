@@ -107,6 +107,24 @@ def case_conv2d(lib, dev, Cin, Cout, kF, kT, stride, padF, padT, Fin, T, act='no
     assert rel_l2(uncl(y.cpu()), ref) < TOL16
 
 
+def case_conv_tiny(lib, dev, Cin, Cout, Fq, T, B=2, act='relu', seed=15):
+    """Pointwise conv with few channels written into a frequency-major [B, T, F*M] destination (the first FTB's squeeze,
+    engine._encode): exercises aero_conv_tiny_kernel."""
+    ops = Ops(lib)
+    w = _rand((Cout, Cin, 1, 1), seed, 1.0 / math.sqrt(Cin))
+    b = _rand((Cout,), seed + 1)
+    x = _rand((B, Cin, Fq, T), seed + 2)
+    taps, df, dt = pack.conv2d_taps(q16(w), 0, 0)
+    actc = {'none': _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'gelu': _lib.ACT_GELU}[act]
+    spec = pack.make_conv_spec(taps, b, Cin, 0, df, dt, dev, act=actc)
+    dst = torch.zeros(B, T, Fq * Cout, dtype=torch.float16, device=dev)
+    ops.conv(spec, cl(x).to(dev), None, B, Fq, Fq, T, dst=dst, dst_strides=(T * Fq * Cout, Cout, Fq * Cout))
+    ref = F.conv2d(q16(x), q16(w), b)
+    ref = {'none': lambda v: v, 'relu': F.relu, 'gelu': F.gelu}[act](ref)            # [B, M, F, T]
+    got = dst.cpu().float().view(B, T, Fq, Cout).permute(0, 3, 2, 1)
+    assert rel_l2(got, ref) < TOL16
+
+
 def case_conv1d(lib, dev, Cin, Cout, k, dil, R, T, seed=20):
     ops = Ops(lib)
     w = _rand((Cout, Cin, k), seed, 1.0 / math.sqrt(Cin * k))

@@ -66,6 +66,11 @@ def test_conv2d(emu, kw):
     oc.case_conv2d(emu, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Cin=2, Cout=5, Fq=40, T=70), dict(Cin=2, Cout=5, Fq=64, T=64, act='none'), dict(Cin=4, Cout=6, Fq=33, T=130, B=1, act='gelu'), dict(Cin=3, Cout=3, Fq=7, T=20)])
+def test_conv_tiny(emu, kw):
+    oc.case_conv_tiny(emu, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(Cin=48, Cout=12, k=3, dil=1, R=6, T=131), dict(Cin=16, Cout=4, k=3, dil=2, R=3, T=60),
                                 dict(Cin=40, Cout=16, k=9, dil=1, R=2, T=50)])
 def test_conv1d(emu, kw):

@@ -47,6 +47,11 @@ def test_conv2d(lib, kw):
     oc.case_conv2d(lib, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Cin=2, Cout=5, Fq=256, T=501, B=4), dict(Cin=4, Cout=6, Fq=33, T=130, B=1, act='gelu'), dict(Cin=3, Cout=3, Fq=7, T=20)])
+def test_conv_tiny(lib, kw):
+    oc.case_conv_tiny(lib, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(Cin=48, Cout=12, k=3, dil=1, R=128, T=501), dict(Cin=384, Cout=96, k=3, dil=2, R=8, T=501),
                                 dict(Cin=512, Cout=48, k=9, dil=1, R=2, T=501)])
 def test_conv1d(lib, kw):
