@@ -879,6 +879,185 @@ __global__ __launch_bounds__(256) void aero_conv_skinny_kernel(AeroConvK p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Lean form of the skinny kernel for the shapes the model actually runs (one 16-byte-aligned source, regular tap grid,
+// at most six K-chunks per segment, dense destination).  PMC on the general kernel above: 13 k vector + 14 k scalar
+// instructions per wave for 420 MFMAs -- the generic iterator, 64-bit per-lane address arithmetic and per-lane validity
+// selects made a streaming kernel issue-bound.  Here:
+//   * everything about a slot that does not depend on the row (tap, channel chunk, weight offset) is fixed per kernel;
+//   * per-lane addressing is one 32-bit offset computed once, a slot adds a block-uniform 32-bit offset to a
+//     block-uniform 64-bit row pointer; interior slots (all 64 steps inside [0, T), all 32 channels present) issue four
+//     unconditional loads;
+//   * a transposed conv whose `fstride` weight sets fit into the 16 MFMA rows together (fstride * M <= 16: the last
+//     decoder, 4 x 2) is computed from the INPUT side: one pass over source rows (q, q-1) yields all `fstride` output
+//     rows 4q..4q+3, instead of re-reading the source once per output row (8x less L2 traffic, 4x fewer MFMAs).
+#define AERO_STREAM_SLOTS 6
+__global__ __launch_bounds__(256) void aero_conv_stream_kernel(AeroConvK p) {
+    __shared__ AERO_LDS_ALIGN h16 Ws[16 * AERO_SKINNY_WMAX];
+    __shared__ AERO_LDS_ALIGN h16 Xs[4][64 * 32];
+    constexpr int NS = AERO_STREAM_SLOTS;
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int M = d.M, T = d.T, C0 = d.C0;
+    const int stack = d.transposed ? d.fstride : 1;               // weight sets stacked into the MFMA rows
+    const int WS = p.Ktot + 8;
+    const int kv = p.Ktot >> 3;
+    for (int v = tid; v < 16 * kv; v += 256) {
+        const int R = v / kv, q = v - R * kv;
+        const int r = R / M, m = R - r * M;
+        h16x8 w = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < stack) w = *(const h16x8*)((const h16*)d.weight + ((int64_t)r * p.Mpad + m) * p.Ktot + q * 8);
+        *(h16x8*)&Ws[R * WS + q * 8] = w;
+    }
+    __syncthreads();
+    h16* Xw = Xs[wave];
+    const h16* s0 = (const h16*)d.src0;
+    const int st = (int)d.s0_t;
+    const int lp = lane >> 2, lq = lane & 3;
+    const int voff = lp * st + lq * 8;
+    const h16* Wl = Ws + (lane & 15) * WS + (lane >> 4) * 8;
+    const h16* zpv = aero_zero_page;
+    // per-lane output rows: R = (lane>>4)*4 + rr  ->  (weight set r, channel m)
+    int o_r[4], o_m[4];
+    float bv[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int R = (lane >> 4) * 4 + rr;
+        o_r[rr] = R / M;
+        o_m[rr] = R - o_r[rr] * M;
+        bv[rr] = (d.bias && o_r[rr] < stack) ? d.bias[o_m[rr]] : 0.f;
+    }
+    // slot table (block-uniform, fixed for the whole kernel): slot s = (segment s / nk, chunk k = s % nk)
+    const int cpt = p.cpt, nT = p.nT;
+    const int nk = d.ntaps * cpt;
+    const int SG = p.nmt;
+    int sl_seg[NS], sl_jf[NS], sl_dt[NS], sl_cc[NS], sl_kofs[NS];
+    bool sl_last[NS];
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+        const int sg = sidx / nk, k = sidx - sg * nk;
+        const int tap = k / cpt;
+        sl_seg[sidx] = sg < SG ? sg : -1;
+        sl_cc[sidx] = k - tap * cpt;
+        sl_jf[sidx] = tap / nT;
+        sl_dt[sidx] = p.t_lo + (tap - sl_jf[sidx] * nT) * p.t_step;
+        sl_kofs[sidx] = k * 32;
+        sl_last[sidx] = k == nk - 1;
+    }
+    h16* dst16 = (h16*)d.dst;
+    float* dst32 = (float*)d.dst;
+    const int nseg = (T + 63) >> 6;
+    const int ngrp = (nseg + SG - 1) / SG;
+    const int NR = d.transposed ? (d.Fout + d.fstride - 1) / d.fstride : d.Fout;
+    const int nitems = d.B * NR * ngrp;
+    for (int item = (int)blockIdx.x * 4 + wave; item < nitems; item += (int)gridDim.x * 4) {
+        const int grp = item % ngrp;
+        const int row = item / ngrp;
+        const int b = row / NR, q = row - b * NR;
+        const int fbase = (d.transposed ? q : q * d.fstride) + p.f_lo;
+        const h16* sb = s0 + (int64_t)b * d.s0_b;
+        // ---- all loads of the item first
+        h16x8 nb[NS][4];
+        bool ok[NS];
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            const int seg = grp * SG + sl_seg[sidx];
+            const int fi = fbase + sl_jf[sidx] * p.f_step;
+            ok[sidx] = sl_seg[sidx] >= 0 && seg < nseg && fi >= 0 && fi < d.Fin;
+            if (!ok[sidx]) continue;
+            const h16* rb = sb + (int64_t)fi * d.s0_f;
+            const int tb = seg * 64 + sl_dt[sidx];
+            const int uo = tb * st + sl_cc[sidx] * 32;
+            if (tb >= 0 && tb + 64 <= T && (sl_cc[sidx] + 1) * 32 <= C0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nb[sidx][i] = *(const h16x8*)(rb + (voff + uo + i * 16 * st));
+            } else {
+                const bool cok = sl_cc[sidx] * 32 + lq * 8 < C0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = tb + lp + i * 16;
+                    const h16* sp = rb + (voff + uo + i * 16 * st);
+                    nb[sidx][i] = *(const h16x8*)((cok && t >= 0 && t < T) ? sp : zpv);
+                }
+            }
+        }
+        // ---- transpose + MFMA slot by slot; a segment's output leaves after its last chunk
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
+        const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            if (ok[sidx]) {
+                aero_wave_sync();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(h16x8*)&Xw[aero_tile_off(i * 16 + lp, lq)] = nb[sidx][i];
+                aero_wave_sync();
+                const h16x8 af = *(const h16x8*)(Wl + sl_kofs[sidx]);
+                h16x8 bf[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bf[g] = *(const h16x8*)&Xw[aero_tile_off(g * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[g], acc[g], 0, 0, 0);
+            }
+            const int seg = grp * SG + sl_seg[sidx];
+            if (!sl_last[sidx] || sl_seg[sidx] < 0 || seg >= nseg) continue;
+            // epilogue of segment `seg`: stage [set r][step][m] in the wave's LDS tile, then dense coalesced stores
+            const int npos = T - seg * 64 < 64 ? T - seg * 64 : 64;
+            aero_wave_sync();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int pos = g * 16 + (lane & 15);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    float x = acc[g][rr] + bv[rr];
+                    if (d.act == AERO_ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (d.act == AERO_ACT_GELU) x = aero_gelu(x);
+                    x = x * bsc + bsh;
+                    acc[g][rr] = 0.f;
+                    if (o_r[rr] < stack) {
+                        const int li = (o_r[rr] * 64 + pos) * M + o_m[rr];
+                        if (d.dst_f32) ((float*)Xw)[li] = x;
+                        else Xw[li] = (h16)x;
+                    }
+                }
+            }
+            aero_wave_sync();
+            const int N = npos * M;
+            for (int r = 0; r < stack; ++r) {
+                const int fo = d.transposed ? q * d.fstride + r : q;
+                const int fdst = fo - d.dst_f_off;
+                if (fo >= d.Fout || fdst < 0 || fdst >= d.dst_F) continue;
+                const int64_t E0 = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)seg * 64 * M;
+                if (d.dst_f32) {
+                    const float* lsrc = (const float*)Xw + r * 64 * M;
+                    for (int idx = lane; idx < N; idx += 64) dst32[E0 + idx] = lsrc[idx];
+                } else {
+                    const h16* lsrc = Xw + r * 64 * M;
+                    const int a = (int)(E0 & 1);                // halves between the dword boundary and the segment start
+                    const int ndw = (a + N + 1) >> 1;
+                    uint32_t* gw = (uint32_t*)(dst16 + (E0 - a));
+                    for (int w = lane; w < ndw; w += 64) {
+                        const int le = 2 * w - a;
+                        const bool lo = le >= 0, hi = le + 1 < N;
+                        if (lo && hi) {
+                            union { h16 h[2]; uint32_t u; } pk;
+                            pk.h[0] = lsrc[le];
+                            pk.h[1] = lsrc[le + 1];
+                            gw[w] = pk.u;
+                        } else if (lo) {
+                            dst16[E0 + le] = lsrc[le];
+                        } else if (hi) {
+                            dst16[E0 + le + 1] = lsrc[le + 1];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Pointwise conv with a handful of channels on both sides and a FREQUENCY-major destination ([b][t][f][m], d_f = M,
 // d_t = F*M): the first FTB's 2 -> 5 squeeze, whose output feeds a conv1d over (f, m) (reference modules.py:287-289,
 // 309-311).  Per position that is C FMAs per output, so the MFMA tile machinery is pure overhead; what matters is
@@ -1224,6 +1403,29 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     }
     static int skinny = -1;
     if (skinny < 0) { const char* e = getenv("AERO_CONV_SKINNY"); skinny = (e && e[0] == '0') ? 0 : 1; }
+    // lean streaming form: one aligned source, regular taps, <= 6 chunks per segment, dense destination
+    static int stream_on = -1;
+    if (stream_on < 0) { const char* e = getenv("AERO_CONV_STREAM"); stream_on = (e && e[0] == '0') ? 0 : 1; }
+    if (skinny && stream_on && p.vec_in && d->src0 && d->C1 == 0 && d->act != AERO_ACT_GLU && !d->res && !d->post_add && !d->stat_mode) {
+        const int stack = d->transposed ? d->fstride : 1;
+        const int nk = d->ntaps * p.cpt;
+        const bool dense = d->d_t == d->M && (((uintptr_t)d->dst & 3) == 0);
+        const bool small = (int64_t)d->B * d->s0_b < 0x7fffffffLL && (int64_t)(d->T + 64) * d->s0_t + p.Cp < 0x7fffffffLL &&
+                           (int64_t)d->B * d->Fout * ((d->T + 63) / 64) < 0x7fffffffLL;
+        if (stack * d->M <= 16 && nk <= AERO_STREAM_SLOTS && dense && small && p.Ktot + 8 <= AERO_SKINNY_WMAX &&
+            aero_conv_regular_taps(d, &p) && (!d->transposed || (p.f_step == -1 && p.f_lo == 0))) {
+            p.nmt = AERO_STREAM_SLOTS / nk;                       // segments per wave item
+            const int nseg = (d->T + 63) / 64;
+            const int NR = d->transposed ? (d->Fout + d->fstride - 1) / d->fstride : d->Fout;
+            const long nitems = (long)d->B * NR * ((nseg + p.nmt - 1) / p.nmt);
+            const long want = (nitems + 3) / 4;
+            const long nb = want < 256 * 2 ? want : 256 * 2;
+            if (name) snprintf(name, 96, "aero_conv_stream_kernel");
+            else AERO_LAUNCH(aero_conv_stream_kernel, dim3((unsigned)nb), block, stream, p);
+            return AERO_OK;
+        }
+        p.nT = 1; p.f_lo = p.f_step = p.t_lo = p.t_step = 0;
+    }
     if (skinny && d->M <= 16 && (d->transposed ? d->fstride : 1) * (p.Ktot + 8) <= AERO_SKINNY_WMAX && d->act != AERO_ACT_GLU &&
         !d->res && !d->post_add && !d->stat_mode) {
         const int nkmax = d->ntaps * p.cpt;                    // worst-case K-chunks per 64-step segment
