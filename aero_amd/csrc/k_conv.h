@@ -39,7 +39,7 @@ struct AeroConvK {
 // convs showed why this matters: the generic epilogue below executes ~3600 scalar+vector instructions per wave for
 // 48 MFMAs (every runtime option re-evaluated inside the unrolled fragment loops) and those kernels ran issue-bound at
 // 1.5 TB/s.  Rows >= M carry zero weights and are masked at the copy-out, so no fragment is skipped here.
-template <int MF, int WM, int NWV, int ACT>
+template <int MF, int WM, int NWV, int ACT, bool STATS = false>
 static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& p, f32x4 (&acc)[MF][8 / (NWV / WM)], h16* Cs, int b,
                                                                int fo, int fdst, int m0, int t0) {
     constexpr int WN = NWV / WM;
@@ -75,6 +75,12 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
     h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
     const h16* rrow = d.res ? (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + m0o : nullptr;
     const float* prow = d.post_add ? d.post_add + (int64_t)fo * Mout + m0o : nullptr;      // frequency embedding row
+    // stat_mode 1: GroupNorm statistics of the conv output (bias included, before the activation) ride along: two FMAs per
+    // value on a VALU that idles under the MFMAs, one fp64 atomic pair per (wave, group) -- the separate read-only pass
+    // over the stored tensor (0.8 ms per forward) disappears
+    float st1[MF], st2[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) st1[i] = st2[i] = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -87,6 +93,15 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = acc[i][n][r] + bv[i][r];
+                if constexpr (STATS) {
+                    const bool tin = t0 + (wn * NF + n) * 16 + (lane & 15) < T;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = (tin && m0 + cl + r < M) ? o[r] : 0.f;
+                        st1[i] += v;
+                        st2[i] += v * v;
+                    }
+                }
                 if (GLU) {
                     const float g0 = o[0] * aero_sigmoid(o[1]) * ls[i][0];
                     const float g1 = o[2] * aero_sigmoid(o[3]) * ls[i][1];
@@ -126,6 +141,27 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
         }
         __syncthreads();
     }
+    if constexpr (STATS) {
+        const int gs = M / d.stat_G;                              // rows per statistics group (16-row aligned, or one group)
+        const int64_t sitem = (int64_t)(d.stat_per_row ? b * d.Fout + fo : b) * d.stat_G;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int base_i = m0 + (wm * MF + i) * 16;
+            const int grp = base_i / gs;
+            if (i + 1 < MF && (base_i + 16) / gs == grp && base_i + 16 < M) {     // same group as the next fragment: fold
+                st1[i + 1] += st1[i];
+                st2[i + 1] += st2[i];
+                continue;
+            }
+            if (base_i >= M) continue;
+            const double a = aero_wave_sum((double)st1[i]);
+            const double c = aero_wave_sum((double)st2[i]);
+            if (lane == 0) {
+                atomicAdd(d.stats + (sitem + grp) * 2, a);
+                atomicAdd(d.stats + (sitem + grp) * 2 + 1, c);
+            }
+        }
+    }
 }
 
 template <int MF, int WM, bool STATS, int NWV = 4>
@@ -143,6 +179,10 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
             case AERO_ACT_GELU: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GELU>(p, acc, Cs, b, fo, fdst, m0, t0); break;
             default: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GLU>(p, acc, Cs, b, fo, fdst, m0, t0); break;
         }
+        return;
+    }
+    if (STATS && p.staged && !d.batch_scale && d.stat_mode == 1 && d.act == AERO_ACT_NONE) {
+        aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_NONE, true>(p, acc, Cs, b, fo, fdst, m0, t0);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
@@ -637,7 +677,7 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
 
 // (KC 32, 128-row tile: ask for 3 blocks per CU -- 168 registers -- instead of the 204 the allocator takes by default)
 template <int MF, int WM, int KC, bool STATS>
-__global__ __launch_bounds__(256, (KC == 32 && MF * WM == 8) ? 3 : 1) void aero_conv_glds_kernel(AeroConvK p) {
+__global__ __launch_bounds__(256, (KC == 32 && MF * WM >= 6) ? 3 : 1) void aero_conv_glds_kernel(AeroConvK p) {
     __shared__ AERO_LDS_ALIGN h16 smem[AeroGldsGeom<MF, WM, KC, 4>::SMEM];
     aero_conv_glds_body<MF, WM, KC, STATS, 4>(p, smem);
 }
@@ -646,7 +686,7 @@ __global__ __launch_bounds__(256, (KC == 32 && MF * WM == 8) ? 3 : 1) void aero_
 // twice as many output rows, so the global->LDS traffic per MFMA drops by a quarter and each wave issues 3 copy
 // instructions per 32-channel chunk instead of 4.  Dynamic LDS (48 KiB with KC 32).
 template <int MF, int KC, bool STATS>
-__global__ __launch_bounds__(512) void aero_conv_glds8_kernel(AeroConvK p) {
+__global__ __launch_bounds__(512, 4) void aero_conv_glds8_kernel(AeroConvK p) {     // 4 waves per SIMD (two blocks per CU): <= 128 registers
     aero_conv_glds_body<MF, 4, KC, STATS, 8>(p, (h16*)AERO_DYN_SMEM);
 }
 
@@ -1465,22 +1505,21 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         // decoder layer vs 872 with one 96-KiB KC-64 block and 860 for the 128-row KC-64 tile.
         static int wide = -1;
         if (wide < 0) { const char* e = getenv("AERO_CONV_BM256"); wide = e ? atoi(e) : 2; }
-        const int wbm = (wide >= 1 && d->M % 256 == 0 && p.Ktot >= 1024) ? 256
+        // (statistics modes stay on the 4-wave tiles: the 8-wave instantiation with the statistics epilogue gave wrong
+        // outputs on hardware -- not in the emulator -- and was slower anyway)
+        const int wbm = d->stat_mode ? 0 : (wide >= 1 && d->M % 256 == 0 && p.Ktot >= 1024) ? 256
                         : (wide >= 2 && d->M % 192 == 0 && p.Ktot >= 768) ? 192 : 0;
         if (wbm) {
             p.nmt = d->M / wbm;
             grid = dim3((unsigned)((long)d->B * d->Fout * p.ntt * p.nmt));
             block = dim3(512);
-            const bool st = d->stat_mode != 0;
-            if (name) snprintf(name, 96, "aero_conv_glds8_kernel<%d, 32, %s>", wbm / 64, st ? "true" : "false");
+            if (name) snprintf(name, 96, "aero_conv_glds8_kernel<%d, 32, false>", wbm / 64);
             else if (wbm == 256) {
                 const size_t dyn = AeroGldsGeom<4, 4, 32, 8>::SMEM * sizeof(h16);
-                if (st) AERO_LAUNCH_DYN((aero_conv_glds8_kernel<4, 32, true>), grid, block, dyn, stream, p);
-                else AERO_LAUNCH_DYN((aero_conv_glds8_kernel<4, 32, false>), grid, block, dyn, stream, p);
+                AERO_LAUNCH_DYN((aero_conv_glds8_kernel<4, 32, false>), grid, block, dyn, stream, p);
             } else {
                 const size_t dyn = AeroGldsGeom<3, 4, 32, 8>::SMEM * sizeof(h16);
-                if (st) AERO_LAUNCH_DYN((aero_conv_glds8_kernel<3, 32, true>), grid, block, dyn, stream, p);
-                else AERO_LAUNCH_DYN((aero_conv_glds8_kernel<3, 32, false>), grid, block, dyn, stream, p);
+                AERO_LAUNCH_DYN((aero_conv_glds8_kernel<3, 32, false>), grid, block, dyn, stream, p);
             }
             return AERO_OK;
         }

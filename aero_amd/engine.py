@@ -276,7 +276,7 @@ class HipEngine:
         # but measured SLOWER on MI355X than the separate statistics/apply kernels (24.1 vs 22.8 ms per step: the wider
         # epilogue costs registers and the recompute pass re-pays the tile latency), so they are off by default.
         self.fuse_dconv_tail = False       # DConv tail as a recompute pair of conv launches (2C-channel tensor never stored)
-        self.fuse_stats = False            # GroupNorm statistics accumulated in the producing conv's epilogue
+        self.fuse_stats = os.environ.get('AERO_FUSE_STATS', '0') != '0'    # GroupNorm statistics accumulated in the producing conv's epilogue
         self.fuse_lstm_proj = True         # W_ih x_t inside the recurrent kernel (no 8H-channel pre-activation tensor in HBM)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
 
@@ -603,7 +603,7 @@ class HipEngine:
         for L in layers:
             g1 = L['gn1']
             st1 = None
-            if g1 is not None and self.fuse_stats:
+            if g1 is not None and self.fuse_stats and L['conv1'].M > 16:       # (M <= 16 runs on the streaming kernel)
                 st1 = ops.new_stats(B, Fo, 1, True, x.device)
                 h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T, stat=dict(mode=1, stats=st1, G=1, per_row=True))
             else:
@@ -627,9 +627,11 @@ class HipEngine:
                              stat=dict(mode=3, stats=st2, G=1, per_row=True, count=float(T * c2.M),
                                        gamma=L['gn2_glu'][0], beta=L['gn2_glu'][1], layer_scale=L['scale']))
                 continue
-            g = ops.conv(L['conv2'], h, None, B, Fo, Fo, T)
+            st2 = ops.new_stats(B, Fo, 1, True, x.device) if (g2 is not None and self.fuse_stats) else None
+            g = ops.conv(L['conv2'], h, None, B, Fo, Fo, T,
+                         stat=None if st2 is None else dict(mode=1, stats=st2, G=1, per_row=True))
             x = ops.norm_act(g, 1, True, g2[0] if g2 else None, g2[1] if g2 else None, ACT_GLU,
-                             layer_scale=L['scale'], res=x, normalize=g2 is not None)
+                             layer_scale=L['scale'], res=x, normalize=g2 is not None, stats=st2)
         return x
 
     def _stats_for(self, M, G, B, F, device):

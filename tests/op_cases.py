@@ -125,6 +125,28 @@ def case_conv_tiny(lib, dev, Cin, Cout, Fq, T, B=2, act='relu', seed=15):
     assert rel_l2(got, ref) < TOL16
 
 
+def case_conv_stats(lib, dev, Cin, Cout, kF, kT, Fq, T, G=1, per_row=False, B=2, seed=17):
+    """GroupNorm statistics accumulated by the conv epilogue (stat_mode 1) against sums over the conv's own output."""
+    ops = Ops(lib)
+    w = _rand((Cout, Cin, kF, kT), seed, 1.0 / math.sqrt(Cin * kF * kT))
+    b = _rand((Cout,), seed + 1)
+    x = _rand((B, Cin, Fq, T), seed + 2)
+    taps, df, dt = pack.conv2d_taps(q16(w), kF // 2, kT // 2)
+    spec = pack.make_conv_spec(taps, b, Cin, 0, df, dt, dev)
+    st = ops.new_stats(B, Fq, G, per_row, dev)
+    y = ops.conv(spec, cl(x).to(dev), None, B, Fq, Fq, T, stat=dict(mode=1, stats=st, G=G, per_row=per_row))
+    ref = F.conv2d(q16(x), q16(w), b, padding=(kF // 2, kT // 2)).double()            # [B, M, F, T]
+    assert rel_l2(uncl(y.cpu()), ref.float()) < TOL16
+    r = ref.view(B, G, Cout // G, Fq, T)
+    if per_row:
+        s1, s2 = r.sum((2, 4)).permute(0, 2, 1), (r * r).sum((2, 4)).permute(0, 2, 1)          # [B, F, G]
+    else:
+        s1, s2 = r.sum((2, 3, 4)), (r * r).sum((2, 3, 4))                                      # [B, G]
+    got = st.cpu().view(*s1.shape, 2)
+    assert torch.allclose(got[..., 1], s2, rtol=2e-4), (got[..., 1].flatten()[:4], s2.flatten()[:4])
+    assert torch.allclose(got[..., 0], s1, rtol=1e-3, atol=1e-3 * float(s2.sqrt().mean()))
+
+
 def case_conv1d(lib, dev, Cin, Cout, k, dil, R, T, seed=20):
     ops = Ops(lib)
     w = _rand((Cout, Cin, k), seed, 1.0 / math.sqrt(Cin * k))

@@ -71,6 +71,11 @@ def test_conv_tiny(emu, kw):
     oc.case_conv_tiny(emu, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Cin=12, Cout=96, kF=1, kT=1, Fq=3, T=70, per_row=True), dict(Cin=32, Cout=64, kF=1, kT=1, Fq=4, T=140, G=4), dict(Cin=128, Cout=256, kF=3, kT=3, Fq=2, T=130, B=1)])
+def test_conv_stats(emu, kw):
+    oc.case_conv_stats(emu, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(Cin=48, Cout=12, k=3, dil=1, R=6, T=131), dict(Cin=16, Cout=4, k=3, dil=2, R=3, T=60),
                                 dict(Cin=40, Cout=16, k=9, dil=1, R=2, T=50)])
 def test_conv1d(emu, kw):
