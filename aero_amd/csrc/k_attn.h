@@ -32,7 +32,10 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
     const int dh = C / d.heads;
     const int s_blk = blockIdx.x * 128;
     const h16* base = (const h16*)d.qkvd + (int64_t)row * T * d.ld;
-    const float qscale = 1.0f / sqrtf((float)dh);
+    // the softmax runs in the log2 domain: log2(e) is folded into the query scale, the decay slope and the self-kill value,
+    // so every probability is ONE subtraction and one bare v_exp_f32
+    constexpr float L2E = 1.4426950408889634f;
+    const float qscale = L2E / sqrtf((float)dh);
 
     // staging moves 4 channels (8 bytes) per step when the head slices are 8-byte aligned, else scalars
     const bool vec4 = (dh % 4 == 0) && (d.ld % 4 == 0) && (C % 4 == 0) && (((uintptr_t)d.qkvd & 7) == 0);
@@ -64,8 +67,12 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
     if (s < T) {
         const h16* dp = base + (int64_t)s * d.ld + 3 * C + h * d.ndecay;
         for (int f = 0; f < d.ndecay; ++f) Dq += (float)(f + 1) * aero_sigmoid((float)dp[f]);
-        Dq *= 0.5f / sqrtf((float)(d.ndecay > 0 ? d.ndecay : 1));
+        Dq *= L2E * 0.5f / sqrtf((float)(d.ndecay > 0 ? d.ndecay : 1));
     }
+    float koff[8];                                           // position of key slot e inside a 32-key block (lane constant)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) koff[e] = (float)(((e >> 2) << 4) + g * 4 + (e & 3));
+    const int sw_lo = s_blk + wave * 16, sw_hi = sw_lo + 16;  // this wave's queries
     float m = -1e30f, l = 0.f;
     f32x4 O[DT];
 #pragma unroll
@@ -112,29 +119,38 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
             const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
             const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf, z4, 0, 0, 0);
             const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf, z4, 0, 0, 0);
+            // key e of this lane sits at t = kc0 + tb + koff[e]; distance to the query = |u + koff[e]| with u = kc0 + tb - s
+            const int t_blk = kc0 + tb;
+            const float u = (float)(t_blk - s);
             float sc[8];
-            float cmax = -1e30f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int t = kc0 + tb + ((e >> 2) << 4) + g * 4 + (e & 3);
-                float v = (e < 4) ? s0[e & 3] : s1[e & 3];
-                const int dist = t > s ? t - s : s - t;
-                v -= (float)dist * Dq;
-                if (t == s) v = -100.f;                    // modules.py:120 "kill self reference"
-                if (t >= T) v = -1e30f;
-                sc[e] = v;
-                cmax = fmaxf(cmax, v);
+                const float x = u + koff[e];
+                sc[e] = ((e < 4) ? s0[e & 3] : s1[e & 3]) - fabsf(x) * Dq;
             }
+            // the self reference (modules.py:120) and the keys beyond T only exist in blocks that overlap the wave's own
+            // queries / the end of the row: block-uniform tests keep them out of the common path
+            if (t_blk < sw_hi && t_blk + 32 > sw_lo) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (u + koff[e] == 0.f) sc[e] = -100.f * L2E;
+            }
+            if (t_blk + 32 > T) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (t_blk + (int)koff[e] >= T) sc[e] = -1e30f;
+            }
+            float cmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
             cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
             cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
             const float mn = fmaxf(m, cmax);
-            const float alpha = aero_fast_exp(m - mn);
+            const float alpha = aero_exp2(m - mn);
             m = mn;
             float psum = 0.f;
             h16x8 pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float pw = aero_fast_exp(sc[e] - mn);
+                const float pw = aero_exp2(sc[e] - mn);
                 psum += pw;
                 pf[e] = (h16)pw;
             }
