@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ('post_add', fp), ('batch_scale', fp), ('batch_shift', fp),
                 ('stats', dp), ('stat_count', C.c_double),
                 ('stat_mode', i32), ('stat_G', i32), ('stat_per_row', i32), ('stat_eps', C.c_float),
-                ('gamma', fp), ('beta', fp), ('layer_scale', fp)]
+                ('gamma', fp), ('beta', fp), ('layer_scale', fp),
+                ('scatter_M', i32), ('scatter_stride', i32), ('scatter_off', i32), ('scatter_F', i32)]
 
 
 class NormDesc(C.Structure):

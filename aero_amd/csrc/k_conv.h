@@ -136,6 +136,14 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + prow[cv * 8 + e]);
                 }
+                if (d.scatter_M) {                              // transposed conv from the input side: channel block -> row
+                    const int cg = m0o + cv * 8;
+                    const int r = cg / d.scatter_M;
+                    const int frow = fo * d.scatter_stride + r - d.scatter_off;
+                    if (frow >= 0 && frow < d.scatter_F)
+                        *(h16x8*)(dst16 + (int64_t)b * d.d_b + (int64_t)frow * d.d_f + (int64_t)t * d.d_t + (cg - r * d.scatter_M)) = v;
+                    continue;
+                }
                 *(h16x8*)(drow + (int64_t)t * d.d_t + cv * 8) = v;
             }
         }
@@ -542,7 +550,7 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
     const int row = id / p.ntt;
     const int b = row / d.Fout, fo = row % d.Fout;
     const int fdst = fo - d.dst_f_off;
-    if (fdst < 0 || fdst >= d.dst_F) return;
+    if (!d.scatter_M && (fdst < 0 || fdst >= d.dst_F)) return;
     const int m0 = mt * BM, t0 = tt * BN;
     const int wset = d.transposed ? (fo % d.fstride) : 0;
     const int fbase = (d.transposed ? (fo / d.fstride) : (fo * d.fstride)) + p.f_lo;
@@ -1388,6 +1396,11 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         if (d->stat_mode == 3 && ((d->gamma == nullptr) != (d->beta == nullptr))) { *err = "conv: gamma/beta"; return AERO_ERR_ARG; }
         if (d->dst_f_off != 0 || d->dst_F != d->Fout) { *err = "conv: statistics and frequency trim do not combine"; return AERO_ERR_UNSUPPORTED; }
     }
+    if (d->scatter_M) {
+        if (d->scatter_M < 8 || d->scatter_M % 8 || d->M % d->scatter_M || d->scatter_stride < 1 || d->scatter_F < 1 || d->transposed ||
+            d->dst_f32 || d->stat_mode || d->res || d->post_add || d->batch_scale || d->act == AERO_ACT_GLU || d->dst_f_off != 0 ||
+            d->dst_F != d->Fout) { *err = "conv: row scatter needs a plain fp16 conv with scatter_M % 8 == 0"; return AERO_ERR_UNSUPPORTED; }
+    }
     AeroConvK p;
     p.d = *d;
     p.Cp = (d->C0 + d->C1 + 31) / 32 * 32;
@@ -1429,7 +1442,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
                 d->M, d->C0, d->C1, d->ntaps, d->B, d->Fin, d->Fout, d->T, d->transposed, d->fstride, d->act, p.vec_in, d->dst_f32,
                 d->res != nullptr, d->post_add != nullptr, d->src0 != nullptr);
     // few channels in, few out, frequency-major destination: the transposing pointwise kernel
-    if (d->ntaps == 1 && d->df[0] == 0 && d->dt[0] == 0 && !d->transposed && d->fstride == 1 && d->C1 == 0 && d->src0 && d->C0 <= 8 &&
+    if (!d->scatter_M && d->ntaps == 1 && d->df[0] == 0 && d->dt[0] == 0 && !d->transposed && d->fstride == 1 && d->C1 == 0 && d->src0 && d->C0 <= 8 &&
         d->M <= 8 && d->act != AERO_ACT_GLU && !d->res && !d->post_add && !d->batch_scale && !d->stat_mode && !d->dst_f32 &&
         d->d_f == d->M && d->d_t == (int64_t)d->Fout * d->M && d->dst_f_off == 0 && d->dst_F == d->Fout && d->Fin == d->Fout &&
         getenv("AERO_CONV_TINY_OFF") == nullptr) {
@@ -1446,7 +1459,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     // lean streaming form: one aligned source, regular taps, <= 6 chunks per segment, dense destination
     static int stream_on = -1;
     if (stream_on < 0) { const char* e = getenv("AERO_CONV_STREAM"); stream_on = (e && e[0] == '0') ? 0 : 1; }
-    if (skinny && stream_on && p.vec_in && d->src0 && d->C1 == 0 && d->act != AERO_ACT_GLU && !d->res && !d->post_add && !d->stat_mode) {
+    if (skinny && stream_on && !d->scatter_M && p.vec_in && d->src0 && d->C1 == 0 && d->act != AERO_ACT_GLU && !d->res && !d->post_add && !d->stat_mode) {
         const int stack = d->transposed ? d->fstride : 1;
         const int nk = d->ntaps * p.cpt;
         const bool dense = d->d_t == d->M && (((uintptr_t)d->dst & 3) == 0);
@@ -1466,7 +1479,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         }
         p.nT = 1; p.f_lo = p.f_step = p.t_lo = p.t_step = 0;
     }
-    if (skinny && d->M <= 16 && (d->transposed ? d->fstride : 1) * (p.Ktot + 8) <= AERO_SKINNY_WMAX && d->act != AERO_ACT_GLU &&
+    if (skinny && !d->scatter_M && d->M <= 16 && (d->transposed ? d->fstride : 1) * (p.Ktot + 8) <= AERO_SKINNY_WMAX && d->act != AERO_ACT_GLU &&
         !d->res && !d->post_add && !d->stat_mode) {
         const int nkmax = d->ntaps * p.cpt;                    // worst-case K-chunks per 64-step segment
         p.nmt = nkmax >= AERO_SKINNY_SLOTS ? 1 : AERO_SKINNY_SLOTS / nkmax;      // segments per wave item
@@ -1489,6 +1502,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         else AERO_LAUNCH(aero_conv_skinny_kernel<1>, dim3((unsigned)nb), block, stream, p);
         return AERO_OK;
     }
+    if (d->scatter_M && !(p.staged && p.vec_in && p.glds)) { *err = "conv: row scatter needs aligned fp16 operands (direct-to-LDS pipeline)"; return AERO_ERR_UNSUPPORTED; }
     if (bm == 128 && p.vec_in && !p.glds && !d->stat_mode && aero_conv_is_3x3(d)) {
         if (name) snprintf(name, 96, "aero_conv3x3_kernel");
         else AERO_LAUNCH(aero_conv3x3_kernel, grid, block, stream, p);
@@ -1544,6 +1558,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         }
         return AERO_OK;
     }
+    if (d->scatter_M) { *err = "conv: row scatter needs a regular tap grid"; return AERO_ERR_UNSUPPORTED; }
     switch (bm) {
         case 128: AERO_CONV_GO2(aero_conv_kernel, 4, 2); break;
         case 96: AERO_CONV_GO2(aero_conv_kernel, 3, 2); break;

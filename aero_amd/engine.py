@@ -81,7 +81,7 @@ class Ops:
     # -- convolution family --------------------------------------------------------------------
     def conv(self, spec, src0, src1, B, Fin, Fout, T, dst=None, dst_f32=False, dst_f_off=0, dst_F=None, res=None,
              post_add=None, batch_scale=None, batch_shift=None, act=None, dst_strides=None, src0_strides=None,
-             stat=None):
+             stat=None, scatter=None):
         """src0/src1: channels-last [B,Fin,T,C] tensors (src0 may be None = zeros).  Returns dst."""
         dev = spec.weight.device
         act = spec.act if act is None else act
@@ -110,6 +110,8 @@ class Ops:
             d.stat_mode, d.stat_G, d.stat_per_row, d.stat_eps = stat['mode'], stat['G'], int(stat['per_row']), stat.get('eps', 1e-5)
             d.gamma, d.beta, d.layer_scale = _ptr(stat.get('gamma')), _ptr(stat.get('beta')), _ptr(stat.get('layer_scale'))
         d.dst_f_off, d.dst_F = dst_f_off, dst_F
+        if scatter is not None:                     # (scatter_M, stride, first kept row, kept rows): aero_hip.h "row scatter"
+            d.scatter_M, d.scatter_stride, d.scatter_off, d.scatter_F = scatter
         d.B, d.Fin, d.Fout, d.T, d.M = B, Fin, Fout, T, spec.M
         d.transposed, d.fstride = spec.transposed, spec.fstride
         d.ntaps = len(spec.df)
@@ -374,6 +376,11 @@ class HipEngine:
             act = ACT_NONE if (dec.norm or dec.last) else ACT_GELU
             L['conv_tr'] = mk(w, sd[f'{p}.conv_tr.bias'], w.shape[-1], 0, df, dt, device, transposed=1,
                               fstride=dec.stride, act=act)
+            if not dec.last and os.environ.get('AERO_CONVTR_STACK', '0') != '0':
+                # input-side form (all `stride` residue classes from one pass over the source rows), when Cout % 8 == 0
+                st = pack.convtr_stacked_spec(sd[f'{p}.conv_tr.weight'], sd[f'{p}.conv_tr.bias'], dec.stride, device, act=act)
+                if st is not None:
+                    L['conv_tr_stacked'] = st
             if dec.norm:
                 L['norm2'] = (sd[f'{p}.norm2.weight'].to(device), sd[f'{p}.norm2.bias'].to(device))
             if dec.dconv is not None:
@@ -689,11 +696,25 @@ class HipEngine:
             if dec.last:
                 raise NotImplementedError('GroupNorm on the last decoder layer (norm_starts = 0)')
             st = self._stats_for(L['conv_tr'].M, dec.norm_groups, B, Fu, y.device)
-            z = ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T, stat=self._acc(st, dec.norm_groups))
+            if st is None and 'conv_tr_stacked' in L:
+                z = self._convtr_stacked(L['conv_tr_stacked'], y, B, Fq, T, dec.stride, 0, Fu)
+            else:
+                z = ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T, stat=self._acc(st, dec.norm_groups))
             return ops.norm_act(z, dec.norm_groups, False, L['norm2'][0], L['norm2'][1],
                                 ACT_NONE if dec.last else ACT_GELU, f_lo=dec.pad, f_cnt=Ft, stats=st)
         if dec.last:
             # aero.py:497-498: x*std + mean fused into the last epilogue; fp32 [B,F0,T,2] == complex64 [B,1,F0,T]
             return ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T, dst_f32=True, dst_f_off=dec.pad, dst_F=Ft,
                             batch_scale=std, batch_shift=mean)
+        if 'conv_tr_stacked' in L:
+            return self._convtr_stacked(L['conv_tr_stacked'], y, B, Fq, T, dec.stride, dec.pad, Ft)
         return ops.conv(L['conv_tr'], y, None, B, Fq, Fu, T, dst_f_off=dec.pad, dst_F=Ft)
+
+    def _convtr_stacked(self, spec, y, B, Fq, T, stride, first, rows):
+        """ConvTranspose2d from the input side: rows q = 0..ceil(Fu/stride)-1, channel block r -> frequency row q*stride+r."""
+        Mo = spec.extra['scatter_M']
+        NR = Fq - 1 + len(spec.df)                                 # input-aligned rows that touch any output row
+        out = torch.empty(B, rows, T, Mo, dtype=torch.float16, device=y.device)
+        self.ops.conv(spec, y, None, B, Fq, NR, T, dst=out.view(B, rows, T, Mo), dst_F=NR,
+                      dst_strides=_strides4(out), scatter=(Mo, stride, first, rows))
+        return out

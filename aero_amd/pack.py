@@ -98,6 +98,21 @@ def convtr_taps(w, stride):
     return taps, [-j for j in range(nt)], [0] * nt
 
 
+def convtr_stacked_spec(w, bias, stride, device, act=_lib.ACT_NONE):
+    """nn.ConvTranspose2d [Cin, Cout, K, 1] computed from the input side (aero_hip.h, row scatter): the `stride` residue
+    classes are stacked into M = stride*Cout rows (row r*Cout + m), taps df = 0, -1, ...; output channel block r of the
+    input-aligned row q belongs to frequency row q*stride + r.  None when Cout is not a multiple of 8."""
+    Cin, Cout, K, kT = w.shape
+    if Cout % 8 or kT != 1:
+        return None
+    taps, df, dt = convtr_taps(w, stride)                        # [stride, Cout, nt, Cin]
+    stacked = taps.reshape(1, stride * Cout, taps.shape[2], Cin)
+    b = None if bias is None else bias.detach().float().repeat(stride)
+    spec = make_conv_spec(stacked, b, Cin, 0, df, dt, device, act=act)
+    spec.extra.update(scatter_M=Cout, scatter_stride=stride)
+    return spec
+
+
 def lstm_gate_perm(H):
     """row index 4*j+gate of the kernel <- row gate*H + j of nn.LSTM (i,f,g,o blocks)."""
     j = torch.arange(H)

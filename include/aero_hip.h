@@ -95,6 +95,13 @@ typedef struct {
     double* stats; double stat_count;
     int32_t stat_mode, stat_G, stat_per_row; float stat_eps;
     const float* gamma; const float* beta; const float* layer_scale;
+    /* Row scatter (0 = off): a ConvTranspose2d along frequency (aero.py:311, stride s) computed from the INPUT side.  The
+     * weight image stacks the s residue classes (M = s * scatter_M rows, row r*scatter_M + m), the launch is a plain conv
+     * over the Fout = ceil(rows / s) input-aligned rows q (taps df = 0, -1, ...), and output channel block r of row q goes
+     * to destination frequency row q*scatter_stride + r - scatter_off when that lies in [0, scatter_F).  One pass over the
+     * source rows feeds all s residue classes.  Needs fp16 output with scatter_M % 8 == 0; no statistics, residual,
+     * frequency embedding or per-item affine (AERO_ERR_UNSUPPORTED otherwise). */
+    int32_t scatter_M, scatter_stride, scatter_off, scatter_F;
 } aero_conv_desc;
 int aero_conv_fwd(const aero_conv_desc* d, void* stream);
 /* rows per block (16/32/48/64/128) of the kernel instantiation aero_conv_fwd picks for M output channels */

@@ -183,6 +183,29 @@ def case_convtr(lib, dev, Cin, Cout, K, stride, Fin, T, trim=True, f32_affine=Fa
     assert rel_l2(uncl(y.cpu()), ref) < TOL16
 
 
+def case_convtr_stacked(lib, dev, Cin, Cout, K, stride, Fin, T, trim=True, act='none', B=2, seed=33):
+    """ConvTranspose2d computed from the input side (stacked residue classes + row scatter, aero_hip.h) against
+    F.conv_transpose2d, with and without the frequency trim."""
+    from aero_amd.engine import HipEngine
+    w = _rand((Cin, Cout, K, 1), seed, 1.0 / math.sqrt(Cin * K / stride))
+    b = _rand((Cout,), seed + 1)
+    x = _rand((B, Cin, Fin, T), seed + 2)
+    actc = {'none': _lib.ACT_NONE, 'gelu': _lib.ACT_GELU}[act]
+    spec = pack.convtr_stacked_spec(q16(w), b, stride, dev, act=actc)
+    assert spec is not None
+    ref = F.conv_transpose2d(q16(x), q16(w), b, stride=(stride, 1))
+    if act == 'gelu':
+        ref = F.gelu(ref)
+    Fu = ref.shape[2]
+    pad = (K - stride) // 2 if trim else 0
+    if pad:
+        ref = ref[:, :, pad:Fu - pad]
+    eng = HipEngine.__new__(HipEngine)
+    eng.lib, eng.ops = lib, Ops(lib)
+    y = eng._convtr_stacked(spec, cl(x).to(dev), B, Fin, T, stride, pad, Fu - 2 * pad)
+    assert rel_l2(uncl(y.cpu()), ref) < TOL16
+
+
 def case_freq_emb_epilogue(lib, dev, seed=40):
     """1x1 rewrite + fused GLU + frequency-embedding post-add (aero.py:133,475-480)."""
     ops = Ops(lib)

@@ -91,6 +91,11 @@ def test_convtr(emu, kw):
     oc.case_convtr(emu, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Cin=32, Cout=16, K=8, stride=2, Fin=4, T=40), dict(Cin=64, Cout=8, K=8, stride=4, Fin=5, T=133, act='gelu'), dict(Cin=256, Cout=96, K=8, stride=2, Fin=3, T=70, trim=False, B=1), dict(Cin=16, Cout=24, K=4, stride=2, Fin=3, T=20)])
+def test_convtr_stacked(emu, kw):
+    oc.case_convtr_stacked(emu, DEV, **kw)
+
+
 def test_freq_emb_epilogue(emu):
     oc.case_freq_emb_epilogue(emu, DEV)
 

@@ -70,6 +70,11 @@ def test_convtr(lib, kw):
     oc.case_convtr(lib, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Cin=768, Cout=192, K=8, stride=2, Fin=4, T=501), dict(Cin=384, Cout=96, K=8, stride=2, Fin=8, T=501, trim=False), dict(Cin=192, Cout=48, K=8, stride=4, Fin=16, T=501, act='gelu'), dict(Cin=16, Cout=24, K=4, stride=2, Fin=3, T=20)])
+def test_convtr_stacked(lib, kw):
+    oc.case_convtr_stacked(lib, DEV, **kw)
+
+
 def test_freq_emb_epilogue(lib):
     oc.case_freq_emb_epilogue(lib, DEV)
 
