@@ -555,7 +555,8 @@ class HipEngine:
         ops = self.ops
         if 'ftb0' in L and self.collapse_first_ftb:
             Cc, rp = L['ftb0']['C'], L['ftb_rp']
-            c1 = torch.zeros(B, T, Fq * rp, dtype=torch.float16, device=x.device)
+            # pad channels (rp > r) must read as zero; with rp == r the conv writes every element
+            c1 = (torch.empty if rp == L['ftb0_c1'].M else torch.zeros)(B, T, Fq * rp, dtype=torch.float16, device=x.device)
             ops.conv(L['ftb0_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
             gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)      # [B,1,T,Cc]
             ones = self._tables.setdefault(('ones', B, T, str(x.device)),
@@ -572,7 +573,7 @@ class HipEngine:
             x = ops.conv(L['pre'], x, None, B, Fq, Fq, T)
         if 'ftb_c1' in L:
             Cc, rp = L['ftb_c2'].M, L['ftb_rp']
-            c1 = torch.zeros(B, T, Fq * rp, dtype=torch.float16, device=x.device)
+            c1 = (torch.empty if rp == L['ftb_c1'].M else torch.zeros)(B, T, Fq * rp, dtype=torch.float16, device=x.device)
             ops.conv(L['ftb_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
             gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)      # [B,1,T,Cc]
             fc = ops.freqfc(x, L['ftb_fc'], gate.view(B, T, Cc))
