@@ -13,6 +13,7 @@
 #include "aero_common.h"
 
 #define AERO_FFT_MAX_N 512   /* complex points = n_fft/2  ->  n_fft <= 1024 */
+#define AERO_STFT_SPAN 1536  /* samples of signal a block's frames may share through LDS */
 
 static __device__ __forceinline__ f32x2 aero_cmul(f32x2 a, f32x2 b) {
     return (f32x2){a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]};
@@ -21,12 +22,19 @@ static __device__ __forceinline__ f32x2 aero_cmul(f32x2 a, f32x2 b) {
 // tw[k] = exp(-2*pi*i*k/n_fft), k in [0, n_fft/2)
 static __device__ __forceinline__ void aero_fft_init_twiddles(f32x2* tw, int n_fft) {
     for (int k = threadIdx.x; k < n_fft / 2; k += 256) {
+#ifdef AERO_EMU
         const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)n_fft;
         tw[k] = (f32x2){(float)cos(a), (float)sin(a)};
+#else
+        // sincospi on the exactly representable fraction -2k/n_fft: float-accurate without a double sin/cos per block
+        float sn, cs;
+        sincospif(-2.0f * (float)k / (float)n_fft, &sn, &cs);
+        tw[k] = (f32x2){cs, sn};
+#endif
     }
 }
 
-// Stockham radix-2 autosort FFT of n points, one problem per wavefront, all 4 waves in lockstep.
+// Stockham radix-2 autosort FFT of n points, one problem per wavefront (waves run independently).
 // Returns the buffer (a or b) that holds the natural-order result.
 static __device__ __forceinline__ f32x2* aero_fft_wave(f32x2* a, f32x2* b, int n, int n_fft, const f32x2* tw) {
     const int lane = aero_lane();
@@ -43,7 +51,7 @@ static __device__ __forceinline__ f32x2* aero_fft_wave(f32x2* a, f32x2* b, int n
             dst[jj] = u0 + v;
             dst[jj + p] = u0 - v;
         }
-        __syncthreads();
+        aero_wave_sync();              // a wave owns its two buffers: LDS is in-order per wave, no block barrier needed
         f32x2* tmp = src;
         src = dst;
         dst = tmp;
@@ -61,6 +69,8 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
     __shared__ AERO_LDS_ALIGN f32x2 bufA[4][AERO_FFT_MAX_N];
     __shared__ AERO_LDS_ALIGN f32x2 bufB[4][AERO_FFT_MAX_N];
     __shared__ AERO_LDS_ALIGN f32x2 tile[2048 + 64];
+    __shared__ float wl[2 * AERO_FFT_MAX_N];
+    __shared__ float xsp[AERO_STFT_SPAN];
     __shared__ double red[2][4];
     const int n = p.n_fft >> 1;
     const int lane = aero_lane(), wave = aero_wave();
@@ -69,6 +79,21 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
     const float* xs = p.x + (int64_t)sig * p.L;
     const float scale = 1.0f / sqrtf((float)p.n_fft);
     aero_fft_init_twiddles(tw, p.n_fft);
+    // The block's frames overlap (hop << n_fft): the window and the reflect-padded signal span they share are staged in
+    // LDS once, with independent coalesced loads.  (Reading window[ni] and then, if non-zero, x[...] from global memory
+    // per element made every frame a chain of ~16 dependent L2 round trips: 134 us for a 68-MB kernel.)
+    const int span = (p.FPB - 1) * p.hop + p.n_fft;
+    const bool staged = span <= AERO_STFT_SPAN;
+    for (int i = threadIdx.x; i < p.n_fft; i += 256) wl[i] = p.window[i];
+    if (staged) {
+        for (int j = threadIdx.x; j < span; j += 256) {
+            int xi = tbase * p.hop + j - n;                      // index into the hop-padded signal
+            if (xi < 0) xi = -xi;                                // reflect (no edge repeat)
+            if (xi >= p.Lp) xi = 2 * (p.Lp - 1) - xi;
+            xsp[j] = (xi >= 0 && xi < p.L) ? xs[xi] : 0.f;       // [L, Lp) is the zero pad of aero.py:410
+        }
+    }
+    __syncthreads();
     float s = 0.f, ss = 0.f;
     const int rounds = (p.FPB + 3) / 4;
     for (int r = 0; r < rounds; ++r) {
@@ -81,12 +106,14 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int ni = 2 * m + e;
-                    const float w = p.window[ni];
-                    if (w != 0.f) {
-                        int xi = t * p.hop + ni - n;             // index into the hop-padded signal
-                        if (xi < 0) xi = -xi;                    // reflect (no edge repeat)
+                    const float w = wl[ni];
+                    if (staged) {
+                        g[e] = w * xsp[fr * p.hop + ni];
+                    } else if (w != 0.f) {
+                        int xi = t * p.hop + ni - n;
+                        if (xi < 0) xi = -xi;
                         if (xi >= p.Lp) xi = 2 * (p.Lp - 1) - xi;
-                        g[e] = (xi < p.L) ? w * xs[xi] : 0.f;    // [L, Lp) is the zero pad of aero.py:410
+                        g[e] = (xi < p.L) ? w * xs[xi] : 0.f;
                     }
                 }
             }
