@@ -39,7 +39,7 @@ struct AeroConvK {
 // convs showed why this matters: the generic epilogue below executes ~3600 scalar+vector instructions per wave for
 // 48 MFMAs (every runtime option re-evaluated inside the unrolled fragment loops) and those kernels ran issue-bound at
 // 1.5 TB/s.  Rows >= M carry zero weights and are masked at the copy-out, so no fragment is skipped here.
-template <int MF, int WM, int NWV, int ACT, bool STATS = false>
+template <int MF, int WM, int NWV, int ACT, int SM = 0>
 static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& p, f32x4 (&acc)[MF][8 / (NWV / WM)], h16* Cs, int b,
                                                                int fo, int fdst, int m0, int t0) {
     constexpr int WN = NWV / WM;
@@ -56,14 +56,41 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
     const int T = d.T, M = d.M;
     const int Mout = GLU ? (M >> 1) : M;
     const int m0o = GLU ? (m0 >> 1) : m0;
-    float bv[MF][4], ls[MF][2];
+    // SM (statistics mode of aero_hip.h): 0 none; 1 accumulate GroupNorm sums of the conv output while storing it;
+    // 2 accumulate only (nothing is stored: first half of a recompute pair); 3 normalise with previously accumulated sums:
+    // v = (acc + bias - mean) * rstd * gamma + beta folds into ONE FMA per value (av, bv) before the activation.
+    float bv[MF][4], av[MF][4], ls[MF][2];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int mbase = m0 + (wm * MF + i) * 16 + (lane >> 4) * 4;
+        float mean = 0.f, rstd = 1.f;
+        if constexpr (SM == 3) {
+            const int gs3 = M / d.stat_G;
+            int grp = (m0 + (wm * MF + i) * 16) / gs3;
+            grp = grp < d.stat_G ? grp : d.stat_G - 1;
+            const double* sp = d.stats + ((int64_t)(d.stat_per_row ? b * d.Fout + fo : b) * d.stat_G + grp) * 2;
+            const double inv = 1.0 / d.stat_count;
+            const double mu = sp[0] * inv;
+            double var = sp[1] * inv - mu * mu;
+            if (var < 0) var = 0;
+            const float vf = (float)var + d.stat_eps;
+            float rs = aero_rsqrt(vf);
+            rs = rs * (1.5f - 0.5f * vf * rs * rs);
+            mean = (float)mu;
+            rstd = rs;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mi = mbase + r < M ? mbase + r : M - 1;
-            bv[i][r] = d.bias ? d.bias[mi] : 0.f;
+            const float bias = d.bias ? d.bias[mi] : 0.f;
+            if constexpr (SM == 3) {
+                const float gm = d.gamma ? d.gamma[mi] * rstd : rstd;
+                av[i][r] = gm;
+                bv[i][r] = (bias - mean) * gm + (d.gamma ? d.beta[mi] : 0.f);
+            } else {
+                av[i][r] = 1.f;
+                bv[i][r] = bias;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -92,8 +119,8 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
                 const int pc = wn * PH + nn * 16 + (lane & 15);
                 float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[i][n][r] + bv[i][r];
-                if constexpr (STATS) {
+                for (int r = 0; r < 4; ++r) o[r] = (SM == 3) ? acc[i][n][r] * av[i][r] + bv[i][r] : acc[i][n][r] + bv[i][r];
+                if constexpr (SM == 1 || SM == 2) {
                     const bool tin = t0 + (wn * NF + n) * 16 + (lane & 15) < T;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -102,6 +129,7 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
                         st2[i] += v * v;
                     }
                 }
+                if constexpr (SM == 2) continue;                 // statistics only
                 if (GLU) {
                     const float g0 = o[0] * aero_sigmoid(o[1]) * ls[i][0];
                     const float g1 = o[2] * aero_sigmoid(o[3]) * ls[i][1];
@@ -118,6 +146,7 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
                 }
             }
         }
+        if constexpr (SM == 2) continue;
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < (64 * NVEC + NWV * 64 - 1) / (NWV * 64); ++it) {
@@ -149,7 +178,7 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
         }
         __syncthreads();
     }
-    if constexpr (STATS) {
+    if constexpr (SM == 1 || SM == 2) {
         const int gs = M / d.stat_G;                              // rows per statistics group (16-row aligned, or one group)
         const int64_t sitem = (int64_t)(d.stat_per_row ? b * d.Fout + fo : b) * d.stat_G;
 #pragma unroll
@@ -173,26 +202,13 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
 }
 
 template <int MF, int WM, bool STATS, int NWV = 4>
-static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f32x4 (&acc)[MF][8 / (NWV / WM)], h16* Cs, int b, int fo,
+static __device__ __forceinline__ void aero_conv_epilogue_generic(const AeroConvK& p, f32x4 (&acc)[MF][8 / (NWV / WM)], h16* Cs, int b, int fo,
                                                           int fdst, int m0, int t0) {
     constexpr int WN = NWV / WM;
     constexpr int NF = 8 / WN;
     constexpr int BM = 16 * MF * WM;
     constexpr int CS = BM + 8;
     const aero_conv_desc& d = p.d;
-    if (p.staged && !d.batch_scale && (!STATS || d.stat_mode == 0)) {
-        switch (d.act) {
-            case AERO_ACT_NONE: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_NONE>(p, acc, Cs, b, fo, fdst, m0, t0); break;
-            case AERO_ACT_RELU: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_RELU>(p, acc, Cs, b, fo, fdst, m0, t0); break;
-            case AERO_ACT_GELU: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GELU>(p, acc, Cs, b, fo, fdst, m0, t0); break;
-            default: aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_GLU>(p, acc, Cs, b, fo, fdst, m0, t0); break;
-        }
-        return;
-    }
-    if (STATS && p.staged && !d.batch_scale && d.stat_mode == 1 && d.act == AERO_ACT_NONE) {
-        aero_conv_epilogue_fast<MF, WM, NWV, AERO_ACT_NONE, true>(p, acc, Cs, b, fo, fdst, m0, t0);
-        return;
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int T = d.T;
@@ -350,6 +366,34 @@ static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f3
                 atomicAdd(d.stats + (sitem + grp) * 2 + 1, c);
             }
         }
+    }
+}
+
+// Epilogue dispatcher.  STATS instantiations contain ONLY the lean statistics paths (the host refuses anything else), so
+// they do not carry the generic epilogue's registers; plain instantiations pick the lean path when they can.
+#define AERO_EPI_FAST(ACT_, SM_) aero_conv_epilogue_fast<MF, WM, NWV, ACT_, SM_>(p, acc, Cs, b, fo, fdst, m0, t0)
+template <int MF, int WM, bool STATS, int NWV = 4>
+static __device__ __forceinline__ void aero_conv_epilogue(const AeroConvK& p, f32x4 (&acc)[MF][8 / (NWV / WM)], h16* Cs, int b, int fo,
+                                                          int fdst, int m0, int t0) {
+    const aero_conv_desc& d = p.d;
+    if constexpr (STATS) {
+        if (d.stat_mode == 1) AERO_EPI_FAST(AERO_ACT_NONE, 1);
+        else if (d.stat_mode == 2) AERO_EPI_FAST(AERO_ACT_NONE, 2);
+        else if (d.act == AERO_ACT_GLU) AERO_EPI_FAST(AERO_ACT_GLU, 3);
+        else if (d.act == AERO_ACT_GELU) AERO_EPI_FAST(AERO_ACT_GELU, 3);
+        else if (d.act == AERO_ACT_RELU) AERO_EPI_FAST(AERO_ACT_RELU, 3);
+        else AERO_EPI_FAST(AERO_ACT_NONE, 3);
+    } else {
+        if (p.staged && !d.batch_scale) {
+            switch (d.act) {
+                case AERO_ACT_NONE: AERO_EPI_FAST(AERO_ACT_NONE, 0); break;
+                case AERO_ACT_RELU: AERO_EPI_FAST(AERO_ACT_RELU, 0); break;
+                case AERO_ACT_GELU: AERO_EPI_FAST(AERO_ACT_GELU, 0); break;
+                default: AERO_EPI_FAST(AERO_ACT_GLU, 0); break;
+            }
+            return;
+        }
+        aero_conv_epilogue_generic<MF, WM, false, NWV>(p, acc, Cs, b, fo, fdst, m0, t0);
     }
 }
 
@@ -1432,6 +1476,8 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
                (((uintptr_t)d->dst & 15) == 0) && (bm % 16 == 0);
     if (d->res && ((d->r_b % 8) || (d->r_f % 8) || (d->r_t % 8) || ((uintptr_t)d->res & 15))) p.staged = 0;
     if (d->stat_mode == 2) p.staged = 0;
+    if ((d->stat_mode == 1 || d->stat_mode == 3) && !p.staged) { *err = "conv: statistics modes need an fp16 destination with 8-channel aligned rows"; return AERO_ERR_UNSUPPORTED; }
+    if (d->stat_mode && (d->batch_scale || d->post_add || d->scatter_M)) { *err = "conv: statistics modes do not combine with per-item affine / frequency embedding / row scatter"; return AERO_ERR_UNSUPPORTED; }
     const long nwg = (long)d->B * d->Fout * p.ntt * p.nmt;
     if (nwg <= 0 || nwg > 0x7fffffffL) { *err = "conv: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);

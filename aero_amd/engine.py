@@ -165,7 +165,7 @@ class Ops:
     @staticmethod
     def can_fuse_stats(M, G):
         """the conv epilogue can accumulate GroupNorm statistics when a group is 16-row aligned (or there is one group)"""
-        return G == 1 or (M % G == 0 and (M // G) % 16 == 0)
+        return M % 8 == 0 and (G == 1 or (M % G == 0 and (M // G) % 16 == 0))
 
     # -- GroupNorm + activation ----------------------------------------------------------------
     def norm_act(self, x, G, per_row, gamma, beta, act, snake_a=None, layer_scale=None, res=None, normalize=True,
@@ -274,10 +274,12 @@ class HipEngine:
         self._key = None
         self._tables = {}
         self.streams = int(os.environ.get('AERO_STREAMS', '1'))   # sub-batches in flight on separate HIP streams
-        # GroupNorm fused into conv epilogues (stat_mode 1-3 of aero_conv_fwd).  Both are correct (tested against golden)
-        # but measured SLOWER on MI355X than the separate statistics/apply kernels (24.1 vs 22.8 ms per step: the wider
-        # epilogue costs registers and the recompute pass re-pays the tile latency), so they are off by default.
-        self.fuse_dconv_tail = False       # DConv tail as a recompute pair of conv launches (2C-channel tensor never stored)
+        # GroupNorm fused into conv epilogues (stat_mode 1-3 of aero_conv_fwd, lean epilogue paths).  Measured on MI355X:
+        #  * DConv tail as a recompute pair (statistics pass without stores + normalise/GLU/LayerScale/skip pass): the
+        #    2C-channel tensor never reaches HBM; -0.3 ms per forward for the layers with vector-aligned operands -> on.
+        #  * statistics of the encoder/decoder norms accumulated by the producing conv: removes 0.8 ms of statistics
+        #    passes but the statistics instantiations lose the 8-wave tiles -> slower overall (+0.3 ms) -> off.
+        self.fuse_dconv_tail = os.environ.get('AERO_FUSE_DCONV', '1') != '0'       # DConv tail as a recompute pair of conv launches (2C-channel tensor never stored)
         self.fuse_stats = os.environ.get('AERO_FUSE_STATS', '0') != '0'    # GroupNorm statistics accumulated in the producing conv's epilogue
         self.fuse_lstm_proj = True         # W_ih x_t inside the recurrent kernel (no 8H-channel pre-activation tensor in HBM)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
@@ -611,7 +613,7 @@ class HipEngine:
         for L in layers:
             g1 = L['gn1']
             st1 = None
-            if g1 is not None and self.fuse_stats and L['conv1'].M > 16:       # (M <= 16 runs on the streaming kernel)
+            if g1 is not None and self.fuse_stats and L['conv1'].M > 16 and L['conv1'].M % 8 == 0:       # (M <= 16 runs on the streaming kernel)
                 st1 = ops.new_stats(B, Fo, 1, True, x.device)
                 h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T, stat=dict(mode=1, stats=st1, G=1, per_row=True))
             else:
@@ -626,7 +628,7 @@ class HipEngine:
                 att = ops.localstate(qkvd, B * Fo, T, dc.hidden, heads, ndecay)
                 h = ops.conv(L['attn_proj'], att.view(B, Fo, T, dc.hidden), None, B, Fo, Fo, T, res=h)
             g2 = L['gn2']
-            if g2 is not None and self.fuse_dconv_tail:
+            if g2 is not None and self.fuse_dconv_tail and L['conv2_glu'].M % 16 == 0 and L['conv2_glu'].C0 % 8 == 0:
                 # pass 0: statistics of conv2(h) only (nothing stored); pass 1: recompute, normalise, GLU, scale, + skip
                 st2 = ops.new_stats(B, Fo, 1, True, x.device)
                 c2 = L['conv2_glu']
@@ -635,7 +637,7 @@ class HipEngine:
                              stat=dict(mode=3, stats=st2, G=1, per_row=True, count=float(T * c2.M),
                                        gamma=L['gn2_glu'][0], beta=L['gn2_glu'][1], layer_scale=L['scale']))
                 continue
-            st2 = ops.new_stats(B, Fo, 1, True, x.device) if (g2 is not None and self.fuse_stats) else None
+            st2 = ops.new_stats(B, Fo, 1, True, x.device) if (g2 is not None and self.fuse_stats and L['conv2'].M % 8 == 0) else None
             g = ops.conv(L['conv2'], h, None, B, Fo, Fo, T,
                          stat=None if st2 is None else dict(mode=1, stats=st2, G=1, per_row=True))
             x = ops.norm_act(g, 1, True, g2[0] if g2 else None, g2[1] if g2 else None, ACT_GLU,
