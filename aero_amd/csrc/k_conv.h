@@ -1565,21 +1565,22 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         // decoder layer vs 872 with one 96-KiB KC-64 block and 860 for the 128-row KC-64 tile.
         static int wide = -1;
         if (wide < 0) { const char* e = getenv("AERO_CONV_BM256"); wide = e ? atoi(e) : 2; }
-        // (statistics modes stay on the 4-wave tiles: the 8-wave instantiation with the statistics epilogue gave wrong
-        // outputs on hardware -- not in the emulator -- and was slower anyway)
-        const int wbm = d->stat_mode ? 0 : (wide >= 1 && d->M % 256 == 0 && p.Ktot >= 1024) ? 256
+        const int wbm = (wide >= 1 && d->M % 256 == 0 && p.Ktot >= 1024) ? 256
                         : (wide >= 2 && d->M % 192 == 0 && p.Ktot >= 768) ? 192 : 0;
         if (wbm) {
             p.nmt = d->M / wbm;
             grid = dim3((unsigned)((long)d->B * d->Fout * p.ntt * p.nmt));
             block = dim3(512);
-            if (name) snprintf(name, 96, "aero_conv_glds8_kernel<%d, 32, false>", wbm / 64);
+            const bool st = d->stat_mode != 0;
+            if (name) snprintf(name, 96, "aero_conv_glds8_kernel<%d, 32, %s>", wbm / 64, st ? "true" : "false");
             else if (wbm == 256) {
                 const size_t dyn = AeroGldsGeom<4, 4, 32, 8>::SMEM * sizeof(h16);
-                AERO_LAUNCH_DYN((aero_conv_glds8_kernel<4, 32, false>), grid, block, dyn, stream, p);
+                if (st) AERO_LAUNCH_DYN((aero_conv_glds8_kernel<4, 32, true>), grid, block, dyn, stream, p);
+                else AERO_LAUNCH_DYN((aero_conv_glds8_kernel<4, 32, false>), grid, block, dyn, stream, p);
             } else {
                 const size_t dyn = AeroGldsGeom<3, 4, 32, 8>::SMEM * sizeof(h16);
-                AERO_LAUNCH_DYN((aero_conv_glds8_kernel<3, 32, false>), grid, block, dyn, stream, p);
+                if (st) AERO_LAUNCH_DYN((aero_conv_glds8_kernel<3, 32, true>), grid, block, dyn, stream, p);
+                else AERO_LAUNCH_DYN((aero_conv_glds8_kernel<3, 32, false>), grid, block, dyn, stream, p);
             }
             return AERO_OK;
         }
