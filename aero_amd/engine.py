@@ -430,6 +430,15 @@ class HipEngine:
             if dc.norm:
                 L['gn2_glu'] = (pack.glu_interleave(sd[f'{q}.conv2.1.weight']).to(device).contiguous(),
                                 pack.glu_interleave(sd[f'{q}.conv2.1.bias']).to(device).contiguous())
+            hid = w.shape[-1]
+            if hid % 8 and not dc.lstm and not dc.time_attn:
+                # hidden width not a multiple of 8 (first layer: 12): the activation is kept with a channel pitch of 16 and
+                # zero pad channels so that conv2 reads 16-byte aligned rows (direct-to-LDS pipeline, recompute pair)
+                hp = (hid + 7) // 8 * 8
+                wp = torch.zeros(w.shape[0], w.shape[1], w.shape[2], hp)
+                wp[..., :hid] = w
+                L['conv2_glu_pad'] = mk(wp, sd[f'{q}.conv2.0.bias'], hp, 0, df, dt, device, act=ACT_GLU)
+                L['hid_pad'] = hp
             out.append(L)
         return out
 
@@ -644,8 +653,25 @@ class HipEngine:
                 h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T, stat=dict(mode=1, stats=st1, G=1, per_row=True))
             else:
                 h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T)
+            g2 = L['gn2']
+            hp = L.get('hid_pad') if (g2 is not None and self.fuse_dconv_tail and L['conv2_glu'].M % 16 == 0) else None
+            hdst = None
+            if hp:
+                hid = h.shape[-1]
+                key = ('hidpad', B, Fo, T, hp, str(x.device), self.ops.stream(x))
+                if key not in self._tables:                   # pad channels are zero and never written afterwards
+                    self._tables[key] = torch.zeros(B, Fo, T, hp, dtype=torch.float16, device=x.device)
+                hdst = self._tables[key][..., :hid]
             h = ops.norm_act(h, 1, True, g1[0] if g1 else None, g1[1] if g1 else None, act,
-                             snake_a=L.get('snake_a'), normalize=g1 is not None, stats=st1)
+                             snake_a=L.get('snake_a'), normalize=g1 is not None, stats=st1, dst=hdst)
+            if hp:
+                st2 = ops.new_stats(B, Fo, 1, True, x.device)
+                c2, hb = L['conv2_glu_pad'], self._tables[key]
+                ops.conv(c2, hb, None, B, Fo, Fo, T, act=ACT_NONE, stat=dict(mode=2, stats=st2, G=1, per_row=True))
+                x = ops.conv(c2, hb, None, B, Fo, Fo, T, res=x,
+                             stat=dict(mode=3, stats=st2, G=1, per_row=True, count=float(T * c2.M),
+                                       gamma=L['gn2_glu'][0], beta=L['gn2_glu'][1], layer_scale=L['scale']))
+                continue
             if 'lstm' in L:
                 h = self._blstm(dc, L, h, B, Fo, T)
             if 'attn_qkvd' in L:
@@ -653,7 +679,6 @@ class HipEngine:
                 qkvd = ops.conv(L['attn_qkvd'], h, None, B, Fo, Fo, T)
                 att = ops.localstate(qkvd, B * Fo, T, dc.hidden, heads, ndecay)
                 h = ops.conv(L['attn_proj'], att.view(B, Fo, T, dc.hidden), None, B, Fo, Fo, T, res=h)
-            g2 = L['gn2']
             if g2 is not None and self.fuse_dconv_tail and L['conv2_glu'].M % 16 == 0 and L['conv2_glu'].C0 % 8 == 0:
                 # pass 0: statistics of conv2(h) only (nothing stored); pass 1: recompute, normalise, GLU, scale, + skip
                 st2 = ops.new_stats(B, Fo, 1, True, x.device)
