@@ -42,6 +42,12 @@ class NormDesc(C.Structure):
                 ('dst', vp), ('d_b', i64), ('d_f', i64), ('d_t', i64)]
 
 
+class GramDesc(C.Structure):
+    _fields_ = [('x', vp), ('s_b', i64), ('s_f', i64), ('s_t', i64),
+                ('B', i32), ('F', i32), ('T', i32), ('C', i32),
+                ('G', dp), ('g1', dp), ('stats', dp)]
+
+
 class LstmDesc(C.Structure):
     _fields_ = [('xproj', vp), ('xbias', vp), ('whh', vp), ('out', vp),
                 ('H', i32), ('nseq', i32), ('W', i32), ('in_mode', i32), ('out_mode', i32),
@@ -76,6 +82,7 @@ _PROTOS = {
     'aero_conv_kernel_name': (i32, [C.POINTER(ConvDesc), C.c_char_p, i32]),
     'aero_norm_stats': (i32, [C.POINTER(NormDesc), vp]),
     'aero_norm_apply': (i32, [C.POINTER(NormDesc), vp]),
+    'aero_gram_stats': (i32, [C.POINTER(GramDesc), vp]),
     'aero_lstm_fwd': (i32, [C.POINTER(LstmDesc), vp]),
     'aero_lstm_geometry': (i32, [i32, C.POINTER(i32), C.POINTER(i32)]),
     'aero_lstm_geometry_in': (i32, [i32, i32, C.POINTER(i32)]),

@@ -9,6 +9,7 @@
 #include "k_ftb.h"
 #include "k_lstm.h"
 #include "k_norm.h"
+#include "k_gram.h"
 #include "k_stft.h"
 
 #include <stdio.h>
@@ -84,6 +85,12 @@ int aero_conv_kernel_name(const aero_conv_desc* d, char* name, int32_t cap) {
 int aero_norm_stats(const aero_norm_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_norm_stats_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_gram_stats(const aero_gram_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_gram_stats_launch(d, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 

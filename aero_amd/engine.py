@@ -202,6 +202,18 @@ class Ops:
                    B * f_cnt * T * (Cc + Cout + (Cout if res is not None else 0)) * 2, C.byref(d), self.stream(x))
         return out
 
+    def gram_stats(self, x, tables, stats):
+        """GroupNorm(1) sums of a pointwise conv's output from the Gram matrix of its input x [B,F,T,C] (aero_gram_stats)."""
+        B, F, T, Cc = x.shape
+        d = _lib.GramDesc()
+        d.x = _ptr(x)
+        d.s_b, d.s_f, d.s_t = _strides4(x)
+        d.B, d.F, d.T, d.C = B, F, T, Cc
+        d.G, d.g1, d.stats = _ptr(tables[0]), _ptr(tables[1]), _ptr(stats)
+        self._call('aero_gram_stats', 'aero_gram_stats_kernel', 2.0 * B * F * T * (Cc + 1) ** 2, x.numel() * 2,
+                   C.byref(d), self.stream(x))
+        return stats
+
     # -- LSTM / attention / FTB ----------------------------------------------------------------
     def lstm(self, xproj, xbias, whh, H, nseq, W, in_mode, out_mode, nframes, S, T, out, x=None, fused=None):
         """one bidirectional layer.  Either (xproj, xbias) = precomputed input projection, or (x, fused=(wih, bias, in_ch)):
@@ -281,6 +293,7 @@ class HipEngine:
         #  * statistics of the encoder/decoder norms accumulated by the producing conv: removes 0.8 ms of statistics
         #    passes but the statistics instantiations lose the 8-wave tiles -> slower overall (+0.3 ms) -> off.
         self.fuse_dconv_tail = os.environ.get('AERO_FUSE_DCONV', '1') != '0'       # DConv tail as a recompute pair of conv launches (2C-channel tensor never stored)
+        self.gram_stats = os.environ.get('AERO_GRAM_STATS', '1') != '0'    # DConv tail statistics from the Gram matrix of conv2's input (k_gram.h)
         self.fuse_stats = os.environ.get('AERO_FUSE_STATS', '0') != '0'    # GroupNorm statistics accumulated in the producing conv's epilogue
         self.fuse_lstm_proj = True         # W_ih x_t inside the recurrent kernel (no 8H-channel pre-activation tensor in HBM)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
@@ -431,6 +444,8 @@ class HipEngine:
                 L['gn2_glu'] = (pack.glu_interleave(sd[f'{q}.conv2.1.weight']).to(device).contiguous(),
                                 pack.glu_interleave(sd[f'{q}.conv2.1.bias']).to(device).contiguous())
             hid = w.shape[-1]
+            if hid + 1 <= 112:                                      # statistics of conv2's output from the Gram matrix of its input
+                L['gram'] = pack.gram_tables(w[0, :, 0, :], sd[f'{q}.conv2.0.bias'], device)
             if hid % 8 and not dc.lstm and not dc.time_attn:
                 # hidden width not a multiple of 8 (first layer: 12): the activation is kept with a channel pitch of 16 and
                 # zero pad channels so that conv2 reads 16-byte aligned rows (direct-to-LDS pipeline, recompute pair)
@@ -439,6 +454,7 @@ class HipEngine:
                 wp[..., :hid] = w
                 L['conv2_glu_pad'] = mk(wp, sd[f'{q}.conv2.0.bias'], hp, 0, df, dt, device, act=ACT_GLU)
                 L['hid_pad'] = hp
+                L['gram_pad'] = pack.gram_tables(wp[0, :, 0, :], sd[f'{q}.conv2.0.bias'], device)
             out.append(L)
         return out
 
@@ -667,7 +683,10 @@ class HipEngine:
             if hp:
                 st2 = ops.new_stats(B, Fo, 1, True, x.device)
                 c2, hb = L['conv2_glu_pad'], self._tables[key]
-                ops.conv(c2, hb, None, B, Fo, Fo, T, act=ACT_NONE, stat=dict(mode=2, stats=st2, G=1, per_row=True))
+                if self.gram_stats and 'gram_pad' in L:
+                    ops.gram_stats(hb, L['gram_pad'], st2)
+                else:
+                    ops.conv(c2, hb, None, B, Fo, Fo, T, act=ACT_NONE, stat=dict(mode=2, stats=st2, G=1, per_row=True))
                 x = ops.conv(c2, hb, None, B, Fo, Fo, T, res=x,
                              stat=dict(mode=3, stats=st2, G=1, per_row=True, count=float(T * c2.M),
                                        gamma=L['gn2_glu'][0], beta=L['gn2_glu'][1], layer_scale=L['scale']))
@@ -683,7 +702,10 @@ class HipEngine:
                 # pass 0: statistics of conv2(h) only (nothing stored); pass 1: recompute, normalise, GLU, scale, + skip
                 st2 = ops.new_stats(B, Fo, 1, True, x.device)
                 c2 = L['conv2_glu']
-                ops.conv(c2, h, None, B, Fo, Fo, T, act=ACT_NONE, stat=dict(mode=2, stats=st2, G=1, per_row=True))
+                if self.gram_stats and 'gram' in L:
+                    ops.gram_stats(h, L['gram'], st2)
+                else:
+                    ops.conv(c2, h, None, B, Fo, Fo, T, act=ACT_NONE, stat=dict(mode=2, stats=st2, G=1, per_row=True))
                 x = ops.conv(c2, h, None, B, Fo, Fo, T, res=x,
                              stat=dict(mode=3, stats=st2, G=1, per_row=True, count=float(T * c2.M),
                                        gamma=L['gn2_glu'][0], beta=L['gn2_glu'][1], layer_scale=L['scale']))

@@ -113,6 +113,21 @@ def convtr_stacked_spec(w, bias, stride, device, act=_lib.ACT_NONE):
     return spec
 
 
+def gram_tables(w, bias, device):
+    """fp64 tables of aero_gram_stats for a pointwise conv y = W x + b (w [M, C] as the kernels see it, i.e. rounded to
+    fp16; bias [M] fp32 or None): G = W'^T W' and g1 = sum_m W'[m] with W' = [W b], zero padded to Cp = 16*ceil((C+1)/16)."""
+    M, Cc = w.shape
+    wq = w.detach().half().double()
+    b = torch.zeros(M, dtype=torch.float64) if bias is None else bias.detach().double().cpu()
+    wa = torch.cat([wq.cpu(), b[:, None]], 1)                     # [M, C+1]
+    Cp = _round_up(Cc + 1, 16)
+    G = torch.zeros(Cp, Cp, dtype=torch.float64)
+    G[:Cc + 1, :Cc + 1] = wa.t() @ wa
+    g1 = torch.zeros(Cp, dtype=torch.float64)
+    g1[:Cc + 1] = wa.sum(0)
+    return G.to(device).contiguous(), g1.to(device).contiguous()
+
+
 def lstm_gate_perm(H):
     """row index 4*j+gate of the kernel <- row gate*H + j of nn.LSTM (i,f,g,o blocks)."""
     j = torch.arange(H)

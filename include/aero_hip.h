@@ -134,6 +134,22 @@ typedef struct {
 int aero_norm_stats(const aero_norm_desc* d, void* stream);
 int aero_norm_apply(const aero_norm_desc* d, void* stream);
 
+/* GroupNorm(1, M) statistics of a POINTWISE conv's output without running the conv (DConv tail, modules.py:209-210):
+ * for y_t = W x_t + b over the T steps of one (b, f) row,
+ *     sum_t sum_m y       = g1 . S[:, C]                 S = sum_t x'_t x'_t^T,  x' = (x, 1)   ((C+1) x (C+1) Gram matrix)
+ *     sum_t sum_m y^2     = sum_ij G[i][j] S[i][j]       G = W'^T W',  W' = [W b],  g1 = sum_m W'[m]
+ * so the kernel reads only the C-channel input rows (C = M/8 here), forms S with MFMAs and contracts it with the
+ * caller's fp64 tables G [Cp][Cp] and g1 [Cp] (Cp = (C+1) rounded up to 16, zero padded).  One block per row, no
+ * atomics: stats[(b*F + f)*2 + {0,1}] are WRITTEN (sum, sum of squares), the format aero_norm_apply / aero_conv_fwd
+ * stat_mode 3 read with stat_count = T*M.  x fp16 [B,F,T,C] channels-last (channel stride 1, strides in elements). */
+typedef struct aero_gram_desc {
+    const void* x; int64_t s_b, s_f, s_t;
+    int32_t B, F, T, C;
+    const double* G; const double* g1;
+    double* stats;
+} aero_gram_desc;
+int aero_gram_stats(const aero_gram_desc* d, void* stream);
+
 /* K10 -- the recurrent part of nn.LSTM(bidirectional) inside BLSTM (modules.py:28,46), both
  * directions of ONE layer per call; the input projection is an aero_conv_fwd 1x1.
  * xproj fp16 [npos][8H]: gate pre-activations incl. both biases, channel = dir*4H + 4*j + gate

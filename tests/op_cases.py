@@ -147,6 +147,27 @@ def case_conv_stats(lib, dev, Cin, Cout, kF, kT, Fq, T, G=1, per_row=False, B=2,
     assert torch.allclose(got[..., 0], s1, rtol=1e-3, atol=1e-3 * float(s2.sqrt().mean()))
 
 
+def case_gram_stats(lib, dev, Cc, M, Fq, T, B=2, pitch=None, seed=19):
+    """aero_gram_stats: sum / sum of squares of y = W x + b per (b, f) row from the Gram matrix of x, against the direct
+    evaluation in float64 (same fp16-rounded W and x)."""
+    ops = Ops(lib)
+    w = _rand((M, Cc), seed, 1.0 / math.sqrt(Cc))
+    b = _rand((M,), seed + 1)
+    x = _rand((B, Fq, T, Cc), seed + 2)
+    pitch = pitch or Cc
+    buf = torch.zeros(B, Fq, T, pitch, dtype=torch.float16)
+    buf[..., :Cc] = x.half()
+    xd = buf.to(dev)[..., :Cc]
+    tables = pack.gram_tables(w, b, dev)
+    st = torch.full((B * Fq, 2), -1.0, dtype=torch.float64, device=dev)
+    ops.gram_stats(xd, tables, st)
+    y = q16(x).double() @ q16(w).double().t() + b.double()                                  # [B, F, T, M]
+    s1, s2 = y.sum((2, 3)).reshape(-1), (y * y).sum((2, 3)).reshape(-1)
+    got = st.cpu()
+    assert torch.allclose(got[:, 1], s2, rtol=2e-5), (got[:4, 1], s2[:4])
+    assert torch.allclose(got[:, 0], s1, rtol=1e-4, atol=1e-4 * float(s2.sqrt().mean()))
+
+
 def case_conv1d(lib, dev, Cin, Cout, k, dil, R, T, seed=20):
     ops = Ops(lib)
     w = _rand((Cout, Cin, k), seed, 1.0 / math.sqrt(Cin * k))

@@ -76,6 +76,11 @@ def test_conv_stats(emu, kw):
     oc.case_conv_stats(emu, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Cc=12, M=96, Fq=3, T=70), dict(Cc=16, M=96, Fq=2, T=300, B=1), dict(Cc=12, M=96, Fq=2, T=133, pitch=16), dict(Cc=96, M=768, Fq=1, T=130, B=1), dict(Cc=5, M=10, Fq=2, T=20)])
+def test_gram_stats(emu, kw):
+    oc.case_gram_stats(emu, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(Cin=48, Cout=12, k=3, dil=1, R=6, T=131), dict(Cin=16, Cout=4, k=3, dil=2, R=3, T=60),
                                 dict(Cin=40, Cout=16, k=9, dil=1, R=2, T=50)])
 def test_conv1d(emu, kw):

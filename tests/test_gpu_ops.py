@@ -57,6 +57,11 @@ def test_conv_stats(lib, kw):
     oc.case_conv_stats(lib, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Cc=16, M=96, Fq=64, T=501), dict(Cc=24, M=192, Fq=16, T=501), dict(Cc=48, M=384, Fq=8, T=501), dict(Cc=96, M=768, Fq=4, T=501), dict(Cc=12, M=96, Fq=8, T=501, pitch=16)])
+def test_gram_stats(lib, kw):
+    oc.case_gram_stats(lib, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(Cin=48, Cout=12, k=3, dil=1, R=128, T=501), dict(Cin=384, Cout=96, k=3, dil=2, R=8, T=501),
                                 dict(Cin=512, Cout=48, k=9, dil=1, R=2, T=501)])
 def test_conv1d(lib, kw):
