@@ -137,24 +137,24 @@ struct AeroFtbFirstK {
     int Kp;
 };
 
+// One block owns a whole (b, f) row and walks over its 128-step tiles: the weight tile and the epilogue coefficients are
+// fetched ONCE per block.  The pre_conv coefficients (k0/k1/kb) are deliberately re-read per tile and k-step: with all
+// 48 of them hoisted into registers as well the kernel was 25 % faster but returned run-to-run different results on the
+// MI355X (lanes 48-63 of the waves building the operand tile; never in the emulator; not cured by draining vmcnt between
+// load groups or by extra barriers -- tools/dbg_ftb.py reproduces it).  Root cause not found; this form is bit-reproducible.
 template <int MF>
 __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
     constexpr int BM = MF * 16, BN = 128, KT = 2;              // C <= 64: two k-steps of 32 channels
     constexpr int CS = BM + 8;
-    constexpr int SMEM = KT * (BM + BN) * 32 > BN * CS ? KT * (BM + BN) * 32 : BN * CS;
-    __shared__ AERO_LDS_ALIGN h16 smem[SMEM];
-    h16* As = smem;                       // [KT][BM][32]
-    h16* Bs = smem + KT * BM * 32;        // [KT][BN][32]
-    h16* Cs = smem;                       // [BN][CS] output staging (after the MFMAs)
+    constexpr int SB = KT * BN * 32 > BN * CS ? KT * BN * 32 : BN * CS;
+    __shared__ AERO_LDS_ALIGN h16 As[KT * BM * 32];            // [KT][BM][32] weights, resident
+    __shared__ AERO_LDS_ALIGN h16 Bs[SB];                      // [KT][BN][32] operand tile, then [BN][CS] output staging
+    h16* Cs = Bs;
     const aero_ftb_first_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int C = d.C, T = d.T;
-    int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
-    const int ntt = (T + BN - 1) / BN;
-    const int tt = id % ntt;
-    const int row = id / ntt;
+    const int row = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const int b = row / d.F, f = row % d.F;
-    const int t0 = tt * BN;
     // weights -> LDS
     for (int v = tid; v < KT * BM * 4; v += 256) {
         const int kt = v / (BM * 4), rem = v - kt * (BM * 4);
@@ -163,98 +163,107 @@ __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
         if (kt * 32 < p.Kp) w = *(const h16x8*)((const h16*)d.w2a + (int64_t)r * p.Kp + kt * 32 + q * 8);
         *(h16x8*)&As[kt * BM * 32 + aero_tile_off(r, q)] = w;
     }
-    // attention-branch operand att[pos][c] built on the fly
     const h16* xn = (const h16*)d.xn + ((int64_t)row * T) * 2;
     const h16* un = (const h16*)d.u + ((int64_t)row * T) * 2;
     const h16* gate = (const h16*)d.gate + (int64_t)b * T * C;
+    h16* drow = (h16*)d.dst + ((int64_t)row * T) * C;
     const float rsf = d.rs[f];
-    // thread tid always builds the same 8-channel slot (q = tid & 3) of k-step kt = i: its per-channel coefficients
-    // (pre_conv weights / bias) are loaded once into registers, the per-position work is 3 FMA + 1 MUL per channel
+    // thread tid always builds the same 8-channel slot (q = tid & 3) of each k-step: its per-channel coefficients
+    // (pre_conv weights / bias) live in registers, the per-position work is 3 FMA + 1 MUL per channel
     const int qf = tid & 3;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const int c = kt * 32 + qf * 8;
-        float k0[8], k1[8], kb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool in = c + e < C;
-            k0[e] = in ? d.p0[c + e] : 0.f;
-            k1[e] = in ? d.p1[c + e] : 0.f;
-            kb[e] = in ? d.pb[c + e] * rsf : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < BN * 4 / 256; ++i) {
-            const int pos = (tid + 256 * i) >> 2;
-            const int t = t0 + pos;
-            h16x8 o = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (t < T && c < C) {
-                const h16x2 uu = *(const h16x2*)(un + (int64_t)t * 2);
-                const float ur = (float)uu[0], ui = (float)uu[1];
-                const h16x8 g8 = *(const h16x8*)(gate + (int64_t)t * C + c);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (h16)((float)g8[e] * (k0[e] * ur + k1[e] * ui + kb[e]));
-            }
-            *(h16x8*)&Bs[kt * BN * 32 + aero_tile_off(pos, qf)] = o;
-        }
-    }
-    __syncthreads();
-    f32x4 acc[MF][2];
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        h16x8 bf[2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) bf[n] = *(const h16x8*)&Bs[kt * BN * 32 + aero_tile_off((wave * 2 + n) * 16 + (lane & 15), lane >> 4)];
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const h16x8 a = *(const h16x8*)&As[kt * BM * 32 + aero_tile_off(i * 16 + (lane & 15), lane >> 4)];
-            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[0], acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[1], acc[i][1], 0, 0, 0);
-        }
-    }
-    __syncthreads();                                           // operands consumed: smem becomes the output tile
-    float re[2], im[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int t = t0 + (wave * 2 + n) * 16 + (lane & 15);
-        re[n] = im[n] = 0.f;
-        if (t < T) {
-            const h16x2 vv = *(const h16x2*)(xn + (int64_t)t * 2);
-            re[n] = (float)vv[0];
-            im[n] = (float)vv[1];
-        }
-    }
+    float ar[MF][4], ai[MF][4], bb[MF][4];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int m = i * 16 + (lane >> 4) * 4;
-        float ar[4], ai[4], bb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool in = m + r < C;
-            ar[r] = in ? d.a_re[m + r] : 0.f;
-            ai[r] = in ? d.a_im[m + r] : 0.f;
-            bb[r] = in ? d.bias[m + r] : 0.f;
-        }
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int pos = (wave * 2 + n) * 16 + (lane & 15);
-            h16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (h16)fmaxf(acc[i][n][r] + ar[r] * re[n] + ai[r] * im[n] + bb[r], 0.f);
-            *(h16x4*)&Cs[pos * CS + m] = o;
+            const int mi = m + r < C ? m + r : C - 1;
+            ar[i][r] = d.a_re[mi];
+            ai[i][r] = d.a_im[mi];
+            bb[i][r] = d.bias[mi];
         }
     }
-    __syncthreads();
     const int nvec = C >> 3;
-    h16* drow = (h16*)d.dst + ((int64_t)row * T) * C;
-    for (int idx = tid; idx < BN * nvec; idx += 256) {
-        const int pos = idx / nvec, cv = idx - pos * nvec;
-        const int t = t0 + pos;
-        if (t < T) *(h16x8*)(drow + (int64_t)t * C + cv * 8) = *(const h16x8*)&Cs[pos * CS + cv * 8];
+    const int ntt = (T + BN - 1) / BN;
+    for (int tt = 0; tt < ntt; ++tt) {
+        const int t0 = tt * BN;
+        // attention-branch operand att[pos][c] built on the fly
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int c = kt * 32 + qf * 8;
+            float k0[KT][8], k1[KT][8], kb[KT][8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool in = c + e < C;
+                k0[kt][e] = in ? d.p0[c + e] : 0.f;
+                k1[kt][e] = in ? d.p1[c + e] : 0.f;
+                kb[kt][e] = in ? d.pb[c + e] * rsf : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < BN * 4 / 256; ++i) {
+                const int pos = (tid + 256 * i) >> 2;
+                const int t = t0 + pos;
+                h16x8 o = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (t < T && c < C) {
+                    const h16x2 uu = *(const h16x2*)(un + (int64_t)t * 2);
+                    const float ur = (float)uu[0], ui = (float)uu[1];
+                    const h16x8 g8 = *(const h16x8*)(gate + (int64_t)t * C + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (h16)((float)g8[e] * (k0[kt][e] * ur + k1[kt][e] * ui + kb[kt][e]));
+                }
+                *(h16x8*)&Bs[kt * BN * 32 + aero_tile_off(pos, qf)] = o;
+            }
+        }
+        float re[2], im[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int t = t0 + (wave * 2 + n) * 16 + (lane & 15);
+            re[n] = im[n] = 0.f;
+            if (t < T) {
+                const h16x2 vv = *(const h16x2*)(xn + (int64_t)t * 2);
+                re[n] = (float)vv[0];
+                im[n] = (float)vv[1];
+            }
+        }
+        __syncthreads();
+        f32x4 acc[MF][2];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            h16x8 bf[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bf[n] = *(const h16x8*)&Bs[kt * BN * 32 + aero_tile_off((wave * 2 + n) * 16 + (lane & 15), lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const h16x8 a = *(const h16x8*)&As[kt * BM * 32 + aero_tile_off(i * 16 + (lane & 15), lane >> 4)];
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[1], acc[i][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                       // operand tile consumed: it becomes the output tile
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int pos = (wave * 2 + n) * 16 + (lane & 15);
+                h16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (h16)fmaxf(acc[i][n][r] + ar[i][r] * re[n] + ai[i][r] * im[n] + bb[i][r], 0.f);
+                *(h16x4*)&Cs[pos * CS + m] = o;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BN * nvec; idx += 256) {
+            const int pos = idx / nvec, cv = idx - pos * nvec;
+            const int t = t0 + pos;
+            if (t < T) *(h16x8*)(drow + (int64_t)t * C + cv * 8) = *(const h16x8*)&Cs[pos * CS + cv * 8];
+        }
+        __syncthreads();                                       // staging read out before the next tile overwrites it
     }
 }
 
@@ -265,7 +274,7 @@ static int aero_ftb_first_launch(const aero_ftb_first_desc* d, hipStream_t strea
     AeroFtbFirstK p;
     p.d = *d;
     p.Kp = (d->C + 31) / 32 * 32;
-    const long nwg = (long)d->B * d->F * ((d->T + 127) / 128);
+    const long nwg = (long)d->B * d->F;
     if (nwg > 0x7fffffffL) { *err = "ftb_first: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);
     const int mf = (d->C + 15) / 16;
