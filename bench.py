@@ -187,6 +187,10 @@ def main():
                    'precision': 'fp16 operands/storage, fp32 accumulate; STFT/iSTFT/statistics fp32'},
         'roofline': roof, 'cpu_baseline': cpu,
         'kernels_ms_per_step': {n: round(v['ms'] / max(1, min(args.steps, 5)), 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
+        # per kernel over the same launches: [executed TFLOP/s, algorithmic GB/s] (HIP-event time; 0 = not applicable)
+        'kernels_achieved': {n: [round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) if v['ms'] > 0 else 0.0,
+                                 round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else 0.0]
+                             for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
     }
     print(json.dumps(out))
     distrib.close()
