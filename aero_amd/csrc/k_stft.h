@@ -34,14 +34,37 @@ static __device__ __forceinline__ void aero_fft_init_twiddles(f32x2* tw, int n_f
     }
 }
 
-// Stockham radix-2 autosort FFT of n points, one problem per wavefront (waves run independently).
+// Stockham autosort FFT of n points, one problem per wavefront (waves run independently): radix-4 passes (each the
+// exact composition of two radix-2 passes, same twiddle table entries, so results equal the radix-2 form bit for bit)
+// and one closing radix-2 pass when log2(n) is odd.  n = 256 is 4 passes of one butterfly per lane.
 // Returns the buffer (a or b) that holds the natural-order result.
 static __device__ __forceinline__ f32x2* aero_fft_wave(f32x2* a, f32x2* b, int n, int n_fft, const f32x2* tw) {
     const int lane = aero_lane();
-    const int half = n >> 1;
+    const int half = n >> 1, quarter = n >> 2;
     f32x2* src = a;
     f32x2* dst = b;
-    for (int p = 1; p < n; p <<= 1) {
+    int p = 1;
+    for (; 4 * p <= n; p <<= 2) {
+        const int tws2 = n_fft / (2 * p), tws4 = n_fft / (4 * p);
+        for (int i = lane; i < quarter; i += 64) {
+            const int k = i & (p - 1);
+            const f32x2 w2 = tw[k * tws2], w1 = tw[k * tws4], w3 = tw[(k + p) * tws4];
+            const f32x2 A = src[i], B = src[i + quarter], Cc = src[i + half], D = src[i + half + quarter];
+            const f32x2 c2 = aero_cmul(w2, Cc), d2 = aero_cmul(w2, D);
+            const f32x2 m0 = A + c2, m1 = A - c2, m2 = B + d2, m3 = B - d2;
+            const f32x2 e = aero_cmul(w1, m2), f = aero_cmul(w3, m3);
+            const int jj = ((i - k) << 2) + k;
+            dst[jj] = m0 + e;
+            dst[jj + p] = m1 + f;
+            dst[jj + 2 * p] = m0 - e;
+            dst[jj + 3 * p] = m1 - f;
+        }
+        aero_wave_sync();              // a wave owns its two buffers: LDS is in-order per wave, no block barrier needed
+        f32x2* tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    if (p < n) {
         const int tws = n_fft / (2 * p);
         for (int i = lane; i < half; i += 64) {
             const int k = i & (p - 1);
@@ -51,7 +74,7 @@ static __device__ __forceinline__ f32x2* aero_fft_wave(f32x2* a, f32x2* b, int n
             dst[jj] = u0 + v;
             dst[jj + p] = u0 - v;
         }
-        aero_wave_sync();              // a wave owns its two buffers: LDS is in-order per wave, no block barrier needed
+        aero_wave_sync();
         f32x2* tmp = src;
         src = dst;
         dst = tmp;
@@ -64,15 +87,22 @@ struct AeroStftK {
     int nsig, L, Lp, n_fft, hop, n_bins, T, sig_per_item, FPB;
 };
 
+// dynamic LDS sized by the actual n = n_fft/2 and frames per block (statically sized for n_fft = 1024 it was 62 KiB:
+// two blocks per CU):   tw[n] | bufA[4][n] | bufB[4][n] | tile[n_bins*FPB]   (f32x2)   then   wl[n_fft] | xsp[SPAN]   (float)
+static inline size_t aero_stft_lds_bytes(int n_fft, int n_bins, int fpb) {
+    const size_t n = (size_t)n_fft / 2;
+    return (n + 8 * n + (size_t)n_bins * fpb) * sizeof(f32x2) + ((size_t)n_fft + AERO_STFT_SPAN) * sizeof(float);
+}
+
 __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
-    __shared__ AERO_LDS_ALIGN f32x2 tw[AERO_FFT_MAX_N];
-    __shared__ AERO_LDS_ALIGN f32x2 bufA[4][AERO_FFT_MAX_N];
-    __shared__ AERO_LDS_ALIGN f32x2 bufB[4][AERO_FFT_MAX_N];
-    __shared__ AERO_LDS_ALIGN f32x2 tile[2048 + 64];
-    __shared__ float wl[2 * AERO_FFT_MAX_N];
-    __shared__ float xsp[AERO_STFT_SPAN];
     __shared__ double red[2][4];
     const int n = p.n_fft >> 1;
+    f32x2* tw = (f32x2*)AERO_DYN_SMEM;
+    f32x2* bufA0 = tw + n;
+    f32x2* bufB0 = bufA0 + 4 * n;
+    f32x2* tile = bufB0 + 4 * n;
+    float* wl = (float*)(tile + p.n_bins * p.FPB);
+    float* xsp = wl + p.n_fft;
     const int lane = aero_lane(), wave = aero_wave();
     const int sig = blockIdx.y;
     const int tbase = blockIdx.x * p.FPB;
@@ -117,10 +147,10 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
                     }
                 }
             }
-            bufA[wave][m] = g;
+            bufA0[wave * n + m] = g;
         }
         __syncthreads();
-        const f32x2* R = aero_fft_wave(bufA[wave], bufB[wave], n, p.n_fft, tw);
+        const f32x2* R = aero_fft_wave(bufA0 + wave * n, bufB0 + wave * n, n, p.n_fft, tw);
         if (fr < p.FPB) {
             for (int k = lane; k < p.n_bins; k += 64) {
                 f32x2 X;
@@ -145,8 +175,9 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
     }
     const int total = p.n_bins * p.FPB;
     f32x2* out = (f32x2*)p.spec + (int64_t)sig * p.n_bins * p.T;
+    const int lf = 31 - __builtin_clz(p.FPB);                    // FPB is a power of two
     for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int k = idx / p.FPB, fr = idx % p.FPB;
+        const int k = idx >> lf, fr = idx & (p.FPB - 1);
         const int t = tbase + fr;
         if (t < p.T) out[(int64_t)k * p.T + t] = tile[idx];
     }
@@ -186,11 +217,14 @@ struct AeroIstftK {
     int nsig, F, T, n_fft, hop, Lout, FPB, SEG;
 };
 
+// dynamic LDS: tw[n] | fbuf[FPB][n] | sbuf[4][n]   (f32x2)
+static inline size_t aero_istft_lds_bytes(int n_fft, int fpb) { return (size_t)(n_fft / 2) * (5 + fpb) * sizeof(f32x2); }
+
 __global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
-    __shared__ AERO_LDS_ALIGN f32x2 tw[AERO_FFT_MAX_N];
-    __shared__ AERO_LDS_ALIGN f32x2 fbuf[4096];            // [FPB][n], FPB*n <= 4096
-    __shared__ AERO_LDS_ALIGN f32x2 sbuf[4][AERO_FFT_MAX_N];
     const int n = p.n_fft >> 1;
+    f32x2* tw = (f32x2*)AERO_DYN_SMEM;
+    f32x2* fbuf = tw + n;                                  // [FPB][n]
+    f32x2* sbuf0 = fbuf + p.FPB * n;
     const int lane = aero_lane(), wave = aero_wave();
     const int sig = blockIdx.y;
     const int o0 = blockIdx.x * p.SEG;
@@ -203,34 +237,39 @@ __global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
     aero_fft_init_twiddles(tw, p.n_fft);
     __syncthreads();
     const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * p.T;
-    // phase 1: Hermitian unpack of each frame into conj(Z), Z = E + iO  (frames are the fast index)
-    for (int idx = threadIdx.x; idx < p.FPB * n; idx += 256) {
-        const int fr = idx % p.FPB, k = idx / p.FPB;
-        f32x2 zc = (f32x2){0.f, 0.f};
-        if (fr < nfr) {
-            const int t = t_lo + fr;
-            f32x2 xa = X[(int64_t)k * p.T + t];
-            f32x2 xb = (f32x2){0.f, 0.f};                   // conj(X[n-k]); X[n] is the implicit zero Nyquist bin
-            if (k == 0) {
-                xa[1] = 0.f;                                 // irfft ignores the imaginary part of DC
-            } else {
-                const f32x2 q = X[(int64_t)(n - k) * p.T + t];
-                xb = (f32x2){q[0], -q[1]};
-            }
-            const f32x2 E = (xa + xb) * 0.5f;
-            const f32x2 D = (xa - xb) * 0.5f;
-            const f32x2 O = aero_cmul(D, (f32x2){tw[k][0], -tw[k][1]});
-            zc = (f32x2){E[0] - O[1], -(E[1] + O[0])};
+    // phase 1: Hermitian unpack of each frame into conj(Z), Z = E + iO  (frames are the fast index: runs of FPB frames
+    // per bin).  Bins k and n-k need the same two spectrum values, so one thread loads the pair once and writes both.
+    const int lf = 31 - __builtin_clz(p.FPB);              // FPB is a power of two
+    auto unpack = [&](f32x2 xa, f32x2 xb, int k) -> f32x2 {
+        const f32x2 E = (xa + xb) * 0.5f;
+        const f32x2 D = (xa - xb) * 0.5f;
+        const f32x2 O = aero_cmul(D, (f32x2){tw[k][0], -tw[k][1]});
+        return (f32x2){E[0] - O[1], -(E[1] + O[0])};
+    };
+    for (int idx = threadIdx.x; idx < ((n >> 1) + 1) << lf; idx += 256) {
+        const int fr = idx & (p.FPB - 1), k = idx >> lf;
+        const bool livef = fr < nfr;
+        const int t = t_lo + (livef ? fr : 0);
+        f32x2 xa = X[(int64_t)k * p.T + t];
+        if (k == 0) {                                       // pairs with the implicit zero Nyquist bin X[n]
+            xa[1] = 0.f;                                    // irfft ignores the imaginary part of DC
+            const f32x2 z = unpack(xa, (f32x2){0.f, 0.f}, 0);
+            fbuf[fr * n] = livef ? z : (f32x2){0.f, 0.f};
+        } else {
+            const f32x2 xq = X[(int64_t)(n - k) * p.T + t];
+            const f32x2 z0 = unpack(xa, (f32x2){xq[0], -xq[1]}, k);
+            const f32x2 z1 = unpack(xq, (f32x2){xa[0], -xa[1]}, n - k);
+            fbuf[fr * n + k] = livef ? z0 : (f32x2){0.f, 0.f};
+            fbuf[fr * n + n - k] = livef ? z1 : (f32x2){0.f, 0.f};
         }
-        fbuf[fr * n + k] = zc;
     }
     __syncthreads();
     // phase 2: one frame per wave per round
     const int rounds = (p.FPB + 3) / 4;
     for (int r = 0; r < rounds; ++r) {
         const int fr = r * 4 + wave;
-        f32x2* a = fr < p.FPB ? fbuf + fr * n : sbuf[wave];  // (FPB is a multiple of 4 in practice)
-        f32x2* R = aero_fft_wave(a, sbuf[wave], n, p.n_fft, tw);
+        f32x2* a = fr < p.FPB ? fbuf + fr * n : sbuf0 + wave * n;  // (FPB is a multiple of 4 in practice)
+        f32x2* R = aero_fft_wave(a, sbuf0 + wave * n, n, p.n_fft, tw);
         if (R != a) {
             for (int m = lane; m < n; m += 64) a[m] = R[m];
         }
@@ -274,12 +313,16 @@ static int aero_stft_launch(const float* x, int nsig, int L, int Lp, int n_fft, 
     p.x = x; p.window = window; p.spec = spec; p.stats = stats;
     p.nsig = nsig; p.L = L; p.Lp = Lp; p.n_fft = n_fft; p.hop = hop; p.n_bins = n_bins; p.T = T;
     p.sig_per_item = sig_per_item > 0 ? sig_per_item : 1;
-    int fpb = 2048 / n;
+    int fpb = 2048 / n;                                     // frames per block: a power of two, 4..32
     if (fpb > 32) fpb = 32;
     if (fpb < 4) fpb = 4;
+    if (const char* e = getenv("AERO_STFT_FPB")) {          // A/B switch: longer runs along the frame axis vs. LDS per block
+        const int v = atoi(e);
+        if ((v == 4 || v == 8 || v == 16 || v == 32) && aero_stft_lds_bytes(n_fft, n_bins, v) <= 64 * 1024) fpb = v;
+    }
     p.FPB = fpb;
     dim3 grid((unsigned)((T + fpb - 1) / fpb), (unsigned)nsig), block(256);
-    AERO_LAUNCH(aero_stft_kernel, grid, block, stream, p);
+    AERO_LAUNCH_DYN(aero_stft_kernel, grid, block, aero_stft_lds_bytes(n_fft, n_bins, fpb), stream, p);
     return AERO_OK;
 }
 
@@ -304,13 +347,17 @@ static int aero_istft_launch(const float* spec, int nsig, int F, int T, int n_ff
     AeroIstftK p;
     p.spec = spec; p.window = window; p.inv_env = inv_env; p.y = y;
     p.nsig = nsig; p.F = F; p.T = T; p.n_fft = n_fft; p.hop = hop; p.Lout = Lout;
-    int fpb = 4096 / n;
+    int fpb = 4096 / n;                                    // frame ring: a power of two, at most 32
     if (fpb > 32) fpb = 32;
+    if (const char* e = getenv("AERO_ISTFT_FPB")) {         // A/B switch: a longer ring re-transforms fewer overlap frames
+        const int v = atoi(e);
+        if ((v == 8 || v == 16 || v == 32 || v == 64) && aero_istft_lds_bytes(n_fft, v) <= 128 * 1024) fpb = v;
+    }
     const int need = (n_fft + hop - 1) / hop;              // frames overlapping one sample
     if (fpb <= need) { *err = "istft: hop too small for the LDS frame ring"; return AERO_ERR_UNSUPPORTED; }
     p.FPB = fpb;
     p.SEG = (fpb - need) * hop;
     dim3 grid((unsigned)((Lout + p.SEG - 1) / p.SEG), (unsigned)nsig), block(256);
-    AERO_LAUNCH(aero_istft_kernel, grid, block, stream, p);
+    AERO_LAUNCH_DYN(aero_istft_kernel, grid, block, aero_istft_lds_bytes(n_fft, fpb), stream, p);
     return AERO_OK;
 }
