@@ -38,47 +38,77 @@ static __device__ __forceinline__ void aero_fft_init_twiddles(f32x2* tw, int n_f
 // exact composition of two radix-2 passes, same twiddle table entries, so results equal the radix-2 form bit for bit)
 // and one closing radix-2 pass when log2(n) is odd.  n = 256 is 4 passes of one butterfly per lane.
 // Returns the buffer (a or b) that holds the natural-order result.
-static __device__ __forceinline__ f32x2* aero_fft_wave(f32x2* a, f32x2* b, int n, int n_fft, const f32x2* tw) {
+// LDS position of element idx in the buffer a pass with butterfly span p writes: ds_write_b64 is serviced in groups of
+// 16 lanes over 32 banks, and the Stockham scatter of the first two radix-4 passes (stride 4, then runs of 4 every 16)
+// would put a group on 4 of its 16 element slots (4-way conflicts).  XOR-ing bits 4-5 of idx into the low bits keeps every
+// aligned 16-element run a permutation of itself, so the contiguous reads of the next pass stay conflict-free.
+static __device__ __forceinline__ int aero_fft_swz(int idx, int p) {
+    return p == 1 ? idx ^ ((idx >> 4) & 3) : p == 4 ? idx ^ (((idx >> 4) & 3) << 2) : idx;
+}
+
+// LOGN > 0: n = 2^LOGN is a compile-time constant, every pass and lane loop unrolls and strides, twiddle steps and
+// swizzles fold (the kernels were instruction-bound: ~1200 VALU + ~800 SALU per wave for two frames with runtime n).
+// LOGN = 0: the same code with n at run time (other power-of-two sizes).
+template <int LOGN>
+static __device__ __forceinline__ f32x2* aero_fft_wave(f32x2* a, f32x2* b, int n_rt, const f32x2* tw) {
+    const int n = LOGN ? (1 << LOGN) : n_rt;
+    const int n_fft = 2 * n;
     const int lane = aero_lane();
     const int half = n >> 1, quarter = n >> 2;
+    const int logn = LOGN ? LOGN : 31 - __builtin_clz(n);
+    const int np4 = logn >> 1;                                   // radix-4 passes
     f32x2* src = a;
     f32x2* dst = b;
-    int p = 1;
-    for (; 4 * p <= n; p <<= 2) {
+#pragma unroll(LOGN ? 8 : 1)
+    for (int s4 = 0; s4 < np4; ++s4) {
+        const int p = 1 << (2 * s4);
         const int tws2 = n_fft / (2 * p), tws4 = n_fft / (4 * p);
-        for (int i = lane; i < quarter; i += 64) {
-            const int k = i & (p - 1);
-            const f32x2 w2 = tw[k * tws2], w1 = tw[k * tws4], w3 = tw[(k + p) * tws4];
-            const f32x2 A = src[i], B = src[i + quarter], Cc = src[i + half], D = src[i + half + quarter];
-            const f32x2 c2 = aero_cmul(w2, Cc), d2 = aero_cmul(w2, D);
-            const f32x2 m0 = A + c2, m1 = A - c2, m2 = B + d2, m3 = B - d2;
-            const f32x2 e = aero_cmul(w1, m2), f = aero_cmul(w3, m3);
-            const int jj = ((i - k) << 2) + k;
-            dst[jj] = m0 + e;
-            dst[jj + p] = m1 + f;
-            dst[jj + 2 * p] = m0 - e;
-            dst[jj + 3 * p] = m1 - f;
+        const int pr = p >> 2;                                   // the pass that wrote src (0: linear input)
+        const int iters = (quarter + 63) >> 6;
+#pragma unroll(LOGN ? 8 : 1)
+        for (int it = 0; it < iters; ++it) {
+            const int i = lane + 64 * it;
+            if (i < quarter) {
+                const int k = i & (p - 1);
+                const f32x2 w2 = tw[k * tws2], w1 = tw[k * tws4], w3 = tw[(k + p) * tws4];
+                const f32x2 A = src[aero_fft_swz(i, pr)], B = src[aero_fft_swz(i + quarter, pr)];
+                const f32x2 Cc = src[aero_fft_swz(i + half, pr)], D = src[aero_fft_swz(i + half + quarter, pr)];
+                const f32x2 c2 = aero_cmul(w2, Cc), d2 = aero_cmul(w2, D);
+                const f32x2 m0 = A + c2, m1 = A - c2, m2 = B + d2, m3 = B - d2;
+                const f32x2 e = aero_cmul(w1, m2), f = aero_cmul(w3, m3);
+                const int jj = ((i - k) << 2) + k;
+                dst[aero_fft_swz(jj, p)] = m0 + e;
+                dst[aero_fft_swz(jj + p, p)] = m1 + f;
+                dst[aero_fft_swz(jj + 2 * p, p)] = m0 - e;
+                dst[aero_fft_swz(jj + 3 * p, p)] = m1 - f;
+            }
         }
         aero_wave_sync();              // a wave owns its two buffers: LDS is in-order per wave, no block barrier needed
         f32x2* tmp = src;
         src = dst;
         dst = tmp;
     }
-    if (p < n) {
-        const int tws = n_fft / (2 * p);
-        for (int i = lane; i < half; i += 64) {
-            const int k = i & (p - 1);
-            const f32x2 u0 = src[i];
-            const f32x2 v = aero_cmul(tw[k * tws], src[i + half]);
-            const int jj = ((i - k) << 1) + k;
-            dst[jj] = u0 + v;
-            dst[jj + p] = u0 - v;
+    if (logn & 1) {                    // closing radix-2 pass
+        const int p = half;
+        const int pr = p >> 2;
+        const int iters = (half + 63) >> 6;
+#pragma unroll(LOGN ? 8 : 1)
+        for (int it = 0; it < iters; ++it) {
+            const int i = lane + 64 * it;
+            if (i < half) {            // k = i: p = half, tw step n_fft / (2p) = 2
+                const f32x2 u0 = src[aero_fft_swz(i, pr)];
+                const f32x2 v = aero_cmul(tw[2 * i], src[aero_fft_swz(i + half, pr)]);
+                dst[i] = u0 + v;
+                dst[i + p] = u0 - v;
+            }
         }
         aero_wave_sync();
         f32x2* tmp = src;
         src = dst;
         dst = tmp;
     }
+    // (the result is linear: a closing radix-2 pass writes linearly, p >= 16 passes are not swizzled, and the only sizes
+    // that end on a p = 1 / p = 4 pass are n = 4 / 16, where idx >> 4 = 0)
     return src;
 }
 
@@ -91,30 +121,37 @@ struct AeroStftK {
 // two blocks per CU):   tw[n] | bufA[4][n] | bufB[4][n] | tile[n_bins*FPB]   (f32x2)   then   wl[n_fft] | xsp[SPAN]   (float)
 static inline size_t aero_stft_lds_bytes(int n_fft, int n_bins, int fpb) {
     const size_t n = (size_t)n_fft / 2;
-    return (n + 8 * n + (size_t)n_bins * fpb) * sizeof(f32x2) + ((size_t)n_fft + AERO_STFT_SPAN) * sizeof(float);
+    return (n + 8 * n + (size_t)n_bins * (fpb + 1)) * sizeof(f32x2) + ((size_t)n_fft + AERO_STFT_SPAN) * sizeof(float);
 }
 
+static inline int aero_stft_fpb(int n) { int f = 2048 / n; return f > 32 ? 32 : (f < 4 ? 4 : f); }   // frames per block (power of two)
+
+template <int LOGN>
 __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
     __shared__ double red[2][4];
-    const int n = p.n_fft >> 1;
+    const int n = LOGN ? (1 << LOGN) : (p.n_fft >> 1);
+    const int n_fft = 2 * n;
+    const int FPB = LOGN ? ((2048 >> LOGN) > 32 ? 32 : ((2048 >> LOGN) < 4 ? 4 : (2048 >> LOGN))) : p.FPB;
+    const int TS = FPB + 1;                                      // odd tile row stride: a ds_write group's 16 lanes hit 16 slots
     f32x2* tw = (f32x2*)AERO_DYN_SMEM;
     f32x2* bufA0 = tw + n;
     f32x2* bufB0 = bufA0 + 4 * n;
     f32x2* tile = bufB0 + 4 * n;
-    float* wl = (float*)(tile + p.n_bins * p.FPB);
-    float* xsp = wl + p.n_fft;
-    const int lane = aero_lane(), wave = aero_wave();
+    float* wl = (float*)(tile + p.n_bins * TS);
+    float* xsp = wl + n_fft;
+    const int lane = aero_lane(), wave = aero_uniform(aero_wave());
     const int sig = blockIdx.y;
-    const int tbase = blockIdx.x * p.FPB;
+    const int tbase = blockIdx.x * FPB;
     const float* xs = p.x + (int64_t)sig * p.L;
-    const float scale = 1.0f / sqrtf((float)p.n_fft);
-    aero_fft_init_twiddles(tw, p.n_fft);
+    const float scale = 1.0f / sqrtf((float)n_fft);
+    aero_fft_init_twiddles(tw, n_fft);
     // The block's frames overlap (hop << n_fft): the window and the reflect-padded signal span they share are staged in
     // LDS once, with independent coalesced loads.  (Reading window[ni] and then, if non-zero, x[...] from global memory
     // per element made every frame a chain of ~16 dependent L2 round trips: 134 us for a 68-MB kernel.)
-    const int span = (p.FPB - 1) * p.hop + p.n_fft;
+    const int span = (FPB - 1) * p.hop + n_fft;
     const bool staged = span <= AERO_STFT_SPAN;
-    for (int i = threadIdx.x; i < p.n_fft; i += 256) wl[i] = p.window[i];
+    const bool vec = staged && !(p.hop & 1);                     // 8-byte LDS reads (the scalar form is a stride-2 bank pattern)
+    for (int i = threadIdx.x; i < n_fft; i += 256) wl[i] = p.window[i];
     if (staged) {
         for (int j = threadIdx.x; j < span; j += 256) {
             int xi = tbase * p.hop + j - n;                      // index into the hop-padded signal
@@ -125,14 +162,25 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
     }
     __syncthreads();
     float s = 0.f, ss = 0.f;
-    const int rounds = (p.FPB + 3) / 4;
+    const int rounds = (FPB + 3) / 4;
+    f32x2* bufA = bufA0 + wave * n;
+    f32x2* bufB = bufB0 + wave * n;
+#pragma unroll(LOGN ? 2 : 1)
     for (int r = 0; r < rounds; ++r) {
         const int fr = r * 4 + wave;
         const int t = tbase + fr;
-        const bool live = fr < p.FPB && t < p.T;
-        for (int m = lane; m < n; m += 64) {
+        const bool live = fr < FPB && t < p.T;
+        const int miters = (n + 63) >> 6;
+#pragma unroll(LOGN ? 8 : 1)
+        for (int it = 0; it < miters; ++it) {
+            const int m = lane + 64 * it;
+            if (m >= n) break;
             f32x2 g = (f32x2){0.f, 0.f};
-            if (live) {
+            if (live && vec) {
+                const f32x2 w = *(const f32x2*)(wl + 2 * m);
+                const f32x2 xv = *(const f32x2*)(xsp + fr * p.hop + 2 * m);
+                g = w * xv;
+            } else if (live) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int ni = 2 * m + e;
@@ -147,12 +195,16 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
                     }
                 }
             }
-            bufA0[wave * n + m] = g;
+            bufA[m] = g;
         }
-        __syncthreads();
-        const f32x2* R = aero_fft_wave(bufA0 + wave * n, bufB0 + wave * n, n, p.n_fft, tw);
-        if (fr < p.FPB) {
-            for (int k = lane; k < p.n_bins; k += 64) {
+        aero_wave_sync();                                        // a wave packs and transforms its own frame
+        const f32x2* R = aero_fft_wave<LOGN>(bufA, bufB, n, tw);
+        if (fr < FPB) {
+            const int kiters = (n >> 6) + 1;
+#pragma unroll(LOGN ? 9 : 1)
+            for (int it = 0; it < kiters; ++it) {
+                const int k = lane + 64 * it;
+                if (k >= p.n_bins) break;
                 f32x2 X;
                 if (k == 0) {
                     X = (f32x2){R[0][0] + R[0][1], 0.f};
@@ -167,19 +219,20 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
                     X = E + aero_cmul(tw[k], O);
                 }
                 X = X * scale;
-                tile[k * p.FPB + fr] = X;
+                tile[k * TS + fr] = X;
                 if (live) { s += X[0] + X[1]; ss += X[0] * X[0] + X[1] * X[1]; }
             }
         }
-        __syncthreads();
+        aero_wave_sync();                                        // the next round's pack reuses bufA/bufB of this wave only
     }
-    const int total = p.n_bins * p.FPB;
+    __syncthreads();
+    const int total = p.n_bins * FPB;
     f32x2* out = (f32x2*)p.spec + (int64_t)sig * p.n_bins * p.T;
-    const int lf = 31 - __builtin_clz(p.FPB);                    // FPB is a power of two
+    const int lf = 31 - __builtin_clz(FPB);                      // FPB is a power of two
     for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int k = idx >> lf, fr = idx & (p.FPB - 1);
+        const int k = idx >> lf, fr = idx & (FPB - 1);
         const int t = tbase + fr;
-        if (t < p.T) out[(int64_t)k * p.T + t] = tile[idx];
+        if (t < p.T) out[k * p.T + t] = tile[idx + k];
     }
     if (p.stats) {
         double ds = aero_wave_sum((double)s), dss = aero_wave_sum((double)ss);
@@ -214,85 +267,101 @@ __global__ __launch_bounds__(256) void aero_spec_normalize_kernel(const float* s
 
 struct AeroIstftK {
     const float* spec; const float* window; const float* inv_env; float* y;
-    int nsig, F, T, n_fft, hop, Lout, FPB, SEG;
+    int nsig, F, T, n_fft, hop, hsh, Lout, FPB, SEG;         // hsh = log2(hop) if hop is a power of two, else -1
 };
 
-// dynamic LDS: tw[n] | fbuf[FPB][n] | sbuf[4][n]   (f32x2)
-static inline size_t aero_istft_lds_bytes(int n_fft, int fpb) { return (size_t)(n_fft / 2) * (5 + fpb) * sizeof(f32x2); }
+static inline int aero_istft_fpb(int n) { int f = 4096 / n; return f > 32 ? 32 : f; }   // frame ring (power of two)
 
+// dynamic LDS: tw[n] | fbuf[FPB][n + 1] | sbuf[4][n]   (f32x2)   then   wl[n_fft]   (float)
+static inline size_t aero_istft_lds_bytes(int n_fft, int fpb) {
+    return ((size_t)(n_fft / 2) * (5 + fpb) + fpb) * sizeof(f32x2) + (size_t)n_fft * sizeof(float);
+}
+
+template <int LOGN>
 __global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
-    const int n = p.n_fft >> 1;
+    const int n = LOGN ? (1 << LOGN) : (p.n_fft >> 1);
+    const int n_fft = 2 * n;
+    const int FPB = LOGN ? ((4096 >> LOGN) > 32 ? 32 : (4096 >> LOGN)) : p.FPB;
+    const int fs = n + 1;                                  // frame stride: phase 1 writes with the frame as the fast lane index
     f32x2* tw = (f32x2*)AERO_DYN_SMEM;
-    f32x2* fbuf = tw + n;                                  // [FPB][n]
-    f32x2* sbuf0 = fbuf + p.FPB * n;
-    const int lane = aero_lane(), wave = aero_wave();
+    f32x2* fbuf = tw + n;                                  // [FPB][n + 1]
+    f32x2* sbuf0 = fbuf + FPB * fs;
+    float* wl = (float*)(sbuf0 + 4 * n);
+    const int lane = aero_lane(), wave = aero_uniform(aero_wave());
     const int sig = blockIdx.y;
     const int o0 = blockIdx.x * p.SEG;
     const int i0 = o0 + n;                                  // first overlap-add index of this block
-    const int num = i0 - p.n_fft + p.hop;
-    const int t_lo = num > 0 ? num / p.hop : 0;
-    int t_hi = (i0 + p.SEG - 1) / p.hop;
+    auto div_hop = [&](int v) { return p.hsh >= 0 ? v >> p.hsh : v / p.hop; };      // v >= 0
+    const int num = i0 - n_fft + p.hop;
+    const int t_lo = num > 0 ? div_hop(num) : 0;
+    int t_hi = div_hop(i0 + p.SEG - 1);
     if (t_hi > p.T - 1) t_hi = p.T - 1;
     const int nfr = t_hi - t_lo + 1;                        // <= FPB by construction of SEG
-    aero_fft_init_twiddles(tw, p.n_fft);
+    aero_fft_init_twiddles(tw, n_fft);
+    for (int i = threadIdx.x; i < n_fft; i += 256) wl[i] = p.window[i];
     __syncthreads();
-    const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * p.T;
+    const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * p.T + t_lo;
     // phase 1: Hermitian unpack of each frame into conj(Z), Z = E + iO  (frames are the fast index: runs of FPB frames
     // per bin).  Bins k and n-k need the same two spectrum values, so one thread loads the pair once and writes both.
-    const int lf = 31 - __builtin_clz(p.FPB);              // FPB is a power of two
+    const int lf = 31 - __builtin_clz(FPB);                // FPB is a power of two
     auto unpack = [&](f32x2 xa, f32x2 xb, int k) -> f32x2 {
         const f32x2 E = (xa + xb) * 0.5f;
         const f32x2 D = (xa - xb) * 0.5f;
         const f32x2 O = aero_cmul(D, (f32x2){tw[k][0], -tw[k][1]});
         return (f32x2){E[0] - O[1], -(E[1] + O[0])};
     };
-    for (int idx = threadIdx.x; idx < ((n >> 1) + 1) << lf; idx += 256) {
-        const int fr = idx & (p.FPB - 1), k = idx >> lf;
+    const int npair = ((n >> 1) + 1) << lf;
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < npair; idx += 256) {
+        const int fr = idx & (FPB - 1), k = idx >> lf;
         const bool livef = fr < nfr;
-        const int t = t_lo + (livef ? fr : 0);
-        f32x2 xa = X[(int64_t)k * p.T + t];
+        const int t = livef ? fr : 0;
+        f32x2 xa = X[k * p.T + t];
         if (k == 0) {                                       // pairs with the implicit zero Nyquist bin X[n]
             xa[1] = 0.f;                                    // irfft ignores the imaginary part of DC
             const f32x2 z = unpack(xa, (f32x2){0.f, 0.f}, 0);
-            fbuf[fr * n] = livef ? z : (f32x2){0.f, 0.f};
+            fbuf[fr * fs] = livef ? z : (f32x2){0.f, 0.f};
         } else {
-            const f32x2 xq = X[(int64_t)(n - k) * p.T + t];
+            const f32x2 xq = X[(n - k) * p.T + t];
             const f32x2 z0 = unpack(xa, (f32x2){xq[0], -xq[1]}, k);
             const f32x2 z1 = unpack(xq, (f32x2){xa[0], -xa[1]}, n - k);
-            fbuf[fr * n + k] = livef ? z0 : (f32x2){0.f, 0.f};
-            fbuf[fr * n + n - k] = livef ? z1 : (f32x2){0.f, 0.f};
+            fbuf[fr * fs + k] = livef ? z0 : (f32x2){0.f, 0.f};
+            fbuf[fr * fs + n - k] = livef ? z1 : (f32x2){0.f, 0.f};
         }
     }
     __syncthreads();
     // phase 2: one frame per wave per round
-    const int rounds = (p.FPB + 3) / 4;
+    const int rounds = (FPB + 3) / 4;
+    f32x2* sb = sbuf0 + wave * n;
+#pragma unroll(LOGN ? 2 : 1)
     for (int r = 0; r < rounds; ++r) {
         const int fr = r * 4 + wave;
-        f32x2* a = fr < p.FPB ? fbuf + fr * n : sbuf0 + wave * n;  // (FPB is a multiple of 4 in practice)
-        f32x2* R = aero_fft_wave(a, sbuf0 + wave * n, n, p.n_fft, tw);
+        f32x2* a = fr < FPB ? fbuf + fr * fs : sb;          // (FPB is a multiple of 4 in practice)
+        f32x2* R = aero_fft_wave<LOGN>(a, sb, n, tw);
         if (R != a) {
             for (int m = lane; m < n; m += 64) a[m] = R[m];
+            aero_wave_sync();
         }
-        __syncthreads();
     }
+    __syncthreads();
     // phase 3: output-stationary overlap-add
-    const float scale = sqrtf((float)p.n_fft) / (float)n;
+    const float scale = sqrtf((float)n_fft) / (float)n;
     float* ys = p.y + (int64_t)sig * p.Lout;
     for (int o = threadIdx.x; o < p.SEG; o += 256) {
         const int oo = o0 + o;
         if (oo >= p.Lout) break;
         const int i = oo + n;
-        const int num2 = i - p.n_fft + p.hop;
-        int ta = num2 > 0 ? num2 / p.hop : 0;
+        const int num2 = i - n_fft + p.hop;
+        int ta = num2 > 0 ? div_hop(num2) : 0;
         if (ta < t_lo) ta = t_lo;
-        int tb = i / p.hop;
+        int tb = div_hop(i);
         if (tb > t_hi) tb = t_hi;
         float acc = 0.f;
         for (int t = ta; t <= tb; ++t) {
             const int ni = i - t * p.hop;
-            const f32x2 R = fbuf[(t - t_lo) * n + (ni >> 1)];
+            const f32x2 R = fbuf[(t - t_lo) * fs + (ni >> 1)];
             const float g = (ni & 1) ? -R[1] : R[0];
-            acc += p.window[ni] * g;
+            acc += wl[ni] * g;
         }
         ys[oo] = acc * scale * p.inv_env[i];
     }
@@ -313,16 +382,17 @@ static int aero_stft_launch(const float* x, int nsig, int L, int Lp, int n_fft, 
     p.x = x; p.window = window; p.spec = spec; p.stats = stats;
     p.nsig = nsig; p.L = L; p.Lp = Lp; p.n_fft = n_fft; p.hop = hop; p.n_bins = n_bins; p.T = T;
     p.sig_per_item = sig_per_item > 0 ? sig_per_item : 1;
-    int fpb = 2048 / n;                                     // frames per block: a power of two, 4..32
-    if (fpb > 32) fpb = 32;
-    if (fpb < 4) fpb = 4;
-    if (const char* e = getenv("AERO_STFT_FPB")) {          // A/B switch: longer runs along the frame axis vs. LDS per block
-        const int v = atoi(e);
-        if ((v == 4 || v == 8 || v == 16 || v == 32) && aero_stft_lds_bytes(n_fft, n_bins, v) <= 64 * 1024) fpb = v;
-    }
+    const int fpb = aero_stft_fpb(n);
     p.FPB = fpb;
     dim3 grid((unsigned)((T + fpb - 1) / fpb), (unsigned)nsig), block(256);
-    AERO_LAUNCH_DYN(aero_stft_kernel, grid, block, aero_stft_lds_bytes(n_fft, n_bins, fpb), stream, p);
+    const size_t lds = aero_stft_lds_bytes(n_fft, n_bins, fpb);
+    switch (n) {                                            // compile-time sizes for the usual n_fft; run-time n otherwise
+        case 64: AERO_LAUNCH_DYN(aero_stft_kernel<6>, grid, block, lds, stream, p); break;
+        case 128: AERO_LAUNCH_DYN(aero_stft_kernel<7>, grid, block, lds, stream, p); break;
+        case 256: AERO_LAUNCH_DYN(aero_stft_kernel<8>, grid, block, lds, stream, p); break;
+        case 512: AERO_LAUNCH_DYN(aero_stft_kernel<9>, grid, block, lds, stream, p); break;
+        default: AERO_LAUNCH_DYN(aero_stft_kernel<0>, grid, block, lds, stream, p); break;
+    }
     return AERO_OK;
 }
 
@@ -347,17 +417,20 @@ static int aero_istft_launch(const float* spec, int nsig, int F, int T, int n_ff
     AeroIstftK p;
     p.spec = spec; p.window = window; p.inv_env = inv_env; p.y = y;
     p.nsig = nsig; p.F = F; p.T = T; p.n_fft = n_fft; p.hop = hop; p.Lout = Lout;
-    int fpb = 4096 / n;                                    // frame ring: a power of two, at most 32
-    if (fpb > 32) fpb = 32;
-    if (const char* e = getenv("AERO_ISTFT_FPB")) {         // A/B switch: a longer ring re-transforms fewer overlap frames
-        const int v = atoi(e);
-        if ((v == 8 || v == 16 || v == 32 || v == 64) && aero_istft_lds_bytes(n_fft, v) <= 128 * 1024) fpb = v;
-    }
+    const int fpb = aero_istft_fpb(n);
     const int need = (n_fft + hop - 1) / hop;              // frames overlapping one sample
     if (fpb <= need) { *err = "istft: hop too small for the LDS frame ring"; return AERO_ERR_UNSUPPORTED; }
     p.FPB = fpb;
     p.SEG = (fpb - need) * hop;
+    p.hsh = (hop & (hop - 1)) == 0 ? aero_ilog2(hop) : -1;
     dim3 grid((unsigned)((Lout + p.SEG - 1) / p.SEG), (unsigned)nsig), block(256);
-    AERO_LAUNCH_DYN(aero_istft_kernel, grid, block, aero_istft_lds_bytes(n_fft, fpb), stream, p);
+    const size_t lds = aero_istft_lds_bytes(n_fft, fpb);
+    switch (n) {
+        case 64: AERO_LAUNCH_DYN(aero_istft_kernel<6>, grid, block, lds, stream, p); break;
+        case 128: AERO_LAUNCH_DYN(aero_istft_kernel<7>, grid, block, lds, stream, p); break;
+        case 256: AERO_LAUNCH_DYN(aero_istft_kernel<8>, grid, block, lds, stream, p); break;
+        case 512: AERO_LAUNCH_DYN(aero_istft_kernel<9>, grid, block, lds, stream, p); break;
+        default: AERO_LAUNCH_DYN(aero_istft_kernel<0>, grid, block, lds, stream, p); break;
+    }
     return AERO_OK;
 }

@@ -17,12 +17,12 @@ DEV = 'cpu'
 
 
 @pytest.mark.parametrize('geom', [(128, 4, 32, 400), (512, 16, 128, 1000), (512, 64, 512, 1536), (1024, 64, 256, 2003),
-                                  (256, 8, 64, 799)])
+                                  (256, 8, 64, 799), (64, 8, 32, 300), (32, 4, 32, 123)])
 def test_stft(emu, geom):
     oc.case_stft(emu, DEV, *geom)
 
 
-@pytest.mark.parametrize('geom', [(128, 16, 128, 26), (512, 64, 512, 33), (1024, 256, 1024, 9), (256, 32, 252, 40)])
+@pytest.mark.parametrize('geom', [(128, 16, 128, 26), (512, 64, 512, 33), (1024, 256, 1024, 9), (256, 32, 252, 40), (64, 16, 64, 30), (32, 8, 32, 17)])
 def test_istft(emu, geom):
     oc.case_istft(emu, DEV, *geom)
 

@@ -19,12 +19,12 @@ def lib():
 
 
 @pytest.mark.parametrize('geom', [(512, 16, 128, 8000), (512, 64, 512, 32000), (1024, 64, 256, 24000), (128, 4, 32, 999),
-                                  (512, 16, 128, 7999)])
+                                  (512, 16, 128, 7999), (64, 8, 32, 300), (32, 4, 32, 123), (256, 8, 64, 799)])
 def test_stft(lib, geom):
     oc.case_stft(lib, DEV, *geom, B=3)
 
 
-@pytest.mark.parametrize('geom', [(512, 64, 512, 501), (1024, 256, 1024, 376), (128, 16, 128, 101), (512, 128, 512, 251)])
+@pytest.mark.parametrize('geom', [(512, 64, 512, 501), (1024, 256, 1024, 376), (128, 16, 128, 101), (512, 128, 512, 251), (64, 16, 64, 30), (32, 8, 32, 17), (256, 32, 252, 40)])
 def test_istft(lib, geom):
     oc.case_istft(lib, DEV, *geom, B=3)
 
