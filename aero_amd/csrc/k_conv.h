@@ -655,6 +655,7 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
     const int t_base = t0 + p.t_lo;
     int jf = -1, jt = nT - 1, cc = cpt - 1, fi = 0;
     int kofs = 0, tsh = 0, off0 = 0, off1 = 0;
+    bool tin[NIB];                                              // source time of this lane's position inside [0, T): per tap
     auto next_chunk = [&]() -> bool {
         if (++cc < cpt) {
             kofs += KC; off0 += KC; off1 += KC;
@@ -671,6 +672,8 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
         }
         kofs = (jf * nT + jt) * Cpk + cc_lo * KC;
         tsh = t_base + jt * t_step;
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) tin[i] = (unsigned)(b_pos[i] + tsh) < (unsigned)Tv;
         off0 = fi * s0f + tsh * st0 + cc_lo * KC;
         off1 = fi * s1f + tsh * st1 + cc_lo * KC;
         return true;
@@ -684,12 +687,26 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
             if (wave + NWV * i < BM * SLOTS / 64) aero_glds16(a_ptr[i] + kofs, As + (wave + NWV * i) * 512);
         const int c_lo = cc * KC;
         const int lim0 = C0 - c_lo, lim1 = C01 - c_lo;        // channel q8 comes from src0 if q8 < lim0, src1 if q8 < lim1
+        // A chunk that comes whole from one source (every chunk but a straddling or ragged one): the select is
+        // block-uniform and the copy address is the lane pointer plus one scalar offset.  (PMC: the per-lane form below
+        // cost ~22 vector instructions per copy, next to 6-16 MFMAs per chunk.)  Two separate branches on purpose: a
+        // select between the two sources' variables makes the compiler keep them in scratch and select their addresses.
+        if (lim0 >= KC) {
+#pragma unroll
+            for (int i = 0; i < NIB; ++i)
+                aero_glds16((tin[i] && has0) ? pb0[i] + off0 : zpv, Bs + (wave + NWV * i) * 512);
+            return;
+        }
+        if (lim0 <= 0 && lim1 >= KC) {
+#pragma unroll
+            for (int i = 0; i < NIB; ++i)
+                aero_glds16(tin[i] ? pb1[i] + off1 : zpv, Bs + (wave + NWV * i) * 512);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NIB; ++i) {
-            const int tpos = b_pos[i] + tsh;
-            const bool tin = tpos >= 0 && tpos < Tv;
             const bool u0 = b_q8[i] < lim0;
-            const bool ok = tin && (u0 ? has0 : (b_q8[i] < lim1));
+            const bool ok = tin[i] && (u0 ? has0 : (b_q8[i] < lim1));
             const h16* ptr = u0 ? pb0[i] + off0 : pb1[i] + off1;
             aero_glds16(ok ? ptr : zpv, Bs + (wave + NWV * i) * 512);
         }
