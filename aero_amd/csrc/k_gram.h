@@ -12,34 +12,43 @@
 #define AERO_GRAM_TT 128
 #define AERO_GRAM_CMAX 112                    /* channels + 1 <= 112  ->  up to 7 x 7 blocks of 16 */
 
-__global__ __launch_bounds__(256) void aero_gram_stats_kernel(aero_gram_desc d, int Cp) {
+// NB = 16 x 16 blocks per side of S (compile time: the block loops unroll without predication and the LDS tile is sized
+// to the channel count; with a run-time count this kernel ran VALU-bound at ~3100 vector instructions per wave).
+template <int NB>
+__global__ __launch_bounds__(256) void aero_gram_stats_kernel(aero_gram_desc d) {
+    constexpr int Cp = NB * 16;
     constexpr int TS = AERO_GRAM_TT + 8;                        // padded row: conflict-free b128 fragment reads
-    __shared__ AERO_LDS_ALIGN h16 Ht[AERO_GRAM_CMAX * TS];
+    constexpr int NA = NB > 4 ? 2 : 1;                          // block rows per wave: bi = wave, wave + 4
+    __shared__ AERO_LDS_ALIGN h16 Ht[Cp * TS];
     __shared__ double red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int row = blockIdx.x;
     const int b = row / d.F, f = row - b * d.F;
     const int C = d.C, T = d.T;
-    const int nb = Cp >> 4;                                     // 16 x 16 blocks per side
     const h16* src = (const h16*)d.x + (int64_t)b * d.s_b + (int64_t)f * d.s_f;
     const bool vec = (C % 8 == 0) && (d.s_t % 8 == 0) && ((((uintptr_t)src) & 15) == 0);
-    // this wave's block rows bi = wave, wave + 4 (nb <= 7): accumulators for all nb block columns
-    f32x4 acc[2][7];
+    const int st = (int)d.s_t;                                  // a row spans < 2^31 elements (checked on the host)
+    f32x4 acc[NA][NB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int j = 0; j < 7; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NB; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // channels above C are zero for the whole row: written once (channel C, the constant one, is rewritten per tile)
+    for (int idx = tid; idx < (Cp - C) * TS; idx += 256) Ht[C * TS + idx] = (h16)0;
     for (int t0 = 0; t0 < T; t0 += AERO_GRAM_TT) {
         __syncthreads();                                        // previous tile consumed
-        // stage [step][channel] -> Ht[channel][step]; channel C is the constant one (valid steps only), the rest zero
+        // stage [step][channel] -> Ht[channel][step].  Vector path: a lane takes 8 channels of TWO adjacent steps and
+        // writes 8 dwords (step pairs), a wave's lanes hitting consecutive dwords.
         if (vec) {
             const int cv = C >> 3;
-            for (int idx = tid; idx < AERO_GRAM_TT * cv; idx += 256) {
-                const int tl = idx / cv, c8 = idx - tl * cv;
-                h16x8 v = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (t0 + tl < T) v = *(const h16x8*)(src + (int64_t)(t0 + tl) * d.s_t + c8 * 8);
+            for (int idx = tid; idx < (AERO_GRAM_TT / 2) * cv; idx += 256) {
+                const int tp = idx & (AERO_GRAM_TT / 2 - 1), c8 = idx >> 6;
+                const int t = t0 + 2 * tp;
+                h16x8 v0 = (h16x8){0, 0, 0, 0, 0, 0, 0, 0}, v1 = v0;
+                if (t < T) v0 = *(const h16x8*)(src + t * st + c8 * 8);
+                if (t + 1 < T) v1 = *(const h16x8*)(src + (t + 1) * st + c8 * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) Ht[(c8 * 8 + e) * TS + tl] = v[e];
+                for (int e = 0; e < 8; ++e) *(h16x2*)&Ht[(c8 * 8 + e) * TS + 2 * tp] = (h16x2){v0[e], v1[e]};
             }
         } else {
             for (int idx = tid; idx < AERO_GRAM_TT * C; idx += 256) {
@@ -47,44 +56,40 @@ __global__ __launch_bounds__(256) void aero_gram_stats_kernel(aero_gram_desc d, 
                 Ht[c * TS + tl] = (t0 + tl < T) ? src[(int64_t)(t0 + tl) * d.s_t + c] : (h16)0;
             }
         }
-        for (int idx = tid; idx < AERO_GRAM_TT * (Cp - C); idx += 256) {
-            const int c = C + idx / AERO_GRAM_TT, tl = idx % AERO_GRAM_TT;
-            Ht[c * TS + tl] = (c == C && t0 + tl < T) ? (h16)1.0f : (h16)0;
-        }
+        if (tid < AERO_GRAM_TT) Ht[C * TS + tid] = (t0 + tid < T) ? (h16)1.0f : (h16)0;      // valid steps only
         __syncthreads();
+        if (wave < NB) {
 #pragma unroll
-        for (int ks = 0; ks < AERO_GRAM_TT / 32; ++ks) {
-            const int ko = ks * 32 + (lane >> 4) * 8;
-            h16x8 bf[7];
+            for (int ks = 0; ks < AERO_GRAM_TT / 32; ++ks) {
+                const int ko = ks * 32 + (lane >> 4) * 8;
+                h16x8 bf[NB];
 #pragma unroll
-            for (int j = 0; j < 7; ++j)
-                if (j < nb) bf[j] = *(const h16x8*)&Ht[(j * 16 + (lane & 15)) * TS + ko];
+                for (int j = 0; j < NB; ++j) bf[j] = *(const h16x8*)&Ht[(j * 16 + (lane & 15)) * TS + ko];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int bi = wave + 4 * a;
-                if (bi >= nb) continue;
-                const h16x8 af = *(const h16x8*)&Ht[(bi * 16 + (lane & 15)) * TS + ko];
+                for (int a = 0; a < NA; ++a) {
+                    const int bi = wave + 4 * a;
+                    if (bi >= NB) continue;
+                    const h16x8 af = *(const h16x8*)&Ht[(bi * 16 + (lane & 15)) * TS + ko];
 #pragma unroll
-                for (int j = 0; j < 7; ++j)
-                    if (j < nb) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[a][j], 0, 0, 0);
+                    for (int j = 0; j < NB; ++j) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[a][j], 0, 0, 0);
+                }
             }
         }
     }
     // contraction with the fp64 tables: D block (bi, bj), lane -> rows i = bi*16 + (lane>>4)*4 + r, column j = bj*16 + (lane&15)
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < NA; ++a) {
         const int bi = wave + 4 * a;
-        if (bi >= nb) continue;
+        if (bi >= NB) continue;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            if (j >= nb) continue;
+        for (int j = 0; j < NB; ++j) {
             const int col = j * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = bi * 16 + (lane >> 4) * 4 + r;
                 const double sv = (double)acc[a][j][r];
-                s2 += d.G[(int64_t)i * Cp + col] * sv;
+                s2 += d.G[i * Cp + col] * sv;
                 if (col == C) s1 += d.g1[i] * sv;               // S[i][C] = sum_t x'_i
             }
         }
@@ -105,7 +110,16 @@ static int aero_gram_stats_launch(const aero_gram_desc* d, hipStream_t stream, c
     if (d->C + 1 > AERO_GRAM_CMAX) { *err = "gram_stats: more than 111 input channels unsupported"; return AERO_ERR_UNSUPPORTED; }
     const long rows = (long)d->B * d->F;
     if (rows > 0x7fffffffL) { *err = "gram_stats: grid too large"; return AERO_ERR_ARG; }
-    const int Cp = (d->C + 1 + 15) / 16 * 16;
-    AERO_LAUNCH(aero_gram_stats_kernel, dim3((unsigned)rows), dim3(256), stream, *d, Cp);
+    if ((int64_t)d->T * d->s_t > 0x7fffffffLL) { *err = "gram_stats: row span exceeds 32 bits"; return AERO_ERR_UNSUPPORTED; }
+    const dim3 grid((unsigned)rows), block(256);
+    switch ((d->C + 1 + 15) / 16) {
+        case 1: AERO_LAUNCH(aero_gram_stats_kernel<1>, grid, block, stream, *d); break;
+        case 2: AERO_LAUNCH(aero_gram_stats_kernel<2>, grid, block, stream, *d); break;
+        case 3: AERO_LAUNCH(aero_gram_stats_kernel<3>, grid, block, stream, *d); break;
+        case 4: AERO_LAUNCH(aero_gram_stats_kernel<4>, grid, block, stream, *d); break;
+        case 5: AERO_LAUNCH(aero_gram_stats_kernel<5>, grid, block, stream, *d); break;
+        case 6: AERO_LAUNCH(aero_gram_stats_kernel<6>, grid, block, stream, *d); break;
+        default: AERO_LAUNCH(aero_gram_stats_kernel<7>, grid, block, stream, *d); break;
+    }
     return AERO_OK;
 }
