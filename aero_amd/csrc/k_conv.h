@@ -1469,8 +1469,8 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     p.Ktot = d->ntaps * p.Cp;
     p.Mpad = (d->M + 127) / 128 * 128;
     const int bm = aero_conv_pick_bm(d->M, p.Mpad);
-    p.nmt = (d->M + bm - 1) / bm;
     p.ntt = (d->T + 127) / 128;
+    p.nmt = (d->M + bm - 1) / bm;
     auto al8 = [](int64_t v) { return (v & 7) == 0; };
     int vin = (d->C0 % 8 == 0) && (d->C1 % 8 == 0);
     if (d->src0) vin = vin && al8(d->s0_b) && al8(d->s0_f) && al8(d->s0_t) && (((uintptr_t)d->src0 & 15) == 0);
