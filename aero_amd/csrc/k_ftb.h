@@ -168,6 +168,15 @@ __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
     const h16* gate = (const h16*)d.gate + (int64_t)b * T * C;
     h16* drow = (h16*)d.dst + ((int64_t)row * T) * C;
     const float rsf = d.rs[f];
+    // pre_conv coefficients of the attention branch, staged once per block: [p0 | p1 | pb * rs[f]] (zero above C)
+    __shared__ AERO_LDS_ALIGN float kc[3][64];
+    if (tid < 64) {
+        const bool in = tid < C;
+        kc[0][tid] = in ? d.p0[tid] : 0.f;
+        kc[1][tid] = in ? d.p1[tid] : 0.f;
+        kc[2][tid] = in ? d.pb[tid] * rsf : 0.f;
+    }
+    __syncthreads();
     // thread tid always builds the same 8-channel slot (q = tid & 3) of each k-step: its per-channel coefficients
     // (pre_conv weights / bias) live in registers, the per-position work is 3 FMA + 1 MUL per channel
     const int qf = tid & 3;
@@ -193,11 +202,10 @@ __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
             const int c = kt * 32 + qf * 8;
             float k0[KT][8], k1[KT][8], kb[KT][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool in = c + e < C;
-                k0[kt][e] = in ? d.p0[c + e] : 0.f;
-                k1[kt][e] = in ? d.p1[c + e] : 0.f;
-                kb[kt][e] = in ? d.pb[c + e] * rsf : 0.f;
+            for (int e = 0; e < 8; ++e) {                        // (re-read per tile: see DESIGN.md, ftb_first determinism)
+                k0[kt][e] = kc[0][c + e];
+                k1[kt][e] = kc[1][c + e];
+                kb[kt][e] = kc[2][c + e];
             }
 #pragma unroll
             for (int i = 0; i < BN * 4 / 256; ++i) {
