@@ -50,6 +50,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define AERO_LDS_ALIGN __attribute__((aligned(16)))
 
+// Block barrier that orders LDS traffic only: it waits for this wave's LDS operations (lgkmcnt) but NOT for its global
+// loads/stores (vmcnt).  __syncthreads() is a workgroup fence and drains both, which makes every tile of a streaming
+// kernel wait for its own output stores to be acknowledged before the next tile may start.
+static __device__ __forceinline__ void aero_lds_barrier() {
+#ifdef AERO_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 // 64 zero bytes+: source of masked lanes of the direct global->LDS copies (padding, out-of-range rows/channels)
 static __device__ h16 aero_zero_page[64];
 

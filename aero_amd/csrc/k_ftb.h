@@ -146,10 +146,11 @@ template <int MF>
 __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
     constexpr int BM = MF * 16, BN = 128, KT = 2;              // C <= 64: two k-steps of 32 channels
     constexpr int CS = BM + 8;
-    constexpr int SB = KT * BN * 32 > BN * CS ? KT * BN * 32 : BN * CS;
+    constexpr int NI = MF;                                      // operand items per thread: BN * (C/8) / 256 <= MF
     __shared__ AERO_LDS_ALIGN h16 As[KT * BM * 32];            // [KT][BM][32] weights, resident
-    __shared__ AERO_LDS_ALIGN h16 Bs[SB];                      // [KT][BN][32] operand tile, then [BN][CS] output staging
-    h16* Cs = Bs;
+    __shared__ AERO_LDS_ALIGN h16 Bs[KT * BN * 32];            // [KT][BN][32] operand tile (slots above C stay zero)
+    __shared__ AERO_LDS_ALIGN h16 Cs[BN * CS];                 // [BN][CS] output staging (its own buffer: 2 barriers/tile)
+    __shared__ AERO_LDS_ALIGN float kc[3][64];                 // pre_conv coefficients [p0 | p1 | pb * rs[f]], zero above C
     const aero_ftb_first_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int C = d.C, T = d.T;
@@ -163,77 +164,86 @@ __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
         if (kt * 32 < p.Kp) w = *(const h16x8*)((const h16*)d.w2a + (int64_t)r * p.Kp + kt * 32 + q * 8);
         *(h16x8*)&As[kt * BM * 32 + aero_tile_off(r, q)] = w;
     }
+    for (int v = tid; v < KT * BN * 4; v += 256) *(h16x8*)&Bs[v * 8] = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
     const h16* xn = (const h16*)d.xn + ((int64_t)row * T) * 2;
     const h16* un = (const h16*)d.u + ((int64_t)row * T) * 2;
     const h16* gate = (const h16*)d.gate + (int64_t)b * T * C;
     h16* drow = (h16*)d.dst + ((int64_t)row * T) * C;
     const float rsf = d.rs[f];
-    // pre_conv coefficients of the attention branch, staged once per block: [p0 | p1 | pb * rs[f]] (zero above C)
-    __shared__ AERO_LDS_ALIGN float kc[3][64];
     if (tid < 64) {
         const bool in = tid < C;
         kc[0][tid] = in ? d.p0[tid] : 0.f;
         kc[1][tid] = in ? d.p1[tid] : 0.f;
         kc[2][tid] = in ? d.pb[tid] * rsf : 0.f;
     }
-    __syncthreads();
-    // thread tid always builds the same 8-channel slot (q = tid & 3) of each k-step: its per-channel coefficients
-    // (pre_conv weights / bias) live in registers, the per-position work is 3 FMA + 1 MUL per channel
-    const int qf = tid & 3;
-    float ar[MF][4], ai[MF][4], bb[MF][4];
+    // epilogue coefficients of this lane's output rows, as pairs for the packed-fp32 FMAs
+    f32x2 ar[MF][2], ai[MF][2], bb[MF][2];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
         const int m = i * 16 + (lane >> 4) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mi = m + r < C ? m + r : C - 1;
-            ar[i][r] = d.a_re[mi];
-            ai[i][r] = d.a_im[mi];
-            bb[i][r] = d.bias[mi];
+            ar[i][r >> 1][r & 1] = d.a_re[mi];
+            ai[i][r >> 1][r & 1] = d.a_im[mi];
+            bb[i][r >> 1][r & 1] = d.bias[mi];
         }
     }
+    // operand items: (position, 8-channel slot) pairs, nvec = C/8 slots per position and no idle lanes: item j = tid +
+    // 256 i -> position j / nvec, slot j % nvec.  The mapping does not depend on the tile: computed once.
     const int nvec = C >> 3;
+    int it_pos[NI], it_c[NI], it_off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = tid + 256 * i;
+        const int pos = j / nvec, sl = j - pos * nvec;
+        const bool live = j < BN * nvec;
+        it_pos[i] = live ? pos : -1;
+        it_c[i] = sl * 8;
+        it_off[i] = (sl >> 2) * BN * 32 + aero_tile_off(live ? pos : 0, sl & 3);
+    }
+    __syncthreads();
     const int ntt = (T + BN - 1) / BN;
     for (int tt = 0; tt < ntt; ++tt) {
         const int t0 = tt * BN;
-        // attention-branch operand att[pos][c] built on the fly
+        // attention-branch operand att[pos][c] = gate * (p0*U_re + p1*U_im + pb*rs), built on the fly (the pre_conv
+        // coefficients are re-read from LDS per tile: see the note above the kernel)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int c = kt * 32 + qf * 8;
-            float k0[KT][8], k1[KT][8], kb[KT][8];
+        for (int i = 0; i < NI; ++i) {
+            const int t = t0 + it_pos[i];
+            if (it_pos[i] < 0) continue;
+            h16x8 o = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (t < T) {
+                const h16x2 uu = *(const h16x2*)(un + t * 2);
+                const f32x2 ur = {(float)uu[0], (float)uu[0]}, ui = {(float)uu[1], (float)uu[1]};
+                const h16x8 g8 = *(const h16x8*)(gate + t * C + it_c[i]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {                        // (re-read per tile: see DESIGN.md, ftb_first determinism)
-                k0[kt][e] = kc[0][c + e];
-                k1[kt][e] = kc[1][c + e];
-                kb[kt][e] = kc[2][c + e];
-            }
-#pragma unroll
-            for (int i = 0; i < BN * 4 / 256; ++i) {
-                const int pos = (tid + 256 * i) >> 2;
-                const int t = t0 + pos;
-                h16x8 o = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (t < T && c < C) {
-                    const h16x2 uu = *(const h16x2*)(un + (int64_t)t * 2);
-                    const float ur = (float)uu[0], ui = (float)uu[1];
-                    const h16x8 g8 = *(const h16x8*)(gate + (int64_t)t * C + c);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (h16)((float)g8[e] * (k0[kt][e] * ur + k1[kt][e] * ui + kb[kt][e]));
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 k0 = *(const f32x2*)&kc[0][it_c[i] + 2 * e];
+                    const f32x2 k1 = *(const f32x2*)&kc[1][it_c[i] + 2 * e];
+                    const f32x2 kb = *(const f32x2*)&kc[2][it_c[i] + 2 * e];
+                    const f32x2 g = {(float)g8[2 * e], (float)g8[2 * e + 1]};
+                    const f32x2 v = g * (k0 * ur + (k1 * ui + kb));
+                    o[2 * e] = (h16)v[0];
+                    o[2 * e + 1] = (h16)v[1];
                 }
-                *(h16x8*)&Bs[kt * BN * 32 + aero_tile_off(pos, qf)] = o;
             }
+            *(h16x8*)&Bs[it_off[i]] = o;
         }
-        float re[2], im[2];
+        f32x2 re[2], im[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int t = t0 + (wave * 2 + n) * 16 + (lane & 15);
-            re[n] = im[n] = 0.f;
+            float r0 = 0.f, i0 = 0.f;
             if (t < T) {
-                const h16x2 vv = *(const h16x2*)(xn + (int64_t)t * 2);
-                re[n] = (float)vv[0];
-                im[n] = (float)vv[1];
+                const h16x2 vv = *(const h16x2*)(xn + t * 2);
+                r0 = (float)vv[0];
+                i0 = (float)vv[1];
             }
+            re[n] = (f32x2){r0, r0};
+            im[n] = (f32x2){i0, i0};
         }
-        __syncthreads();
+        aero_lds_barrier();                                    // operand tile complete (and the previous tile's staging read out)
         f32x4 acc[MF][2];
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -252,26 +262,24 @@ __global__ __launch_bounds__(256) void aero_ftb_first_kernel(AeroFtbFirstK p) {
                 acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[1], acc[i][1], 0, 0, 0);
             }
         }
-        __syncthreads();                                       // operand tile consumed: it becomes the output tile
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const int m = i * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int pos = (wave * 2 + n) * 16 + (lane & 15);
-                h16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (h16)fmaxf(acc[i][n][r] + ar[i][r] * re[n] + ai[i][r] * im[n] + bb[i][r], 0.f);
+                const f32x2 lo = ar[i][0] * re[n] + (ai[i][0] * im[n] + ((f32x2){acc[i][n][0], acc[i][n][1]} + bb[i][0]));
+                const f32x2 hi = ar[i][1] * re[n] + (ai[i][1] * im[n] + ((f32x2){acc[i][n][2], acc[i][n][3]} + bb[i][1]));
+                const h16x4 o = {(h16)fmaxf(lo[0], 0.f), (h16)fmaxf(lo[1], 0.f), (h16)fmaxf(hi[0], 0.f), (h16)fmaxf(hi[1], 0.f)};
                 *(h16x4*)&Cs[pos * CS + m] = o;
             }
         }
-        __syncthreads();
+        aero_lds_barrier();                                    // staging complete; every wave is done reading the operand tile
         for (int idx = tid; idx < BN * nvec; idx += 256) {
             const int pos = idx / nvec, cv = idx - pos * nvec;
             const int t = t0 + pos;
-            if (t < T) *(h16x8*)(drow + (int64_t)t * C + cv * 8) = *(const h16x8*)&Cs[pos * CS + cv * 8];
+            if (t < T) *(h16x8*)(drow + t * C + cv * 8) = *(const h16x8*)&Cs[pos * CS + cv * 8];
         }
-        __syncthreads();                                       // staging read out before the next tile overwrites it
     }
 }
 
@@ -284,6 +292,7 @@ static int aero_ftb_first_launch(const aero_ftb_first_desc* d, hipStream_t strea
     p.Kp = (d->C + 31) / 32 * 32;
     const long nwg = (long)d->B * d->F;
     if (nwg > 0x7fffffffL) { *err = "ftb_first: grid too large"; return AERO_ERR_ARG; }
+    if ((int64_t)d->T * d->C > 0x7fffffffLL) { *err = "ftb_first: row span exceeds 32 bits"; return AERO_ERR_UNSUPPORTED; }
     dim3 grid((unsigned)nwg), block(256);
     const int mf = (d->C + 15) / 16;
     if (mf == 1) AERO_LAUNCH((aero_ftb_first_kernel<1>), grid, block, stream, p);
