@@ -95,24 +95,21 @@ __global__ __launch_bounds__(256) void aero_norm_stats_kernel(aero_norm_desc d, 
         if (!wide) {
             // four time steps per trip, all loads issued before the first use: one wave keeps 4 KiB in flight instead of 1
             const h16* colp = base + v * VEC;
-            int t = t0 + ty;
-            for (; t + 3 * TY < t1; t += 4 * TY) {
+            // (the last trip is predicated per step rather than finished by a one-load-at-a-time remainder loop)
+            for (int t = t0 + ty; t < t1; t += 4 * TY) {
                 typename AeroVecT<VEC>::type r[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) r[k] = aero_load_raw<VEC>(colp + (int64_t)(t + k * TY) * d.s_t);
+                for (int k = 0; k < 4; ++k)
+                    if (t + k * TY < t1) r[k] = aero_load_raw<VEC>(colp + (int64_t)(t + k * TY) * d.s_t);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float x[VEC];
-                    aero_cvt_vec<VEC>(r[k], x);
+                    if (t + k * TY < t1) {
+                        float x[VEC];
+                        aero_cvt_vec<VEC>(r[k], x);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) { s += x[i]; ss += x[i] * x[i]; }
+                        for (int i = 0; i < VEC; ++i) { s += x[i]; ss += x[i] * x[i]; }
+                    }
                 }
-            }
-            for (; t < t1; t += TY) {
-                float x[VEC];
-                aero_load_vec<VEC>(colp + (int64_t)t * d.s_t, x);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) { s += x[i]; ss += x[i] * x[i]; }
             }
         } else {
             for (int t = t0 + ty; t < t1; t += TY) {
@@ -260,33 +257,31 @@ __global__ __launch_bounds__(256) void aero_norm_apply_kernel(aero_norm_desc d, 
     // load per trip the kernel sat at 3.5 TB/s, latency-bound)
     constexpr int UNR = 4;
     typedef typename AeroVecT<VEC>::type raw_t;
-    int t = t0 + ty;
-    for (; t + (UNR - 1) * TY < t1; t += UNR * TY) {
+    // (one loop, the last trip predicated per step: a scalar remainder loop -- one load in flight per thread -- ran
+    // 23 of the 63 steps of a typical chunk latency-bound)
+    for (int t = t0 + ty; t < t1; t += UNR * TY) {
         raw_t rx[UNR], rz[UNR], rr[UNR];
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
-            const int64_t tk = t + k * TY;
-            rx[k] = aero_load_raw<VEC>(src + tk * d.s_t);
-            if (glu) rz[k] = aero_load_raw<VEC>(src + tk * d.s_t + Cout);
-            if (res) rr[k] = aero_load_raw<VEC>(res + tk * d.r_t);
+            const int tk = t + k * TY;
+            if (tk < t1) {
+                rx[k] = aero_load_raw<VEC>(src + (int64_t)tk * d.s_t);
+                if (glu) rz[k] = aero_load_raw<VEC>(src + (int64_t)tk * d.s_t + Cout);
+                if (res) rr[k] = aero_load_raw<VEC>(res + (int64_t)tk * d.r_t);
+            }
         }
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
-            float x[VEC], z[VEC], r[VEC], o[VEC];
-            aero_cvt_vec<VEC>(rx[k], x);
-            if (glu) aero_cvt_vec<VEC>(rz[k], z);
-            if (res) aero_cvt_vec<VEC>(rr[k], r);
-            step(x, z, r, o);
-            aero_store_vec<VEC>(dst + (int64_t)(t + k * TY) * d.d_t, o);
+            const int tk = t + k * TY;
+            if (tk < t1) {
+                float x[VEC], z[VEC], r[VEC], o[VEC];
+                aero_cvt_vec<VEC>(rx[k], x);
+                if (glu) aero_cvt_vec<VEC>(rz[k], z);
+                if (res) aero_cvt_vec<VEC>(rr[k], r);
+                step(x, z, r, o);
+                aero_store_vec<VEC>(dst + (int64_t)tk * d.d_t, o);
+            }
         }
-    }
-    for (; t < t1; t += TY) {
-        float x[VEC], z[VEC], r[VEC], o[VEC];
-        aero_load_vec<VEC>(src + (int64_t)t * d.s_t, x);
-        if (glu) aero_load_vec<VEC>(src + (int64_t)t * d.s_t + Cout, z);
-        if (res) aero_load_vec<VEC>(res + (int64_t)t * d.r_t, r);
-        step(x, z, r, o);
-        aero_store_vec<VEC>(dst + (int64_t)t * d.d_t, o);
     }
 }
 
