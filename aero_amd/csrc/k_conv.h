@@ -59,6 +59,37 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
     // SM (statistics mode of aero_hip.h): 0 none; 1 accumulate GroupNorm sums of the conv output while storing it;
     // 2 accumulate only (nothing is stored: first half of a recompute pair); 3 normalise with previously accumulated sums:
     // v = (acc + bias - mean) * rstd * gamma + beta folds into ONE FMA per value (av, bv) before the activation.
+    h16* dst16 = (h16*)d.dst;
+    h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
+    const h16* rrow = d.res ? (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + m0o : nullptr;
+    const float* prow = d.post_add ? d.post_add + (int64_t)fo * Mout + m0o : nullptr;      // frequency embedding row
+    // copy-out item `it` of half-tile `pass` of this thread: staged position pc, 8-channel vector cv, time step t
+    constexpr int NIT = (64 * NVEC + NWV * 64 - 1) / (NWV * 64);
+    auto locate = [&](int pass, int it, int& pc, int& cv, int& t) -> bool {
+        const int idx = tid + it * NWV * 64;
+        pc = idx / NVEC;
+        cv = idx - pc * NVEC;
+        const int wq = pc / PH, rr = pc - wq * PH;
+        t = t0 + (wq * NF + pass * NH + (rr >> 4)) * 16 + (rr & 15);
+        return idx < 64 * NVEC && t < T && m0o + cv * 8 < Mout;
+    };
+    // The residual tile is fetched HERE, together with the coefficient loads below, not inside the copy-out: a short-K
+    // block (the DConv tail: one K chunk, 24 KiB of output) otherwise pays three more dependent memory latencies after
+    // its K loop -- coefficients, residual of half 0, residual of half 1.  (4-wave tiles only: the 8-wave tiles run at
+    // 128 registers and have no room for it.)
+    constexpr bool PRE = (NWV == 4) && SM != 2;
+    h16x8 rpre[PRE ? 2 : 1][PRE ? NIT : 1];
+    if constexpr (PRE) {
+        if (rrow) {
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    int pc, cv, t;
+                    if (locate(pass, it, pc, cv, t)) rpre[pass][it] = *(const h16x8*)(rrow + (int64_t)t * d.r_t + cv * 8);
+                }
+        }
+    }
     float bv[MF][4], av[MF][4], ls[MF][2];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
@@ -98,10 +129,6 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
             ls[i][r] = (GLU && d.layer_scale) ? d.layer_scale[ci] : 1.f;
         }
     }
-    h16* dst16 = (h16*)d.dst;
-    h16* drow = dst16 + (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + m0o;
-    const h16* rrow = d.res ? (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)fdst * d.r_f + m0o : nullptr;
-    const float* prow = d.post_add ? d.post_add + (int64_t)fo * Mout + m0o : nullptr;      // frequency embedding row
     // stat_mode 1: GroupNorm statistics of the conv output (bias included, before the activation) ride along: two FMAs per
     // value on a VALU that idles under the MFMAs, one fp64 atomic pair per (wave, group) -- the separate read-only pass
     // over the stored tensor (0.8 ms per forward) disappears
@@ -147,17 +174,16 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
             }
         }
         if constexpr (SM == 2) continue;
-        __syncthreads();
+        aero_lds_barrier();                                 // (LDS only: no wait for the other half's global stores)
 #pragma unroll
-        for (int it = 0; it < (64 * NVEC + NWV * 64 - 1) / (NWV * 64); ++it) {
-            const int idx = tid + it * NWV * 64;
-            const int pc = idx / NVEC, cv = idx - pc * NVEC;
-            const int wq = pc / PH, rr = pc - wq * PH;
-            const int t = t0 + (wq * NF + pass * NH + (rr >> 4)) * 16 + (rr & 15);
-            if (idx < 64 * NVEC && t < T && m0o + cv * 8 < Mout) {
+        for (int it = 0; it < NIT; ++it) {
+            int pc, cv, t;
+            if (locate(pass, it, pc, cv, t)) {
                 h16x8 v = *(const h16x8*)&Cs[pc * CS + cv * 8];
                 if (rrow) {
-                    const h16x8 r8 = *(const h16x8*)(rrow + (int64_t)t * d.r_t + cv * 8);
+                    h16x8 r8;
+                    if constexpr (PRE) r8 = rpre[pass][it];
+                    else r8 = *(const h16x8*)(rrow + (int64_t)t * d.r_t + cv * 8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] + (float)r8[e]);
                 }
@@ -176,7 +202,7 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
                 *(h16x8*)(drow + (int64_t)t * d.d_t + cv * 8) = v;
             }
         }
-        __syncthreads();
+        aero_lds_barrier();
     }
     if constexpr (SM == 1 || SM == 2) {
         const int gs = M / d.stat_G;                              // rows per statistics group (16-row aligned, or one group)
