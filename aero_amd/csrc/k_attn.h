@@ -113,7 +113,9 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
         }
         __syncthreads();
         if (kc0 == 0) qf = *(const h16x8*)&Qs[aero_tile_off(wave * 16 + col, g)];
-        for (int tb = 0; tb < kn32; tb += 32) {
+        // Two 32-key blocks per trip: their score -> softmax -> PV chains are independent until the shared running maximum,
+        // so one block's MFMA / exp latencies hide behind the other's, and the accumulator is rescaled once per 64 keys.
+        auto scores = [&](int tb, float* sc) {
             const h16x8 k0 = *(const h16x8*)&Ks[aero_tile_off(tb + col, g)];
             const h16x8 k1 = *(const h16x8*)&Ks[aero_tile_off(tb + 16 + col, g)];
             const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -122,7 +124,6 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
             // key e of this lane sits at t = kc0 + tb + koff[e]; distance to the query = |u + koff[e]| with u = kc0 + tb - s
             const int t_blk = kc0 + tb;
             const float u = (float)(t_blk - s);
-            float sc[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float x = u + koff[e];
@@ -140,30 +141,50 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
                 for (int e = 0; e < 8; ++e)
                     if (t_blk + (int)koff[e] >= T) sc[e] = -1e30f;
             }
-            float cmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-            const float mn = fmaxf(m, cmax);
-            const float alpha = aero_exp2(m - mn);
-            m = mn;
-            float psum = 0.f;
-            h16x8 pf;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float pw = aero_exp2(sc[e] - mn);
-                psum += pw;
-                pf[e] = (h16)pw;
-            }
-            l = l * alpha + psum;
+        };
+        auto max8 = [](const float* sc) {
+            return fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+        };
+        auto pv = [&](int tb, const h16x8& pf) {
 #pragma unroll
             for (int i = 0; i < DT; ++i) {
                 const h16* vr = &Vt[(i * 16 + col) * AERO_ATTN_VS + tb + g * 4];
                 const h16x4 va = *(const h16x4*)vr;
                 const h16x4 vb = *(const h16x4*)(vr + 16);
                 const h16x8 vf = (h16x8){va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-                O[i] = O[i] * alpha;
                 O[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, O[i], 0, 0, 0);
             }
+        };
+        for (int tb = 0; tb < kn32; tb += 64) {
+            const bool two = tb + 32 < kn32;                  // block-uniform
+            float sa[8], sb[8];
+            scores(tb, sa);
+            if (two) {
+                scores(tb + 32, sb);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sb[e] = -1e30f;
+            }
+            float cmax = fmaxf(max8(sa), max8(sb));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const float mn = fmaxf(m, cmax);
+            const float alpha = aero_exp2(m - mn);
+            m = mn;
+            float psum = 0.f;
+            h16x8 pfa, pfb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pa = aero_exp2(sa[e] - mn), pb = aero_exp2(sb[e] - mn);
+                psum += pa + pb;
+                pfa[e] = (h16)pa;
+                pfb[e] = (h16)pb;
+            }
+            l = l * alpha + psum;
+#pragma unroll
+            for (int i = 0; i < DT; ++i) O[i] = O[i] * alpha;
+            pv(tb, pfa);
+            if (two) pv(tb + 32, pfb);
         }
     }
     l += __shfl_xor(l, 16);
