@@ -307,6 +307,8 @@ class HipEngine:
         if key != self._key:
             self._pack(device)
             self._key = key
+            for k in [k for k in self._tables if isinstance(k, tuple) and k and k[0] == 'graph']:
+                del self._tables[k]                     # captured graphs point at the previous packed weights
 
     def _pack(self, device):
         m = self.model
@@ -551,9 +553,9 @@ class HipEngine:
         outputs are cloned out of it (the graph's memory is reused by the next replay)."""
         key = ('graph', tuple(mix.shape), str(mix.device), want_spec, want_lr_spec,
                self.fuse_dconv_tail, self.fuse_stats, self.collapse_first_ftb, self.fuse_lstm_proj)
+        self._prepare(mix.device)                       # (drops the captured graphs if the weights changed)
         ent = self._tables.get(key)
         if ent is None:
-            self._prepare(mix.device)
             static_in = mix.clone()
             for _ in range(2):                          # warm-up outside capture: lazy one-time setup (attributes, tables)
                 self._forward_one(static_in, want_spec, want_lr_spec)

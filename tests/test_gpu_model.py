@@ -91,6 +91,15 @@ def test_hip_graph_replay_equals_eager(meta):
             got = _fwd(m, x)
             for a, b in zip(got, r):
                 assert torch.equal(a, b)
+        # new weights: the engine repacks them and must drop the graphs captured over the old packed buffers
+        with torch.no_grad():
+            m.decoder[0].rewrite.weight.mul_(1.5)
+        got = _fwd(m, xs[0])
+        eng.use_graph = False
+        want = _fwd(m, xs[0])
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        assert not torch.equal(got[0], ref[0][0])
     finally:
         eng.use_graph = False
 
