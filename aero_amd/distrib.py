@@ -96,6 +96,16 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def count_ranks(device=None):
+    """Number of ranks that take part in an all-reduce of ones (1 without a process group): proof that the
+    collective backend (RCCL over xGMI with "nccl") is up on every rank, not just that WORLD_SIZE was set."""
+    if world_size == 1:
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=_device_for_collective())
+    _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
 def shard_indices(n, r=None, w=None):
     """Eval sharding rule of the reference: item i -> rank i mod world (distrib.py:100)."""
     r = rank if r is None else r

@@ -22,24 +22,68 @@ def get_estimate(model, lr_sig):
         return model(lr_sig)
 
 
-def predict_signal(model, lr_sig, sr, device=None, batch_chunks=True):
+MAX_CLIPS_PER_FORWARD = 64         # bound on chunk-channels per forward: activation memory stays constant for any file length
+
+
+def _forward_groups(model, groups, device):
+    """Run the [n_i, 1, L] host batches of `groups` through the model, one forward each.  On the GPU the uploads and
+    downloads run on their own HIP streams through pinned buffers, so group g+1's H2D copy and group g-1's D2H copy
+    overlap with group g's kernels (predict.py:76-80 moves one chunk at a time, synchronously)."""
+    dev = torch.device(device)
+    if dev.type != 'cuda' or len(groups) == 0:
+        return [model(g.to(dev)).cpu() for g in groups]
+    main = torch.cuda.current_stream(dev)
+    s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    outs, pending = [], None
+    with torch.cuda.stream(s_in):
+        nxt = groups[0].pin_memory().to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(s_in)
+    for i in range(len(groups)):
+        x, ev_x = nxt, ev
+        if i + 1 < len(groups):
+            with torch.cuda.stream(s_in):
+                nxt = groups[i + 1].pin_memory().to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(s_in)
+        main.wait_event(ev_x)
+        x.record_stream(main)
+        y = model(x)
+        done = torch.cuda.Event()
+        done.record(main)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(done)
+            y.record_stream(s_out)
+            host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
+            host.copy_(y, non_blocking=True)
+        outs.append(host)
+    s_out.synchronize()
+    return outs
+
+
+def predict_signal(model, lr_sig, sr, device=None, batch_chunks=True, max_clips=MAX_CLIPS_PER_FORWARD):
     """predict.py:61-85 for one file: lr_sig [channels, samples] -> [channels, samples*scale].
 
-    All full-length chunks go through ONE batched forward (they are independent, predict.py:76-80 loops
-    over them); the short tail chunk is run separately.  Results are identical per chunk.
+    The full-length chunks are independent (predict.py:76-80 loops over them): they are batched, at most `max_clips`
+    chunk-channels per forward (bounded activation memory whatever the file length), with host<->device copies
+    overlapped with compute; the short tail chunk is run separately.  Results are identical per chunk.
     """
     device = device or next(model.parameters()).device
     ranges = chunk_ranges(lr_sig.shape[-1], sr)
     out = [None] * len(ranges)
     model.eval()
+    ch = lr_sig.shape[0]
     with torch.no_grad():
         full = [i for i, (a, b) in enumerate(ranges) if b - a == sr * SEGMENT_DURATION_SEC]
         if batch_chunks and len(full) > 1:
-            x = torch.stack([lr_sig[:, a:b] for a, b in (ranges[i] for i in full)], 0)        # [n, ch, L]
-            n, ch, L = x.shape
-            y = model(x.reshape(n * ch, 1, L).to(device)).reshape(n, ch, -1).cpu()
-            for k, i in enumerate(full):
-                out[i] = y[k]
+            per = max(1, max_clips // ch)                                                     # chunks per forward
+            idx_groups = [full[k:k + per] for k in range(0, len(full), per)]
+            groups = [torch.stack([lr_sig[:, ranges[i][0]:ranges[i][1]] for i in g], 0).reshape(len(g) * ch, 1, -1)
+                      for g in idx_groups]
+            for g, y in zip(idx_groups, _forward_groups(model, groups, device)):
+                y = y.reshape(len(g), ch, -1)
+                for k, i in enumerate(g):
+                    out[i] = y[k]
         for i, (a, b) in enumerate(ranges):
             if out[i] is None:
                 out[i] = model(lr_sig[:, a:b].unsqueeze(1).to(device)).squeeze(1).cpu()
@@ -70,18 +114,72 @@ def match_signal(signal, ref_len):
     return signal
 
 
+class _Inert:
+    """Stand-in for classes a reference checkpoint pickles but the generator path never needs: the GAN critics
+    (`src.models.discriminators.*`, every aero config trains with `adversarial: true`), the Seanet baseline and the
+    omegaconf / hydra containers of the `args` entry (model_serializer.py:22,47).  Accepts any construction/state."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Inert()
+
+    def __setstate__(self, state):
+        self.__dict__['_state'] = state
+
+    def __reduce_ex__(self, protocol):
+        return (_Inert, ())
+
+
+def _tolerant_pickle():
+    """A `pickle_module` for torch.load whose Unpickler maps classes that cannot be imported here (or that live in the
+    reference's training-only modules) to inert stubs instead of raising ModuleNotFoundError / AttributeError."""
+    import importlib
+    import pickle
+    import types
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                root = module.split('.')[0]
+                if root in ('src', 'omegaconf', 'hydra', 'antlr4', 'wandb') or module.startswith('src.'):
+                    return type(name, (_Inert,), {'__module__': module})
+                raise
+
+    mod = types.ModuleType('aero_amd_tolerant_pickle')
+    mod.__dict__.update({k: getattr(pickle, k) for k in dir(pickle) if not k.startswith('__')})
+    mod.Unpickler = Unpickler
+    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
+    importlib.invalidate_caches()
+    return mod
+
+
+def load_package(path):
+    """torch.load of a checkpoint written by the reference's serializer (model_serializer.py:40-54), tolerant of the
+    pickled training-only classes."""
+    return torch.load(str(path), map_location='cpu', weights_only=False, pickle_module=_tolerant_pickle())
+
+
 def load_generator(args, device='cuda'):
-    """predict.py:24-38 / test.py:25-39: build the generator from the experiment config and load a checkpoint
-    written by the reference's serializer ({'models': {'generator': {'state': ...}}}, model_serializer.py:19-48)."""
+    """predict.py:24-38 / test.py:25-39: build the generator from the experiment config and load a checkpoint written
+    by the reference's serializer ({'models': {'generator': {'state': ...}}, 'best_states': ..., 'args': ...}).
+    Like the reference (torch.load on a missing path raises), a configured but absent checkpoint is an error; random
+    weights are only used when the caller says so (`+random_init=true`), e.g. for plumbing runs and benchmarks."""
     from .modules import Aero
     model = Aero(**args.experiment.aero)
     ckpt = args.get('checkpoint_file')
-    if ckpt and os.path.exists(str(ckpt)):
-        package = torch.load(str(ckpt), map_location='cpu', weights_only=False)
-        if args.get('continue_best'):
-            best = package['best_states']
-            state = best['models']['generator']['state'] if 'models' in best else best['generator']
-        else:
-            state = package['models']['generator']['state']
-        model.load_state_dict(state)
+    if args.get('random_init'):
+        return model.to(device).eval()
+    if not ckpt or not os.path.exists(str(ckpt)):
+        raise FileNotFoundError(f"checkpoint_file '{ckpt}' not found (pass +random_init=true to run with random-init weights)")
+    package = load_package(ckpt)
+    if args.get('continue_best'):
+        best = package['best_states']
+        state = best['models']['generator']['state'] if 'models' in best else best['generator']
+    else:
+        state = package['models']['generator']['state']
+    model.load_state_dict(state)
     return model.to(device).eval()

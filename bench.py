@@ -1,6 +1,6 @@
 """bench.py -- real-time factor of Aero.forward (STFT + U-Net + iSTFT) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts N ranks itself, aero_amd/launcher.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one forward pass of the hot path over one batch of synthetic clips already resident in
@@ -97,15 +97,28 @@ def main():
         print(json.dumps(cpu_baseline_worker(2.0, FULL_CFG['lr_sr'])))
         return
 
+    from aero_amd import distrib, launcher
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU path in the product)'
+    if args.gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    if torch.cuda.device_count() < args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible')
+    if args.gpus > 1 and not launcher.under_launcher():
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, supervised); rank 0's
+        # stdout (the JSON line) is inherited.  Under torchrun the environment is already there and we are a rank.
+        ok = launcher.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        sys.exit(0 if ok else 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU path in the product)'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    from aero_amd import distrib
     distrib.init_from_env()                                   # RCCL process group when WORLD_SIZE > 1
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    ranks_verified = distrib.count_ranks(dev)                 # all-reduce of ones over RCCL: every rank really joined
+    if ranks_verified != args.gpus:
+        sys.exit(f'bench.py: {ranks_verified} rank(s) answered the all-reduce, expected {args.gpus}')
 
     from aero_amd import Aero
     torch.manual_seed(2036)
@@ -178,7 +191,7 @@ def main():
     audio_s = world * B * secs * args.steps
     out = {
         'metric': 'real-time-factor (audio-sec/wall-sec), Aero.forward STFT+U-Net+iSTFT, 4->16kHz nfft=512 hop=64 batch=64 per GPU',
-        'value': round(audio_s / dt, 2), 'unit': 'audio-sec/wall-sec', 'n_gpus': world, 'steps': args.steps,
+        'value': round(audio_s / dt, 2), 'unit': 'audio-sec/wall-sec', 'n_gpus': ranks_verified, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
         'config': {'workload': f'batch={B} synthetic 2s white-noise clips per GPU, 4->16 kHz, aero_4-16_512_64 '

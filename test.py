@@ -45,12 +45,14 @@ def main(argv=None):
     model = enhance.load_generator(args, device='cuda')
     files = _listing(args)
 
+    mine = [files[i] for i in distrib.shard_indices(len(files))]     # file i -> rank i mod W, sharded BEFORE any decoding
+
     def pairs():
-        for lr_path, hr_path in files:
+        for lr_path, hr_path in mine:
             lr, _ = audio_io.load(lr_path)
             hr, _ = audio_io.load(hr_path)
             yield lr[:1].unsqueeze(0), hr[:1].unsqueeze(0)
-    total, count, _ = evaluate.evaluate(model, pairs(), device='cuda', rank=distrib.rank, world_size=distrib.world_size)
+    total, count, _ = evaluate.evaluate(model, pairs(), device='cuda')
     lsd = distrib.average([total / max(count, 1)], count)[0]          # file-weighted mean over ranks (distrib.py:43-55)
     logger.info(f'Done evaluation.  LSD={lsd} , VISQOL=0 (external binary not configured), files={len(files)}')
     return lsd

@@ -100,6 +100,82 @@ def test_src_import_paths_and_checkpoint_format(tmp_path, meta):
     assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), g.state_dict().values()))
 
 
+def test_reference_shaped_checkpoint_with_training_only_classes(tmp_path, meta):
+    """A package as the reference's serializer writes it (model_serializer.py:19-48): generator AND critic entries whose
+    `class` fields are class objects of modules this repo does not ship, plus an omegaconf DictConfig under `args`.
+    load_generator must read the generator state out of it (the classes of the other entries become inert stubs)."""
+    import pickle
+    import sys
+    import types
+    from src.models.aero import Aero
+    c = load_config(os.path.join(ROOT, 'conf'), ['experiment=aero_4-16_512_64'])
+    c.experiment.aero.update(channels=4, nfft=128, hop_length=16)
+    g = Aero(**c.experiment.aero)
+    # fabricate the foreign classes only while pickling, then remove them again (as on a box without the reference)
+    fake = {}
+    for modname, clsname in (('src.models.discriminators', 'Discriminator'), ('omegaconf.dictconfig', 'DictConfig'),
+                             ('omegaconf.base', 'ContainerMetadata')):
+        mod = types.ModuleType(modname)
+        cls = type(clsname, (), {'__module__': modname, '__init__': lambda self, **kw: self.__dict__.update(kw)})
+        setattr(mod, clsname, cls)
+        fake[modname] = (mod, cls)
+    saved = {k: sys.modules.get(k) for k in list(fake) + ['omegaconf']}
+    sys.modules.update({k: v[0] for k, v in fake.items()})
+    sys.modules['omegaconf'] = types.ModuleType('omegaconf')
+    try:
+        Disc, DictConfig, Meta = (fake[k][1] for k in fake)
+        pkg = {'models': {'generator': {'class': g.__class__, 'args': (), 'kwargs': dict(g._init_args_kwargs[1]), 'state': g.state_dict()},
+                          'msd_melgan': {'class': Disc, 'args': (), 'kwargs': {}, 'state': {'w': torch.ones(3)}}},
+               'optimizers': {'optimizer': {'state': {}, 'param_groups': []}}, 'history': [{'train': 1.0}],
+               'best_states': {'generator': g.state_dict()},
+               'args': DictConfig(_metadata=Meta(flags={'x': 1}), _content={'lr': 3e-4})}
+        p = str(tmp_path / 'checkpoint.th')
+        torch.save(pkg, p)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    with pytest.raises((ModuleNotFoundError, AttributeError, pickle.UnpicklingError)):
+        torch.load(p, map_location='cpu', weights_only=False)        # what a plain load does without the reference's modules
+    c.checkpoint_file = p
+    m2 = enhance.load_generator(c, device='cpu')
+    assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), g.state_dict().values()))
+    c.continue_best = True
+    m3 = enhance.load_generator(c, device='cpu')
+    assert all(torch.equal(a, b) for a, b in zip(m3.state_dict().values(), g.state_dict().values()))
+    pkg2 = enhance.load_package(p)
+    assert type(pkg2['models']['msd_melgan']['class']).__name__ == 'type' and pkg2['history'] == [{'train': 1.0}]
+
+
+def test_missing_checkpoint_is_an_error_unless_random_init_is_requested(tmp_path):
+    c = load_config(os.path.join(ROOT, 'conf'), ['experiment=aero_4-16_512_64'])
+    c.experiment.aero.update(channels=4, nfft=128, hop_length=16)
+    c.checkpoint_file = str(tmp_path / 'nope.th')
+    with pytest.raises(FileNotFoundError):
+        enhance.load_generator(c, device='cpu')
+    c.random_init = True
+    assert len(enhance.load_generator(c, device='cpu').state_dict()) > 0
+
+
+def test_predict_signal_bounds_the_clips_per_forward(meta):
+    """Long files are processed in groups of at most `max_clips` chunk-channels; the result does not depend on the bound."""
+    from emu.build_emu import build
+    m = build_model(meta, 'tiny')
+    object.__setattr__(m, '_engine', HipEngine(m, lib=_lib.load(build())))
+    sizes = []
+    fwd = m.forward
+    object.__setattr__(m, 'forward', lambda x, *a, **k: (sizes.append(x.shape[0]), fwd(x, *a, **k))[1])
+    sr = 40
+    sig = torch.randn(2, 5 * 400 + 123, generator=torch.Generator().manual_seed(9))           # stereo, 5 full chunks + tail
+    pr = enhance.predict_signal(m, sig, sr, device='cpu', max_clips=4)
+    assert sizes == [4, 4, 2, 2]                                                                # 2+2+1 chunks x 2 channels, tail
+    sizes.clear()
+    pr1 = enhance.predict_signal(m, sig, sr, device='cpu', batch_chunks=False)
+    assert sizes == [2] * 6 and torch.equal(pr, pr1)
+
+
 def test_lsd_matches_an_independent_numpy_restatement():
     """metrics.py:58-70 (STFT 2048/512, periodic hann, reflect centre padding): numpy restatement vs aero_amd.evaluate."""
     import numpy as np
