@@ -270,18 +270,34 @@ def _bn_eval(x, sd, pre):
     return (x - rm.view(shape)) / torch.sqrt(rv.view(shape) + 1e-5) * w.view(shape) + b.view(shape)
 
 
-def ftb(sd, pre, x):
-    """modules.py:304-325 (Appendix B4), eval-mode BatchNorm (running stats)."""
+def _bn_train(x, sd, pre, new_stats=None, momentum=0.1):
+    """nn.BatchNorm{1,2}d in training mode (modules.py:287,293,300): normalise with the statistics of THIS batch (biased
+    variance) and, when `new_stats` is a dict, record the running-statistics update PyTorch performs
+    (running = (1-m) running + m batch, with the UNBIASED batch variance; num_batches_tracked + 1)."""
+    dims = [0] + list(range(2, x.dim()))
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    n = x.numel() // x.shape[1]
+    mean = x.mean(dim=dims)
+    var = x.var(dim=dims, unbiased=False)
+    if new_stats is not None:
+        new_stats[f'{pre}.running_mean'] = (1 - momentum) * sd[f'{pre}.running_mean'] + momentum * mean
+        new_stats[f'{pre}.running_var'] = (1 - momentum) * sd[f'{pre}.running_var'] + momentum * var * (n / (n - 1))
+        new_stats[f'{pre}.num_batches_tracked'] = sd[f'{pre}.num_batches_tracked'] + 1
+    return (x - mean.view(shape)) / torch.sqrt(var.view(shape) + 1e-5) * sd[f'{pre}.weight'].view(shape) + sd[f'{pre}.bias'].view(shape)
+
+
+def ftb(sd, pre, x, train=False, new_stats=None):
+    """modules.py:304-325 (Appendix B4).  eval: BatchNorm on running statistics; train: on batch statistics."""
+    bn = (lambda v, q: _bn_train(v, sd, q, new_stats)) if train else (lambda v, q: _bn_eval(v, sd, q))
     B, C, D, T = x.shape
-    c1 = F.relu(_bn_eval(F.conv2d(x, sd[f'{pre}.conv1.0.weight'], sd[f'{pre}.conv1.0.bias']), sd, f'{pre}.conv1.1'))
+    c1 = F.relu(bn(F.conv2d(x, sd[f'{pre}.conv1.0.weight'], sd[f'{pre}.conv1.0.bias']), f'{pre}.conv1.1'))
     r = c1.shape[1]
     c1 = c1.reshape(B, r * D, T)
-    c2 = F.relu(_bn_eval(F.conv1d(c1, sd[f'{pre}.conv1d.0.weight'], sd[f'{pre}.conv1d.0.bias'], padding=4),
-                         sd, f'{pre}.conv1d.1'))
+    c2 = F.relu(bn(F.conv1d(c1, sd[f'{pre}.conv1d.0.weight'], sd[f'{pre}.conv1d.0.bias'], padding=4), f'{pre}.conv1d.1'))
     att = c2.reshape(B, C, 1, T) * x
     att = (att.transpose(2, 3) @ sd[f'{pre}.freq_fc.weight'].t()).transpose(2, 3)
     cat = torch.cat([att, x], 1)
-    return F.relu(_bn_eval(F.conv2d(cat, sd[f'{pre}.conv2.0.weight'], sd[f'{pre}.conv2.0.bias']), sd, f'{pre}.conv2.1'))
+    return F.relu(bn(F.conv2d(cat, sd[f'{pre}.conv2.0.weight'], sd[f'{pre}.conv2.0.bias']), f'{pre}.conv2.1'))
 
 
 def _norm(sd, pre, x, groups):
@@ -290,14 +306,14 @@ def _norm(sd, pre, x, groups):
     return x
 
 
-def enc_layer(sd, i, x, cfg, fast=False):
+def enc_layer(sd, i, x, cfg, fast=False, train=False, new_stats=None):
     """aero.py:108-135 (Appendix B3)."""
     p = f'encoder.{i}'
     s = cfg['strides'][i]
     if f'{p}.pre_conv.weight' in sd:
         x = F.conv2d(x, sd[f'{p}.pre_conv.weight'], sd[f'{p}.pre_conv.bias'])
     if f'{p}.freq_attn_block.freq_fc.weight' in sd:
-        x = ftb(sd, f'{p}.freq_attn_block', x)
+        x = ftb(sd, f'{p}.freq_attn_block', x, train, new_stats)
     w = sd[f'{p}.conv.weight']
     K = w.shape[2]
     x = F.conv2d(x, w, sd[f'{p}.conv.bias'], stride=(s, 1), padding=((K - s) // 2, 0))
@@ -361,10 +377,12 @@ def ispec(z, cfg):
     return istft(z, int(hop_in * sc), int(win_in * sc))
 
 
-def aero_forward(sd, cfg, mix, return_spec=False, return_lr_spec=False, fast=False, taps=None):
+def aero_forward(sd, cfg, mix, return_spec=False, return_lr_spec=False, fast=False, taps=None, train=False, new_stats=None):
     """aero.py:446-523.  `sd` is a state_dict of fp32 CPU tensors, `cfg` the ctor kwargs.
 
     `taps`, if a dict, receives intermediate tensors (for drift localisation in tests).
+    `train`: the module in training mode -- the only forward-path difference is the FTB's BatchNorm (batch statistics);
+    `new_stats` (a dict) then receives the updated running statistics.
     """
     cfg = {**DEFAULT_CFG, **cfg}
     sc, _, _ = derive_geometry(cfg['nfft'], cfg['hop_length'], cfg['lr_sr'], cfg['hr_sr'], cfg['spec_upsample'])
@@ -378,7 +396,7 @@ def aero_forward(sd, cfg, mix, return_spec=False, return_lr_spec=False, fast=Fal
     saved = []
     depth = len(cfg['strides'])
     for i in range(depth):
-        x = enc_layer(sd, i, x, cfg, fast)
+        x = enc_layer(sd, i, x, cfg, fast, train, new_stats)
         if i == 0 and 'freq_emb.embedding.weight' in sd:
             emb = (sd['freq_emb.embedding.weight'] * cfg['emb_scale']).t()[None, :, :, None]
             x = x + cfg['freq_emb'] * emb

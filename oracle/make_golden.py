@@ -143,6 +143,112 @@ def main():
         y, s = wide(x, return_spec=True)
     np.savez_compressed(os.path.join(OUT, 'wide_io.npz'), y=y.numpy(), spec=s.numpy().astype(np.complex64))
 
+    # ---- config 4 at FULL size: [32, 1, 24000]; the first clip's outputs (clips are independent units) ----------
+    xw = seeded((32, 1, 24000), 41)
+    with torch.no_grad():
+        y, s = wide(xw[:1], return_spec=True)
+    np.savez_compressed(os.path.join(OUT, 'wide_full_io.npz'), y=y.numpy()[..., ::4], spec=s.numpy().astype(np.complex64)[:, :, ::4, ::3])
+    meta['wide_full_input_seed'] = 41
+
+    # ---- "trained-like" stress models: LayerScale O(1), live decay, perturbed norms ----------
+    import importlib.util                      # by path: the repo root must NOT be importable here (its `src` shims would
+    sp = importlib.util.spec_from_file_location('aero_stress', os.path.join(HERE, 'stress.py'))   # shadow the reference's)
+    stress_mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(stress_mod)
+    trained_like_ = stress_mod.trained_like_
+    torch.manual_seed(21)
+    st_small = trained_like_(Aero(**SMALL_CFG).eval(), 23)
+    meta['stress_small_seed'], meta['stress_small_perturb_seed'] = 21, 23
+    meta['stress_small_checksums'] = checksums(st_small.state_dict())
+    so = {}
+    with torch.no_grad():
+        for L in (800, 2003):
+            x = seeded((3, 1, L), 2000 + L)
+            y, s = st_small(x, return_spec=True)
+            so[f'y_{L}'], so[f'spec_{L}'] = y.numpy(), s.numpy().astype(np.complex64)
+    np.savez_compressed(os.path.join(OUT, 'stress_small_io.npz'), **so)
+    torch.manual_seed(2036)
+    st_full = trained_like_(Aero(**FULL_CFG).eval(), 2038)
+    meta['stress_full_seed'], meta['stress_full_perturb_seed'] = 2036, 2038
+    meta['stress_full_checksums'] = checksums(st_full.state_dict())
+    x = seeded((2, 1, 8000), 0)
+    taps = {}
+    hooks = [m.register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(f'enc{i}', out)) for i, m in enumerate(st_full.encoder)]
+    hooks += [m.register_forward_hook(lambda mod, inp, out, j=j: taps.__setitem__(f'dec{j}', out)) for j, m in enumerate(st_full.decoder)]
+    with torch.no_grad():
+        y, s = st_full(x, return_spec=True)
+    for h in hooks:
+        h.remove()
+    meta['stress_full_layer_rms'] = {k: float(v.pow(2).mean().sqrt()) for k, v in taps.items()}
+    np.savez_compressed(os.path.join(OUT, 'stress_full_io.npz'), y=y.numpy(), spec=s.numpy().astype(np.complex64),
+                        **{k: v.numpy()[:, ::7, :, ::9].astype(np.float32) for k, v in taps.items()})
+
+    # ---- train mode (FTB BatchNorm on batch statistics + running-stat update, modules.py:287,293,300) ----------
+    torch.manual_seed(11)
+    tr = Aero(**TINY_CFG)
+    randomize_running_stats(tr, 12)
+    tr.train()
+    x = seeded((3, 1, 400), 1400)
+    with torch.no_grad():
+        y, s = tr(x, return_spec=True)
+    bn = {k: v.numpy() for k, v in tr.state_dict().items() if 'running_' in k or 'num_batches' in k}
+    np.savez_compressed(os.path.join(OUT, 'train_tiny_io.npz'), x=x.numpy(), y=y.numpy(), spec=s.numpy().astype(np.complex64),
+                        **{'buf.' + k: v for k, v in bn.items()})
+
+    # ---- op-level vectors from the reference's own modules (modules.py:32-65,94-127,304-325) ----------
+    from src.models.modules import BLSTM, DConv, FTB, LocalState
+    from src.models.snake import Snake
+    from src.models.aero import HDecLayer, HEncLayer
+    mods = {}
+
+    def put(tag, module, outs, **ins):
+        for k, v in module.state_dict().items():
+            mods[f'{tag}.w.{k}'] = v.numpy()
+        for k, v in ins.items():
+            mods[f'{tag}.in.{k}'] = v.numpy()
+        for k, v in outs.items():
+            mods[f'{tag}.out.{k}'] = v.numpy()
+    with torch.no_grad():
+        torch.manual_seed(51)
+        m = BLSTM(8, layers=2, max_steps=200, skip=True).eval()
+        xa, xb = seeded((3, 8, 251), 52), seeded((3, 8, 150), 53)
+        put('blstm', m, dict(framed=m(xa), unframed=m(xb)), framed=xa, unframed=xb)
+        torch.manual_seed(54)
+        m = LocalState(16, heads=4, ndecay=4).eval()
+        m.query_decay.weight.mul_(40.0)
+        m.query_decay.bias.add_(1.0)
+        xa = seeded((2, 16, 77), 55)
+        put('localstate', m, dict(y=m(xa)), x=xa)
+        torch.manual_seed(56)
+        m = FTB(input_dim=16, in_channel=8)
+        randomize_running_stats(m, 57)
+        xa = seeded((3, 8, 16, 21), 58)
+        m.eval()
+        ye = m(xa)
+        m.train()
+        yt = m(xa)
+        put('ftb', m, dict(eval=ye, train=yt), x=xa)                 # weights saved AFTER the train-mode call
+        torch.manual_seed(59)
+        m = Snake(6).eval()
+        xa = seeded((2, 5, 9, 6), 60)
+        put('snake', m, dict(y=m(xa)), x=xa)
+        torch.manual_seed(61)
+        m = DConv(16, compress=4, depth=2, init=0.5, norm=True, time_attn=True, heads=4, ndecay=4, lstm=True,
+                  act_func='snake', freq_dim=4, reshape=True).eval()
+        xa = seeded((2, 16, 4, 40), 62)
+        put('dconv', m, dict(y=m(xa)), x=xa)
+        torch.manual_seed(63)
+        m = HEncLayer(4, 8, kernel_size=8, stride=4, norm_groups=4, freq=True, dconv=False, is_first=False, freq_attn=False,
+                      freq_dim=32, norm=True, context=0, pad=True, rewrite=True).eval()
+        xa = seeded((2, 4, 32, 19), 64)
+        put('henc', m, dict(y=m(xa)), x=xa)
+        torch.manual_seed(65)
+        m = HDecLayer(16, 4, last=False, kernel_size=8, stride=4, norm_groups=4, freq=True, dconv=False, norm=True, context=1,
+                      pad=True, context_freq=True, rewrite=True).eval()
+        xa, sk = seeded((2, 8, 8, 19), 66), seeded((2, 8, 8, 19), 67)
+        put('hdec', m, dict(y=m(xa, sk, None)), x=xa, skip=sk)
+    np.savez_compressed(os.path.join(OUT, 'modules.npz'), **mods)
+
     with open(os.path.join(OUT, 'meta.json'), 'w') as f:
         json.dump(meta, f, indent=1)
     print('golden vectors written to', os.path.abspath(OUT))

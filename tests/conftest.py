@@ -49,9 +49,13 @@ def randomize_running_stats(model, seed):
 
 
 def build_model(meta, which):
-    """Seed-construct the tiny/small/full/wide model exactly as oracle/make_golden.py did."""
+    """Seed-construct the tiny/small/full/wide model exactly as oracle/make_golden.py did.  `stress_small` /
+    `stress_full` are the "trained-like" variants (oracle/stress.py: LayerScale O(1), live attention decay, ...)."""
     from aero_amd import Aero
     torch.manual_seed(meta[f'{which}_seed'])
+    if which.startswith('stress_'):
+        from oracle.stress import trained_like_
+        return trained_like_(Aero(**meta[which[7:] + '_cfg']).eval(), meta[f'{which}_perturb_seed'])
     m = Aero(**meta[f'{which}_cfg']).eval()
     randomize_running_stats(m, meta[f'{which}_bn_seed'])
     return m
