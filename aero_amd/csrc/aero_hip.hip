@@ -6,6 +6,7 @@
 #include "aero_common.h"
 #include "k_attn.h"
 #include "k_conv.h"
+#include "k_conv_ring.h"
 #include "k_ftb.h"
 #include "k_lstm.h"
 #include "k_norm.h"

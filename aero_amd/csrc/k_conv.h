@@ -18,12 +18,8 @@
 #include <stdlib.h>
 
 #include "aero_common.h"
+#include "k_conv_common.h"
 
-struct AeroConvK {
-    aero_conv_desc d;
-    int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec4, vec_out, staged, glds;
-    int nT, f_lo, f_step, t_lo, t_step;      // regular tap grid: df = f_lo + (j / nT) * f_step, dt = t_lo + (j % nT) * t_step
-};
 
 // Shared epilogue of the tiled kernels: D[m = (lane>>4)*4 + r][n = lane&15] per fragment.
 //   v = acc + bias
@@ -580,16 +576,6 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
 // PMC on the first version showed the loop was ISSUE-bound by integer overhead (~200 scalar/vector instructions per
 // 16 MFMAs), not by LDS or HBM: everything lane-dependent is therefore hoisted out of the loop (per-lane pointers and
 // 32-bit offsets), the per-chunk part is a handful of block-uniform scalars, and KC = 64 halves what is left.
-template <int KC>
-static __device__ __forceinline__ int aero_tile_off_kc(int row, int slot) {
-    if (KC == 32) return row * 32 + ((slot ^ ((0 - (row >> 2)) & 3)) << 3);
-    return row * 64 + ((slot ^ ((row >> 1) & 7)) << 3);
-}
-template <int KC>
-static __device__ __forceinline__ int aero_tile_swz(int row) {
-    return KC == 32 ? ((0 - (row >> 2)) & 3) : ((row >> 1) & 7);
-}
-
 template <int MF, int WM, int KC, int NWV>
 struct AeroGldsGeom {
     static constexpr int BM = 16 * MF * WM;
@@ -1465,6 +1451,9 @@ static int aero_conv_pick_bm(int M, int Mpad) {
         else AERO_LAUNCH((K<A, B, false>), grid, block, stream, p);                                            \
     } while (0)
 
+// k_conv_ring.h: the software-pipelined 8-wave kernel for the wide contractions; returns true if it took the launch
+static bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStream_t stream, char* name);
+
 static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const char** err, char* name = nullptr) {
     if (!d || !d->weight || (!d->dst && d->stat_mode != 2)) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
     if (d->ntaps < 1 || d->ntaps > 9) { *err = "conv: ntaps must be 1..9"; return AERO_ERR_ARG; }
@@ -1606,6 +1595,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         // 256-/192-row tiles (8 waves) for the wide compute-bound contractions; AERO_CONV_BM256=0 disables (A/B),
         // =1 only the 256-row tile.  KC 32 here: two 48-KiB blocks (16 waves) per CU measured 937 TF/s on the first
         // decoder layer vs 872 with one 96-KiB KC-64 block and 860 for the 128-row KC-64 tile.
+        if (aero_conv_ring_try(d, p, stream, name)) return AERO_OK;
         static int wide = -1;
         if (wide < 0) { const char* e = getenv("AERO_CONV_BM256"); wide = e ? atoi(e) : 2; }
         const int wbm = (wide >= 1 && d->M % 256 == 0 && p.Ktot >= 1024) ? 256

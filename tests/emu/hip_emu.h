@@ -174,6 +174,27 @@ static inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu::eh8 a, emu::eh8
     return d;
 }
 
+typedef float emu_f16v __attribute__((ext_vector_type(16)));
+// v_mfma_f32_32x32x16_f16: A lane l holds A[i=l&31][k=(l>>5)*8+e]; B lane l holds B[k=(l>>5)*8+e][j=l&31];
+// D lane l reg r holds D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31].
+static inline emu_f16v __builtin_amdgcn_mfma_f32_32x32x16_f16(emu::eh8 a, emu::eh8 b, emu_f16v c, int, int, int) {
+    emu::WaveCtx& w = emu::g_blk->waves[emu::me().wave];
+    int lane = emu::me().lane;
+    w.A[lane] = a;
+    w.B[lane] = b;
+    emu::wave_barrier();
+    emu_f16v d;
+    int j = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float s = c[r];
+        for (int k = 0; k < 16; ++k) s += (float)w.A[i + 32 * (k >> 3)][k & 7] * (float)w.B[j + 32 * (k >> 3)][k & 7];
+        d[r] = s;
+    }
+    emu::wave_barrier();
+    return d;
+}
+
 #define AERO_LAUNCH(kern, grid, block, stream, ...) \
     emu::launch(grid, block, [=]() { kern(__VA_ARGS__); })
 #define AERO_LAUNCH_DYN(kern, grid, block, dyn_bytes, stream, ...) \

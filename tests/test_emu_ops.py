@@ -54,6 +54,15 @@ def test_istft(emu, geom):
     dict(Cin=1024, Cout=256, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=1, T=90, residual=True, B=2),
     dict(Cin=96, Cout=192, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=3, T=150, split=48, act='glu', B=1),   # 192-row tile
     dict(Cin=64, Cout=384, kF=8, kT=1, stride=2, padF=3, padT=0, Fin=6, T=66, B=1, act='gelu'),
+    # software-pipelined ring kernel (aero_conv_ring_kernel): 256x256 / 128x512 / 64x512 tiles, ring of 3-4 K-chunks
+    dict(Cin=128, Cout=256, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=3, T=300, split=64, null0=True, B=1),   # 2 t-tiles, NULL source
+    dict(Cin=112, Cout=256, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=2, T=70, split=48, B=1, act='glu'),    # chunk spans both sources, ragged Cp
+    dict(Cin=1056, Cout=256, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=1, T=61, B=2, act='relu'),             # 33 chunks, one tap
+    dict(Cin=96, Cout=384, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=2, T=530, split=48, B=1, act='glu'),    # <1,8,4>: 128 x 512, 2 t-tiles
+    dict(Cin=96, Cout=128, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=1, T=40, B=1),                          # one row: only 1 f-tap valid
+    dict(Cin=96, Cout=192, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=3, T=501, split=48, B=1, act='glu'),    # <1,8,2>: 64 x 512 (decoder 3)
+    dict(Cin=32, Cout=64, kF=8, kT=1, stride=2, padF=3, padT=0, Fin=6, T=66, B=1, act='gelu') if False else
+    dict(Cin=128, Cout=64, kF=8, kT=1, stride=2, padF=3, padT=0, Fin=6, T=66, B=1, act='gelu'),              # strided taps on <1,8,2>
     # skinny-M streaming kernel (aero_conv_skinny_kernel): two sources, chunk spanning both, NULL first source
     dict(Cin=80, Cout=7, kF=1, kT=3, stride=1, padF=0, padT=1, Fin=3, T=300, split=24, act='gelu'),
     dict(Cin=64, Cout=16, kF=3, kT=1, stride=1, padF=1, padT=0, Fin=4, T=77, split=32, null0=True),

@@ -137,3 +137,73 @@ def test_cpu_tensor_is_refused(meta):
     m = build_model(meta, 'tiny').cuda()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 1, 400))
+
+
+@pytest.mark.parametrize('L', [800, 2003])
+def test_stress_small_model_golden(meta, L):
+    """"Trained-like" weights (oracle/stress.py: LayerScale U(0.2,1), live attention decay, perturbed norms, wide Snake
+    spread): the DConv branch -- LSTM, LocalState, Snake, both conv1d -- is no longer scaled away by 1e-3, so the
+    end-to-end bar of 1e-3 on the complex spectrogram now covers those kernels too."""
+    m = build_model(meta, 'stress_small').cuda()
+    io = load_npz('stress_small_io.npz')
+    y, s, _ = _fwd(m, torch.from_numpy(load_npz('small_io.npz')[f'x_{L}']))
+    e_spec, e_wav = rel_l2(s, io[f'spec_{L}']), rel_l2(y, io[f'y_{L}'])
+    print(f'stress small L={L}: spectrogram rel-L2 {e_spec:.3e}, waveform rel-L2 {e_wav:.3e}')
+    assert e_spec < 1e-3
+    assert e_wav < 5e-3
+
+
+def test_stress_full_model_golden(meta):
+    m = build_model(meta, 'stress_full').cuda()
+    io = load_npz('stress_full_io.npz')
+    x = torch.randn(2, 1, 8000, generator=torch.Generator().manual_seed(0))
+    y, s, _ = _fwd(m, x)
+    e_spec, e_wav = rel_l2(s, io['spec']), rel_l2(y, io['y'])
+    print(f'stress full: spectrogram rel-L2 {e_spec:.3e}, waveform rel-L2 {e_wav:.3e}')
+    assert e_spec < 1e-3
+    assert e_wav < 5e-3
+
+
+def test_config4_full_size(meta):
+    """BASELINE config 4 at full size: [32, 1, 24000] (12->48 kHz, nfft 1024, hop 256, F=512, T=376).  Clip 0 against the
+    reference's output; then size-independent properties over the whole batch: every clip equals its single-clip
+    forward (independence), output length int(L*scale), finite."""
+    m = build_model(meta, 'wide').cuda()
+    io = load_npz('wide_full_io.npz')
+    x = torch.randn(32, 1, 24000, generator=torch.Generator().manual_seed(meta['wide_full_input_seed']))
+    y, s, lr = _fwd(m, x)
+    assert y.shape == (32, 1, 96000) and s.shape == (32, 1, 512, 376) and lr.shape == (32, 1, 512, 376)
+    e_spec, e_wav = rel_l2(s[:1, :, ::4, ::3], io['spec']), rel_l2(y[:1, ..., ::4], io['y'])
+    print(f'config 4 full size: spectrogram rel-L2 {e_spec:.3e}, waveform rel-L2 {e_wav:.3e}')
+    assert e_spec < 1e-3 and e_wav < 5e-3
+    assert torch.isfinite(y).all() and torch.isfinite(torch.view_as_real(s)).all()
+    for i in (0, 17, 31):
+        yi, si, _ = _fwd(m, x[i:i + 1])
+        assert rel_l2(si, s[i:i + 1]) < 1e-5 and rel_l2(yi, y[i:i + 1]) < 1e-5
+    from oracle import aero_oracle as O
+    assert rel_l2(lr[:2], O.spec(x[:2], meta['wide_cfg'])) < 2e-6
+
+
+def test_predict_path_on_a_wav_file(meta, tmp_path):
+    """predict.py's path (BASELINE config 1 plumbing, on the GPU): an 85000-sample 4 kHz wav -> chunks [0,40000),
+    [40000,80000), [80000,85000) (exact), two full chunks batched in ONE forward with overlapped copies, tail alone;
+    the result equals the chunk-by-chunk forward and has 4x the samples; the written file round-trips."""
+    from aero_amd import audio_io, enhance
+    m = build_model(meta, 'full').cuda()
+    sig = 0.1 * torch.randn(1, 85000, generator=torch.Generator().manual_seed(4))
+    p = str(tmp_path / 'in.wav')
+    audio_io.save(p, sig, 4000)
+    lr_sig, sr = audio_io.load(p)
+    assert sr == 4000 and torch.equal(lr_sig, sig)
+    assert enhance.chunk_ranges(85000, sr) == [(0, 40000), (40000, 80000), (80000, 85000)]
+    pr = enhance.predict_signal(m, lr_sig, sr)
+    assert pr.shape == (1, 340000) and torch.isfinite(pr).all()
+    with torch.no_grad():
+        ref = torch.cat([m(lr_sig[:, a:b].unsqueeze(1).cuda()).squeeze(1).cpu() for a, b in enhance.chunk_ranges(85000, sr)], -1)
+    assert rel_l2(pr, ref) < 1e-5
+    pr2 = enhance.predict_signal(m, lr_sig, sr, max_clips=1)          # bounded batches: one chunk per forward, same result
+    assert rel_l2(pr2, ref) < 1e-5
+    out = str(tmp_path / 'out_pr.wav')
+    enhance.write(pr, out, 16000)
+    back, sr2 = audio_io.load(out)
+    assert sr2 == 16000 and torch.allclose(back, pr / max(float(pr.abs().max()), 1.0))

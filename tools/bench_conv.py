@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--T', type=int, default=501)
+    ap.add_argument('--race', type=int, default=0, help='repeat each launch this many times and require bit-identical outputs')
     a = ap.parse_args()
     dev = 'cuda'
     ops = Ops(_lib.load())
@@ -60,6 +61,14 @@ def main():
         for _ in range(3):
             ops.conv(spec, x, sk, a.batch, F, F, a.T, dst=out)
         torch.cuda.synchronize()
+        if a.race:
+            ref = out.clone()
+            bad = 0
+            for _ in range(a.race):
+                out.fill_(float('nan'))
+                ops.conv(spec, x, sk, a.batch, F, F, a.T, dst=out)
+                bad += int((out != ref).sum())
+            print(f'{name}: race screen x{a.race}: {bad} differing elements; finite={bool(torch.isfinite(out).all())}', flush=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
