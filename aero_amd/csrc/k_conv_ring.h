@@ -40,6 +40,11 @@ struct AeroRingGeom {
     static constexpr int SMEM = NS * SLOT > EPI ? NS * SLOT : EPI;                // h16 elements
 };
 
+static __device__ __forceinline__ void aero_sched_fence() {
+#ifndef AERO_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 template <int N>
 static __device__ __forceinline__ void aero_wait_vm() {
 #ifndef AERO_EMU
@@ -55,10 +60,14 @@ static __device__ __forceinline__ void aero_phase_barrier() {
     // the BUILTIN wait (not inline asm) so that hipcc's own scoreboard knows the operand registers fetched during this
     // phase are ready: with an asm wait it re-waits `lgkmcnt(0)` in front of the next phase's first MFMA, i.e. also for
     // the fragment reads just issued for the phase after -- the prefetch would never overlap the MFMAs.
+    // sched_barrier(0): nothing moves across -- hipcc otherwise hoists register-only MFMAs of the next phase over the
+    // s_barrier (legal, but it then waits for this phase's prefetch reads in front of them)
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0); vmcnt / expcnt fields at their maxima
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #endif
 }
 
@@ -124,7 +133,10 @@ static __device__ __forceinline__ void aero_ring_epilogue(const AeroConvK& p, f3
     }
 }
 
-template <int WM, int WN, int NRB>
+// ABL: ablation bits for profiling builds (results are WRONG with any bit set): 1 no barriers in the K loop, 2 no copies
+// in the loop, 4 no fragment reads in the loop, 8 no interleave hints, 16 frozen chunk iterator, 32 no counted vmcnt wait,
+// 64 every copy reads the zero page, 128 no K loop at all (prologue + epilogue only)
+template <int WM, int WN, int NRB, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void aero_conv_ring_kernel(AeroConvK p) {
     typedef AeroRingGeom<WM, WN, NRB> G;
     constexpr int BM = G::BM, BN = G::BN, NS = G::NS, NPH = G::NPH, NIA = G::NIA, NIB = G::NIB, SLOT = G::SLOT;
@@ -186,61 +198,75 @@ __global__ __launch_bounds__(512, 2) void aero_conv_ring_kernel(AeroConvK p) {
     asm volatile("" : "+v"(Tv));
 #endif
 
-    // ---- chunk iterator (frequency tap jf, channel chunk cc, time tap jt -- jt FASTEST so that the three time taps of a
-    // 3x3 re-read the same activation lines back to back: L1/L2 hits instead of a reuse distance of a whole row)
+    // ---- chunk sequence: (frequency tap jf, channel chunk cc, time tap jt), jt FASTEST so that the three time taps of a
+    // 3x3 re-read the same activation lines back to back (L1/L2 hits instead of a reuse distance of a whole row).
+    // The valid frequency taps of a regular grid are a contiguous range [jf_lo, jf_hi), so the number of chunks nk is known
+    // up front and the iterator is BRANCH-FREE (scalar selects): the loop body is straight-line code that the scheduler can
+    // interleave with the MFMAs.  PMC on the first version (branchy iterator, MFMA cluster after it): 6 SALU + 3.6 VALU per
+    // MFMA executed in lockstep by all eight waves BEFORE each 8-MFMA group, MFMA pipe 36 % busy, waves parked 33 %.
     const int nT = p.nT, f_step = p.f_step, t_step = p.t_step, Cpk = p.Cp;
     const int s0f = (int)d.s0_f, s1f = (int)d.s1_f;
     const int t_base = t0 + p.t_lo;
-    int jf = -1, jt = nT - 1, cc = cpt - 1, fi = 0;
-    int kofs = 0, off0 = 0, off1 = 0;
-    bool tin[NIB];
-    auto next_chunk = [&]() -> bool {
-        if (++jt >= nT) {
-            jt = 0;
-            if (++cc >= cpt) {
-                cc = cc_lo;
-                for (;;) {
-                    if (++jf >= nF) return false;
-                    fi = fbase + jf * f_step;
-                    if (fi >= 0 && fi < d.Fin) break;
-                }
+    int jf_lo = 0, jf_hi = 0;
+    {
+        bool seen = false;
+#pragma unroll 1
+        for (int j = 0; j < nF; ++j) {
+            const int f = fbase + j * f_step;
+            if (f >= 0 && f < d.Fin) {
+                if (!seen) jf_lo = j;
+                seen = true;
+                jf_hi = j + 1;
             }
         }
-        kofs = (jf * nT + jt) * Cpk + cc * KC;
-        const int tsh = t_base + jt * t_step;
-#pragma unroll
-        for (int i = 0; i < NIB; ++i) tin[i] = (unsigned)(b_pos[i] + tsh) < (unsigned)Tv;
-        off0 = fi * s0f + tsh * st0 + cc * KC;
-        off1 = fi * s1f + tsh * st1 + cc * KC;
-        return true;
-    };
+    }
+    const int ncc = cpt - cc_lo;
+    const int nk = (ABL & 128) ? 0 : (jf_hi - jf_lo) * ncc * nT;      // K-chunks of this block (block-uniform)
+    int it_jt = 0, it_cc = cc_lo, it_jf = jf_lo, it_n = 0;             // the NEXT chunk to issue
+    int kofs = 0, off0 = 0, off1 = 0, tsh = 0, c_lo = 0, Teff = 0;
+    bool ok = false;
     const bool has0 = s0 != nullptr;
-    // copy instructions [lo, hi) of the current chunk into ring slot `slot`; order: A pieces first, then B pieces
+    // state of chunk it_n -> copy parameters, then advance (no branches)
+    auto next_chunk = [&]() {
+        ok = (ABL & 64) ? false : it_n < nk;
+        const int fi = fbase + it_jf * f_step;
+        kofs = (it_jf * nT + it_jt) * Cpk + it_cc * KC;
+        tsh = t_base + it_jt * t_step;
+        c_lo = it_cc * KC;
+        off0 = fi * s0f + tsh * st0 + c_lo;
+        off1 = fi * s1f + tsh * st1 + c_lo;
+        Teff = ok ? T : 0;                                             // past the end: every B lane reads the zero page
+        ++it_n;
+        const int jt1 = it_jt + 1;
+        const bool wt = jt1 == nT;
+        it_jt = wt ? 0 : jt1;
+        const int cc1 = it_cc + (wt ? 1 : 0);
+        const bool wc = cc1 == cpt;
+        it_cc = wc ? cc_lo : cc1;
+        it_jf += wc ? 1 : 0;
+    };
+    // copy instructions [lo, hi) of the current chunk into ring slot `slot`; order: A pieces first, then B pieces.
+    // Past the last chunk (ok == false) the copies are still issued, from the zero page into a slot nobody reads: the
+    // copy counts per phase -- and with them the counted vmcnt waits -- stay the same for every trip of the loop.
     auto issue = [&](int slot, int lo, int hi) {
         h16* As = smem + slot * SLOT;
         h16* Bs = As + BM * KC;
-        const int c_lo = cc * KC;
         const int lim0 = C0 - c_lo, lim1 = C01 - c_lo;
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
             if (i < lo || i >= hi) continue;
             int s = wave + 8 * i;
             if (s >= BM / 16) s -= BM / 16;
-            aero_glds16(a_ptr[i] + kofs, As + s * 512);
+            aero_glds16(ok ? a_ptr[i] + kofs : zpv, As + s * 512);
         }
 #pragma unroll
         for (int i = 0; i < NIB; ++i) {
             if (NIA + i < lo || NIA + i >= hi) continue;
-            const h16* src;
-            if (lim0 >= KC) src = (tin[i] && has0) ? pb0[i] + off0 : zpv;
-            else if (lim0 <= 0 && lim1 >= KC) src = tin[i] ? pb1[i] + off1 : zpv;
-            else {
-                const bool u0 = b_q8[i] < lim0;
-                const bool ok = tin[i] && (u0 ? has0 : (b_q8[i] < lim1));
-                const h16* ptr = u0 ? pb0[i] + off0 : pb1[i] + off1;
-                src = ok ? ptr : zpv;
-            }
-            aero_glds16(src, Bs + (wave + 8 * i) * 512);
+            const bool tin = (unsigned)(b_pos[i] + tsh) < (unsigned)Teff;
+            const bool u0 = b_q8[i] < lim0;
+            const bool okl = tin && (u0 ? has0 : (b_q8[i] < lim1));
+            const h16* ptr = u0 ? pb0[i] + off0 : pb1[i] + off1;
+            aero_glds16(okl ? ptr : zpv, Bs + (wave + 8 * i) * 512);
         }
     };
 
@@ -277,9 +303,6 @@ __global__ __launch_bounds__(512, 2) void aero_conv_ring_kernel(AeroConvK p) {
             for (int ks = 0; ks < 2; ++ks) Bf[n][ks] = *(const h16x8*)&S[fb_off[ks] + n * 1024];
     };
     auto mma = [&](const h16x8 (&A)[2][2], const h16x8 (&Bf)[2][2], int rb0) {
-#ifndef AERO_EMU
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -287,89 +310,91 @@ __global__ __launch_bounds__(512, 2) void aero_conv_ring_kernel(AeroConvK p) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[rb0 + i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][ks], Bf[n][ks], acc[rb0 + i][n], 0, 0, 0);
+    };
+    // ask the scheduler to spread the phase's bookkeeping (fragment reads, copy issue, iterator) over the gaps between its
+    // eight MFMAs instead of running it as a block in front of them: with two waves per SIMD a wave's MFMA gap is ~64
+    // cycles, i.e. ~10 issue slots.  Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read, 0x4 SALU, 0x2 VALU.
+    auto interleave = [&](int n_ds, int n_vmem) {
 #ifndef AERO_EMU
-        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            if (g < n_ds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x4, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+            if (g >= 2 && g - 2 < n_vmem) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        }
 #endif
     };
 
     // ---- prologue: AHEAD chunks in flight, chunk 0 landed, its first operands in registers
-    int issued = 0;                       // chunks whose copies have been issued
-    bool more = true;                     // the iterator has not run out
     int wslot = 0;                        // ring slot of the next chunk to issue
-#pragma unroll 1
+    auto next_slot = [&](int s) { return s + 1 == NS ? 0 : s + 1; };
+#pragma unroll
     for (int a = 0; a < G::AHEAD; ++a) {
-        more = more && next_chunk();
-        if (!more) break;
+        next_chunk();
         issue(wslot, 0, G::NI);
-        wslot = wslot + 1 == NS ? 0 : wslot + 1;
-        ++issued;
+        wslot = next_slot(wslot);
     }
-    if (more) aero_wait_vm<(G::AHEAD - 1) * G::NI>();
-    else aero_wait_vm<0>();
+    aero_wait_vm<(G::AHEAD - 1) * G::NI>();
     aero_phase_barrier();
     h16x8 A0[2][2], A1[2][2], B0[2][2], B1[2][2];
-    if (issued > 0) {
-        read_a(A0, 0, 0);
-        read_b(B0, 0);
-    }
+    read_a(A0, 0, 0);
+    read_b(B0, 0);
 #ifndef AERO_EMU
     // (the loop must be ENTERED with hipcc's LDS scoreboard empty: otherwise the merged state at the loop header makes it
     // wait lgkmcnt(0) in front of every phase-0 MFMA group, i.e. also for the prefetch reads issued just before)
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
     if constexpr (NPH == 1) {
-        // chunk 1 must have landed before phase 0 reads it
-        if (more) aero_wait_vm<(G::AHEAD - 2) * G::NI>();
-        else aero_wait_vm<0>();
+        aero_wait_vm<(G::AHEAD - 2) * G::NI>();             // chunk 1 must have landed before phase 0 reads it
         aero_phase_barrier();
     }
 
+    if constexpr ((ABL & 4) != 0) {           // (profiling builds without fragment reads in the loop: defined operands)
+        read_a(A1, 0, 2);
+        read_b(B1, 0);
+    }
     int rslot = 0;                        // ring slot of the chunk being computed
-    auto next_slot = [&](int s) { return s + 1 == NS ? 0 : s + 1; };
-    // One K-chunk.  (Ac, Bc): operands of this chunk's first phase, already in registers; (An, Bn): receive the next chunk's.
-    auto tile = [&](h16x8 (&Ac)[2][2], h16x8 (&Bc)[2][2], h16x8 (&An)[2][2], h16x8 (&Bn)[2][2]) {
-        const int nslot = next_slot(rslot);
-        if constexpr (NPH == 2) {
-            // phase 0: row blocks 0,1; fetch row blocks 2,3 of this chunk; first half of the copies AHEAD chunks ahead
-            read_a(An, rslot, 2);
-            more = more && next_chunk();
-            if (more) issue(wslot, 0, G::IPP0);
-            mma(Ac, Bc, 0);
-            if (more) aero_wait_vm<G::VMW>();               // chunk k+1 has landed (this wave's part)
-            else aero_wait_vm<0>();
-            aero_phase_barrier();
-            // phase 1: row blocks 2,3; fetch the next chunk's first operands; second half of the copies
-            read_a(Ac, nslot, 0);
-            read_b(Bn, nslot);
-            if (more) {
-                issue(wslot, G::IPP0, G::NI);
-                wslot = next_slot(wslot);
-                ++issued;
-            }
-            mma(An, Bc, 2);
-            aero_phase_barrier();
-        } else {
-            read_a(An, nslot, 0);
-            read_b(Bn, nslot);
-            more = more && next_chunk();
-            if (more) {
-                issue(wslot, 0, G::NI);
-                wslot = next_slot(wslot);
-                ++issued;
-            }
-            mma(Ac, Bc, 0);
-            if (more) aero_wait_vm<G::VMW>();               // chunk k+2 has landed
-            else aero_wait_vm<0>();
-            aero_phase_barrier();
-        }
-        rslot = nslot;
-    };
     // One chunk per trip; the operands fetched for the next chunk are handed over by register copies (16-32 v_mov per
     // 16 MFMAs).  Alternating the two register sets by NAME over an unrolled pair of chunks looked free but made the
     // allocator spill 130+ registers, accumulators included (hipcc keeps both role assignments live across the back edge).
 #pragma unroll 1
-    for (int k = 0; k < issued; ++k) {
-        tile(A0, B0, A1, B1);
+    for (int k = 0; k < nk; ++k) {
+        const int nslot = next_slot(rslot);
+        if constexpr (NPH == 2) {
+            // phase 0: row blocks 0,1; fetch row blocks 2,3 of this chunk; first half of the copies AHEAD chunks ahead
+            if constexpr (!(ABL & 4)) read_a(A1, rslot, 2);
+            if constexpr (!(ABL & 16)) next_chunk();
+            if constexpr (!(ABL & 2)) issue(wslot, 0, G::IPP0);
+            mma(A0, B0, 0);
+            if constexpr (!(ABL & 8)) interleave(4, G::IPP0);
+            if constexpr (!(ABL & 2) && !(ABL & 32)) aero_wait_vm<G::VMW>();          // chunk k+1 has landed (this wave's part)
+            if constexpr (!(ABL & 1)) aero_phase_barrier();
+            else aero_sched_fence();
+            // phase 1: row blocks 2,3; fetch the next chunk's first operands; second half of the copies
+            if constexpr (!(ABL & 4)) {
+                read_a(A0, nslot, 0);
+                read_b(B1, nslot);
+            }
+            if constexpr (!(ABL & 2)) issue(wslot, G::IPP0, G::NI);
+            wslot = next_slot(wslot);
+            mma(A1, B0, 2);
+            if constexpr (!(ABL & 8)) interleave(8, G::NI - G::IPP0);
+            if constexpr (!(ABL & 1)) aero_phase_barrier();
+            else aero_sched_fence();
+        } else {
+            read_a(A1, nslot, 0);
+            read_b(B1, nslot);
+            next_chunk();
+            issue(wslot, 0, G::NI);
+            wslot = next_slot(wslot);
+            mma(A0, B0, 0);
+            interleave(8, G::NI);
+            aero_wait_vm<G::VMW>();                         // chunk k+2 has landed
+            aero_phase_barrier();
+        }
+        rslot = nslot;
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -409,7 +434,31 @@ static void aero_conv_ring_go(AeroConvK& p, hipStream_t stream, char* name) {
         return;
     }
     const long nwg = (long)d.B * d.Fout * p.ntt * p.nmt;
-    AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB>), dim3((unsigned)nwg), dim3(512), G::SMEM * sizeof(h16), stream, p);
+    const dim3 grid((unsigned)nwg), block(512);
+    const size_t lds = G::SMEM * sizeof(h16);
+#ifdef AERO_RING_ABLATION
+    if constexpr (WM == 2) {
+        static int abl = -1;
+        if (abl < 0) { const char* e = getenv("AERO_RING_ABL"); abl = e ? atoi(e) : 0; }
+        switch (abl) {
+            case 1: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 1>), grid, block, lds, stream, p); return;
+            case 2: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 2>), grid, block, lds, stream, p); return;
+            case 4: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 4>), grid, block, lds, stream, p); return;
+            case 6: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 6>), grid, block, lds, stream, p); return;
+            case 7: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 7>), grid, block, lds, stream, p); return;
+            case 8: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 8>), grid, block, lds, stream, p); return;
+            case 16: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 16>), grid, block, lds, stream, p); return;
+            case 22: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 22>), grid, block, lds, stream, p); return;
+            case 23: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 23>), grid, block, lds, stream, p); return;
+            case 32: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 32>), grid, block, lds, stream, p); return;
+            case 64: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 64>), grid, block, lds, stream, p); return;
+            case 96: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 96>), grid, block, lds, stream, p); return;
+            case 128: AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB, 128>), grid, block, lds, stream, p); return;
+            default: break;
+        }
+    }
+#endif
+    AERO_LAUNCH_DYN((aero_conv_ring_kernel<WM, WN, NRB>), grid, block, lds, stream, p);
 }
 
 #ifndef AERO_RING_ONLY

@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void aero_norm_stats_kernel(aero_norm_desc d, 
     __shared__ double red[2][4];
     const int gs = d.C / d.G;
     const int item = blockIdx.z / d.G, g = blockIdx.z % d.G;
-    const int b = d.per_row ? item / d.F : item;
-    const int f = d.per_row ? item % d.F : blockIdx.y;
+    const int b = d.per_row == 1 ? item / d.F : item;
+    const int f = d.per_row == 1 ? item % d.F : blockIdx.y;
     const int vpp = gs / VEC;
     const int tid = threadIdx.x;
     const bool wide = vpp > 256;
@@ -127,8 +127,10 @@ __global__ __launch_bounds__(256) void aero_norm_stats_kernel(aero_norm_desc d, 
     if (aero_lane() == 0) { red[0][aero_wave()] = ds; red[1][aero_wave()] = dss; }
     __syncthreads();
     if (tid == 0) {
-        atomicAdd(d.stats + (int64_t)blockIdx.z * 2 + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(d.stats + (int64_t)blockIdx.z * 2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        // per_row == 2: one accumulator pair per group for the WHOLE batch (BatchNorm in training mode, modules.py:287)
+        const int64_t slot = d.per_row == 2 ? g : (int64_t)blockIdx.z;
+        atomicAdd(d.stats + slot * 2 + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(d.stats + slot * 2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
 }
 
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void aero_norm_apply_kernel(aero_norm_desc d, 
     const int v = tid % vpp, ty = tid / vpp;
     if (ty >= TY) return;
     const int b = blockIdx.z, f = blockIdx.y;
-    const int item = d.per_row ? b * d.F + f : b;
+    const int item = d.per_row == 1 ? b * d.F + f : (d.per_row == 2 ? 0 : b);
     const int gs = d.C / d.G;
     const int c0 = v * VEC;
     // y = x*A + Bc  (normalisation and affine folded), per owned channel; second half for GLU gates.
@@ -332,12 +334,14 @@ static int aero_norm_stats_launch(const aero_norm_desc* d, hipStream_t stream, c
     if (!d->stats) { *err = "norm_stats: null stats"; return AERO_ERR_ARG; }
     const int gs = d->C / d->G;
     const int vec = aero_norm_pick_vec(gs, d->src, nullptr, nullptr, d->s_b, d->s_f, d->s_t, 0, 0, 0, 0, 0, 0);
-    const int64_t items = d->per_row ? (int64_t)d->B * d->F : d->B;
+    const int64_t items = d->per_row == 1 ? (int64_t)d->B * d->F : d->B;
     if (items * d->G > 65535) { *err = "norm_stats: more than 65535 (item, group) pairs in one launch"; return AERO_ERR_ARG; }
-    const int nf = d->per_row ? 1 : d->F;
+    const int nf = d->per_row == 1 ? 1 : d->F;
     const int vpp = gs / vec;
     const int TY = vpp > 256 ? 1 : 256 / vpp;
-    const int tchunk = aero_norm_tchunk(d->T, TY, items * d->G * nf, gs * 2);
+    // (chunking from the rows of ONE item x 16, not from the batch: a clip's partial sums -- fp32 per thread over a chunk --
+    // must not depend on how many other clips share the launch, or its output would differ between batch sizes / ranks)
+    const int tchunk = aero_norm_tchunk(d->T, TY, (items / d->B) * 16 * d->G * nf, gs * 2);
     dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)nf, (unsigned)(items * d->G)), block(256);
     if (vec == 8) AERO_LAUNCH((aero_norm_stats_kernel<8>), grid, block, stream, *d, tchunk);
     else if (vec == 4) AERO_LAUNCH((aero_norm_stats_kernel<4>), grid, block, stream, *d, tchunk);
@@ -359,7 +363,7 @@ static int aero_norm_apply_launch(const aero_norm_desc* d, hipStream_t stream, c
     const int vpp = Cout / vec;
     if (vpp > 256) { *err = "norm_apply: more than 256 channel vectors per position (C too large)"; return AERO_ERR_UNSUPPORTED; }
     const int TY = 256 / vpp;
-    const int tchunk = aero_norm_tchunk(d->T, TY, (int64_t)d->B * d->F, d->C * 2);
+    const int tchunk = aero_norm_tchunk(d->T, TY, (int64_t)16 * d->F, d->C * 2);
     dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)d->F, (unsigned)d->B), block(256);
     if (vec == 8) AERO_LAUNCH((aero_norm_apply_kernel<8>), grid, block, stream, *d, tchunk);
     else if (vec == 4) AERO_LAUNCH((aero_norm_apply_kernel<4>), grid, block, stream, *d, tchunk);

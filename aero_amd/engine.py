@@ -152,7 +152,7 @@ class Ops:
         self._cur = ar
 
     def new_stats(self, B, F, G, per_row, device):
-        n = (B * F if per_row else B) * G * 2
+        n = (B * F if per_row == 1 else (1 if per_row == 2 else B)) * G * 2
         ar = self._cur
         if ar is not None and ar[0].device == torch.device(device):
             ar[2] += n
@@ -169,15 +169,16 @@ class Ops:
 
     # -- GroupNorm + activation ----------------------------------------------------------------
     def norm_act(self, x, G, per_row, gamma, beta, act, snake_a=None, layer_scale=None, res=None, normalize=True,
-                 f_lo=0, f_cnt=None, eps=1e-5, dst=None, stats=None):
-        """x [B,F,T,C] fp16.  Statistics over all F rows; output only rows [f_lo, f_lo+f_cnt)."""
+                 f_lo=0, f_cnt=None, eps=1e-5, dst=None, stats=None, dst_strides=None):
+        """x [B,F,T,C] fp16.  Statistics over all F rows; output only rows [f_lo, f_lo+f_cnt).
+        per_row: 0 = per (b, group), 1 = per (b, f) row and group, 2 = per group over the whole batch (BatchNorm, training)."""
         B, F, T, Cc = x.shape
         d = _lib.NormDesc()
         d.src = _ptr(x)
         d.s_b, d.s_f, d.s_t = _strides4(x)
         d.B, d.F, d.T, d.C, d.G, d.per_row, d.eps = B, F, T, Cc, G, int(per_row), eps
         if normalize:
-            d.stat_count = float((1 if per_row else F) * T * (Cc // G))
+            d.stat_count = float((1 if per_row == 1 else (B * F if per_row == 2 else F)) * T * (Cc // G))
             if stats is None:                       # not already accumulated by the producing conv's epilogue
                 stats = self.new_stats(B, F, G, per_row, x.device)
                 d.stats = _ptr(stats)
@@ -187,7 +188,7 @@ class Ops:
         assert not (per_row and (f_lo or f_cnt != F))
         Cout = Cc // 2 if act == ACT_GLU else Cc
         out = dst if dst is not None else torch.empty(B, f_cnt, T, Cout, dtype=torch.float16, device=x.device)
-        assert out.shape == (B, f_cnt, T, Cout)
+        assert dst_strides is not None or out.shape == (B, f_cnt, T, Cout)
         d.src = x.data_ptr() + f_lo * x.stride(1) * x.element_size()
         d.F = f_cnt
         d.gamma, d.beta = _ptr(gamma), _ptr(beta)
@@ -197,7 +198,8 @@ class Ops:
         if res is not None:
             d.r_b, d.r_f, d.r_t = _strides4(res)
         d.dst = _ptr(out)
-        d.d_b, d.d_f, d.d_t = _strides4(out)
+        d.d_b, d.d_f, d.d_t = dst_strides if dst_strides is not None else _strides4(out)
+        self._last_stats = stats
         self._call('aero_norm_apply', 'aero_norm_apply_kernel', 0,
                    B * f_cnt * T * (Cc + Cout + (Cout if res is not None else 0)) * 2, C.byref(d), self.stream(x))
         return out
@@ -513,11 +515,15 @@ class HipEngine:
         return y.view(B, Cc, -1)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, mix, want_spec=False, want_lr_spec=False):
-        """Clips are independent units: with `self.streams` > 1 the batch is cut into that many sub-batches whose
+    def forward(self, mix, want_spec=False, want_lr_spec=False, train=False):
+        """`train`: the module is in training mode -- the FTB's BatchNorms use the statistics of this batch and their
+        running statistics are updated (modules.py:287,293,300); nothing else in the forward path depends on the mode.
+        Clips are independent units: with `self.streams` > 1 the batch is cut into that many sub-batches whose
         kernel sequences are enqueued on separate HIP streams, so latency-bound launches of one sub-batch (the
         recurrent LSTM kernel: one block per CU, 200 dependent steps) overlap with bandwidth/MFMA-bound launches of
         the others.  Results are identical to the single-stream order (per-clip arithmetic does not change)."""
+        if train:
+            return self._forward_one(mix, want_spec, want_lr_spec, train=True)
         ns = min(self.streams, mix.shape[0]) if mix.is_cuda else 1
         if self.use_graph and mix.is_cuda and self.ops.prof is None and not self.lib.is_emulator:
             return self._forward_graph(mix, want_spec, want_lr_spec)
@@ -569,8 +575,9 @@ class HipEngine:
         g.replay()
         return tuple(None if t is None else t.clone() for t in static_out)
 
-    def _forward_one(self, mix, want_spec=False, want_lr_spec=False):
+    def _forward_one(self, mix, want_spec=False, want_lr_spec=False, train=False):
         m, ops, P = self.model, self.ops, None
+        self._train = train
         self._check_input(mix)
         if m.in_channels != 1 or m.out_channels != 1:
             raise NotImplementedError('only in_channels = out_channels = 1 (all reference configs)')
@@ -608,6 +615,9 @@ class HipEngine:
 
     def _encode(self, i, enc, L, x, B, Fq, T):
         ops = self.ops
+        if getattr(self, '_train', False) and 'ftb_c1' in L:
+            x = self._encode_head_train(i, enc, L, x, B, Fq, T)
+            return self._encode_tail(i, enc, L, x, B, Fq, T)
         if 'ftb0' in L and self.collapse_first_ftb:
             Cc, rp = L['ftb0']['C'], L['ftb_rp']
             # pad channels (rp > r) must read as zero; with rp == r the conv writes every element
@@ -634,6 +644,65 @@ class HipEngine:
             fc = ops.freqfc(x, L['ftb_fc'], gate.view(B, T, Cc))
             x = ops.conv(L['ftb_c2'], fc, x, B, Fq, Fq, T)
         return x
+
+    def _encode_head_train(self, i, enc, L, x, B, Fq, T):
+        """pre_conv + FTB with the BatchNorms in TRAINING mode (modules.py:304-325 under nn.Module.train()): each conv runs
+        with its raw weights, the per-channel statistics of its output over the whole batch are accumulated
+        (aero_norm_stats, per_row = 2, G = C), BatchNorm + ReLU are applied with them (aero_norm_apply) and the module's
+        running statistics are updated as nn.BatchNorm does (momentum 0.1, unbiased variance)."""
+        ops, dev = self.ops, x.device
+        R = self._train_specs(i, enc, dev)
+        ftb = enc.freq_attn_block
+        if 'pre' in L:
+            x = ops.conv(L['pre'], x, None, B, Fq, Fq, T)
+        Cc, rp, r = R['c2'].M, L['ftb_rp'], R['c1'].M
+
+        def bn(y, bnmod, dst=None, dst_strides=None):
+            Bq, Fy, Ty, Cy = y.shape
+            out = ops.norm_act(y, Cy, 2, bnmod.weight.detach().float(), bnmod.bias.detach().float(), ACT_RELU, eps=bnmod.eps,
+                               dst=dst, dst_strides=dst_strides)
+            st = ops._last_stats                                     # fp64 [Cy, 2]: sum, sum of squares over (B, F, T)
+            n = float(Bq * Fy * Ty)
+            with torch.no_grad():                                    # buffer bookkeeping of nn.BatchNorm (not the data path)
+                mean = st[:, 0] / n
+                var = (st[:, 1] / n - mean * mean).clamp_min(0)
+                mom = bnmod.momentum
+                bnmod.running_mean.mul_(1 - mom).add_(mean.to(bnmod.running_mean.dtype), alpha=mom)
+                bnmod.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(bnmod.running_var.dtype), alpha=mom)
+                bnmod.num_batches_tracked.add_(1)
+            return out
+        y1 = ops.conv(R['c1'], x, None, B, Fq, Fq, T)                                        # [B,F,T,r], pre-BatchNorm
+        c1 = (torch.empty if rp == r else torch.zeros)(B, T, Fq * rp, dtype=torch.float16, device=dev)
+        bn(y1, ftb.conv1[1], dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))                 # -> [B, T, F*rp] image
+        y2 = ops.conv(R['c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)                 # [B,1,T,C]
+        gate = bn(y2, ftb.conv1d[1])
+        fc = ops.freqfc(x, L['ftb_fc'], gate.view(B, T, Cc))
+        y3 = ops.conv(R['c2'], fc, x, B, Fq, Fq, T)
+        return bn(y3, ftb.conv2[1])
+
+    def _train_specs(self, i, enc, device):
+        """conv specs of the FTB with the RAW weights (no BatchNorm fold, no activation): training-mode forward only"""
+        key = ('train_specs', i, self._key)
+        if key not in self._tables:
+            mk = pack.make_conv_spec
+            sd = {k: v.detach().float().cpu() for k, v in enc.freq_attn_block.state_dict().items()}
+            ftb = enc.freq_attn_block
+            Fd, Cc, r = ftb.input_dim, ftb.in_channel, ftb.r_channel
+            rp = r if (Fd * r) % 8 == 0 else 8 * ((r + 7) // 8)
+            w, df, dt = pack.conv2d_taps(sd['conv1.0.weight'], 0, 0)
+            R = {'c1': mk(w, sd['conv1.0.bias'], Cc, 0, df, dt, device)}
+            w = sd['conv1d.0.weight']
+            k9 = w.shape[-1]
+            w = w.view(Cc, r, Fd, k9).permute(0, 3, 2, 1)
+            wp = torch.zeros(Cc, k9, Fd, rp)
+            wp[..., :r] = w
+            R['c1d'] = mk(wp.reshape(1, Cc, k9, Fd * rp), sd['conv1d.0.bias'], Fd * rp, 0, [0] * k9, [j - (k9 // 2) for j in range(k9)], device)
+            w, df, dt = pack.conv2d_taps(sd['conv2.0.weight'], 0, 0)
+            R['c2'] = mk(w, sd['conv2.0.bias'], Cc, Cc, df, dt, device)
+            for k in [k for k in self._tables if isinstance(k, tuple) and k and k[0] == 'train_specs' and k[1] == i]:
+                del self._tables[k]
+            self._tables[key] = R
+        return self._tables[key]
 
     def _encode_tail(self, i, enc, L, x, B, Fq, T):
         ops = self.ops

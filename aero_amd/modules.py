@@ -303,11 +303,12 @@ class Aero(nn.Module):
 
     def forward(self, mix, return_spec=False, return_lr_spec=False):
         """aero.py:446-523.  `mix` [B, in_channels, L] float32 on the MI355X device."""
-        if self.training:
-            raise NotImplementedError('aero_amd runs the forward/inverse spectral path for inference: call '
-                                      'model.eval() first (train-mode BatchNorm statistics and the HIP '
-                                      'backward are not built yet)')
-        x, spec, lr_spec = self._get_engine().forward(mix, want_spec=return_spec, want_lr_spec=return_lr_spec)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('aero_amd: the training-mode FORWARD runs on the MI355X (batch-statistics BatchNorm, '
+                                      'running-stat update), but there are no HIP backward kernels yet -- call it under '
+                                      'torch.no_grad() (or freeze the parameters); autograd through forward is not built')
+        x, spec, lr_spec = self._get_engine().forward(mix, want_spec=return_spec, want_lr_spec=return_lr_spec,
+                                                      train=self.training)
         if return_spec:
             return (x, spec, lr_spec) if return_lr_spec else (x, spec)
         return x

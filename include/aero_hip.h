@@ -114,6 +114,8 @@ int aero_conv_kernel_name(const aero_conv_desc* d, char* name, int32_t cap);
  * +residual) / Snake (aero.py:127,133,198,214; modules.py:141,232-236,244; snake.py:67).
  * per_row == 0: statistics per (b, group) over (f, t, c in group)   [GroupNorm on B,C,F,T]
  * per_row == 1: statistics per (b, f) row and group                 [GroupNorm on B*F,C,T]
+ * per_row == 2: statistics per group over the WHOLE batch (b, f, t, c in group): with G == C this is nn.BatchNorm2d /
+ *               BatchNorm1d in training mode (the FTB's three BatchNorms, modules.py:287,293,300); stats has G pairs
  * aero_norm_stats ADDS sum and sum of squares to stats[(item*G+g)*2 + {0,1}] (fp64; the caller zeroes them);
  * aero_norm_apply derives mean / biased variance from them with stat_count = elements per (item, group)
  * (lets the statistics cover more rows than are output: the trim of aero.py:206-209) and computes

@@ -85,10 +85,44 @@ def test_cpu_input_without_emulator_fails_loudly(meta):
         m(x)
 
 
-def test_train_mode_is_refused(emu, meta):
+def _train_golden(m, io):
+    """Aero.forward in TRAINING mode against the reference's train-mode output (tests/golden/train_tiny_io.npz): the FTB's
+    BatchNorms on batch statistics (modules.py:287,293,300) and the running-statistics update of nn.BatchNorm."""
+    m.train()
+    dev = next(m.parameters()).device
+    with torch.no_grad():
+        y, s = m(torch.from_numpy(io['x']).to(dev), return_spec=True)
+    assert rel_l2(s.cpu(), io['spec']) < 1e-3
+    assert rel_l2(y.cpu(), io['y']) < 5e-3
+    bufs = {k[4:]: v for k, v in io.items() if k.startswith('buf.')}
+    sd = m.state_dict()
+    assert len(bufs) == 36
+    for k, v in bufs.items():
+        got = sd[k].cpu()
+        if k.endswith('num_batches_tracked'):
+            assert int(got) == int(v), k
+        else:                                               # batch statistics of fp16 activations: 2e-3 relative
+            assert torch.allclose(got.double(), torch.from_numpy(v).double(), rtol=3e-3, atol=2e-4), k
+    # the updated running statistics are what the NEXT eval-mode forward folds into the convs
+    m.eval()
+    with torch.no_grad():
+        y2 = m(torch.from_numpy(io['x']).to(dev))
+    assert torch.isfinite(y2).all() and rel_l2(y2.cpu(), y.cpu()) > 1e-4
+
+
+def test_train_mode_forward_golden(emu, meta):
+    _train_golden(_with_engine(build_model(meta, 'tiny'), emu), load_npz('train_tiny_io.npz'))
+
+
+def test_train_mode_with_autograd_is_refused(emu, meta):
+    """There are no HIP backward kernels: a training-mode call that autograd would have to differentiate must fail
+    loudly instead of returning a tensor without a graph."""
     m = _with_engine(build_model(meta, 'tiny'), emu).train()
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 1, 400))
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert m(torch.randn(1, 1, 400, generator=torch.Generator().manual_seed(2))).shape == (1, 1, 1600)
 
 
 def test_weight_update_repacks(emu, meta):

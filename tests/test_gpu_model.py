@@ -207,3 +207,10 @@ def test_predict_path_on_a_wav_file(meta, tmp_path):
     enhance.write(pr, out, 16000)
     back, sr2 = audio_io.load(out)
     assert sr2 == 16000 and torch.allclose(back, pr / max(float(pr.abs().max()), 1.0))
+
+
+def test_train_mode_forward_golden(meta):
+    """Training-mode forward on the MI355X (batch-statistics BatchNorm in the FTBs + running-stat update) against the
+    reference's train-mode output."""
+    from test_emu_model import _train_golden
+    _train_golden(build_model(meta, 'tiny').cuda(), load_npz('train_tiny_io.npz'))

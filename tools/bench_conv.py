@@ -26,10 +26,11 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--T', type=int, default=501)
+    ap.add_argument('--lib', default=None, help='alternative build of the C-ABI library (profiling variants)')
     ap.add_argument('--race', type=int, default=0, help='repeat each launch this many times and require bit-identical outputs')
     a = ap.parse_args()
     dev = 'cuda'
-    ops = Ops(_lib.load())
+    ops = Ops(_lib.load(a.lib))
     for name in a.layers.split(','):
         if name in PW:
             C, M, F = PW[name]
