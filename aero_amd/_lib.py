@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ('stats', dp), ('stat_count', C.c_double),
                 ('stat_mode', i32), ('stat_G', i32), ('stat_per_row', i32), ('stat_eps', C.c_float),
                 ('gamma', fp), ('beta', fp), ('layer_scale', fp),
-                ('scatter_M', i32), ('scatter_stride', i32), ('scatter_off', i32), ('scatter_F', i32)]
+                ('scatter_M', i32), ('scatter_stride', i32), ('scatter_off', i32), ('scatter_F', i32),
+                ('weight_tiled', vp), ('tiled_bm', i32)]
 
 
 class NormDesc(C.Structure):
@@ -74,11 +75,13 @@ class FtbFirstDesc(C.Structure):
 _PROTOS = {
     'aero_version': (C.c_char_p, []),
     'aero_last_error': (C.c_char_p, []),
+    'aero_last_kernel_name': (C.c_char_p, []),
     'aero_stft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, i32, fp, i32, dp, i32, vp]),
     'aero_spec_normalize': (i32, [fp, i32, i64, dp, vp, fp, vp]),
     'aero_istft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, fp, fp, i32, vp]),
     'aero_conv_fwd': (i32, [C.POINTER(ConvDesc), vp]),
     'aero_conv_tile_m': (i32, [i32]),
+    'aero_conv_ring_bm': (i32, [i32, i32]),
     'aero_conv_kernel_name': (i32, [C.POINTER(ConvDesc), C.c_char_p, i32]),
     'aero_norm_stats': (i32, [C.POINTER(NormDesc), vp]),
     'aero_norm_apply': (i32, [C.POINTER(NormDesc), vp]),

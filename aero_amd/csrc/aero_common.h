@@ -24,7 +24,13 @@
 #define aero_rsqrt(x) __builtin_amdgcn_rsqf(x)
 #define aero_med3(x, lo, hi) __builtin_amdgcn_fmed3f((x), (lo), (hi))   /* one-instruction clamp */
 #include <hip/hip_runtime.h>
-#define AERO_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
+// every launch records which instantiation it was: aero_last_kernel_name() (profiling labels that match rocprofv3)
+static thread_local const void* aero_last_kernel_ptr_ = nullptr;
+#define AERO_LAUNCH(kern, grid, block, stream, ...)                                  \
+    do {                                                                             \
+        aero_last_kernel_ptr_ = (const void*)(kern);                                 \
+        hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);               \
+    } while (0)
 // dynamic LDS (up to the full 160 KiB of a CU): one extern array per translation unit
 extern __shared__ __attribute__((aligned(16))) char aero_dyn_smem_[];
 #define AERO_DYN_SMEM aero_dyn_smem_
@@ -35,6 +41,7 @@ extern __shared__ __attribute__((aligned(16))) char aero_dyn_smem_[];
             (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dyn_bytes)); \
             aero_max_dyn_ = (size_t)(dyn_bytes);                                                                      \
         }                                                                                                             \
+        aero_last_kernel_ptr_ = (const void*)(kern);                                                                  \
         hipLaunchKernelGGL(kern, grid, block, dyn_bytes, stream, __VA_ARGS__);                                        \
     } while (0)
 #endif

@@ -15,6 +15,9 @@
 
 #include <stdio.h>
 #include <string.h>
+#ifndef AERO_EMU
+#include <cxxabi.h>
+#endif
 
 static thread_local char g_err[512] = "";
 
@@ -45,6 +48,25 @@ const char* aero_version(void) {
 
 const char* aero_last_error(void) { return g_err; }
 
+const char* aero_last_kernel_name(void) {
+    static thread_local char name[256];
+#ifdef AERO_EMU
+    snprintf(name, sizeof(name), "%s", aero_last_kernel_str_);
+#else
+    name[0] = 0;
+    if (aero_last_kernel_ptr_) {
+        const char* mangled = hipKernelNameRefByPtr(aero_last_kernel_ptr_, nullptr);
+        if (mangled) {
+            int status = 1;
+            char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+            snprintf(name, sizeof(name), "%s", (status == 0 && dem) ? dem : mangled);
+            free(dem);
+        }
+    }
+#endif
+    return name;
+}
+
 int aero_stft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, const float* window,
                   int32_t n_bins, float* spec, int32_t T, double* stats, int32_t sig_per_item, void* stream) {
     const char* err = "";
@@ -74,6 +96,8 @@ int aero_conv_fwd(const aero_conv_desc* d, void* stream) {
 }
 
 int aero_conv_tile_m(int32_t M) { return aero_conv_pick_bm(M, (M + 127) / 128 * 128); }
+
+int aero_conv_ring_bm(int32_t M, int32_t Ktot) { return aero_conv_ring_pick_bm(M, Ktot); }
 
 int aero_conv_kernel_name(const aero_conv_desc* d, char* name, int32_t cap) {
     if (!name || cap < 96) return aero_fail(AERO_ERR_ARG, "conv_kernel_name: buffer of >= 96 bytes required");

@@ -339,9 +339,9 @@ static int aero_norm_stats_launch(const aero_norm_desc* d, hipStream_t stream, c
     const int nf = d->per_row == 1 ? 1 : d->F;
     const int vpp = gs / vec;
     const int TY = vpp > 256 ? 1 : 256 / vpp;
-    // (chunking from the rows of ONE item x 16, not from the batch: a clip's partial sums -- fp32 per thread over a chunk --
-    // must not depend on how many other clips share the launch, or its output would differ between batch sizes / ranks)
-    const int tchunk = aero_norm_tchunk(d->T, TY, (items / d->B) * 16 * d->G * nf, gs * 2);
+    // (chunking from the rows of ONE item x 64, not from the batch: a clip's partial sums -- fp32 per thread over a chunk --
+    // must not depend on how many other clips share the launch (x 64: the batch the chunk sizes were tuned on), or its output would differ between batch sizes / ranks)
+    const int tchunk = aero_norm_tchunk(d->T, TY, (items / d->B) * 64 * d->G * nf, gs * 2);
     dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)nf, (unsigned)(items * d->G)), block(256);
     if (vec == 8) AERO_LAUNCH((aero_norm_stats_kernel<8>), grid, block, stream, *d, tchunk);
     else if (vec == 4) AERO_LAUNCH((aero_norm_stats_kernel<4>), grid, block, stream, *d, tchunk);
@@ -363,7 +363,7 @@ static int aero_norm_apply_launch(const aero_norm_desc* d, hipStream_t stream, c
     const int vpp = Cout / vec;
     if (vpp > 256) { *err = "norm_apply: more than 256 channel vectors per position (C too large)"; return AERO_ERR_UNSUPPORTED; }
     const int TY = 256 / vpp;
-    const int tchunk = aero_norm_tchunk(d->T, TY, (int64_t)16 * d->F, d->C * 2);
+    const int tchunk = aero_norm_tchunk(d->T, TY, (int64_t)64 * d->F, d->C * 2);
     dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)d->F, (unsigned)d->B), block(256);
     if (vec == 8) AERO_LAUNCH((aero_norm_apply_kernel<8>), grid, block, stream, *d, tchunk);
     else if (vec == 4) AERO_LAUNCH((aero_norm_apply_kernel<4>), grid, block, stream, *d, tchunk);

@@ -35,6 +35,8 @@ class Ops:
     def __init__(self, lib):
         self.lib = lib
         self.prof = None          # bench.py sets this to a list to collect per-launch HIP-event timings
+        self.prof_shapes = None   # (tools/launch_table.py) one short shape note per profiled launch
+        self._shape_note = ''
         self._arena, self._cur = {}, None
 
     @staticmethod
@@ -51,7 +53,11 @@ class Ops:
         e0.record()
         self.lib.call(fn, *args)
         e1.record()
-        self.prof.append((kernel, flops, nbytes, e0, e1))
+        name = self.lib.cdll.aero_last_kernel_name().decode() or kernel      # the instantiation as rocprofv3 names it
+        self.prof.append((name, flops, nbytes, e0, e1))
+        if self.prof_shapes is not None:
+            self.prof_shapes.append(self._shape_note)
+        self._shape_note = ''
 
     # -- K1/K2/K15 ---------------------------------------------------------------------------
     def stft(self, x, L, Lp, n_fft, hop, window, n_bins, stats=None, sig_per_item=1):
@@ -100,6 +106,7 @@ class Ops:
             d.s1_b, d.s1_f, d.s1_t = _strides4(src1)
         d.C1 = spec.C1
         d.weight = _ptr(spec.weight)
+        d.weight_tiled, d.tiled_bm = _ptr(spec.weight_tiled), spec.tiled_bm
         d.bias = _ptr(spec.bias)
         d.dst = _ptr(dst)
         if dst is not None:
@@ -130,6 +137,8 @@ class Ops:
             buf = C.create_string_buffer(128)
             self.lib.check(self.lib.cdll.aero_conv_kernel_name(C.byref(d), buf, 128), 'aero_conv_kernel_name')
             kname = buf.value.decode()
+            self._shape_note = (f'conv M={spec.M} C={spec.C0}+{spec.C1}{"(null0)" if src0 is None and spec.C0 else ""} taps={len(spec.df)} '
+                                f'F={Fin}->{Fout} tr={spec.transposed} act={act} res={int(res is not None)} stat={stat["mode"] if stat else 0}')
             pos = B * dst_F * T
             cin_exec = spec.C1 + (spec.C0 if src0 is not None else 0)
             flops = 2.0 * pos * spec.M * len(spec.df) * cin_exec       # executed (NULL source skipped)

@@ -26,6 +26,8 @@ class ConvSpec:
     fstride: int = 1
     act: int = _lib.ACT_NONE
     extra: dict = field(default_factory=dict)
+    weight_tiled: Optional[torch.Tensor] = None     # fp16 [nwset, M/bm, Ktot/32, bm*32]: aero_hip.h "weight_tiled"
+    tiled_bm: int = 0
 
     @property
     def Mout(self):
@@ -56,9 +58,35 @@ def make_conv_spec(w_taps, bias, C0, C1, df, dt, device, transposed=0, fstride=1
     Mpad = _round_up(M, 128)
     img = torch.zeros(nw, Mpad, nt, Cp, dtype=torch.float32)
     img[:, :M, :, :Ct] = w_taps
-    return ConvSpec(weight=img.reshape(nw, Mpad, nt * Cp).to(device=device, dtype=torch.float16).contiguous(),
+    spec = ConvSpec(weight=img.reshape(nw, Mpad, nt * Cp).to(device=device, dtype=torch.float16).contiguous(),
                     bias=None if bias is None else bias.detach().float().to(device).contiguous(),
                     M=M, C0=C0, C1=C1, df=list(df), dt=list(dt), transposed=transposed, fstride=fstride, act=act)
+    bm = ring_bm(M, nt * Cp)
+    if bm:
+        spec.weight_tiled = tile_weights(img.reshape(nw, Mpad, nt * Cp)[:, :M], bm).to(device=device, dtype=torch.float16).contiguous()
+        spec.tiled_bm = bm
+    return spec
+
+
+def ring_bm(M, Ktot):
+    """tile height of the software-pipelined kernel for this contraction (0: not taken) -- asks the library"""
+    try:
+        return int(_lib.load().cdll.aero_conv_ring_bm(M, Ktot))
+    except (ImportError, OSError):
+        return 0
+
+
+def tile_weights(w, bm):
+    """[nw, M, Ktot] -> [nw, M/bm, Ktot/32, bm*32] in the kernel's LDS tile order (include/aero_hip.h, `weight_tiled`):
+    16-byte unit (row, q) of a tile holds channels 8*(q ^ ((-(row >> 2)) & 3)) .. +8 of the 32-channel chunk."""
+    nw, M, K = w.shape
+    assert M % bm == 0 and K % 32 == 0
+    t = w.reshape(nw, M // bm, bm, K // 32, 4, 8).permute(0, 1, 3, 2, 4, 5)          # [nw, mt, kc, row, q_src, 8]
+    row = torch.arange(bm)
+    q = torch.arange(4)
+    src = q[None, :] ^ ((-(row[:, None] >> 2)) & 3)                                    # unit q of `row` reads source slot src
+    idx = src[None, None, None, :, :, None].expand(nw, M // bm, K // 32, bm, 4, 8)
+    return torch.gather(t, 4, idx).reshape(nw, M // bm, K // 32, bm * 32)
 
 
 def bn_fold(w, b, bn_w, bn_b, rm, rv, eps=1e-5):

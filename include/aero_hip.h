@@ -32,6 +32,9 @@ enum { AERO_ACT_NONE = 0, AERO_ACT_RELU = 1, AERO_ACT_GELU = 2, AERO_ACT_GLU = 3
 
 const char* aero_version(void);
 const char* aero_last_error(void);
+/* the kernel instantiation the calling thread's most recent entry-point call launched, as rocprofv3 prints it
+ * (e.g. "void aero_lstm_ring_kernel<12, 2, 3, 6, 4>(AeroLstmK)"); profiling labels only */
+const char* aero_last_kernel_name(void);
 
 /* K1 -- torch.stft(center=True, reflect, normalized=True) of spec.py:12-20 as called by
  * Aero._spec (aero.py:409-421).  x [nsig][L] fp32; the signal is treated as right-zero-padded
@@ -102,10 +105,20 @@ typedef struct {
      * source rows feeds all s residue classes.  Needs fp16 output with scatter_M % 8 == 0; no statistics, residual,
      * frequency embedding or per-item affine (AERO_ERR_UNSUPPORTED otherwise). */
     int32_t scatter_M, scatter_stride, scatter_off, scatter_F;
+    /* Optional second image of the SAME weights, pre-tiled for the software-pipelined wide-contraction kernel (0 = none):
+     * fp16 [nwset][M / tiled_bm][ntaps * Cp / 32][tiled_bm * 32], i.e. one contiguous block per (M-tile, 32-channel
+     * K-chunk kc = tap * Cp/32 + cc) holding the rows of that tile in the kernel's LDS order: 16-byte unit u = row * 4 + q
+     * carries W[m0 + row][kc*32 + 8*(q ^ ((0 - (row >> 2)) & 3)) .. +8).  The kernel then copies a tile with 1-KiB
+     * contiguous reads instead of 16 strided 64-byte pieces per wave instruction.  tiled_bm must equal
+     * aero_conv_ring_bm(M, ntaps * Cp) or the image is ignored. */
+    const void* weight_tiled; int32_t tiled_bm;
 } aero_conv_desc;
 int aero_conv_fwd(const aero_conv_desc* d, void* stream);
 /* rows per block (16/32/48/64/128) of the kernel instantiation aero_conv_fwd picks for M output channels */
 int aero_conv_tile_m(int32_t M);
+/* rows per block (256/128/64) of the software-pipelined kernel for a contraction with M rows and Ktot = ntaps * Cp
+ * columns, or 0 if that kernel does not take the shape: the tile height `weight_tiled` must be prepared for */
+int aero_conv_ring_bm(int32_t M, int32_t Ktot);
 /* the kernel instantiation aero_conv_fwd would launch for this descriptor, as rocprofv3 prints it (e.g.
  * "aero_conv_glds_kernel<4, 2, 64, false>"); nothing is launched.  name must hold >= 96 bytes.  Profiling labels only. */
 int aero_conv_kernel_name(const aero_conv_desc* d, char* name, int32_t cap);

@@ -195,8 +195,9 @@ static inline emu_f16v __builtin_amdgcn_mfma_f32_32x32x16_f16(emu::eh8 a, emu::e
     return d;
 }
 
+static thread_local const char* aero_last_kernel_str_ = "";
 #define AERO_LAUNCH(kern, grid, block, stream, ...) \
-    emu::launch(grid, block, [=]() { kern(__VA_ARGS__); })
+    do { aero_last_kernel_str_ = #kern; emu::launch(grid, block, [=]() { kern(__VA_ARGS__); }); } while (0)
 #define AERO_LAUNCH_DYN(kern, grid, block, dyn_bytes, stream, ...) \
-    emu::launch(grid, block, [=]() { kern(__VA_ARGS__); }, dyn_bytes)
+    do { aero_last_kernel_str_ = #kern; emu::launch(grid, block, [=]() { kern(__VA_ARGS__); }, dyn_bytes); } while (0)
 #define AERO_DYN_SMEM (emu::g_blk->dyn_smem)
