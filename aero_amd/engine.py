@@ -289,13 +289,37 @@ def _hann_padded(win_length, n_fft, device):
     return w.to(device)
 
 
+class _ShapeCache(dict):
+    """Engine-side cache of shape-keyed device buffers / tables / captured graphs.  Entries whose key starts with one of
+    BOUNDED are evicted least-recently-used beyond MAX_PER_KIND per kind: test.py / evaluate feed one variable-length
+    file per forward, and every distinct frame count T would otherwise pin its own padded buffers, envelopes and graphs
+    for the life of the model."""
+    BOUNDED = ('hidpad', 'ones', 'env', 'graph')
+    MAX_PER_KIND = 8
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if isinstance(key, tuple) and key and key[0] in self.BOUNDED:
+            dict.__delitem__(self, key)                       # re-insert: dict order = recency
+            dict.__setitem__(self, key, v)
+        return v
+
+    def __setitem__(self, key, value):
+        dict.__setitem__(self, key, value)
+        if isinstance(key, tuple) and key and key[0] in self.BOUNDED:
+            same = [k for k in self if isinstance(k, tuple) and k and k[0] == key[0]]
+            for k in same[:max(0, len(same) - self.MAX_PER_KIND)]:
+                dict.__delitem__(self, k)
+
+
 class HipEngine:
     def __init__(self, model, lib=None):
         self.model = model
         self.lib = lib if lib is not None else _lib.load()
         self.ops = Ops(self.lib)
         self._key = None
-        self._tables = {}
+        self._params, self._epoch = None, 0
+        self._tables = _ShapeCache()
         self.streams = int(os.environ.get('AERO_STREAMS', '1'))   # sub-batches in flight on separate HIP streams
         self.use_graph = os.environ.get('AERO_GRAPH', '0') != '0'  # replay the forward as a captured HIP graph (per input shape)
         # GroupNorm fused into conv epilogues (stat_mode 1-3 of aero_conv_fwd, lean epilogue paths).  Measured on MI355X:
@@ -311,11 +335,24 @@ class HipEngine:
 
     # ------------------------------------------------------------------ weights
     def _weights_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.model.state_dict(keep_vars=True).values())
+        """(storage address, version counter) of every parameter and buffer.  The tensor list is collected once (the
+        state_dict walk costs more than a small forward); in-place updates through autograd-visible ops bump `_version`,
+        a re-assigned parameter changes the address.  Writes through `.data` (e.g. `p.data.mul_()`) bump NEITHER: call
+        `invalidate()` after such an update."""
+        if self._params is None:
+            self._params = list(self.model.state_dict(keep_vars=True).values())
+        return (str(device), self._epoch) + tuple((p.data_ptr(), p._version) for p in self._params)
+
+    def invalidate(self):
+        """Forget the packed weights (and captured graphs): the next forward repacks from the module's tensors.  Needed
+        only after weight edits the version counters cannot see (`.data` writes, load through external memory)."""
+        self._epoch += 1
+        self._params = None
 
     def _prepare(self, device):
         key = self._weights_key(device)
         if key != self._key:
+            self._params = None                         # re-collect: load_state_dict / new Parameter objects
             self._pack(device)
             self._key = key
             for k in [k for k in self._tables if isinstance(k, tuple) and k and k[0] == 'graph']:
@@ -633,8 +670,10 @@ class HipEngine:
             c1 = (torch.empty if rp == L['ftb0_c1'].M else torch.zeros)(B, T, Fq * rp, dtype=torch.float16, device=x.device)
             ops.conv(L['ftb0_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
             gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)      # [B,1,T,Cc]
-            ones = self._tables.setdefault(('ones', B, T, str(x.device)),
-                                           torch.ones(B, T, 2, dtype=torch.float16, device=x.device))
+            okey = ('ones', B, T, str(x.device))
+            if okey not in self._tables:                # (setdefault would allocate and fill a fresh tensor on every forward)
+                self._tables[okey] = torch.ones(B, T, 2, dtype=torch.float16, device=x.device)
+            ones = self._tables[okey]
             u = ops.freqfc(x, L['ftb_fc'], ones)                                           # freq_fc on (re, im) only
             x = ops.ftb_first(x, u, gate.view(B, T, Cc), L['ftb0'])
         elif 'ftb_c1' in L or 'pre' in L:

@@ -288,6 +288,12 @@ class Aero(nn.Module):
             object.__setattr__(self, '_engine', HipEngine(self))
         return self._engine
 
+    def repack(self):
+        """Tell the device engine that the weights were edited in a way version counters cannot see (writes through
+        `.data`, as `rescale_module` and many EMA helpers do): the next forward repacks them."""
+        if self._engine is not None:
+            self._engine.invalidate()
+
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_engine'] = None

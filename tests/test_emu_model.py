@@ -133,3 +133,25 @@ def test_weight_update_repacks(emu, meta):
         m.decoder[3].conv_tr.bias.add_(1.0)
         y1 = m(x)
     assert not np.allclose(y0.numpy(), y1.numpy())
+
+
+def test_data_writes_need_repack_and_shape_cache_is_bounded(emu, meta):
+    """`.data` writes do not bump version counters: Aero.repack() makes the engine see them.  Shape-keyed engine caches
+    (padded buffers, envelopes, graphs) stay bounded when every forward has a new length (evaluate over a test set)."""
+    m = _with_engine(build_model(meta, 'tiny'), emu)
+    x = torch.randn(1, 1, 400, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        y0 = m(x)
+        m.decoder[3].conv_tr.weight.data.mul_(1.5)          # (weights are repacked to fp16 images: a copy, not a view)
+        y_stale = m(x)
+        m.repack()
+        y1 = m(x)
+        assert torch.equal(y0, y_stale) and not torch.equal(y0, y1)
+        for L in range(400, 400 + 16 * 14, 16):
+            m(torch.zeros(1, 1, L))
+    eng = m._get_engine()
+    kinds = {}
+    for k in eng._tables:
+        if isinstance(k, tuple):
+            kinds[k[0]] = kinds.get(k[0], 0) + 1
+    assert all(n <= 8 for kind, n in kinds.items() if kind in ('hidpad', 'ones', 'env', 'graph')), kinds
