@@ -12,8 +12,9 @@
 #pragma once
 #include "aero_common.h"
 
-#define AERO_FFT_MAX_N 512   /* complex points = n_fft/2  ->  n_fft <= 1024 */
-#define AERO_STFT_SPAN 1536  /* samples of signal a block's frames may share through LDS */
+#define AERO_FFT_MAX_N 512    /* iSTFT: complex points = n_fft/2  ->  n_fft <= 1024 */
+#define AERO_STFT_MAX_N 1024  /* STFT:  n_fft <= 2048 (the loss / metric geometries of stft_loss.py:120-123, metrics.py:58) */
+#define AERO_STFT_SPAN 1536   /* default samples of signal a block's frames share through LDS (grown per launch if needed) */
 
 static __device__ __forceinline__ f32x2 aero_cmul(f32x2 a, f32x2 b) {
     return (f32x2){a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]};
@@ -115,13 +116,14 @@ static __device__ __forceinline__ f32x2* aero_fft_wave(f32x2* a, f32x2* b, int n
 struct AeroStftK {
     const float* x; const float* window; float* spec; double* stats;
     int nsig, L, Lp, n_fft, hop, n_bins, T, sig_per_item, FPB;
+    int span_cap;                                  // floats of LDS reserved for the shared signal span (0: read frames from global)
 };
 
 // dynamic LDS sized by the actual n = n_fft/2 and frames per block (statically sized for n_fft = 1024 it was 62 KiB:
 // two blocks per CU):   tw[n] | bufA[4][n] | bufB[4][n] | tile[n_bins*FPB]   (f32x2)   then   wl[n_fft] | xsp[SPAN]   (float)
-static inline size_t aero_stft_lds_bytes(int n_fft, int n_bins, int fpb) {
+static inline size_t aero_stft_lds_bytes(int n_fft, int n_bins, int fpb, int span_cap) {
     const size_t n = (size_t)n_fft / 2;
-    return (n + 8 * n + (size_t)n_bins * (fpb + 1)) * sizeof(f32x2) + ((size_t)n_fft + AERO_STFT_SPAN) * sizeof(float);
+    return (n + 8 * n + (size_t)n_bins * (fpb + 1)) * sizeof(f32x2) + ((size_t)n_fft + (size_t)span_cap) * sizeof(float);
 }
 
 static inline int aero_stft_fpb(int n) { int f = 2048 / n; return f > 32 ? 32 : (f < 4 ? 4 : f); }   // frames per block (power of two)
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
     // LDS once, with independent coalesced loads.  (Reading window[ni] and then, if non-zero, x[...] from global memory
     // per element made every frame a chain of ~16 dependent L2 round trips: 134 us for a 68-MB kernel.)
     const int span = (FPB - 1) * p.hop + n_fft;
-    const bool staged = span <= AERO_STFT_SPAN;
+    const bool staged = span <= p.span_cap;
     const bool vec = staged && !(p.hop & 1);                     // 8-byte LDS reads (the scalar form is a stride-2 bank pattern)
     for (int i = threadIdx.x; i < n_fft; i += 256) wl[i] = p.window[i];
     if (staged) {
@@ -373,7 +375,7 @@ static int aero_stft_launch(const float* x, int nsig, int L, int Lp, int n_fft, 
                             float* spec, int T, double* stats, int sig_per_item, hipStream_t stream, const char** err) {
     if (!x || !window || !spec) { *err = "stft: null pointer"; return AERO_ERR_ARG; }
     const int n = n_fft / 2;
-    if (n_fft < 16 || (1 << aero_ilog2(n_fft)) != n_fft || n > AERO_FFT_MAX_N) { *err = "stft: n_fft must be a power of two in [16,1024]"; return AERO_ERR_UNSUPPORTED; }
+    if (n_fft < 16 || (1 << aero_ilog2(n_fft)) != n_fft || n > AERO_STFT_MAX_N) { *err = "stft: n_fft must be a power of two in [16,2048]"; return AERO_ERR_UNSUPPORTED; }
     if (hop < 1 || Lp < L || T != 1 + Lp / hop) { *err = "stft: inconsistent L/Lp/hop/T"; return AERO_ERR_ARG; }
     if (Lp <= n) { *err = "stft: signal shorter than the reflect pad"; return AERO_ERR_ARG; }
     if (n_bins != n && n_bins != n + 1) { *err = "stft: n_bins must be n_fft/2 or n_fft/2+1"; return AERO_ERR_ARG; }
@@ -385,12 +387,18 @@ static int aero_stft_launch(const float* x, int nsig, int L, int Lp, int n_fft, 
     const int fpb = aero_stft_fpb(n);
     p.FPB = fpb;
     dim3 grid((unsigned)((T + fpb - 1) / fpb), (unsigned)nsig), block(256);
-    const size_t lds = aero_stft_lds_bytes(n_fft, n_bins, fpb);
+    // the signal span the block's frames share: staged in LDS when it fits next to the FFT buffers (160 KiB per CU)
+    const int span = (fpb - 1) * hop + n_fft;
+    p.span_cap = span > AERO_STFT_SPAN ? span : AERO_STFT_SPAN;
+    if (aero_stft_lds_bytes(n_fft, n_bins, fpb, p.span_cap) > 160 * 1024) p.span_cap = 0;
+    const size_t lds = aero_stft_lds_bytes(n_fft, n_bins, fpb, p.span_cap);
+    if (lds > 160 * 1024) { *err = "stft: frame buffers exceed the LDS"; return AERO_ERR_UNSUPPORTED; }
     switch (n) {                                            // compile-time sizes for the usual n_fft; run-time n otherwise
         case 64: AERO_LAUNCH_DYN(aero_stft_kernel<6>, grid, block, lds, stream, p); break;
         case 128: AERO_LAUNCH_DYN(aero_stft_kernel<7>, grid, block, lds, stream, p); break;
         case 256: AERO_LAUNCH_DYN(aero_stft_kernel<8>, grid, block, lds, stream, p); break;
         case 512: AERO_LAUNCH_DYN(aero_stft_kernel<9>, grid, block, lds, stream, p); break;
+        case 1024: AERO_LAUNCH_DYN(aero_stft_kernel<10>, grid, block, lds, stream, p); break;
         default: AERO_LAUNCH_DYN(aero_stft_kernel<0>, grid, block, lds, stream, p); break;
     }
     return AERO_OK;

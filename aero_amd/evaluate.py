@@ -20,7 +20,12 @@ def stft_mag(x, nfft=2048, hop=512):
 
 
 def lsd(ref_sig, out_sig):
-    """metrics.py:58-70: mean over frames of sqrt(mean over FREQUENCY of (log10|R|^2 - log10|O|^2)^2); inputs [B, T]."""
+    """metrics.py:58-70: mean over frames of sqrt(mean over FREQUENCY of (log10|R|^2 - log10|O|^2)^2); inputs [B, T].
+    Signals on the MI355X go through the HIP STFT (aero_amd.losses.lsd); host tensors (a caller that already moved its
+    results off the device, as run_metrics' reference does) are measured with torch.stft on the host."""
+    if ref_sig.is_cuda and out_sig.is_cuda:
+        from .losses import lsd as lsd_device
+        return lsd_device(ref_sig, out_sig)
     sp = torch.log10(stft_mag(ref_sig).square().clamp(1e-8))
     st = torch.log10(stft_mag(out_sig).square().clamp(1e-8))
     return (sp - st).square().mean(dim=1).sqrt().mean()
@@ -42,6 +47,8 @@ def evaluate_lr_hr(model, lr, hr):
 
 def run_metrics(hr, pr):
     """metrics.py:20-33 without the external ViSQOL binary: (lsd, visqol=0); hr, pr are [B,1,T] CPU tensors."""
+    if hr.is_cuda and pr.is_cuda:
+        return lsd(hr.squeeze(1).float(), pr.squeeze(1).float()).item(), 0         # HIP STFT, tensors stay on the device
     return lsd(hr.squeeze(1).float().cpu(), pr.squeeze(1).float().cpu()).item(), 0
 
 
@@ -55,7 +62,8 @@ def evaluate(model, pairs, device='cuda', rank=0, world_size=1):
             continue
         lr = lr if lr.dim() == 3 else lr.unsqueeze(0)
         hr = hr if hr.dim() == 3 else hr.unsqueeze(0)
-        out = evaluate_lr_hr(model, lr.to(device), hr.to(device))
+        hr = hr.to(device)
+        out = evaluate_lr_hr(model, lr.to(device), hr)
         lsd_i, _ = run_metrics(hr, out['pr'])
         total += lsd_i
         count += 1

@@ -43,13 +43,16 @@ def q16(x):
 
 
 # ------------------------------------------------------------------------------------------------
-def case_stft(lib, dev, nfft, hop, win, L, B=2):
+def case_stft(lib, dev, nfft, hop, win, L, B=2, nyquist=False):
+    """nyquist=True keeps bin n_fft/2 (the loss / metric STFTs of stft_loss.py:22 and metrics.py:50 are one-sided with it)"""
     ops = Ops(lib)
     x = _rand((B, L), 1)
     pad = (hop - L % hop) % hop
     stats = torch.zeros(B, 2, dtype=torch.float64, device=dev)
-    z = ops.stft(x.to(dev), L, L + pad, nfft, hop, _hann_padded(win, nfft, dev), nfft // 2, stats=stats)
-    zr = O.stft(F.pad(x, (0, pad)), nfft, hop, win)[..., :-1, :]
+    z = ops.stft(x.to(dev), L, L + pad, nfft, hop, _hann_padded(win, nfft, dev), nfft // 2 + int(nyquist), stats=stats)
+    zr = O.stft(F.pad(x, (0, pad)), nfft, hop, win)
+    if not nyquist:
+        zr = zr[..., :-1, :]
     assert rel_l2(torch.view_as_complex(z.cpu()), zr) < TOL32
     v = torch.view_as_real(zr).double()
     ref = torch.stack([v.sum(dim=(1, 2, 3)), (v * v).sum(dim=(1, 2, 3))], 1)

@@ -22,6 +22,13 @@ def test_stft(emu, geom):
     oc.case_stft(emu, DEV, *geom)
 
 
+@pytest.mark.parametrize('geom', [(1024, 120, 600, 3000), (2048, 240, 1200, 5000), (512, 50, 240, 1777), (2048, 512, 2048, 6000)])
+def test_stft_loss_and_metric_geometries(emu, geom):
+    """The multi-resolution STFT loss (stft_loss.py:120-123: 1024/120/600, 2048/240/1200, 512/50/240) and LSD (metrics.py:58:
+    2048/512) geometries: hop does not divide n_fft, windows shorter than n_fft and not powers of two, n_fft 2048, Nyquist kept."""
+    oc.case_stft(emu, DEV, *geom, nyquist=True)
+
+
 @pytest.mark.parametrize('geom', [(128, 16, 128, 26), (512, 64, 512, 33), (1024, 256, 1024, 9), (256, 32, 252, 40), (64, 16, 64, 30), (32, 8, 32, 17)])
 def test_istft(emu, geom):
     oc.case_istft(emu, DEV, *geom)

@@ -24,6 +24,12 @@ def test_stft(lib, geom):
     oc.case_stft(lib, DEV, *geom, B=3)
 
 
+@pytest.mark.parametrize('geom', [(1024, 120, 600, 32000), (2048, 240, 1200, 32000), (512, 50, 240, 32000), (2048, 512, 2048, 32000), (2048, 512, 2048, 5000)])
+def test_stft_loss_and_metric_geometries(lib, geom):
+    """stft_loss.py:120-123 and metrics.py:58 geometries on the HIP STFT (<= 2e-6 vs the oracle)."""
+    oc.case_stft(lib, DEV, *geom, B=4, nyquist=True)
+
+
 @pytest.mark.parametrize('geom', [(512, 64, 512, 501), (1024, 256, 1024, 376), (128, 16, 128, 101), (512, 128, 512, 251), (64, 16, 64, 30), (32, 8, 32, 17), (256, 32, 252, 40)])
 def test_istft(lib, geom):
     oc.case_istft(lib, DEV, *geom, B=3)
@@ -106,3 +112,28 @@ def test_localstate(lib, kw):
 @pytest.mark.parametrize('kw', [dict(Fq=256, Cc=48, T=501, B=1), dict(Fq=64, Cc=48, T=501), dict(Fq=8, Cc=192, T=501), dict(Fq=4, Cc=4, T=9, B=1)])
 def test_freqfc(lib, kw):
     oc.case_freqfc(lib, DEV, **kw)
+
+
+def test_spectral_losses_on_the_hip_stft():
+    """aero_amd.losses (stft_loss.py:84-161, metrics.py:58-70 restated on aero_stft_fwd) against torch.stft on the host."""
+    import torch.nn.functional as F
+    from aero_amd import evaluate as ev, losses
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(3, 16000, generator=g)
+    x = y + 0.3 * torch.randn(3, 16000, generator=g)
+
+    def mag(v, n, h, w):
+        z = torch.stft(v, n, h, w, torch.hann_window(w), return_complex=True)
+        return torch.sqrt(torch.clamp(z.real ** 2 + z.imag ** 2, min=1e-7)).transpose(2, 1)
+    sc_ref = mag_ref = 0.0
+    for n, h, w in ((1024, 120, 600), (2048, 240, 1200), (512, 50, 240)):
+        xm, ym = mag(x, n, h, w), mag(y, n, h, w)
+        got = losses.stft_magnitude(x.cuda(), n, h, w).cpu()
+        assert got.shape == xm.shape and oc.rel_l2(got, xm) < 1e-5
+        sc_ref = sc_ref + torch.norm(ym - xm, p='fro') / torch.norm(ym, p='fro')
+        mag_ref = mag_ref + F.l1_loss(torch.log(ym), torch.log(xm))
+    sc, mg = losses.MultiResolutionSTFTLoss()(x.cuda(), y.cuda())
+    assert abs(float(sc) - 0.1 * float(sc_ref) / 3) < 1e-5 and abs(float(mg) - 0.1 * float(mag_ref) / 3) < 1e-5
+    want = float(ev.lsd(y, x))                                   # host path (torch.stft)
+    assert abs(float(ev.lsd(y.cuda(), x.cuda())) - want) < 2e-4 * want
+    assert float(ev.lsd(y.cuda(), y.cuda())) == 0.0
