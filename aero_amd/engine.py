@@ -330,6 +330,7 @@ class HipEngine:
         self.fuse_dconv_tail = os.environ.get('AERO_FUSE_DCONV', '1') != '0'       # DConv tail as a recompute pair of conv launches (2C-channel tensor never stored)
         self.gram_stats = os.environ.get('AERO_GRAM_STATS', '1') != '0'    # DConv tail statistics from the Gram matrix of conv2's input (k_gram.h)
         self.fuse_stats = os.environ.get('AERO_FUSE_STATS', '0') != '0'    # GroupNorm statistics accumulated in the producing conv's epilogue
+        self.ring_stats = os.environ.get('AERO_RING_STATS', '1') != '0'    # GroupNorm statistics in the ring conv kernel's epilogue
         self.fuse_lstm_proj = True         # W_ih x_t inside the recurrent kernel (no 8H-channel pre-activation tensor in HBM)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
 
@@ -836,8 +837,12 @@ class HipEngine:
                              layer_scale=L['scale'], res=x, normalize=g2 is not None, stats=st2)
         return x
 
-    def _stats_for(self, M, G, B, F, device):
-        """fp64 accumulators for a GroupNorm over [B, M, F, T] if the conv epilogue can fill them, else None"""
+    def _stats_for(self, M, G, B, F, device, spec=None):
+        """fp64 accumulators for a GroupNorm over [B, M, F, T] if the conv epilogue can fill them, else None.
+        The software-pipelined wide-contraction kernel (spec.tiled_bm) accumulates them for free in its epilogue when the
+        groups are 32-row aligned; the other tile kernels only on request (AERO_FUSE_STATS: measured slower there)."""
+        if spec is not None and spec.tiled_bm and self.ring_stats and M % G == 0 and (M // G) % 32 == 0:
+            return self.ops.new_stats(B, F, G, False, device)
         if self.fuse_stats and self.ops.can_fuse_stats(M, G):
             return self.ops.new_stats(B, F, G, False, device)
         return None
@@ -878,7 +883,7 @@ class HipEngine:
         ops = self.ops
         if 'rewrite' in L:
             if dec.norm:
-                st = self._stats_for(L['rewrite'].M, dec.norm_groups, B, Fq, skip.device)
+                st = self._stats_for(L['rewrite'].M, dec.norm_groups, B, Fq, skip.device, spec=L['rewrite'])
                 r = ops.conv(L['rewrite'], x, skip, B, Fq, Fq, T, stat=self._acc(st, dec.norm_groups))
                 y = ops.norm_act(r, dec.norm_groups, False, L['norm1'][0], L['norm1'][1], ACT_GLU, stats=st)
             else:

@@ -87,7 +87,9 @@ def test_conv_tiny(emu, kw):
     oc.case_conv_tiny(emu, DEV, **kw)
 
 
-@pytest.mark.parametrize('kw', [dict(Cin=12, Cout=96, kF=1, kT=1, Fq=3, T=70, per_row=True), dict(Cin=32, Cout=64, kF=1, kT=1, Fq=4, T=140, G=4), dict(Cin=128, Cout=256, kF=3, kT=3, Fq=2, T=130, B=1)])
+@pytest.mark.parametrize('kw', [dict(Cin=12, Cout=96, kF=1, kT=1, Fq=3, T=70, per_row=True), dict(Cin=32, Cout=64, kF=1, kT=1, Fq=4, T=140, G=4), dict(Cin=128, Cout=256, kF=3, kT=3, Fq=2, T=130, B=1),
+                                # ring kernel epilogue statistics: 4 groups of 64 / 96 rows, ragged second time tile, 192-row tile
+                                dict(Cin=128, Cout=256, kF=3, kT=3, Fq=2, T=300, B=1, G=4), dict(Cin=96, Cout=384, kF=3, kT=3, Fq=2, T=70, B=2, G=4)])
 def test_conv_stats(emu, kw):
     oc.case_conv_stats(emu, DEV, **kw)
 

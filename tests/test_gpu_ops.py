@@ -58,7 +58,8 @@ def test_conv_tiny(lib, kw):
     oc.case_conv_tiny(lib, DEV, **kw)
 
 
-@pytest.mark.parametrize('kw', [dict(Cin=12, Cout=96, kF=1, kT=1, Fq=64, T=501, per_row=True), dict(Cin=96, Cout=192, kF=1, kT=1, Fq=16, T=501, G=4), dict(Cin=384, Cout=768, kF=3, kT=3, Fq=8, T=501, B=1), dict(Cin=96, Cout=384, kF=3, kT=3, Fq=16, T=501, B=1, G=4), dict(Cin=48, Cout=384, kF=1, kT=1, Fq=8, T=501, per_row=True)])
+@pytest.mark.parametrize('kw', [dict(Cin=12, Cout=96, kF=1, kT=1, Fq=64, T=501, per_row=True), dict(Cin=96, Cout=192, kF=1, kT=1, Fq=16, T=501, G=4), dict(Cin=384, Cout=768, kF=3, kT=3, Fq=8, T=501, B=1), dict(Cin=96, Cout=384, kF=3, kT=3, Fq=16, T=501, B=1, G=4), dict(Cin=48, Cout=384, kF=1, kT=1, Fq=8, T=501, per_row=True),
+                                dict(Cin=384, Cout=1536, kF=3, kT=3, Fq=4, T=501, B=2, G=4)])
 def test_conv_stats(lib, kw):
     oc.case_conv_stats(lib, DEV, **kw)
 
