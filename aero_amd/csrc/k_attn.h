@@ -17,20 +17,26 @@
 #pragma once
 #include "aero_common.h"
 
-#define AERO_ATTN_KC 256                 /* keys per LDS chunk */
-#define AERO_ATTN_VS (AERO_ATTN_KC + 4)  /* V^T row pitch (halfs): +8 B breaks the ds_read_b64 bank pattern */
+#define AERO_ATTN_KC 256                 /* keys per LDS chunk (streaming form) */
+#define AERO_ATTN_KRES 512               /* keys held in LDS by the resident form (T <= 512: every reference config at 2-s clips) */
 
-template <int DT>  // number of 16-row output tiles: head dim <= 16*DT
+// RES = true (T <= AERO_ATTN_KRES; option, off): the block stages K and V^T of its (row, head) ONCE and walks over all query
+// blocks of the row.  The streaming form (one block per 128 queries, keys in chunks of 256) re-stages the whole row's K/V
+// for each of the four query blocks (PMC: 729 MB fetched for a 107-MB tensor) -- but removing that re-fetch did not help,
+// see the launcher.
+template <int DT, bool RES>  // DT = number of 16-row output tiles: head dim <= 16*DT
 __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
-    __shared__ AERO_LDS_ALIGN h16 Ks[AERO_ATTN_KC * 32];
-    __shared__ AERO_LDS_ALIGN h16 Vt[DT * 16 * AERO_ATTN_VS];
+    constexpr int KC = RES ? AERO_ATTN_KRES : AERO_ATTN_KC;
+    constexpr int VS = KC + 4;                                   // V^T row pitch (halfs): +8 B breaks the ds_read_b64 bank pattern
+    __shared__ AERO_LDS_ALIGN h16 Ks[KC * 32];
+    __shared__ AERO_LDS_ALIGN h16 Vt[DT * 16 * VS];
     __shared__ AERO_LDS_ALIGN h16 Qs[128 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int g = lane >> 4, col = lane & 15;
     const int h = blockIdx.y, row = blockIdx.z;
     const int C = d.C, T = d.T;
     const int dh = C / d.heads;
-    const int s_blk = blockIdx.x * 128;
+    const int nqb = RES ? (T + 127) / 128 : 1;                   // query blocks this CTA walks over
     const h16* base = (const h16*)d.qkvd + (int64_t)row * T * d.ld;
     // the softmax runs in the log2 domain: log2(e) is folded into the query scale, the decay slope and the self-kill value,
     // so every probability is ONE subtraction and one bare v_exp_f32
@@ -39,6 +45,13 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
 
     // staging moves 4 channels (8 bytes) per step when the head slices are 8-byte aligned, else scalars
     const bool vec4 = (dh % 4 == 0) && (d.ld % 4 == 0) && (C % 4 == 0) && (((uintptr_t)d.qkvd & 7) == 0);
+    const int nc4 = (dh + 3) >> 2;                               // 8-byte pieces per head slice: only those are requested
+    float koff[8];                                               // position of key slot e inside a 32-key block (lane constant)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) koff[e] = (float)(((e >> 2) << 4) + g * 4 + (e & 3));
+  for (int qb = 0; qb < nqb; ++qb) {
+    const int s_blk = (RES ? qb : (int)blockIdx.x) * 128;
+    if (RES && qb > 0) __syncthreads();                          // every wave has taken its query fragment of the previous block
     // ---- queries of this block: [128][32], pre-scaled by 1/sqrt(dh), zero padded
     if (vec4) {
         for (int idx = tid; idx < 128 * 8; idx += 512) {
@@ -69,9 +82,6 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
         for (int f = 0; f < d.ndecay; ++f) Dq += (float)(f + 1) * aero_sigmoid((float)dp[f]);
         Dq *= L2E * 0.5f / sqrtf((float)(d.ndecay > 0 ? d.ndecay : 1));
     }
-    float koff[8];                                           // position of key slot e inside a 32-key block (lane constant)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) koff[e] = (float)(((e >> 2) << 4) + g * 4 + (e & 3));
     const int sw_lo = s_blk + wave * 16, sw_hi = sw_lo + 16;  // this wave's queries
     float m = -1e30f, l = 0.f;
     f32x4 O[DT];
@@ -79,15 +89,22 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
     for (int i = 0; i < DT; ++i) O[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     h16x8 qf = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
 
-    for (int kc0 = 0; kc0 < T; kc0 += AERO_ATTN_KC) {
+    for (int kc0 = 0; kc0 < T; kc0 += KC) {
         __syncthreads();                                   // previous chunk fully consumed (and Qs written)
-        const int kn = (T - kc0) < AERO_ATTN_KC ? (T - kc0) : AERO_ATTN_KC;
+        const int kn = (T - kc0) < KC ? (T - kc0) : KC;
         const int kn32 = (kn + 31) & ~31;
-        if (vec4) {
+        if (RES && qb > 0) {
+            // K and V^T of the row are already resident
+        } else if (vec4) {
+            // zero fill of the padded channels (once), then only the nc4 live 8-byte pieces of every key are requested:
+            // consecutive lanes cover the consecutive pieces of one key (24 contiguous bytes for a head of 12)
             for (int idx = tid; idx < kn32 * 8; idx += 512) {
                 const int tl = idx >> 3, c4 = idx & 7;
-                h16x4 v = (h16x4){0, 0, 0, 0};
-                if (tl < kn && c4 * 4 < dh) v = *(const h16x4*)(base + (int64_t)(kc0 + tl) * d.ld + C + h * dh + c4 * 4);
+                if (c4 >= nc4 || tl >= kn) *(h16x4*)&Ks[aero_tile_off(tl, c4 >> 1) + (c4 & 1) * 4] = (h16x4){0, 0, 0, 0};
+            }
+            for (int idx = tid; idx < kn * nc4; idx += 512) {
+                const int tl = idx / nc4, c4 = idx - tl * nc4;
+                const h16x4 v = *(const h16x4*)(base + (int64_t)(kc0 + tl) * d.ld + C + h * dh + c4 * 4);
                 *(h16x4*)&Ks[aero_tile_off(tl, c4 >> 1) + (c4 & 1) * 4] = v;
             }
             for (int idx = tid; idx < kn32 * DT * 4; idx += 512) {
@@ -95,7 +112,7 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
                 h16x4 v = (h16x4){0, 0, 0, 0};
                 if (tl < kn && d4 * 4 < dh) v = *(const h16x4*)(base + (int64_t)(kc0 + tl) * d.ld + 2 * C + h * dh + d4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Vt[(d4 * 4 + e) * AERO_ATTN_VS + tl] = v[e];
+                for (int e = 0; e < 4; ++e) Vt[(d4 * 4 + e) * VS + tl] = v[e];
             }
         } else {
             for (int idx = tid; idx < kn32 * 32; idx += 512) {
@@ -108,11 +125,12 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
                 const int tl = idx / (DT * 16), dd = idx - tl * (DT * 16);
                 h16 v = (h16)0;
                 if (tl < kn && dd < dh) v = base[(int64_t)(kc0 + tl) * d.ld + 2 * C + h * dh + dd];
-                Vt[dd * AERO_ATTN_VS + tl] = v;
+                Vt[dd * VS + tl] = v;
             }
         }
         __syncthreads();
         if (kc0 == 0) qf = *(const h16x8*)&Qs[aero_tile_off(wave * 16 + col, g)];
+        (void)nqb;
         // Two 32-key blocks per trip: their score -> softmax -> PV chains are independent until the shared running maximum,
         // so one block's MFMA / exp latencies hide behind the other's, and the accumulator is rescaled once per 64 keys.
         auto scores = [&](int tb, float* sc) {
@@ -148,7 +166,7 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
         auto pv = [&](int tb, const h16x8& pf) {
 #pragma unroll
             for (int i = 0; i < DT; ++i) {
-                const h16* vr = &Vt[(i * 16 + col) * AERO_ATTN_VS + tb + g * 4];
+                const h16* vr = &Vt[(i * 16 + col) * VS + tb + g * 4];
                 const h16x4 va = *(const h16x4*)vr;
                 const h16x4 vb = *(const h16x4*)(vr + 16);
                 const h16x8 vf = (h16x8){va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
                 if (dd < dh) op[dd] = (h16)(O[i][r] * inv);
             }
     }
+  }
 }
 
 static int aero_attn_launch(const aero_attn_desc* d, hipStream_t stream, const char** err) {
@@ -209,8 +228,21 @@ static int aero_attn_launch(const aero_attn_desc* d, hipStream_t stream, const c
     if (d->R > 65535 || d->heads > 65535) { *err = "localstate: too many rows/heads for one launch"; return AERO_ERR_ARG; }
     const int dh = d->C / d->heads;
     if (dh > 32) { *err = "localstate: head dim > 32 unsupported"; return AERO_ERR_UNSUPPORTED; }
-    dim3 grid((unsigned)((d->T + 127) / 128), (unsigned)d->heads, (unsigned)d->R), block(512);
-    if (dh <= 16) AERO_LAUNCH((aero_attn_kernel<1>), grid, block, stream, *d);
-    else AERO_LAUNCH((aero_attn_kernel<2>), grid, block, stream, *d);
+    // AERO_ATTN_RES=1: the resident form.  Measured on MI355X (tools/bench_attn.py): 328 vs 290 us (C = 48), 182 vs 171 us
+    // (C = 96) -- SLOWER although it fetches a quarter of the bytes: the kernel is bound by instruction issue (PMC: ~2200
+    // instructions per wave, 12.7 vector instructions per score), not by the K/V request stream, and 2048 long-lived blocks
+    // balance worse than 8192 short ones.  Kept as a tested option; default off.
+    static int res = -1;
+    if (res < 0) { const char* e = getenv("AERO_ATTN_RES"); res = (e && e[0] == '1') ? 1 : 0; }
+    dim3 block(512);
+    if (res && d->T <= AERO_ATTN_KRES) {
+        dim3 grid(1, (unsigned)d->heads, (unsigned)d->R);
+        if (dh <= 16) AERO_LAUNCH((aero_attn_kernel<1, true>), grid, block, stream, *d);
+        else AERO_LAUNCH((aero_attn_kernel<2, true>), grid, block, stream, *d);
+        return AERO_OK;
+    }
+    dim3 grid((unsigned)((d->T + 127) / 128), (unsigned)d->heads, (unsigned)d->R);
+    if (dh <= 16) AERO_LAUNCH((aero_attn_kernel<1, false>), grid, block, stream, *d);
+    else AERO_LAUNCH((aero_attn_kernel<2, false>), grid, block, stream, *d);
     return AERO_OK;
 }

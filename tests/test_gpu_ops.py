@@ -105,7 +105,8 @@ def test_blstm(lib, kw):
     oc.case_blstm(lib, DEV, **kw)
 
 
-@pytest.mark.parametrize('kw', [dict(Cc=48, heads=4, R=16, T=501), dict(Cc=96, heads=4, R=8, T=501), dict(Cc=4, heads=4, R=3, T=33)])
+@pytest.mark.parametrize('kw', [dict(Cc=48, heads=4, R=16, T=501), dict(Cc=96, heads=4, R=8, T=501), dict(Cc=4, heads=4, R=3, T=33),
+                                dict(Cc=48, heads=4, R=4, T=1724), dict(Cc=96, heads=4, R=2, T=376)])   # streaming form (10-s segments), config 4's T
 def test_localstate(lib, kw):
     oc.case_localstate(lib, DEV, **kw)
 
