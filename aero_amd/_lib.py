@@ -72,6 +72,13 @@ class FtbFirstDesc(C.Structure):
                 ('dst', vp), ('B', i32), ('F', i32), ('T', i32), ('C', i32)]
 
 
+class Enc0Desc(C.Structure):
+    _fields_ = [('xn', vp), ('u', vp), ('g', vp), ('rs', fp), ('a_re', fp), ('a_im', fp), ('bias_f', fp),
+                ('wc', vp), ('bias_c', fp), ('dst', vp),
+                ('B', i32), ('F', i32), ('T', i32), ('C', i32), ('M', i32), ('Fo', i32), ('ktaps', i32), ('stride', i32),
+                ('pad', i32), ('act', i32)]
+
+
 _PROTOS = {
     'aero_version': (C.c_char_p, []),
     'aero_last_error': (C.c_char_p, []),
@@ -92,6 +99,7 @@ _PROTOS = {
     'aero_localstate_fwd': (i32, [C.POINTER(AttnDesc), vp]),
     'aero_freqfc_fwd': (i32, [C.POINTER(FreqFcDesc), vp]),
     'aero_ftb_first_fwd': (i32, [C.POINTER(FtbFirstDesc), vp]),
+    'aero_enc0_fwd': (i32, [C.POINTER(Enc0Desc), vp]),
 }
 
 EXPORTS = tuple(_PROTOS)

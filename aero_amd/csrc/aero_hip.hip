@@ -8,6 +8,7 @@
 #include "k_conv.h"
 #include "k_conv_ring.h"
 #include "k_ftb.h"
+#include "k_enc0.h"
 #include "k_lstm.h"
 #include "k_norm.h"
 #include "k_gram.h"
@@ -155,6 +156,12 @@ int aero_localstate_fwd(const aero_attn_desc* d, void* stream) {
 int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_freqfc_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_enc0_fwd(const aero_enc0_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_enc0_launch(d, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 

@@ -36,6 +36,7 @@ class Ops:
         self.lib = lib
         self.prof = None          # bench.py sets this to a list to collect per-launch HIP-event timings
         self.prof_shapes = None   # (tools/launch_table.py) one short shape note per profiled launch
+        self.tag = ''             # engine-set label of the launches being issued ('stack' = Conv2d / ConvTranspose2d of the U-Net)
         self._shape_note = ''
         self._arena, self._cur = {}, None
 
@@ -54,7 +55,7 @@ class Ops:
         self.lib.call(fn, *args)
         e1.record()
         name = self.lib.cdll.aero_last_kernel_name().decode() or kernel      # the instantiation as rocprofv3 names it
-        self.prof.append((name, flops, nbytes, e0, e1))
+        self.prof.append((name, flops, nbytes, e0, e1, self.tag))
         if self.prof_shapes is not None:
             self.prof_shapes.append(self._shape_note)
         self._shape_note = ''
@@ -282,6 +283,27 @@ def _ftb_first(self, xn, u, gate, P):
 Ops.ftb_first = _ftb_first
 
 
+def _enc0(self, xn, u, g, P, conv, Fo, stride, pad, act):
+    """encoder 0 fused (aero_enc0_fwd): FTB (collapsed, six-term bilinear form) + the strided frequency conv + activation"""
+    B, F, T, _ = xn.shape
+    Cc, M = P['C'], conv.M
+    out = torch.empty(B, Fo, T, M, dtype=torch.float16, device=xn.device)
+    d = _lib.Enc0Desc()
+    d.xn, d.u, d.g = _ptr(xn), _ptr(u), _ptr(g)
+    d.rs, d.a_re, d.a_im, d.bias_f = _ptr(P['rs']), _ptr(P['a_re']), _ptr(P['a_im']), _ptr(P['bias'])
+    d.wc, d.bias_c, d.dst = _ptr(conv.weight), _ptr(conv.bias), _ptr(out)
+    d.B, d.F, d.T, d.C, d.M, d.Fo = B, F, T, Cc, M, Fo
+    d.ktaps, d.stride, d.pad, d.act = len(conv.df), stride, pad, act
+    flops = 2.0 * B * Fo * T * M * len(conv.df) * Cc
+    self._shape_note = f'enc0 C={Cc} M={M} taps={len(conv.df)} F={F}->{Fo}'
+    self._call('aero_enc0_fwd', 'aero_enc0_kernel', flops, B * F * T * 8 + B * Fo * T * M * 2 + g.numel() * 2,
+               C.byref(d), self.stream(out))
+    return out
+
+
+Ops.enc0 = _enc0
+
+
 def _hann_padded(win_length, n_fft, device):
     w = torch.zeros(n_fft, dtype=torch.float32)
     left = (n_fft - win_length) // 2
@@ -333,6 +355,7 @@ class HipEngine:
         self.ring_stats = os.environ.get('AERO_RING_STATS', '1') != '0'    # GroupNorm statistics in the ring conv kernel's epilogue
         self.fuse_lstm_proj = True         # W_ih x_t inside the recurrent kernel (no 8H-channel pre-activation tensor in HBM)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
+        self.fuse_enc0 = os.environ.get('AERO_FUSE_ENC0', '1') != '0'     # ... and fused with the layer's strided conv (k_enc0.h)
 
     # ------------------------------------------------------------------ weights
     def _weights_key(self, device):
@@ -412,6 +435,9 @@ class HipEngine:
                     img[:Cc, :Cc] = w2a
                     A = w2b @ Wp
                     f32 = lambda t: t.float().to(device).contiguous()             # noqa: E731
+                    # G = (w2a * pq) applied to the gate, q = 0..2: the f-independent factors of the attention branch (k_enc0.h)
+                    wg = torch.cat([w2a * Wp[:, 0][None, :], w2a * Wp[:, 1][None, :], w2a * bp[None, :]], 0)      # [3C, C]
+                    L['ftb0_g'] = mk(wg[None, :, None, :], None, Cc, 0, [0], [0], device)
                     L['ftb0'] = dict(C=Cc, w2a=img.to(device=device, dtype=torch.float16).contiguous(),
                                      p0=f32(Wp[:, 0]), p1=f32(Wp[:, 1]), pb=f32(bp), rs=f32(wfc.sum(1)),
                                      a_re=f32(A[:, 0]), a_im=f32(A[:, 1]), bias=f32(w2b @ bp + b2))
@@ -605,7 +631,7 @@ class HipEngine:
         removes the per-launch Python / ctypes / runtime cost.  Inputs are copied into the graph's static buffer;
         outputs are cloned out of it (the graph's memory is reused by the next replay)."""
         key = ('graph', tuple(mix.shape), str(mix.device), want_spec, want_lr_spec,
-               self.fuse_dconv_tail, self.fuse_stats, self.collapse_first_ftb, self.fuse_lstm_proj)
+               self.fuse_dconv_tail, self.fuse_stats, self.collapse_first_ftb, self.fuse_lstm_proj, self.fuse_enc0)
         self._prepare(mix.device)                       # (drops the captured graphs if the weights changed)
         ent = self._tables.get(key)
         if ent is None:
@@ -676,6 +702,15 @@ class HipEngine:
                 self._tables[okey] = torch.ones(B, T, 2, dtype=torch.float16, device=x.device)
             ones = self._tables[okey]
             u = ops.freqfc(x, L['ftb_fc'], ones)                                           # freq_fc on (re, im) only
+            conv = L['conv']
+            if (self.fuse_enc0 and not enc.norm and Cc % 8 == 0 and conv.M % 16 == 0 and conv.M <= 64 and not conv.transposed
+                    and all(t == 0 for t in conv.dt) and list(conv.df) == [j - enc.pad for j in range(len(conv.df))]):
+                G = ops.conv(L['ftb0_g'], gate.view(B, 1, T, Cc), None, B, 1, 1, T)          # [B,1,T,3C]
+                Fo = (Fq + 2 * enc.pad - enc.kernel_size) // enc.stride + 1
+                ops.tag = 'stack'
+                y = ops.enc0(x, u, G, L['ftb0'], conv, Fo, enc.stride, enc.pad, conv.act)
+                ops.tag = ''
+                return self._encode_tail(i, enc, L, None, B, Fq, T, y_pre=y)
             x = ops.ftb_first(x, u, gate.view(B, T, Cc), L['ftb0'])
         elif 'ftb_c1' in L or 'pre' in L:
             x = self._encode_head_unfused(L, x, B, Fq, T)
@@ -753,15 +788,24 @@ class HipEngine:
             self._tables[key] = R
         return self._tables[key]
 
-    def _encode_tail(self, i, enc, L, x, B, Fq, T):
+    def _encode_tail(self, i, enc, L, x, B, Fq, T, y_pre=None):
         ops = self.ops
         Fo = (Fq + 2 * enc.pad - enc.kernel_size) // enc.stride + 1
+        if y_pre is not None:
+            return self._encode_rest(i, enc, L, y_pre, B, Fo, T)
+        ops.tag = 'stack'                               # (SURVEY 8d "conv stack": the Conv2d / ConvTranspose2d of the U-Net proper)
         if enc.norm:
             st = self._stats_for(L['conv'].M, enc.norm_groups, B, Fo, x.device)
             y = ops.conv(L['conv'], x, None, B, Fq, Fo, T, stat=self._acc(st, enc.norm_groups))
+            ops.tag = ''
             y = ops.norm_act(y, enc.norm_groups, False, L['norm1'][0], L['norm1'][1], ACT_GELU, stats=st)
         else:
             y = ops.conv(L['conv'], x, None, B, Fq, Fo, T)
+        ops.tag = ''
+        return self._encode_rest(i, enc, L, y, B, Fo, T)
+
+    def _encode_rest(self, i, enc, L, y, B, Fo, T):
+        ops = self.ops
         if 'dconv' in L:
             y = self._dconv(enc.dconv, L['dconv'], y, B, Fo, T)
         if 'rewrite' in L:
@@ -770,10 +814,14 @@ class HipEngine:
                 if emb is not None:
                     raise NotImplementedError('GroupNorm on encoder 0 together with the frequency embedding')
                 st = self._stats_for(L['rewrite'].M, enc.norm_groups, B, Fo, y.device)
+                ops.tag = 'stack'
                 r = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, stat=self._acc(st, enc.norm_groups))
+                ops.tag = ''
                 y = ops.norm_act(r, enc.norm_groups, False, L['norm2'][0], L['norm2'][1], ACT_GLU, stats=st)
             else:
+                ops.tag = 'stack'
                 y = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, post_add=emb)
+                ops.tag = ''
         elif i == 0 and 'freq_emb' in self.P:
             raise NotImplementedError('frequency embedding without a rewrite conv')
         return y, Fo
@@ -880,6 +928,13 @@ class HipEngine:
         return ops.conv(L['lstm_lin'], out1.view(B, Fo, T, 2 * H), None, B, Fo, Fo, T, res=h)
 
     def _decode(self, j, dec, L, x, skip, B, Fq, T, mean, std):
+        self.ops.tag = 'stack'
+        try:
+            return self._decode_tagged(j, dec, L, x, skip, B, Fq, T, mean, std)
+        finally:
+            self.ops.tag = ''
+
+    def _decode_tagged(self, j, dec, L, x, skip, B, Fq, T, mean, std):
         ops = self.ops
         if 'rewrite' in L:
             if dec.norm:

@@ -65,12 +65,18 @@ def cpu_baseline_worker(seconds_per_clip, lr_sr, budget_s=20.0):
     batch = int(max(1, min(8, budget_s / 3.0 / max(t1, 1e-3))))
     ts = sorted(run(batch) for _ in range(3))
     med = ts[1]
+    # the reference's own inference helper pins ONE thread (enhance.py:12): that figure too (one clip, best of 2)
+    torch.set_num_threads(1)
+    run(1)
+    t_one = min(run(1), run(1))
     return {'value': round(batch * seconds_per_clip / med, 3), 'unit': 'audio-sec/wall-sec', 'cores': threads, 'kind': 'port',
+            'value_1_thread': round(seconds_per_clip / t_one, 3),
             'sample': f'oracle/aero_oracle.py (fp32 CPU port of the reference path), batch {batch} x {seconds_per_clip:g} s clips, '
-                      f'median of 3 after warm-up, {threads} threads of {_usable_cores()} usable cores'}
+                      f'median of 3 after warm-up, {threads} threads of {_usable_cores()} usable cores; value_1_thread: one clip, '
+                      f'torch.set_num_threads(1) as the reference forces (enhance.py:12), best of 2'}
 
 
-def cpu_baseline(seconds_per_clip, lr_sr, timeout_s=150):
+def cpu_baseline(seconds_per_clip, lr_sr, timeout_s=240):
     import subprocess
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker'], capture_output=True,
@@ -152,12 +158,18 @@ def main():
             for _ in range(max(1, min(args.steps, 5))):
                 model(x)
         torch.cuda.synchronize()
-        for kname, flops, nbytes, e0, e1 in eng.ops.prof:
+        nprof = max(1, min(args.steps, 5))
+        stack = {'ms': 0.0, 'flops': 0.0}
+        for kname, flops, nbytes, e0, e1, tag in eng.ops.prof:
             k = kernels.setdefault(kname, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            ms = e0.elapsed_time(e1)
             k['launches'] += 1
-            k['ms'] += e0.elapsed_time(e1)
+            k['ms'] += ms
             k['flops'] += flops
             k['bytes'] += nbytes
+            if tag == 'stack' and 'conv' in kname:
+                stack['ms'] += ms
+                stack['flops'] += flops
         eng.ops.prof = None
         dom = max(kernels, key=lambda n: kernels[n]['ms'])
         k = kernels[dom]
@@ -166,7 +178,7 @@ def main():
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
             try:
-                ent = json.load(open(pmc)).get(dom)
+                ent = json.load(open(pmc)).get(dom.replace('void ', '').split('(')[0])
                 traffic = ent['bytes'] if ent else None       # HBM-side bytes per launch (rocprofv3 --pmc, see tools/pmc_traffic.py)
             except Exception:
                 traffic = None
@@ -181,6 +193,25 @@ def main():
             ach = k['bytes'] / k['launches'] / (avg_ms * 1e-3) / 1e9
             roof = {'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_ms, 4)}
+
+        # the conv stack as a whole (Conv2d + ConvTranspose2d of the encoder / decoder layers -- strided convs,
+        # rewrite convs, transposed convs; executed FLOPs over the summed HIP-event time of exactly those launches)
+        roof_stack = None
+        if stack['ms'] > 0:
+            ach = stack['flops'] / (stack['ms'] * 1e-3) / 1e12
+            roof_stack = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_MFMA_F16_TFLOPS, 'unit': 'TFLOP/s',
+                          'frac': round(ach / PEAK_MFMA_F16_TFLOPS, 4), 'ms_per_step': round(stack['ms'] / nprof, 3),
+                          'flops_per_step': stack['flops'] / nprof}
+        # STFT / iSTFT against the HBM roofline (algorithmic bytes: SURVEY 8d)
+        roof_stft = {}
+        for kname, v in kernels.items():
+            if 'stft_kernel' in kname and v['ms'] > 0:
+                ach = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+                roof_stft[kname] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                    'frac': round(ach / PEAK_HBM_GBS, 4), 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
+                                    'bytes_per_launch': v['bytes'] / v['launches']}
+    else:
+        roof_stack, roof_stft = None, None
 
     if rank != 0:
         distrib.close()
@@ -198,7 +229,7 @@ def main():
                                f'(nfft=512 hop=64), random-init weights seed 2036, inference, inputs resident in HBM',
                    'global_batch': world * B, 'clip_samples': L, 'frames': 501, 'parallelism': f'clips sharded over {world} GPU(s), no data-path collective',
                    'precision': 'fp16 operands/storage, fp32 accumulate; STFT/iSTFT/statistics fp32'},
-        'roofline': roof, 'cpu_baseline': cpu,
+        'roofline': roof, 'roofline_conv_stack': roof_stack, 'roofline_stft': roof_stft, 'cpu_baseline': cpu,
         'kernels_ms_per_step': {n: round(v['ms'] / max(1, min(args.steps, 5)), 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
         # per kernel over the same launches: [executed TFLOP/s, algorithmic GB/s] (HIP-event time; 0 = not applicable)
         'kernels_achieved': {n: [round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) if v['ms'] > 0 else 0.0,

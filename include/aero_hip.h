@@ -226,6 +226,24 @@ typedef struct {
 } aero_ftb_first_desc;
 int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream);
 
+/* K3+K12+K3' fused for encoder 0 -- pre_conv + FTB (as aero_ftb_first_fwd) AND the layer's strided frequency conv with
+ * its activation (aero.py:95,124-127) in one pass; neither the C-channel FTB output nor anything else between the
+ * 2-channel spectrogram and the conv output touches HBM (aero_amd/csrc/k_enc0.h).  The FTB output is evaluated as
+ *   x0[b,f,t,c] = relu( u_re*G0 + u_im*G1 + rs[f]*G2 + a_re[c]*re + a_im[c]*im + bias_f[c] ),
+ * g fp16 [B][T][3][C] = (G0 | G1 | G2)[b,t,c] = sum_c' (w2a[c][c'] * {p0,p1,pb}[c']) * gate[b,t,c']  (a 1x1 conv of the gate,
+ * computed by the caller with aero_conv_fwd), xn / u fp16 [B][F][T][2] as for aero_ftb_first_fwd, rs fp32 [F].
+ *   dst[b,fo,t,m] = act( bias_c[m] + sum_{j<ktaps} sum_c wc[m][j*Cp + c] * x0[b, fo*stride - pad + j, t, c] )   (zero outside [0,F))
+ * wc: the fp16 image aero_conv_fwd takes for that conv ([>= M rows][ktaps*Cp], Cp = roundup(C,32)); dst fp16 contiguous
+ * [B][Fo][T][M].  C multiple of 8 in [8,64], M multiple of 16 in [16,64]. */
+typedef struct {
+    const void* xn; const void* u; const void* g;
+    const float* rs; const float* a_re; const float* a_im; const float* bias_f;
+    const void* wc; const float* bias_c;
+    void* dst;
+    int32_t B, F, T, C, M, Fo, ktaps, stride, pad, act;
+} aero_enc0_desc;
+int aero_enc0_fwd(const aero_enc0_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,3 +349,28 @@ def case_freqfc(lib, dev, Fq, Cc, T, B=2, seed=80):
     att = q16(gate)[:, :, None, :] * q16(x)
     ref = (att.transpose(2, 3) @ w.t()).transpose(2, 3)
     assert rel_l2(uncl(y.cpu()), ref) < TOL16
+
+
+def case_enc0(lib, dev, Cc, M, K, stride, pad, Fq, T, B=2, act='gelu', seed=90):
+    """aero_enc0_fwd: encoder 0's collapsed FTB (six-term bilinear form of the 2-channel spectrogram, k_enc0.h) fused with the
+    layer's strided frequency conv + activation, against the same two steps in fp32 torch (x0 rounded to fp16 in between,
+    as the kernel feeds the MFMA)."""
+    ops = Ops(lib)
+    xn, u = q16(_rand((B, Fq, T, 2), seed)), q16(_rand((B, Fq, T, 2), seed + 1))
+    g = q16(_rand((B, T, 3, Cc), seed + 2, 0.5))
+    rs, a_re, a_im, bf = (_rand((n,), seed + 3 + i) for i, n in enumerate((Fq, Cc, Cc, Cc)))
+    w = _rand((M, Cc, K, 1), seed + 8, 1.0 / math.sqrt(Cc * K))
+    b = _rand((M,), seed + 9)
+    taps, df, dt = pack.conv2d_taps(q16(w), pad, 0)
+    actc = {'none': _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'gelu': _lib.ACT_GELU}[act]
+    spec = pack.make_conv_spec(taps, b, Cc, 0, df, dt, dev, fstride=stride, act=actc)
+    Fo = (Fq + 2 * pad - K) // stride + 1
+    P = dict(C=Cc, rs=rs.to(dev), a_re=a_re.to(dev), a_im=a_im.to(dev), bias=bf.to(dev))
+    y = ops.enc0(xn.half().to(dev), u.half().to(dev), g.half().to(dev).view(B, 1, T, 3 * Cc), P, spec, Fo, stride, pad, actc)
+    G = g[:, None]                                                        # [B,1,T,3,C]
+    x0 = (u[..., 0:1] * G[..., 0, :] + u[..., 1:2] * G[..., 1, :] + rs[None, :, None, None] * G[..., 2, :]
+          + xn[..., 0:1] * a_re + xn[..., 1:2] * a_im + bf).relu()        # [B,F,T,C]
+    ref = F.conv2d(q16(x0).permute(0, 3, 1, 2), q16(w), b, stride=(stride, 1), padding=(pad, 0))
+    ref = {'none': lambda v: v, 'relu': F.relu, 'gelu': F.gelu}[act](ref)
+    assert y.shape == (B, Fo, T, M)
+    assert rel_l2(uncl(y.cpu()), ref) < TOL16

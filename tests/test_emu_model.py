@@ -49,19 +49,24 @@ def test_small_model_golden_groupnorm_fusion_paths(emu, meta, fuse):
     assert rel_l2(y, io['y_2003']) < 5e-3
 
 
-@pytest.mark.parametrize('collapse', [True, False])
-def test_small_model_golden_first_layer_ftb_paths(emu, meta, collapse):
-    """channels=16 model: encoder 0's FTB runs collapsed onto the 2-channel spectrogram (aero_ftb_first_fwd) or layer by
-    layer (pre_conv + aero_freqfc_fwd + convs); both must match the reference's golden output."""
+@pytest.mark.parametrize('collapse,fused', [(True, True), (True, False), (False, False)])
+def test_small_model_golden_first_layer_ftb_paths(emu, meta, collapse, fused):
+    """channels=16 model: encoder 0 runs as ONE kernel (FTB collapsed onto the 2-channel spectrogram + the strided conv,
+    aero_enc0_fwd), with the collapsed FTB on its own (aero_ftb_first_fwd) or layer by layer (pre_conv + aero_freqfc_fwd +
+    convs); all three must match the reference's golden output."""
     m = build_model(meta, 'small')
     eng = HipEngine(m, lib=emu)
-    eng.collapse_first_ftb = collapse
+    eng.collapse_first_ftb, eng.fuse_enc0 = collapse, fused
+    names, call = [], eng.ops.lib.call
+    eng.ops.lib = type('Spy', (), {'call': staticmethod(lambda fn, *a: (names.append(fn), call(fn, *a))[1]),
+                                    '__getattr__': lambda self, k: getattr(emu, k)})()
     object.__setattr__(m, '_engine', eng)
     io = load_npz('small_io.npz')
     with torch.no_grad():
         y, s = m(torch.from_numpy(io['x_800']), return_spec=True)
     assert rel_l2(s, io['spec_800']) < 1e-3
     assert rel_l2(y, io['y_800']) < 5e-3
+    assert ('aero_enc0_fwd' in names) == fused and ('aero_ftb_first_fwd' in names) == (collapse and not fused)
 
 
 def test_spec_ispec_api(emu, meta):

@@ -162,3 +162,11 @@ def test_localstate_resident_form_option():
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_ATTN_RES': '1'}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=48, M=48, K=8, stride=4, pad=2, Fq=32, T=139),
+                                dict(Cc=16, M=16, K=8, stride=4, pad=2, Fq=64, T=130, act='relu'),
+                                dict(Cc=24, M=32, K=3, stride=1, pad=1, Fq=9, T=33, B=1, act='none'),
+                                dict(Cc=64, M=64, K=8, stride=4, pad=2, Fq=20, T=128, B=1)])     # Fo = 5: a ragged last row group
+def test_enc0_fused(emu, kw):
+    oc.case_enc0(emu, DEV, **kw)

@@ -139,3 +139,11 @@ def test_spectral_losses_on_the_hip_stft():
     want = float(ev.lsd(y, x))                                   # host path (torch.stft)
     assert abs(float(ev.lsd(y.cuda(), x.cuda())) - want) < 2e-4 * want
     assert float(ev.lsd(y.cuda(), y.cuda())) == 0.0
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=48, M=48, K=8, stride=4, pad=2, Fq=256, T=501, B=2), dict(Cc=48, M=48, K=8, stride=4, pad=2, Fq=32, T=139),
+                                dict(Cc=16, M=16, K=8, stride=4, pad=2, Fq=64, T=130, act='relu'),
+                                dict(Cc=24, M=32, K=3, stride=1, pad=1, Fq=9, T=33, B=1, act='none'),
+                                dict(Cc=64, M=64, K=8, stride=4, pad=2, Fq=20, T=128, B=1)])     # Fo = 5: a ragged last row group
+def test_enc0_fused(lib, kw):
+    oc.case_enc0(lib, DEV, **kw)
