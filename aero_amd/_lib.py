@@ -79,6 +79,19 @@ class Enc0Desc(C.Structure):
                 ('pad', i32), ('act', i32)]
 
 
+DCONV_MAX_DEPTH = 4
+
+
+class DconvLayer(C.Structure):
+    _fields_ = [('w1', vp), ('b1', fp), ('g1', fp), ('be1', fp), ('snake_a', fp),
+                ('w2', vp), ('b2', fp), ('g2', fp), ('be2', fp), ('scale', fp), ('dilation', i32), ('reserved', i32)]
+
+
+class DconvDesc(C.Structure):
+    _fields_ = [('x', vp), ('y', vp), ('R', i32), ('T', i32), ('C', i32), ('hidden', i32), ('depth', i32), ('act', i32),
+                ('F', i32), ('eps', C.c_float), ('layer', DconvLayer * DCONV_MAX_DEPTH)]
+
+
 _PROTOS = {
     'aero_version': (C.c_char_p, []),
     'aero_last_error': (C.c_char_p, []),
@@ -100,6 +113,8 @@ _PROTOS = {
     'aero_freqfc_fwd': (i32, [C.POINTER(FreqFcDesc), vp]),
     'aero_ftb_first_fwd': (i32, [C.POINTER(FtbFirstDesc), vp]),
     'aero_enc0_fwd': (i32, [C.POINTER(Enc0Desc), vp]),
+    'aero_dconv_row_fwd': (i32, [C.POINTER(DconvDesc), vp]),
+    'aero_dconv_row_fits': (i32, [i32, i32, i32, i32]),
 }
 
 EXPORTS = tuple(_PROTOS)

@@ -9,6 +9,7 @@
 #include "k_conv_ring.h"
 #include "k_ftb.h"
 #include "k_enc0.h"
+#include "k_dconv.h"
 #include "k_lstm.h"
 #include "k_norm.h"
 #include "k_gram.h"
@@ -158,6 +159,14 @@ int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream) {
     int rc = aero_freqfc_launch(d, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
+
+int aero_dconv_row_fwd(const aero_dconv_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_dconv_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_dconv_row_fits(int T, int C, int hidden, int max_dilation) { return aero_dconv_row_fits_impl(T, C, hidden, max_dilation); }
 
 int aero_enc0_fwd(const aero_enc0_desc* d, void* stream) {
     const char* err = "";

@@ -304,6 +304,33 @@ def _enc0(self, xn, u, g, P, conv, Fo, stride, pad, act):
 Ops.enc0 = _enc0
 
 
+def _dconv_row(self, x, layers, act, F, eps=1e-5):
+    """aero_dconv_row_fwd: every layer of a DConv branch (no BLSTM / LocalState) on x [B,F,T,C] in one launch; returns a new tensor"""
+    B, Fq, T, Cc = x.shape
+    out = torch.empty_like(x)
+    d = _lib.DconvDesc()
+    d.x, d.y = _ptr(x), _ptr(out)
+    d.R, d.T, d.C, d.hidden, d.depth, d.act, d.F, d.eps = B * Fq, T, Cc, layers[0]['hidden'], len(layers), act, F, eps
+    flops = 0.0
+    for i, L in enumerate(layers):
+        l = d.layer[i]
+        l.w1, l.b1, l.g1, l.be1, l.snake_a = _ptr(L['w1']), _ptr(L['b1']), _ptr(L['g1']), _ptr(L['be1']), _ptr(L.get('snake_a'))
+        l.w2, l.b2, l.g2, l.be2, l.scale = _ptr(L['w2']), _ptr(L['b2']), _ptr(L['g2']), _ptr(L['be2']), _ptr(L['scale'])
+        l.dilation = L['dilation']
+        flops += 2.0 * B * Fq * T * L['hidden'] * (3 * Cc + 2 * Cc)
+    self._shape_note = f'dconv rows C={Cc} hidden={layers[0]["hidden"]} depth={len(layers)} F={Fq}'
+    self._call('aero_dconv_row_fwd', 'aero_dconv_row_kernel', flops, 2 * x.numel() * 2, C.byref(d), self.stream(x))
+    return out
+
+
+def _dconv_row_fits(self, T, Cc, hidden, maxdil):
+    return bool(self.lib.cdll.aero_dconv_row_fits(T, Cc, hidden, maxdil))
+
+
+Ops.dconv_row = _dconv_row
+Ops.dconv_row_fits = _dconv_row_fits
+
+
 def _hann_padded(win_length, n_fft, device):
     w = torch.zeros(n_fft, dtype=torch.float32)
     left = (n_fft - win_length) // 2
@@ -351,10 +378,14 @@ class HipEngine:
         #    passes but the statistics instantiations lose the 8-wave tiles -> slower overall (+0.3 ms) -> off.
         self.fuse_dconv_tail = os.environ.get('AERO_FUSE_DCONV', '1') != '0'       # DConv tail as a recompute pair of conv launches (2C-channel tensor never stored)
         self.gram_stats = os.environ.get('AERO_GRAM_STATS', '1') != '0'    # DConv tail statistics from the Gram matrix of conv2's input (k_gram.h)
-        self.fuse_stats = os.environ.get('AERO_FUSE_STATS', '0') != '0'    # GroupNorm statistics accumulated in the producing conv's epilogue
+        # GroupNorm statistics accumulated in the producing conv's epilogue (k_conv.h tiles): '1' always, '0' never, default
+        # 'auto' = where the contraction has several taps (there the extra epilogue work costs 3-8 us against a 9-53 us
+        # statistics pass; on the pointwise rewrite convs it costs 45-70 us against 33 us: per-launch table in DESIGN.md)
+        self.fuse_stats = {'0': False, '1': True}.get(os.environ.get('AERO_FUSE_STATS', 'auto'), 'auto')
         self.ring_stats = os.environ.get('AERO_RING_STATS', '1') != '0'    # GroupNorm statistics in the ring conv kernel's epilogue
         self.fuse_lstm_proj = True         # W_ih x_t inside the recurrent kernel (no 8H-channel pre-activation tensor in HBM)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
+        self.fuse_dconv_row = os.environ.get('AERO_DCONV_ROW', '1') != '0'    # DConv branches without LSTM / attention: one launch, the row stays in LDS (k_dconv.h)
         self.fuse_enc0 = os.environ.get('AERO_FUSE_ENC0', '1') != '0'     # ... and fused with the layer's strided conv (k_enc0.h)
 
     # ------------------------------------------------------------------ weights
@@ -521,6 +552,21 @@ class HipEngine:
                 L['gn2_glu'] = (pack.glu_interleave(sd[f'{q}.conv2.1.weight']).to(device).contiguous(),
                                 pack.glu_interleave(sd[f'{q}.conv2.1.bias']).to(device).contiguous())
             hid = w.shape[-1]
+            if not dc.lstm and not dc.time_attn and dc.kernel == 3 and hid % 4 == 0 and hid <= 32 and w.shape[1] % 16 == 0:
+                # whole-branch row kernel (k_dconv.h): conv1 image [HP][3C] with k = tap*C + c, conv2 image [2C][HP] GLU-interleaved
+                w1 = sd[f'{q}.conv1.0.weight']                                               # [hid, C, 3]
+                Cc, HP, K1p = w1.shape[1], pack._round_up(hid, 16), pack._round_up(3 * w1.shape[1], 32)
+                i1 = torch.zeros(HP, K1p)
+                i1[:hid, :3 * Cc] = w1.permute(0, 2, 1).reshape(hid, 3 * Cc)
+                i2 = torch.zeros(2 * Cc, HP)
+                i2[:, :hid] = pack.glu_interleave(sd[f'{q}.conv2.0.weight'][:, :, 0])
+                f32 = lambda t: t.detach().float().to(device).contiguous()                   # noqa: E731
+                L['row'] = dict(w1=i1.to(device=device, dtype=torch.float16).contiguous(), b1=f32(sd[f'{q}.conv1.0.bias']),
+                                g1=f32(sd[f'{q}.conv1.1.weight']) if dc.norm else None, be1=f32(sd[f'{q}.conv1.1.bias']) if dc.norm else None,
+                                w2=i2.to(device=device, dtype=torch.float16).contiguous(), b2=f32(pack.glu_interleave(sd[f'{q}.conv2.0.bias'])),
+                                g2=f32(pack.glu_interleave(sd[f'{q}.conv2.1.weight'])) if dc.norm else None,
+                                be2=f32(pack.glu_interleave(sd[f'{q}.conv2.1.bias'])) if dc.norm else None,
+                                scale=f32(sd[f'{q}.conv2.3.scale']), dilation=dil, C=Cc, hidden=hid)
             if hid + 1 <= 112:                                      # statistics of conv2's output from the Gram matrix of its input
                 L['gram'] = pack.gram_tables(w[0, :, 0, :], sd[f'{q}.conv2.0.bias'], device)
             if hid % 8 and not dc.lstm and not dc.time_attn:
@@ -631,7 +677,7 @@ class HipEngine:
         removes the per-launch Python / ctypes / runtime cost.  Inputs are copied into the graph's static buffer;
         outputs are cloned out of it (the graph's memory is reused by the next replay)."""
         key = ('graph', tuple(mix.shape), str(mix.device), want_spec, want_lr_spec,
-               self.fuse_dconv_tail, self.fuse_stats, self.collapse_first_ftb, self.fuse_lstm_proj, self.fuse_enc0)
+               self.fuse_dconv_tail, self.fuse_stats, self.collapse_first_ftb, self.fuse_lstm_proj, self.fuse_enc0, self.fuse_dconv_row)
         self._prepare(mix.device)                       # (drops the captured graphs if the weights changed)
         ent = self._tables.get(key)
         if ent is None:
@@ -795,7 +841,7 @@ class HipEngine:
             return self._encode_rest(i, enc, L, y_pre, B, Fo, T)
         ops.tag = 'stack'                               # (SURVEY 8d "conv stack": the Conv2d / ConvTranspose2d of the U-Net proper)
         if enc.norm:
-            st = self._stats_for(L['conv'].M, enc.norm_groups, B, Fo, x.device)
+            st = self._stats_for(L['conv'].M, enc.norm_groups, B, Fo, x.device, spec=L['conv'])
             y = ops.conv(L['conv'], x, None, B, Fq, Fo, T, stat=self._acc(st, enc.norm_groups))
             ops.tag = ''
             y = ops.norm_act(y, enc.norm_groups, False, L['norm1'][0], L['norm1'][1], ACT_GELU, stats=st)
@@ -813,7 +859,7 @@ class HipEngine:
             if enc.norm:
                 if emb is not None:
                     raise NotImplementedError('GroupNorm on encoder 0 together with the frequency embedding')
-                st = self._stats_for(L['rewrite'].M, enc.norm_groups, B, Fo, y.device)
+                st = self._stats_for(L['rewrite'].M, enc.norm_groups, B, Fo, y.device, spec=L['rewrite'])
                 ops.tag = 'stack'
                 r = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, stat=self._acc(st, enc.norm_groups))
                 ops.tag = ''
@@ -829,10 +875,16 @@ class HipEngine:
     def _dconv(self, dc, layers, x, B, Fo, T):
         ops = self.ops
         act = {'snake': ACT_SNAKE, 'gelu': ACT_GELU}.get(dc.act_func, ACT_RELU)
+        if (self.fuse_dconv_row and all('row' in L for L in layers) and len(layers) <= _lib.DCONV_MAX_DEPTH and x.is_contiguous()
+                and ops.dconv_row_fits(T, layers[0]['row']['C'], layers[0]['row']['hidden'], max(L['row']['dilation'] for L in layers))):
+            ops.tag = 'stack'
+            y = ops.dconv_row(x, [dict(L['row'], snake_a=L.get('snake_a')) for L in layers], act, Fo)
+            ops.tag = ''
+            return y
         for L in layers:
             g1 = L['gn1']
             st1 = None
-            if g1 is not None and self.fuse_stats and L['conv1'].M > 16 and L['conv1'].M % 8 == 0:       # (M <= 16 runs on the streaming kernel)
+            if g1 is not None and self._want_stats(L['conv1']) and L['conv1'].M > 16 and L['conv1'].M % 8 == 0:       # (M <= 16 runs on the streaming kernel)
                 st1 = ops.new_stats(B, Fo, 1, True, x.device)
                 h = ops.conv(L['conv1'], x, None, B, Fo, Fo, T, stat=dict(mode=1, stats=st1, G=1, per_row=True))
             else:
@@ -878,12 +930,15 @@ class HipEngine:
                              stat=dict(mode=3, stats=st2, G=1, per_row=True, count=float(T * c2.M),
                                        gamma=L['gn2_glu'][0], beta=L['gn2_glu'][1], layer_scale=L['scale']))
                 continue
-            st2 = ops.new_stats(B, Fo, 1, True, x.device) if (g2 is not None and self.fuse_stats and L['conv2'].M % 8 == 0) else None
+            st2 = ops.new_stats(B, Fo, 1, True, x.device) if (g2 is not None and self._want_stats(L['conv2']) and L['conv2'].M % 8 == 0) else None
             g = ops.conv(L['conv2'], h, None, B, Fo, Fo, T,
                          stat=None if st2 is None else dict(mode=1, stats=st2, G=1, per_row=True))
             x = ops.norm_act(g, 1, True, g2[0] if g2 else None, g2[1] if g2 else None, ACT_GLU,
                              layer_scale=L['scale'], res=x, normalize=g2 is not None, stats=st2)
         return x
+
+    def _want_stats(self, spec):
+        return self.fuse_stats is True or (self.fuse_stats == 'auto' and spec is not None and len(spec.df) > 1)
 
     def _stats_for(self, M, G, B, F, device, spec=None):
         """fp64 accumulators for a GroupNorm over [B, M, F, T] if the conv epilogue can fill them, else None.
@@ -891,7 +946,7 @@ class HipEngine:
         groups are 32-row aligned; the other tile kernels only on request (AERO_FUSE_STATS: measured slower there)."""
         if spec is not None and spec.tiled_bm and self.ring_stats and M % G == 0 and (M // G) % 32 == 0:
             return self.ops.new_stats(B, F, G, False, device)
-        if self.fuse_stats and self.ops.can_fuse_stats(M, G):
+        if self._want_stats(spec) and self.ops.can_fuse_stats(M, G):
             return self.ops.new_stats(B, F, G, False, device)
         return None
 
@@ -950,7 +1005,7 @@ class HipEngine:
         if dec.norm:
             if dec.last:
                 raise NotImplementedError('GroupNorm on the last decoder layer (norm_starts = 0)')
-            st = self._stats_for(L['conv_tr'].M, dec.norm_groups, B, Fu, y.device)
+            st = self._stats_for(L['conv_tr'].M, dec.norm_groups, B, Fu, y.device, spec=L['conv_tr'])
             if st is None and 'conv_tr_stacked' in L:
                 z = self._convtr_stacked(L['conv_tr_stacked'], y, B, Fq, T, dec.stride, 0, Fu)
             else:

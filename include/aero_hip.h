@@ -244,6 +244,31 @@ typedef struct {
 } aero_enc0_desc;
 int aero_enc0_fwd(const aero_enc0_desc* d, void* stream);
 
+/* K14: a whole DConv residual branch (modules.py:221-249) for the layers WITHOUT BLSTM / LocalState, one launch, the
+ * activations read from and written to HBM once (aero_amd/csrc/k_dconv.h).  x, y: fp16 [R][T][C] rows (R = B*F items of
+ * the reference's [B*F, C, T] view; y may alias x).  For each of `depth` layers, in place on the row:
+ *   h = conv1d(x; w1, b1, kernel 3, dilation, padding = dilation);  h = act(GroupNorm(1, hidden)(h; g1, be1))   (g1 NULL: no norm)
+ *   v = conv1d(h; w2, b2, kernel 1) [2C];  v = GroupNorm(1, 2C)(v; g2, be2);  x = x + scale * GLU(v)
+ * act: RELU / GELU / SNAKE (snake_a fp32 [F], a of frequency row r % F: modules.py:232-236, snake.py:67) / NONE.
+ * w1: fp16 [HP][K1p], element (j, tap*C + c), taps t-d, t, t+d, HP = roundup(hidden,16), K1p = roundup(3C,32), zero padded.
+ * w2: fp16 [2C][HP] with GLU-interleaved rows (a0, b0, a1, b1, ...: row 2i = output channel i, row 2i+1 = gate C+i);
+ * b2 / g2 / be2 fp32 [2C] in the same row order; scale fp32 [C] (NULL: 1).  C % 8 == 0, hidden % 4 == 0, hidden <= 32,
+ * and the row must fit the LDS: aero_dconv_row_fits(T, C, hidden, largest dilation) == 1. */
+#define AERO_DCONV_MAX_DEPTH 4
+typedef struct {
+    const void* w1; const float* b1; const float* g1; const float* be1; const float* snake_a;
+    const void* w2; const float* b2; const float* g2; const float* be2; const float* scale;
+    int32_t dilation, reserved;
+} aero_dconv_layer;
+typedef struct {
+    const void* x; void* y;
+    int32_t R, T, C, hidden, depth, act, F;
+    float eps;
+    aero_dconv_layer layer[AERO_DCONV_MAX_DEPTH];
+} aero_dconv_desc;
+int aero_dconv_row_fwd(const aero_dconv_desc* d, void* stream);
+int aero_dconv_row_fits(int T, int C, int hidden, int max_dilation);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,6 +174,25 @@ static inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu::eh8 a, emu::eh8
     return d;
 }
 
+// v_mfma_f32_16x16x16_f16: A lane l holds A[i=l&15][k=(l>>4)*4+e]; B lane l holds B[k=(l>>4)*4+e][j=l&15]; D as above.
+typedef _Float16 emu_h4 __attribute__((ext_vector_type(4)));
+static inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x16f16(emu_h4 a, emu_h4 b, emu_f4 c, int, int, int) {
+    emu::WaveCtx& w = emu::g_blk->waves[emu::me().wave];
+    int lane = emu::me().lane;
+    for (int e = 0; e < 4; ++e) { w.A[lane][e] = a[e]; w.B[lane][e] = b[e]; }
+    emu::wave_barrier();
+    emu_f4 d;
+    int j = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int i = (lane >> 4) * 4 + r;
+        float s = c[r];
+        for (int k = 0; k < 16; ++k) s += (float)w.A[i + 16 * (k >> 2)][k & 3] * (float)w.B[j + 16 * (k >> 2)][k & 3];
+        d[r] = s;
+    }
+    emu::wave_barrier();
+    return d;
+}
+
 typedef float emu_f16v __attribute__((ext_vector_type(16)));
 // v_mfma_f32_32x32x16_f16: A lane l holds A[i=l&31][k=(l>>5)*8+e]; B lane l holds B[k=(l>>5)*8+e][j=l&31];
 // D lane l reg r holds D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31].

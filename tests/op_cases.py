@@ -374,3 +374,51 @@ def case_enc0(lib, dev, Cc, M, K, stride, pad, Fq, T, B=2, act='gelu', seed=90):
     ref = {'none': lambda v: v, 'relu': F.relu, 'gelu': F.gelu}[act](ref)
     assert y.shape == (B, Fo, T, M)
     assert rel_l2(uncl(y.cpu()), ref) < TOL16
+
+
+def case_dconv_row(lib, dev, Cc, T, Fq=3, B=2, depth=2, act='gelu', norm=True, seed=100):
+    """aero_dconv_row_fwd: a whole DConv branch (modules.py:221-249 without BLSTM / LocalState) on [B,F,T,C] rows against the
+    same layers in fp32 torch (conv1d dilated -> GroupNorm(1) -> act -> conv1d 1x1 -> GroupNorm(1) -> GLU -> LayerScale -> +x)."""
+    ops = Ops(lib)
+    hid = Cc // 4
+    x = q16(_rand((B, Fq, T, Cc), seed))
+    actc = {'relu': _lib.ACT_RELU, 'gelu': _lib.ACT_GELU, 'snake': _lib.ACT_SNAKE}[act]
+    layers, ref = [], x.reshape(B * Fq, T, Cc).permute(0, 2, 1)                     # [R, C, T]
+    for l in range(depth):
+        dil = 2 ** l
+        w1 = q16(_rand((hid, Cc, 3), seed + 10 * l + 1, 1.0 / math.sqrt(3 * Cc)))
+        b1 = _rand((hid,), seed + 10 * l + 2, 0.3)
+        w2 = q16(_rand((2 * Cc, hid, 1), seed + 10 * l + 3, 1.0 / math.sqrt(hid)))
+        b2 = _rand((2 * Cc,), seed + 10 * l + 4, 0.3)
+        g1, be1 = 1 + _rand((hid,), seed + 10 * l + 5, 0.2), _rand((hid,), seed + 10 * l + 6, 0.2)
+        g2, be2 = 1 + _rand((2 * Cc,), seed + 10 * l + 7, 0.2), _rand((2 * Cc,), seed + 10 * l + 8, 0.2)
+        scale = _rand((Cc,), seed + 10 * l + 9, 0.5)
+        sa = 0.5 + torch.rand(Fq, generator=_g(seed + 10 * l + 10)) * 2
+        HP, K1p = pack._round_up(hid, 16), pack._round_up(3 * Cc, 32)
+        i1 = torch.zeros(HP, K1p)
+        i1[:hid, :3 * Cc] = w1.permute(0, 2, 1).reshape(hid, 3 * Cc)
+        i2 = torch.zeros(2 * Cc, HP)
+        i2[:, :hid] = pack.glu_interleave(w2[:, :, 0])
+        f32 = lambda t: t.float().to(dev).contiguous()                              # noqa: E731
+        layers.append(dict(w1=i1.half().to(dev), b1=f32(b1), g1=f32(g1) if norm else None, be1=f32(be1) if norm else None,
+                           w2=i2.half().to(dev), b2=f32(pack.glu_interleave(b2)), g2=f32(pack.glu_interleave(g2)) if norm else None,
+                           be2=f32(pack.glu_interleave(be2)) if norm else None, scale=f32(scale), dilation=dil, C=Cc, hidden=hid,
+                           snake_a=f32(sa) if act == 'snake' else None))
+        h = F.conv1d(q16(ref), w1, b1, dilation=dil, padding=dil)
+        if norm:
+            h = F.group_norm(h, 1, g1, be1, 1e-5)
+        if act == 'snake':
+            a = sa.repeat(B)[:, None, None]
+            h = h + torch.sin(a * h) ** 2 / a
+        else:
+            h = {'relu': F.relu, 'gelu': F.gelu}[act](h)
+        v = F.conv1d(h, w2, b2)
+        if norm:
+            v = F.group_norm(v, 1, g2, be2, 1e-5)
+        ref = ref + scale[None, :, None] * F.glu(v, 1)
+    assert ops.dconv_row_fits(T, Cc, hid, 2 ** (depth - 1))
+    y = ops.dconv_row(x.half().to(dev), layers, actc, Fq)
+    want = ref.permute(0, 2, 1).reshape(B, Fq, T, Cc)
+    assert y.shape == x.shape
+    err = rel_l2(y.float().cpu(), want)
+    assert err < TOL16, err

@@ -170,3 +170,9 @@ def test_localstate_resident_form_option():
                                 dict(Cc=64, M=64, K=8, stride=4, pad=2, Fq=20, T=128, B=1)])     # Fo = 5: a ragged last row group
 def test_enc0_fused(emu, kw):
     oc.case_enc0(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=48, T=139, act='snake'), dict(Cc=16, T=33, Fq=2, B=1, depth=1, act='relu'),
+                                dict(Cc=96, T=70, Fq=1, depth=3), dict(Cc=32, T=16, Fq=2, norm=False), dict(Cc=128, T=50, Fq=1, B=1)])
+def test_dconv_row(emu, kw):
+    oc.case_dconv_row(emu, DEV, **kw)

@@ -147,3 +147,9 @@ def test_spectral_losses_on_the_hip_stft():
                                 dict(Cc=64, M=64, K=8, stride=4, pad=2, Fq=20, T=128, B=1)])     # Fo = 5: a ragged last row group
 def test_enc0_fused(lib, kw):
     oc.case_enc0(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=48, T=501, Fq=64, B=2), dict(Cc=96, T=501, Fq=16, B=2, act='snake'), dict(Cc=48, T=139, act='snake'), dict(Cc=16, T=33, Fq=2, B=1, depth=1, act='relu'),
+                                dict(Cc=96, T=70, Fq=1, depth=3), dict(Cc=32, T=16, Fq=2, norm=False), dict(Cc=128, T=50, Fq=1, B=1)])
+def test_dconv_row(lib, kw):
+    oc.case_dconv_row(lib, DEV, **kw)
