@@ -83,8 +83,8 @@ DCONV_MAX_DEPTH = 4
 
 
 class DconvLayer(C.Structure):
-    _fields_ = [('w1', vp), ('b1', fp), ('g1', fp), ('be1', fp), ('snake_a', fp),
-                ('w2', vp), ('b2', fp), ('g2', fp), ('be2', fp), ('scale', fp), ('dilation', i32), ('reserved', i32)]
+    _fields_ = [('w1', vp), ('w2', vp), ('consts', fp), ('snake_a', fp),
+                ('dilation', i32), ('norm1', i32), ('norm2', i32), ('reserved', i32)]
 
 
 class DconvDesc(C.Structure):

@@ -9,24 +9,25 @@
 //
 // Per layer, three passes over the row's 16-step column fragments (waves take fragments round-robin):
 //   A  conv1 as MFMA 16x16x32 (A = W1 from LDS, B = 8 consecutive channels of x at t + (tap-1)*dilation straight from the
-//      row image), + bias -> raw h, fp16, into an LDS side buffer [T][hidden]; sum / sum of squares -> GN1 statistics
-//   B  h -> act(GN1(h)) in place; conv2 as MFMA 16x16x16 -- its B operand (lane = time step, 4 consecutive hidden units)
-//      is exactly how the side buffer is read, 8 bytes per lane -- only for the GN2 statistics (the 2C-channel tensor is
-//      never stored: recomputing a K = 16 contraction is cheaper than keeping it)
-//   C  conv2 again, GN2, GLU (rows of W2 are interleaved (a0, b0, a1, b1, ...) so a lane holds both halves), LayerScale,
-//      + x[t][c] read and written in place by the same lane (conv1's neighbours were consumed in pass A)
-// Block-wide reductions: wave shuffles + 8 partials in LDS.  HBM-bound: algorithmic bytes = 4*C per (row, time step).
+//      row image), bias as the accumulator seed -> raw h in REGISTERS (a wave owns at most MAXF fragments); sum / sum of
+//      squares -> GN1 statistics
+//   B  h -> act(GN1(h)), fp16, still in registers: the accumulator layout of conv1 (lane = time step, 4 consecutive hidden
+//      units) IS the B-operand layout of MFMA 16x16x16, so conv2 consumes it without an LDS round trip; conv2 here only
+//      for the GN2 statistics (the 2C-channel tensor is never stored: recomputing a K = 16 contraction is cheaper)
+//   C  conv2 again, GN2 (one FMA per value), GLU (rows of W2 are interleaved (a0, b0, a1, b1, ...) so a lane holds both
+//      halves), LayerScale, + x[t][c] read and written in place by the same lane (conv1's neighbours were consumed in A)
+// Block-wide reductions: wave shuffles + NW partials in LDS.  HBM traffic: 4*C bytes per (row, time step); the kernel
+// itself is bound by the LDS pipe and the VALU (PMC of the first version: LDS pipe 74-85 % busy, half of it bank
+// conflicts on the W2 fragments and the h side buffer -- hence W2 in lane order and h in registers).
 #pragma once
 #include "aero_common.h"
 
 struct AeroDconvK {
     aero_dconv_desc d;
-    int HP;       // hidden rounded up to 16 (rows of the W1 image, k-extent of the W2 image)
-    int hs;       // pitch of the h side buffer in halves (= hidden, a multiple of 4)
-    int K1p;      // 3*C rounded up to 32
+    int HP;       // hidden rounded up to 16 (rows of the W1 image, k-extent of the W2 image)  [template HM * 16]
     int logp;     // 16 pad bytes after every (1 << logp) rows of the row image: b128 reads of 16 consecutive rows conflict-free
     int T16;      // T rounded up to 16
-    int PADR;     // zero rows before t = 0 and after T16 (largest dilation)
+    int PADR;     // zero rows before t = 0 and after T16 (largest dilation, rounded up to 8 rows: fragment rows stay bank-aligned)
 };
 
 static inline int aero_dconv_logp(int C) {
@@ -41,102 +42,110 @@ static inline int aero_dconv_logp(int C) {
 static inline size_t aero_dconv_lds_bytes(int T, int C, int hidden, int maxdil) {
     if (T < 1 || C < 8 || C % 8 || hidden < 4 || hidden % 4 || hidden > 32 || maxdil < 1 || maxdil > 64) return 0;
     const int HP = (hidden + 15) / 16 * 16, K1p = (3 * C + 31) / 32 * 32, T16 = (T + 15) / 16 * 16;
-    const int xrows = T16 + 2 * maxdil, logp = aero_dconv_logp(C);
+    const int padr = (maxdil + 7) / 8 * 8;
+    const int xrows = T16 + 2 * padr, logp = aero_dconv_logp(C);
     const size_t xs = (size_t)xrows * C + (size_t)((xrows >> logp) + 1) * 8;
-    const size_t hb = (size_t)T16 * hidden;
     const size_t w1 = (size_t)HP * K1p, w2 = (size_t)2 * C * HP;
-    const size_t halves = (xs + hb + w1 + w2 + 7) / 8 * 8;
-    const size_t floats = 3 * HP + 3 * 2 * C + C + 2 * 8 * 2 + 8;
+    const size_t halves = (xs + w1 + w2 + 7) / 8 * 8;
+    const size_t floats = 3 * HP + 3 * 2 * C + C + 2 * 16 * 2 + 8;
     return halves * 2 + floats * 4;
 }
 
-template <int HM>                                                // HM = HP / 16: M fragments of conv1 = k-steps of conv2
-__global__ __launch_bounds__(512) void aero_dconv_row_kernel(AeroDconvK p) {
+// 8 waves (two blocks per CU when the row is small) or 16 (one block per CU, or more than 32 fragments); 4 fragments per wave
+static inline int aero_dconv_nw(size_t lds_bytes, int T) { return (lds_bytes > 80 * 1024 || T > 512) ? 16 : 8; }
+
+// HM = HP/16: M fragments of conv1 = k-steps of conv2;  NF2 = C/8 = M fragments of conv2;  NW waves, each owning at most MAXF
+// 16-step column fragments (cf = wave + f*NW): T <= 16 * NW * MAXF
+template <int HM, int NF2, int NW, int MAXF>
+__global__ __launch_bounds__(NW * 64) void aero_dconv_row_kernel(AeroDconvK p) {
+    constexpr int C = NF2 * 8, HP = HM * 16, NK1 = (3 * C + 31) / 32, K1p = NK1 * 32, CU = NF2, NT = NW * 64;
     const aero_dconv_desc& d = p.d;
-    const int C = d.C, T = d.T, HP = p.HP, hs = p.hs, K1p = p.K1p, hidden = d.hidden;
+    const int T = d.T, hidden = d.hidden;
     const int xrows = p.T16 + 2 * p.PADR;
     h16* xs = (h16*)AERO_DYN_SMEM;                                                 // row image, padded (see xoff)
-    h16* hb = xs + (size_t)xrows * C + (size_t)((xrows >> p.logp) + 1) * 8;        // [T16][hs]
-    h16* w1s = hb + (size_t)p.T16 * hs;                                            // [K1p/32][HP][32] tile-swizzled
-    h16* w2s = w1s + (size_t)HP * K1p;                                             // [2C][HP]
-    float* c1 = (float*)(xs + ((size_t)(w2s + (size_t)2 * C * HP - xs) + 7) / 8 * 8);   // [3][HP]   b1 | g1 | be1
-    float* c2 = c1 + 3 * HP;                                                       // [3][2C]   b2 | g2 | be2 (GLU-interleaved)
+    h16* w1s = xs + xrows * C + ((xrows >> p.logp) + 1) * 8;                       // [NK1][HP][32] tile-swizzled
+    h16* w2s = w1s + HP * K1p;                                                     // [NF2][HM][64 lanes][4]: fragments in lane order
+    float* c1 = (float*)(xs + ((int)(w2s + 2 * C * HP - xs) + 7) / 8 * 8);         // [3][HP]   b1 | g1 | be1
+    float* c2 = c1 + 3 * HP;                                                       // [3][2C]   b2 | g2 -> A2 | be2 -> B2 (GLU-interleaved)
     float* sc = c2 + 3 * 2 * C;                                                    // [C]       LayerScale
-    float* red = sc + C;                                                           // [2][8][2] reduction partials
+    float* red = sc + C;                                                           // [2][NW][2] reduction partials (after the constant block)
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int g = lane >> 4, col = lane & 15;
     const int row = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
-    const int nfrag = p.T16 >> 4, cu = C >> 3, nk1 = K1p >> 5, nf2 = (2 * C) >> 4;
+    const int nfrag = p.T16 >> 4;
     auto xoff = [&](int r) { return r * C + ((r >> p.logp) << 3); };
 
-    // the row (and its zero margins) -> LDS, once
+    // the row (and its zero margins) -> LDS, once.  Direct global->LDS copies: every 16-byte unit of the LINEAR LDS image picks its
+    // source (a row unit, or the zero page for margins and pad units), all copies are in flight together and the block waits once.
     {
         const h16* src = (const h16*)d.x + (int64_t)row * T * C;
-        for (int u = tid; u < xrows * cu; u += 512) {
-            const int r = u / cu, s = u - r * cu;
-            const int t = r - p.PADR;
-            h16x8 v = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (t >= 0 && t < T) v = *(const h16x8*)(src + (int64_t)t * C + s * 8);
-            *(h16x8*)&xs[xoff(r) + s * 8] = v;
+        const int gsz = (CU << p.logp) + 1;                      // units per group of (1 << logp) rows + the pad unit
+        const int total = xrows * CU + (xrows >> p.logp) + 1;
+        for (int ub = wave * 64; ub < total; ub += NT) {
+            const int U = ub + lane;
+            const int grp = U / gsz, rem = U - grp * gsz;
+            const int rr = rem / CU, s = rem - rr * CU;
+            const int t = (grp << p.logp) + rr - p.PADR;
+            const h16* sp = (rem < gsz - 1 && t >= 0 && t < T) ? src + (int64_t)t * C + s * 8 : aero_zero_page;
+            if (U < total) aero_glds16(sp, xs + ub * 8);
         }
     }
     float snake_a = 0.f, snake_ia = 0.f;
+    constexpr int NCONST = 3 * HP + 7 * C;                       // floats of a layer's constant block
+    // per-lane LDS offsets (halves / floats), fixed for the whole kernel
+    const int w1lane = aero_tile_off(col, g);                    // + kk*HP*32 + mf*512
+    const int w2lane = lane * 4;                                 // + (mf*HM + ks)*256
+    const bool hin[2] = {g * 4 < hidden, 16 + g * 4 < hidden};   // this lane's four hidden units of k-step 0 / 1 are real
     for (int l = 0; l < d.depth; ++l) {
         const aero_dconv_layer& L = d.layer[l];
         const int dil = L.dilation;
-        const bool norm1 = L.g1 != nullptr, norm2 = L.g2 != nullptr;
-        __syncthreads();                                         // previous layer done with the weights / the row is in
-        for (int u = tid; u < HP * (K1p >> 3); u += 512) {       // W1 image [HP][K1p] -> k-step tiles
-            const int r = u / (K1p >> 3), q8 = u - r * (K1p >> 3);
-            const int kk = q8 >> 2, q = q8 & 3;
-            *(h16x8*)&w1s[(size_t)kk * HP * 32 + aero_tile_off(r, q)] = *(const h16x8*)((const h16*)L.w1 + (size_t)r * K1p + q8 * 8);
+        const bool norm1 = L.norm1 != 0, norm2 = L.norm2 != 0;
+        if (l) __syncthreads();                                  // previous layer done with the weights
+        for (int ub = wave * 64; ub < HP * (K1p >> 3); ub += NT) {       // W1 image [HP][K1p] -> k-step tiles (swizzle on the source side)
+            const int U = ub + lane;
+            const int kk = U / (HP * 4), rem = U - kk * (HP * 4);
+            const int r = rem >> 2, q = (rem & 3) ^ ((0 - (r >> 2)) & 3);
+            if (U < HP * (K1p >> 3)) aero_glds16((const h16*)L.w1 + r * K1p + kk * 32 + q * 8, w1s + ub * 8);
         }
-        for (int u = tid; u < 2 * C * HP / 8; u += 512) *(h16x8*)&w2s[u * 8] = *(const h16x8*)((const h16*)L.w2 + u * 8);
-        for (int u = tid; u < HP; u += 512) {
-            const bool in = u < hidden;
-            c1[u] = in ? L.b1[u] : 0.f;
-            c1[HP + u] = (in && norm1) ? L.g1[u] : 1.f;
-            c1[2 * HP + u] = (in && norm1) ? L.be1[u] : 0.f;
-        }
-        for (int u = tid; u < 2 * C; u += 512) {
-            c2[u] = L.b2[u];
-            c2[2 * C + u] = norm2 ? L.g2[u] : 1.f;
-            c2[4 * C + u] = norm2 ? L.be2[u] : 0.f;
-        }
-        for (int u = tid; u < C; u += 512) sc[u] = L.scale ? L.scale[u] : 1.f;
+        for (int ub = wave * 64; ub < 2 * C * HP / 8; ub += NT)
+            if (ub + lane < 2 * C * HP / 8) aero_glds16((const h16*)L.w2 + (ub + lane) * 8, w2s + ub * 8);
+        for (int ub = wave * 64; ub < NCONST / 4; ub += NT)
+            if (ub + lane < NCONST / 4) aero_glds16((const h16*)(L.consts + (ub + lane) * 4), (h16*)c1 + ub * 8);
         if (d.act == AERO_ACT_SNAKE) { snake_a = L.snake_a[row % d.F]; snake_ia = 1.0f / snake_a; }
-        __syncthreads();
+        __syncthreads();                                         // (drains the copies: vmcnt)
 
-        // ---- pass A: conv1 (+ bias) -> raw h, GN1 statistics
+        // ---- pass A: conv1 (bias = accumulator seed) -> raw h (registers), GN1 statistics
         float s1 = 0.f, s2 = 0.f;
-        for (int cf = wave; cf < nfrag; cf += 8) {
+        f32x4 hraw[MAXF][HM];
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) {
+            const int cf = wave + f * NW;                        // (wave-uniform)
+#pragma unroll
+            for (int mf = 0; mf < HM; ++mf) hraw[f][mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (cf >= nfrag) continue;
             const int t = cf * 16 + col;
             f32x4 acc[HM];
 #pragma unroll
-            for (int mf = 0; mf < HM; ++mf) acc[mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int kk = 0; kk < nk1; ++kk) {
+            for (int mf = 0; mf < HM; ++mf) acc[mf] = *(const f32x4*)&c1[mf * 16 + g * 4];      // (zero above `hidden`)
+#pragma unroll
+            for (int kk = 0; kk < NK1; ++kk) {
                 const int k = kk * 32 + g * 8;
                 const int tap = (k >= C) + (k >= 2 * C);
-                const int c = k - tap * C;
                 h16x8 bfrag = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (k < 3 * C) bfrag = *(const h16x8*)&xs[xoff(t + p.PADR + (tap - 1) * dil) + c];
+                if (kk * 32 + 24 < 3 * C || k < 3 * C) bfrag = *(const h16x8*)&xs[xoff(t + p.PADR + (tap - 1) * dil) + k - tap * C];
 #pragma unroll
                 for (int mf = 0; mf < HM; ++mf) {
-                    const h16x8 a = *(const h16x8*)&w1s[(size_t)kk * HP * 32 + aero_tile_off(mf * 16 + col, g)];
+                    const h16x8 a = *(const h16x8*)&w1s[kk * HP * 32 + mf * 512 + w1lane];
                     acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bfrag, acc[mf], 0, 0, 0);
                 }
             }
+            const float msk = t < T ? 1.f : 0.f;
 #pragma unroll
             for (int mf = 0; mf < HM; ++mf) {
-                const int j = mf * 16 + g * 4;
-                if (j < hidden) {                                // (hidden % 4 == 0: the four rows are all real or all padding)
-                    const f32x4 hv = acc[mf] + *(const f32x4*)&c1[j];
-                    if (t < T) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1 += hv[e]; s2 += hv[e] * hv[e]; }
-                    }
-                    *(h16x4*)&hb[(size_t)t * hs + j] = (h16x4){(h16)hv[0], (h16)hv[1], (h16)hv[2], (h16)hv[3]};
-                }
+                const f32x4 hv = acc[mf];                        // (rows above `hidden`: zero weights, zero bias -> 0)
+                s1 = fmaf(msk, (hv[0] + hv[1]) + (hv[2] + hv[3]), s1);
+                s2 = fmaf(msk, fmaf(hv[0], hv[0], hv[1] * hv[1]) + fmaf(hv[2], hv[2], hv[3] * hv[3]), s2);
+                hraw[f][mf] = hv;
             }
         }
         float mean1 = 0.f, rstd1 = 1.f;
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(512) void aero_dconv_row_kernel(AeroDconvK p) {
             __syncthreads();
             double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) { a += (double)red[w * 2]; b += (double)red[w * 2 + 1]; }
+            for (int w = 0; w < NW; ++w) { a += (double)red[w * 2]; b += (double)red[w * 2 + 1]; }
             const double n = (double)hidden * T, m = a / n;
             double var = b / n - m * m;
             var = var > 0.0 ? var : 0.0;
@@ -157,44 +166,52 @@ __global__ __launch_bounds__(512) void aero_dconv_row_kernel(AeroDconvK p) {
             __syncthreads();                                     // every wave is done READING its neighbours' x rows before pass C writes x
         }
 
-        // ---- pass B: h <- act(GN1(h)) in place; conv2 for the GN2 statistics
+        // ---- pass B: h <- act(GN1(h)) in place; conv2 (bias = seed) for the GN2 statistics
         s1 = s2 = 0.f;
-        for (int cf = wave; cf < nfrag; cf += 8) {
-            const int t = cf * 16 + col;
-            h16x4 hB[HM];
+        f32x4 ga[HM], gb[HM];                                    // GN1 as one FMA: y = h * ga + gb
+#pragma unroll
+        for (int ks = 0; ks < HM; ++ks) {
+            ga[ks] = *(const f32x4*)&c1[HP + ks * 16 + g * 4] * rstd1;
+            gb[ks] = *(const f32x4*)&c1[2 * HP + ks * 16 + g * 4] - ga[ks] * mean1;
+        }
+        h16x4 hB[MAXF][HM];                                      // act(GN1(h)): conv2's B operand, kept for pass C
+        float msk[MAXF];
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) {
+            msk[f] = ((wave + f * NW) * 16 + col < T) ? 1.f : 0.f;
 #pragma unroll
             for (int ks = 0; ks < HM; ++ks) {
-                const int j = ks * 16 + g * 4;
-                hB[ks] = (h16x4){0, 0, 0, 0};
-                if (j < hidden) {
-                    const h16x4 raw = *(const h16x4*)&hb[(size_t)t * hs + j];
-                    const f32x4 gm = *(const f32x4*)&c1[HP + j], bt = *(const f32x4*)&c1[2 * HP + j];
-                    h16x4 o;
+                h16x4 o = (h16x4){0, 0, 0, 0};
+                if (hin[ks]) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float y = ((float)raw[e] - mean1) * rstd1 * gm[e] + bt[e];
+                        float y = fmaf(hraw[f][ks][e], ga[ks][e], gb[ks][e]);
                         if (d.act == AERO_ACT_GELU) y = aero_gelu(y);
                         else if (d.act == AERO_ACT_RELU) y = fmaxf(y, 0.f);
-                        else if (d.act == AERO_ACT_SNAKE) { const float sn = aero_fast_sin(y * snake_a); y = y + snake_ia * sn * sn; }
+                        else if (d.act == AERO_ACT_SNAKE) { const float sn = aero_fast_sin(y * snake_a); y = fmaf(snake_ia * sn, sn, y); }
                         o[e] = (h16)y;
                     }
-                    *(h16x4*)&hb[(size_t)t * hs + j] = o;
-                    hB[ks] = o;
                 }
+                hB[f][ks] = o;
             }
-            if (norm2) {
-                for (int mf = 0; mf < nf2; ++mf) {
-                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // (row fragment of W2 and its constants OUTER, the wave's column fragments inner: one LDS fetch serves MAXF fragments --
+        //  with the column fragment outer the broadcast reads of the constants alone kept the LDS pipe 40 % busy)
+        if (norm2) {
 #pragma unroll
-                    for (int ks = 0; ks < HM; ++ks) {
-                        const h16x4 a = *(const h16x4*)&w2s[(size_t)(mf * 16 + col) * HP + ks * 16 + g * 4];
-                        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, hB[ks], acc, 0, 0, 0);
-                    }
-                    const f32x4 v = acc + *(const f32x4*)&c2[mf * 16 + g * 4];
-                    if (t < T) {
+            for (int mf = 0; mf < NF2; ++mf) {
+                const f32x4 bias = *(const f32x4*)&c2[mf * 16 + g * 4];
+                h16x4 wf[HM];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
-                    }
+                for (int ks = 0; ks < HM; ++ks) wf[ks] = *(const h16x4*)&w2s[(mf * HM + ks) * 256 + w2lane];
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f) {
+                    if (wave + f * NW >= nfrag) continue;
+                    f32x4 v = bias;
+#pragma unroll
+                    for (int ks = 0; ks < HM; ++ks) v = __builtin_amdgcn_mfma_f32_16x16x16f16(wf[ks], hB[f][ks], v, 0, 0, 0);
+                    s1 = fmaf(msk[f], (v[0] + v[1]) + (v[2] + v[3]), s1);
+                    s2 = fmaf(msk[f], fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]), s2);
                 }
             }
         }
@@ -202,54 +219,58 @@ __global__ __launch_bounds__(512) void aero_dconv_row_kernel(AeroDconvK p) {
         if (norm2) {
             s1 = aero_wave_sum(s1);
             s2 = aero_wave_sum(s2);
-            if (lane == 0) { red[16 + wave * 2] = s1; red[16 + wave * 2 + 1] = s2; }
+            if (lane == 0) { red[2 * NW + wave * 2] = s1; red[2 * NW + wave * 2 + 1] = s2; }
             __syncthreads();
             double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) { a += (double)red[16 + w * 2]; b += (double)red[16 + w * 2 + 1]; }
+            for (int w = 0; w < NW; ++w) { a += (double)red[2 * NW + w * 2]; b += (double)red[2 * NW + w * 2 + 1]; }
             const double n = (double)(2 * C) * T, m = a / n;
             double var = b / n - m * m;
             var = var > 0.0 ? var : 0.0;
             mean2 = (float)m;
             rstd2 = (float)(1.0 / sqrt(var + (double)d.eps));
         }
+        // GN2 folded into one FMA per value: v' = acc * A2 + B2, A2 = rstd*g2, B2 = be2 + (b2 - mean) * A2  (in place of g2 / be2)
+        for (int m = tid; m < 2 * C; m += NT) {
+            const float A2 = rstd2 * c2[2 * C + m];
+            c2[4 * C + m] = fmaf(c2[m] - mean2, A2, c2[4 * C + m]);
+            c2[2 * C + m] = A2;
+        }
+        __syncthreads();
 
         // ---- pass C: conv2 again, GN2, GLU, LayerScale, + x in place
-        for (int cf = wave; cf < nfrag; cf += 8) {
-            const int t = cf * 16 + col;
-            h16x4 hB[HM];
+        int xlane[MAXF];
 #pragma unroll
-            for (int ks = 0; ks < HM; ++ks) {
-                const int j = ks * 16 + g * 4;
-                hB[ks] = j < hidden ? *(const h16x4*)&hb[(size_t)t * hs + j] : (h16x4){0, 0, 0, 0};
-            }
-            h16* xr = &xs[xoff(t + p.PADR)];
-            for (int mf = 0; mf < nf2; ++mf) {
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < MAXF; ++f) xlane[f] = xoff((wave + f * NW) * 16 + col + p.PADR) + g * 2;
 #pragma unroll
-                for (int ks = 0; ks < HM; ++ks) {
-                    const h16x4 a = *(const h16x4*)&w2s[(size_t)(mf * 16 + col) * HP + ks * 16 + g * 4];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, hB[ks], acc, 0, 0, 0);
-                }
-                const int m = mf * 16 + g * 4;
-                f32x4 v = acc + *(const f32x4*)&c2[m];
-                const f32x4 gm = *(const f32x4*)&c2[2 * C + m], bt = *(const f32x4*)&c2[4 * C + m];
+        for (int mf = 0; mf < NF2; ++mf) {
+            const f32x4 A2 = *(const f32x4*)&c2[2 * C + mf * 16 + g * 4], B2 = *(const f32x4*)&c2[4 * C + mf * 16 + g * 4];
+            const f32x2 ls = *(const f32x2*)&sc[mf * 8 + g * 2];
+            h16x4 wf[HM];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean2) * rstd2 * gm[e] + bt[e];
-                const int c = mf * 8 + g * 2;
-                const f32x2 ls = *(const f32x2*)&sc[c];
-                const h16x2 xv = *(const h16x2*)&xr[c];
-                const float o0 = (float)xv[0] + v[0] * aero_sigmoid(v[1]) * ls[0];
-                const float o1 = (float)xv[1] + v[2] * aero_sigmoid(v[3]) * ls[1];
-                if (t < T) *(h16x2*)&xr[c] = (h16x2){(h16)o0, (h16)o1};
+            for (int ks = 0; ks < HM; ++ks) wf[ks] = *(const h16x4*)&w2s[(mf * HM + ks) * 256 + w2lane];
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) {
+                if (wave + f * NW >= nfrag) continue;
+                h16* xr = &xs[xlane[f] + mf * 8];
+                const h16x2 xv = *(const h16x2*)xr;
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < HM; ++ks) v = __builtin_amdgcn_mfma_f32_16x16x16f16(wf[ks], hB[f][ks], v, 0, 0, 0);
+                v = v * A2 + B2;
+                constexpr float NL2E = -1.4426950408889634f;
+                const float g0 = aero_rcp(1.f + aero_exp2(v[1] * NL2E)), g1 = aero_rcp(1.f + aero_exp2(v[3] * NL2E));
+                const float o0 = fmaf(v[0] * g0, ls[0], (float)xv[0]);
+                const float o1 = fmaf(v[2] * g1, ls[1], (float)xv[1]);
+                if (msk[f] != 0.f) *(h16x2*)xr = (h16x2){(h16)o0, (h16)o1};
             }
         }
     }
     __syncthreads();
     {
         h16* dst = (h16*)d.y + (int64_t)row * T * C;
-        for (int u = tid; u < T * cu; u += 512) {
-            const int t = u / cu, s = u - t * cu;
+        for (int u = tid; u < T * CU; u += NT) {
+            const int t = u / CU, s = u - t * CU;
             *(h16x8*)(dst + (int64_t)t * C + s * 8) = *(const h16x8*)&xs[xoff(t + p.PADR) + s * 8];
         }
     }
@@ -257,7 +278,9 @@ __global__ __launch_bounds__(512) void aero_dconv_row_kernel(AeroDconvK p) {
 
 static int aero_dconv_row_fits_impl(int T, int C, int hidden, int maxdil) {
     const size_t b = aero_dconv_lds_bytes(T, C, hidden, maxdil);
-    return b != 0 && b <= 160 * 1024;
+    const int nf2 = C / 8;
+    const bool inst = nf2 == 2 || nf2 == 4 || nf2 == 6 || nf2 == 8 || nf2 == 12 || nf2 == 16;      // instantiated widths
+    return b != 0 && b <= 160 * 1024 && inst && T <= (nf2 >= 12 && aero_dconv_nw(b, T) == 16 ? 512 : 1024);
 }
 
 static int aero_dconv_launch(const aero_dconv_desc* d, hipStream_t stream, const char** err) {
@@ -267,11 +290,10 @@ static int aero_dconv_launch(const aero_dconv_desc* d, hipStream_t stream, const
     int maxdil = 1;
     for (int l = 0; l < d->depth; ++l) {
         const aero_dconv_layer& L = d->layer[l];
-        if (!L.w1 || !L.b1 || !L.w2 || !L.b2) { *err = "dconv: null layer weights"; return AERO_ERR_ARG; }
-        if ((L.g1 == nullptr) != (L.be1 == nullptr) || (L.g2 == nullptr) != (L.be2 == nullptr)) { *err = "dconv: gamma/beta"; return AERO_ERR_ARG; }
+        if (!L.w1 || !L.w2 || !L.consts) { *err = "dconv: null layer weights"; return AERO_ERR_ARG; }
         if (d->act == AERO_ACT_SNAKE && !L.snake_a) { *err = "dconv: snake needs a"; return AERO_ERR_ARG; }
         if (L.dilation < 1) { *err = "dconv: dilation"; return AERO_ERR_ARG; }
-        if ((((uintptr_t)L.w1 | (uintptr_t)L.w2) & 15)) { *err = "dconv: unaligned weights"; return AERO_ERR_ARG; }
+        if ((((uintptr_t)L.w1 | (uintptr_t)L.w2 | (uintptr_t)L.consts) & 15)) { *err = "dconv: unaligned weights"; return AERO_ERR_ARG; }
         maxdil = L.dilation > maxdil ? L.dilation : maxdil;
     }
     if ((((uintptr_t)d->x | (uintptr_t)d->y) & 15)) { *err = "dconv: unaligned rows"; return AERO_ERR_ARG; }
@@ -280,14 +302,29 @@ static int aero_dconv_launch(const aero_dconv_desc* d, hipStream_t stream, const
     AeroDconvK p;
     p.d = *d;
     p.HP = (d->hidden + 15) / 16 * 16;
-    p.hs = d->hidden;
-    p.K1p = (3 * d->C + 31) / 32 * 32;
     p.logp = aero_dconv_logp(d->C);
     p.T16 = (d->T + 15) / 16 * 16;
-    p.PADR = maxdil;
+    p.PADR = (maxdil + 7) / 8 * 8;
     const size_t lds = aero_dconv_lds_bytes(d->T, d->C, d->hidden, maxdil);
-    dim3 grid((unsigned)d->R), block(512);
-    if (p.HP == 16) AERO_LAUNCH_DYN((aero_dconv_row_kernel<1>), grid, block, lds, stream, p);
-    else AERO_LAUNCH_DYN((aero_dconv_row_kernel<2>), grid, block, lds, stream, p);
+    const int nw = aero_dconv_nw(lds, d->T), nf2 = d->C / 8;
+    dim3 grid((unsigned)d->R), block((unsigned)nw * 64);
+#define AERO_DCONV_GO(NF2_)                                                                                            \
+    do {                                                                                                               \
+        constexpr int MF16 = NF2_ >= 12 ? 2 : 4;     /* wide rows: 16 waves x 2 fragments (T <= 512; longer rows do not fit the LDS) */ \
+        if (nw == 16 && (d->T + 15) / 16 > 16 * MF16) { *err = "dconv: row too long"; return AERO_ERR_UNSUPPORTED; }    \
+        if (p.HP == 16 && nw == 8) AERO_LAUNCH_DYN((aero_dconv_row_kernel<1, NF2_, 8, 4>), grid, block, lds, stream, p);  \
+        else if (p.HP == 16) AERO_LAUNCH_DYN((aero_dconv_row_kernel<1, NF2_, 16, MF16>), grid, block, lds, stream, p);       \
+        else if (nw == 8) AERO_LAUNCH_DYN((aero_dconv_row_kernel<2, NF2_, 8, 4>), grid, block, lds, stream, p);           \
+        else AERO_LAUNCH_DYN((aero_dconv_row_kernel<2, NF2_, 16, MF16>), grid, block, lds, stream, p);                       \
+    } while (0)
+    switch (nf2) {
+        case 2: AERO_DCONV_GO(2); break;
+        case 4: AERO_DCONV_GO(4); break;
+        case 6: AERO_DCONV_GO(6); break;
+        case 8: AERO_DCONV_GO(8); break;
+        case 12: AERO_DCONV_GO(12); break;
+        default: AERO_DCONV_GO(16); break;
+    }
+#undef AERO_DCONV_GO
     return AERO_OK;
 }

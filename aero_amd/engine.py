@@ -314,9 +314,8 @@ def _dconv_row(self, x, layers, act, F, eps=1e-5):
     flops = 0.0
     for i, L in enumerate(layers):
         l = d.layer[i]
-        l.w1, l.b1, l.g1, l.be1, l.snake_a = _ptr(L['w1']), _ptr(L['b1']), _ptr(L['g1']), _ptr(L['be1']), _ptr(L.get('snake_a'))
-        l.w2, l.b2, l.g2, l.be2, l.scale = _ptr(L['w2']), _ptr(L['b2']), _ptr(L['g2']), _ptr(L['be2']), _ptr(L['scale'])
-        l.dilation = L['dilation']
+        l.w1, l.w2, l.consts, l.snake_a = _ptr(L['w1']), _ptr(L['w2']), _ptr(L['consts']), _ptr(L.get('snake_a'))
+        l.dilation, l.norm1, l.norm2 = L['dilation'], L['norm1'], L['norm2']
         flops += 2.0 * B * Fq * T * L['hidden'] * (3 * Cc + 2 * Cc)
     self._shape_note = f'dconv rows C={Cc} hidden={layers[0]["hidden"]} depth={len(layers)} F={Fq}'
     self._call('aero_dconv_row_fwd', 'aero_dconv_row_kernel', flops, 2 * x.numel() * 2, C.byref(d), self.stream(x))
@@ -554,19 +553,10 @@ class HipEngine:
             hid = w.shape[-1]
             if not dc.lstm and not dc.time_attn and dc.kernel == 3 and hid % 4 == 0 and hid <= 32 and w.shape[1] % 16 == 0:
                 # whole-branch row kernel (k_dconv.h): conv1 image [HP][3C] with k = tap*C + c, conv2 image [2C][HP] GLU-interleaved
-                w1 = sd[f'{q}.conv1.0.weight']                                               # [hid, C, 3]
-                Cc, HP, K1p = w1.shape[1], pack._round_up(hid, 16), pack._round_up(3 * w1.shape[1], 32)
-                i1 = torch.zeros(HP, K1p)
-                i1[:hid, :3 * Cc] = w1.permute(0, 2, 1).reshape(hid, 3 * Cc)
-                i2 = torch.zeros(2 * Cc, HP)
-                i2[:, :hid] = pack.glu_interleave(sd[f'{q}.conv2.0.weight'][:, :, 0])
-                f32 = lambda t: t.detach().float().to(device).contiguous()                   # noqa: E731
-                L['row'] = dict(w1=i1.to(device=device, dtype=torch.float16).contiguous(), b1=f32(sd[f'{q}.conv1.0.bias']),
-                                g1=f32(sd[f'{q}.conv1.1.weight']) if dc.norm else None, be1=f32(sd[f'{q}.conv1.1.bias']) if dc.norm else None,
-                                w2=i2.to(device=device, dtype=torch.float16).contiguous(), b2=f32(pack.glu_interleave(sd[f'{q}.conv2.0.bias'])),
-                                g2=f32(pack.glu_interleave(sd[f'{q}.conv2.1.weight'])) if dc.norm else None,
-                                be2=f32(pack.glu_interleave(sd[f'{q}.conv2.1.bias'])) if dc.norm else None,
-                                scale=f32(sd[f'{q}.conv2.3.scale']), dilation=dil, C=Cc, hidden=hid)
+                g = (lambda n: sd[n]) if dc.norm else (lambda n: None)                       # noqa: E731
+                L['row'] = pack.dconv_row_layer(sd[f'{q}.conv1.0.weight'], sd[f'{q}.conv1.0.bias'], g(f'{q}.conv1.1.weight'),
+                                                g(f'{q}.conv1.1.bias'), sd[f'{q}.conv2.0.weight'][:, :, 0], sd[f'{q}.conv2.0.bias'],
+                                                g(f'{q}.conv2.1.weight'), g(f'{q}.conv2.1.bias'), sd[f'{q}.conv2.3.scale'], dil, device)
             if hid + 1 <= 112:                                      # statistics of conv2's output from the Gram matrix of its input
                 L['gram'] = pack.gram_tables(w[0, :, 0, :], sd[f'{q}.conv2.0.bias'], device)
             if hid % 8 and not dc.lstm and not dc.time_attn:

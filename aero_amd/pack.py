@@ -187,3 +187,30 @@ def pack_lstm_layer(lib, sd, prefix, layer, H, device):
         fused = (wih.to(device=device, dtype=torch.float16).contiguous(), b.float().to(device).contiguous(), in_ch)
     return spec, b.to(device=device, dtype=torch.float16).contiguous(), \
         whh.to(device=device, dtype=torch.float16).contiguous(), fused
+
+
+def dconv_row_layer(w1, b1, g1, be1, w2, b2, g2, be2, scale, dilation, device):
+    """One DConv layer for aero_dconv_row_fwd (include/aero_hip.h, K14).  w1 [hidden, C, 3], w2 [2C, hidden] (Conv1d weights),
+    g*/be* None without GroupNorm.  Returns dict(w1 fp16 [HP][K1p], w2 fp16 [2C][HP] GLU-interleaved, consts fp32, ...)."""
+    hid, Cc = w1.shape[0], w1.shape[1]
+    HP, K1p = _round_up(hid, 16), _round_up(3 * Cc, 32)
+    i1 = torch.zeros(HP, K1p)
+    i1[:hid, :3 * Cc] = w1.detach().float().permute(0, 2, 1).reshape(hid, 3 * Cc)
+    i2 = torch.zeros(2 * Cc, HP)
+    i2[:, :hid] = glu_interleave(w2.detach().float())
+    # MFMA 16x16x16 A fragments in lane order: [mf][ks][lane = g*16 + col][e] = W2[mf*16 + col][ks*16 + g*4 + e]
+    i2 = i2.reshape(2 * Cc // 16, 16, HP // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()       # [mf, ks, g, col, e]
+    c = torch.zeros(3 * HP + 7 * Cc)
+    c[:hid] = b1.detach().float()
+    c[HP:HP + hid] = 1.0 if g1 is None else g1.detach().float()
+    if be1 is not None:
+        c[2 * HP:2 * HP + hid] = be1.detach().float()
+    o = 3 * HP
+    c[o:o + 2 * Cc] = glu_interleave(b2.detach().float())
+    c[o + 2 * Cc:o + 4 * Cc] = 1.0 if g2 is None else glu_interleave(g2.detach().float())
+    if be2 is not None:
+        c[o + 4 * Cc:o + 6 * Cc] = glu_interleave(be2.detach().float())
+    c[o + 6 * Cc:] = 1.0 if scale is None else scale.detach().float()
+    return dict(w1=i1.to(device=device, dtype=torch.float16).contiguous(), w2=i2.to(device=device, dtype=torch.float16).contiguous(),
+                consts=c.to(device).contiguous(), norm1=int(g1 is not None), norm2=int(g2 is not None), dilation=int(dilation),
+                C=Cc, hidden=hid)

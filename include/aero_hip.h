@@ -247,18 +247,20 @@ int aero_enc0_fwd(const aero_enc0_desc* d, void* stream);
 /* K14: a whole DConv residual branch (modules.py:221-249) for the layers WITHOUT BLSTM / LocalState, one launch, the
  * activations read from and written to HBM once (aero_amd/csrc/k_dconv.h).  x, y: fp16 [R][T][C] rows (R = B*F items of
  * the reference's [B*F, C, T] view; y may alias x).  For each of `depth` layers, in place on the row:
- *   h = conv1d(x; w1, b1, kernel 3, dilation, padding = dilation);  h = act(GroupNorm(1, hidden)(h; g1, be1))   (g1 NULL: no norm)
+ *   h = conv1d(x; w1, b1, kernel 3, dilation, padding = dilation);  h = act(GroupNorm(1, hidden)(h; g1, be1))
  *   v = conv1d(h; w2, b2, kernel 1) [2C];  v = GroupNorm(1, 2C)(v; g2, be2);  x = x + scale * GLU(v)
  * act: RELU / GELU / SNAKE (snake_a fp32 [F], a of frequency row r % F: modules.py:232-236, snake.py:67) / NONE.
  * w1: fp16 [HP][K1p], element (j, tap*C + c), taps t-d, t, t+d, HP = roundup(hidden,16), K1p = roundup(3C,32), zero padded.
- * w2: fp16 [2C][HP] with GLU-interleaved rows (a0, b0, a1, b1, ...: row 2i = output channel i, row 2i+1 = gate C+i);
- * b2 / g2 / be2 fp32 [2C] in the same row order; scale fp32 [C] (NULL: 1).  C % 8 == 0, hidden % 4 == 0, hidden <= 32,
- * and the row must fit the LDS: aero_dconv_row_fits(T, C, hidden, largest dilation) == 1. */
+ * w2: fp16 [C/8][HP/16][64][4]: conv2 weights with GLU-interleaved rows (a0, b0, a1, b1, ...: row 2i = output channel i, row
+ * 2i+1 = gate C+i) as MFMA 16x16x16 A fragments in lane order: element [mf][ks][lane][e] = W2[mf*16 + lane%16][ks*16 + (lane/16)*4 + e].
+ * consts: fp32 [3*HP + 7*C] = b1[HP] | g1[HP] | be1[HP] | b2[2C] | g2[2C] | be2[2C] | scale[C]  (entries >= hidden of the first
+ * three zero; b2 / g2 / be2 in the row order of w2; without a norm g = 1, be = 0 and norm1 / norm2 = 0: statistics skipped).
+ * C in {16, 32, 48, 64, 96, 128}, hidden % 4 == 0, hidden <= 32, T <= 1024 and the row must fit the LDS:
+ * aero_dconv_row_fits(T, C, hidden, largest dilation) == 1.  All pointers 16-byte aligned. */
 #define AERO_DCONV_MAX_DEPTH 4
 typedef struct {
-    const void* w1; const float* b1; const float* g1; const float* be1; const float* snake_a;
-    const void* w2; const float* b2; const float* g2; const float* be2; const float* scale;
-    int32_t dilation, reserved;
+    const void* w1; const void* w2; const float* consts; const float* snake_a;
+    int32_t dilation, norm1, norm2, reserved;
 } aero_dconv_layer;
 typedef struct {
     const void* x; void* y;

@@ -394,16 +394,10 @@ def case_dconv_row(lib, dev, Cc, T, Fq=3, B=2, depth=2, act='gelu', norm=True, s
         g2, be2 = 1 + _rand((2 * Cc,), seed + 10 * l + 7, 0.2), _rand((2 * Cc,), seed + 10 * l + 8, 0.2)
         scale = _rand((Cc,), seed + 10 * l + 9, 0.5)
         sa = 0.5 + torch.rand(Fq, generator=_g(seed + 10 * l + 10)) * 2
-        HP, K1p = pack._round_up(hid, 16), pack._round_up(3 * Cc, 32)
-        i1 = torch.zeros(HP, K1p)
-        i1[:hid, :3 * Cc] = w1.permute(0, 2, 1).reshape(hid, 3 * Cc)
-        i2 = torch.zeros(2 * Cc, HP)
-        i2[:, :hid] = pack.glu_interleave(w2[:, :, 0])
-        f32 = lambda t: t.float().to(dev).contiguous()                              # noqa: E731
-        layers.append(dict(w1=i1.half().to(dev), b1=f32(b1), g1=f32(g1) if norm else None, be1=f32(be1) if norm else None,
-                           w2=i2.half().to(dev), b2=f32(pack.glu_interleave(b2)), g2=f32(pack.glu_interleave(g2)) if norm else None,
-                           be2=f32(pack.glu_interleave(be2)) if norm else None, scale=f32(scale), dilation=dil, C=Cc, hidden=hid,
-                           snake_a=f32(sa) if act == 'snake' else None))
+        n = (lambda v: v) if norm else (lambda v: None)                               # noqa: E731
+        Lr = pack.dconv_row_layer(w1, b1, n(g1), n(be1), w2[:, :, 0], b2, n(g2), n(be2), scale, dil, dev)
+        Lr['snake_a'] = sa.float().to(dev).contiguous() if act == 'snake' else None
+        layers.append(Lr)
         h = F.conv1d(q16(ref), w1, b1, dilation=dil, padding=dil)
         if norm:
             h = F.group_norm(h, 1, g1, be1, 1e-5)
