@@ -221,6 +221,314 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Folded form (T <= 512: every reference config at 2-s clips).  PMC of the kernel above: ~12.7 vector instructions per
+// score -- the distance bias (add + fma), the running maximum, the rescale, exp, the row sum and the fp16 pack -- and the
+// kernel is bound by exactly that instruction stream.  Here the per-score work outside the MFMAs is ONE exp2 and half a
+// pack:
+//   * keys and V^T of the (row, head) are resident in LDS, so the scores can be formed twice: pass 1 only takes the
+//     maximum per query (one v_max3 per two scores), pass 2 computes the probabilities against that FIXED maximum -- no
+//     running maximum, no accumulator rescale;
+//   * the head dimension (12 or 24) leaves k-slots of the 16x16x32 score MFMA unused; four of them carry the distance
+//     bias and the maximum: key side (t, t, 1, 1), query side (+-D_hi, +-D_lo, c_hi, c_lo) with D = D_hi + D_lo the decay
+//     slope split into two fp16 (products are exact in the fp32 accumulator) and c = -+D*s - m, so the MFMA returns
+//     S - |t-s|*D - m directly for every key block that lies entirely before or entirely after the wave's 16 queries
+//     (the sign of t - s is then fixed); only the <= 2 blocks around the diagonal and the ragged last block take the
+//     general path (|t-s|, self reference -100, keys >= T);
+//   * V^T carries a row of ones below the head's channels: the softmax denominator falls out of the O += V^T P MFMA;
+//   * a fifth slot (key side -30000 for the padded keys of the last block, query side 1) removes the ragged-end test;
+//   * one block stages K / V^T once and walks over all query blocks of its (row, head): with the score loop this lean the
+//     staging and the per-block setup were 60 % of the instructions (PMC: 1723 vector instructions per wave, ~370 of them
+//     in the two score loops).
+#define AERO_ATTN_FOLD_T 512
+template <int DT>
+__global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
+    constexpr int KC = AERO_ATTN_FOLD_T;
+    constexpr int VS = KC + 4;
+    __shared__ AERO_LDS_ALIGN h16 Ks[KC * 32];
+    __shared__ AERO_LDS_ALIGN h16 Vt[DT * 16 * VS];
+    __shared__ AERO_LDS_ALIGN h16 Qs[128 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const int h = blockIdx.y, row = blockIdx.z;
+    const int C = d.C, T = d.T;
+    const int dh = C / d.heads;
+    const int pos = (dh + 3) & ~3;                               // first of the four bias k-slots
+    const int gx = pos >> 3, e0 = pos & 7;                       // lane group / element offset (0 or 4) that holds them
+    const h16* base = (const h16*)d.qkvd + (int64_t)row * T * d.ld;
+    constexpr float L2E = 1.4426950408889634f;
+    const float qscale = L2E / sqrtf((float)dh);
+    const int kn32 = (T + 31) & ~31;
+    const int nqb = (T + 127) / 128;                             // the block walks over all query blocks of its (row, head)
+    // ---- staging: queries (scaled), keys + bias slots, V^T + the row of ones
+    const bool vec4 = (dh % 4 == 0) && (d.ld % 4 == 0) && (C % 4 == 0) && (((uintptr_t)d.qkvd & 7) == 0);
+    const int nc4 = (dh + 3) >> 2;                               // 8-byte pieces per head slice
+    if (vec4) {
+        // keys: piece nc4 of every key is the bias quadruple (t, t, 1, 1), the pieces above it zero (no loads in this loop) ...
+        for (int idx = tid; idx < kn32 * 8; idx += 512) {
+            const int tl = idx >> 3, c4 = idx & 7;
+            if (c4 >= nc4 || tl >= T) {
+                h16x4 v = (h16x4){0, 0, 0, 0};
+                if (tl < T && c4 == nc4) v = (h16x4){(h16)(float)tl, (h16)(float)tl, (h16)1.f, (h16)1.f};
+                if (tl >= T && c4 == nc4 + 1) v[0] = (h16)-30000.f;                  // padded key: -30000 * (query slot = 1)
+                *(h16x4*)&Ks[aero_tile_off(tl, c4 >> 1) + (c4 & 1) * 4] = v;
+            }
+        }
+        // ... the live 8-byte pieces of K and V come from HBM, FOUR loads in flight per thread before the first LDS store
+        // (one load per trip made the staging of a block eight serialized HBM round trips: the kernel ran at half speed)
+        const int nk = T * nc4;
+        for (int i0 = tid; i0 < nk; i0 += 4 * 512) {
+            h16x4 kv[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * 512;
+                if (idx < nk) {
+                    const int tl = idx / nc4, c4 = idx - tl * nc4;
+                    kv[u] = *(const h16x4*)(base + (int64_t)tl * d.ld + C + h * dh + c4 * 4);
+                    vv[u] = *(const h16x4*)(base + (int64_t)tl * d.ld + 2 * C + h * dh + c4 * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * 512;
+                if (idx < nk) {
+                    const int tl = idx / nc4, c4 = idx - tl * nc4;
+                    *(h16x4*)&Ks[aero_tile_off(tl, c4 >> 1) + (c4 & 1) * 4] = kv[u];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Vt[(c4 * 4 + e) * VS + tl] = vv[u][e];
+                }
+            }
+        }
+        // V^T rows from dh up: the row of ones, then zeros; padded keys zero in every row
+        for (int idx = tid; idx < (DT * 16 - dh) * (kn32 >> 2); idx += 512) {
+            const int rr = idx / (kn32 >> 2), t4 = (idx - rr * (kn32 >> 2)) * 4;
+            h16x4 v = (h16x4){0, 0, 0, 0};
+            if (rr == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (t4 + e < T) ? (h16)1.f : (h16)0;
+            }
+            *(h16x4*)&Vt[(dh + rr) * VS + t4] = v;
+        }
+        for (int idx = tid; idx < dh * (kn32 - T); idx += 512) {
+            const int rr = idx / (kn32 - T), tl = T + idx - rr * (kn32 - T);
+            Vt[rr * VS + tl] = (h16)0;
+        }
+    } else {
+        for (int idx = tid; idx < kn32 * 32; idx += 512) {
+            const int tl = idx >> 5, c = idx & 31;
+            h16 v = (h16)0;
+            if (tl < T) {
+                if (c < dh) v = base[(int64_t)tl * d.ld + C + h * dh + c];
+                else if (c == pos || c == pos + 1) v = (h16)(float)tl;               // (integers <= 2048 are exact in fp16)
+                else if (c == pos + 2 || c == pos + 3) v = (h16)1.f;
+            } else if (c == pos + 4) {
+                v = (h16)-30000.f;
+            }
+            Ks[aero_tile_off(tl, c >> 3) + (c & 7)] = v;
+        }
+        for (int idx = tid; idx < kn32 * DT * 16; idx += 512) {
+            const int tl = idx / (DT * 16), dd = idx - tl * (DT * 16);
+            h16 v = (h16)0;
+            if (tl < T) {
+                if (dd < dh) v = base[(int64_t)tl * d.ld + 2 * C + h * dh + dd];
+                else if (dd == dh) v = (h16)1.f;
+            }
+            Vt[dd * VS + tl] = v;
+        }
+    }
+  for (int qb = 0; qb < nqb; ++qb) {
+    const int s_blk = qb * 128;
+    if (qb) __syncthreads();                                     // every wave has taken its query fragment of the previous block
+    if (vec4) {
+        for (int idx = tid; idx < 128 * 8; idx += 512) {
+            const int sl = idx >> 3, c4 = idx & 7;
+            const int sq = s_blk + sl;
+            h16x4 v = (h16x4){0, 0, 0, 0};
+            if (sq < T && c4 * 4 < dh) {
+                const h16x4 x = *(const h16x4*)(base + (int64_t)sq * d.ld + h * dh + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (h16)((float)x[e] * qscale);
+            }
+            *(h16x4*)&Qs[aero_tile_off(sl, c4 >> 1) + (c4 & 1) * 4] = v;
+        }
+    } else {
+        for (int idx = tid; idx < 128 * 32; idx += 512) {
+            const int sl = idx >> 5, c = idx & 31;
+            const int sq = s_blk + sl;
+            float v = 0.f;
+            if (sq < T && c < dh) v = (float)base[(int64_t)sq * d.ld + h * dh + c] * qscale;
+            Qs[aero_tile_off(sl, c >> 3) + (c & 7)] = (h16)v;
+        }
+    }
+    __syncthreads();                                             // K, V^T (first trip) and the queries are in
+    // this lane's query and its decay slope
+    const int s = s_blk + wave * 16 + col;
+    float Dq = 0.f;
+    if (s < T) {
+        const h16* dp = base + (int64_t)s * d.ld + 3 * C + h * d.ndecay;
+        for (int f = 0; f < d.ndecay; ++f) Dq += (float)(f + 1) * aero_sigmoid((float)dp[f]);
+        Dq *= L2E * 0.5f / sqrtf((float)(d.ndecay > 0 ? d.ndecay : 1));
+    }
+    const int sw_lo = s_blk + wave * 16, sw_hi = sw_lo + 16;    // this wave's queries
+    const h16x8 qf = *(const h16x8*)&Qs[aero_tile_off(wave * 16 + col, g)];
+    float koff[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) koff[e] = (float)(((e >> 2) << 4) + g * 4 + (e & 3));
+    // query fragment with the four bias slots filled in: sign = +1 for key blocks before the queries, -1 after; cc = c
+    auto with_bias = [&](float sign, float cc) {
+        h16x8 q = qf;
+        if (g == gx) {
+            const float Ds = sign * Dq;
+            const h16 d_hi = (h16)Ds, d_lo = (h16)(Ds - (float)d_hi);
+            const h16 c_hi = (h16)cc, c_lo = (h16)(cc - (float)c_hi);
+            if (e0 == 0) { q[0] = d_hi; q[1] = d_lo; q[2] = c_hi; q[3] = c_lo; }
+            else { q[4] = d_hi; q[5] = d_lo; q[6] = c_hi; q[7] = c_lo; }
+        }
+        if (g == ((pos + 4) >> 3)) {                             // slot pos+4: 1 against the -30000 of the padded keys
+            if (e0 == 0) q[4] = (h16)1.f;
+            else q[0] = (h16)1.f;
+        }
+        return q;
+    };
+    // general path (blocks around the diagonal, ragged end): as in the streaming kernel
+    auto scores = [&](int tb, float* sc) {
+        const h16x8 k0 = *(const h16x8*)&Ks[aero_tile_off(tb + col, g)];
+        const h16x8 k1 = *(const h16x8*)&Ks[aero_tile_off(tb + 16 + col, g)];
+        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf, z4, 0, 0, 0);   // (qf: bias slots zero)
+        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf, z4, 0, 0, 0);
+        const float u = (float)(tb - s);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = u + koff[e];
+            sc[e] = ((e < 4) ? s0[e & 3] : s1[e & 3]) - fabsf(x) * Dq;
+            if (x == 0.f) sc[e] = -100.f * L2E;                                          // self reference (modules.py:120)
+            if (tb + (int)koff[e] >= T) sc[e] = -1e30f;
+        }
+    };
+    auto folded = [&](int tb, const h16x8& q, float* sc) {
+        const h16x8 k0 = *(const h16x8*)&Ks[aero_tile_off(tb + col, g)];
+        const h16x8 k1 = *(const h16x8*)&Ks[aero_tile_off(tb + 16 + col, g)];
+        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, q, z4, 0, 0, 0);
+        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, q, z4, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; }
+    };
+    auto max8 = [](const float* sc) {
+        return fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+    };
+    // The key range splits at the 32-key block that holds the wave's 16 queries (sw_lo is a multiple of 16): blocks before it
+    // run with the "before" query fragment, the diagonal block takes the general path, blocks after it the "after" fragment
+    // -- three straight loops, no per-block selection.  Ranges are walked two independent blocks at a time.
+    const int tdiag = sw_lo & ~31;
+    auto walk = [&](int lo, int hi, auto&& two, auto&& one) {    // [lo, hi) in steps of 32
+        int tb = lo;
+        for (; tb + 64 <= hi; tb += 64) two(tb);
+        if (tb < hi) one(tb);
+    };
+
+    // ---- pass 1: the maximum of every query's scores
+    float m = -1e30f;
+    {
+        const h16x8 qb = with_bias(1.f, -Dq * (float)s), qa = with_bias(-1.f, Dq * (float)s);
+        auto run = [&](int lo, int hi, const h16x8& q) {
+            walk(lo, hi,
+                 [&](int tb) { float sa[8], sb[8]; folded(tb, q, sa); folded(tb + 32, q, sb); m = fmaxf(m, fmaxf(max8(sa), max8(sb))); },
+                 [&](int tb) { float sa[8]; folded(tb, q, sa); m = fmaxf(m, max8(sa)); });
+        };
+        run(0, tdiag < kn32 ? tdiag : kn32, qb);
+        if (tdiag < kn32) {
+            float sc[8];
+            scores(tdiag, sc);
+            m = fmaxf(m, max8(sc));
+            run(tdiag + 32, kn32, qa);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+    }
+    // the folded constants must stay inside fp16 (c = -+D*s - m); otherwise every block takes the general path
+    const bool fold_ok = aero_wave_sum((fabsf(m) < 2.0e4f) ? 1 : 0) == 64;
+
+    // ---- pass 2: probabilities against the fixed maximum, O += V^T P (row dh of V^T = ones: the denominator)
+    f32x4 O[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) O[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const h16x8 qb = with_bias(1.f, -Dq * (float)s - m), qa = with_bias(-1.f, Dq * (float)s - m);
+        auto pv = [&](int tb, const h16x8& pf) {
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const h16* vr = &Vt[(i * 16 + col) * VS + tb + g * 4];
+                const h16x4 va = *(const h16x4*)vr;
+                const h16x4 vb = *(const h16x4*)(vr + 16);
+                const h16x8 vf = (h16x8){va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                O[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, O[i], 0, 0, 0);
+            }
+        };
+        auto probs = [&](const float* sc, h16x8& pf) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (h16)aero_exp2(sc[e]);
+        };
+        auto general = [&](int tb) {
+            float sc[8];
+            h16x8 pf;
+            scores(tb, sc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc[e] -= m;
+            probs(sc, pf);
+            pv(tb, pf);
+        };
+        auto run = [&](int lo, int hi, const h16x8& q) {
+            walk(lo, hi,
+                 [&](int tb) {
+                     float sa[8], sb[8];
+                     h16x8 pa, pb;
+                     folded(tb, q, sa);
+                     folded(tb + 32, q, sb);
+                     probs(sa, pa);
+                     probs(sb, pb);
+                     pv(tb, pa);
+                     pv(tb + 32, pb);
+                 },
+                 [&](int tb) { float sa[8]; h16x8 pa; folded(tb, q, sa); probs(sa, pa); pv(tb, pa); });
+        };
+        if (fold_ok) {
+            run(0, tdiag < kn32 ? tdiag : kn32, qb);
+            if (tdiag < kn32) {
+                general(tdiag);
+                run(tdiag + 32, kn32, qa);
+            }
+        } else {
+            for (int tb = 0; tb < kn32; tb += 32) general(tb);
+        }
+    }
+    // the denominator: row dh of O, held by lane group (dh % 16) / 4 in register dh % 4 of tile dh / 16
+    float lsum = 0.f;
+    {
+        const int li = dh >> 4, lr = dh & 3, lg = (dh & 15) >> 2;
+        float mine = 0.f;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i == li && r == lr) mine = O[i][r];
+        lsum = __shfl(mine, lg * 16 + col);
+    }
+    if (s < T) {
+        const float inv = 1.0f / lsum;
+        h16* op = (h16*)d.out + ((int64_t)row * T + s) * C + h * dh;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int dd = i * 16 + g * 4 + r;
+                if (dd < dh) op[dd] = (h16)(O[i][r] * inv);
+            }
+    }
+  }
+}
+
 static int aero_attn_launch(const aero_attn_desc* d, hipStream_t stream, const char** err) {
     if (!d || !d->qkvd || !d->out) { *err = "localstate: null pointer"; return AERO_ERR_ARG; }
     if (d->R < 1 || d->T < 1 || d->C < 1 || d->heads < 1 || d->C % d->heads || d->ndecay < 0) { *err = "localstate: bad geometry"; return AERO_ERR_ARG; }
@@ -235,6 +543,15 @@ static int aero_attn_launch(const aero_attn_desc* d, hipStream_t stream, const c
     static int res = -1;
     if (res < 0) { const char* e = getenv("AERO_ATTN_RES"); res = (e && e[0] == '1') ? 1 : 0; }
     dim3 block(512);
+    // AERO_ATTN_FOLD=0: the streaming kernel also for short rows (A/B)
+    static int fold = -1;
+    if (fold < 0) { const char* e = getenv("AERO_ATTN_FOLD"); fold = (e && e[0] == '0') ? 0 : 1; }
+    if (fold && d->T <= AERO_ATTN_FOLD_T && ((dh + 3) & ~3) + 5 <= 32 && dh + 1 <= 32) {
+        dim3 grid(1, (unsigned)d->heads, (unsigned)d->R);
+        if (dh + 1 <= 16) AERO_LAUNCH((aero_attn_fold_kernel<1>), grid, block, stream, *d);
+        else AERO_LAUNCH((aero_attn_fold_kernel<2>), grid, block, stream, *d);
+        return AERO_OK;
+    }
     if (res && d->T <= AERO_ATTN_KRES) {
         dim3 grid(1, (unsigned)d->heads, (unsigned)d->R);
         if (dh <= 16) AERO_LAUNCH((aero_attn_kernel<1, true>), grid, block, stream, *d);

@@ -150,6 +150,19 @@ def test_freqfc(emu, kw):
     oc.case_freqfc(emu, DEV, **kw)
 
 
+def test_localstate_streaming_form_for_short_rows():
+    """AERO_ATTN_FOLD=0: rows with T <= 512 on the streaming kernel (the default for them is the folded two-pass kernel)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import op_cases as oc\nfrom aero_amd import _lib\nfrom emu.build_emu import build\n"
+            "oc.case_localstate(_lib.load(build()), 'cpu', Cc=48, heads=4, R=1, T=300)\nprint('ok')\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_ATTN_FOLD': '0'}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
+
+
 def test_localstate_resident_form_option():
     """AERO_ATTN_RES=1 (K/V of a row staged once for all query blocks; off by default: measured slower on MI355X) still
     computes the same thing -- run in a fresh interpreter because the switch is read once per process."""
@@ -160,7 +173,7 @@ def test_localstate_resident_form_option():
             "import op_cases as oc\nfrom aero_amd import _lib\nfrom emu.build_emu import build\n"
             "oc.case_localstate(_lib.load(build()), 'cpu', Cc=48, heads=4, R=1, T=300)\nprint('ok')\n"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
-    out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_ATTN_RES': '1'}, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_ATTN_RES': '1', 'AERO_ATTN_FOLD': '0'}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
 
 

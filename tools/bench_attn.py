@@ -12,8 +12,8 @@ for (R, T, C) in ((512, 501, 48), (256, 501, 96)):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20):
+    for _ in range(int(os.environ.get("ITERS", 20))):
         ops.localstate(qkvd, R, T, C, 4, 4)
     e1.record()
     torch.cuda.synchronize()
-    print(f'attn R={R} T={T} C={C}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us', flush=True)
+    print(f'attn R={R} T={T} C={C}: {e0.elapsed_time(e1) / int(os.environ.get("ITERS", 20)) * 1e3:.1f} us', flush=True)
