@@ -48,6 +48,7 @@ class Ops:
         """One C-ABI call = one kernel launch on the current stream; optionally bracketed by HIP events
         (recorded on that same stream) for the roofline numbers of bench.py."""
         if self.prof is None:
+            self._shape_note = ''
             self.lib.call(fn, *args)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -499,7 +500,7 @@ class HipEngine:
             act = ACT_NONE if (dec.norm or dec.last) else ACT_GELU
             L['conv_tr'] = mk(w, sd[f'{p}.conv_tr.bias'], w.shape[-1], 0, df, dt, device, transposed=1,
                               fstride=dec.stride, act=act)
-            if not dec.last and os.environ.get('AERO_CONVTR_STACK', '0') != '0':
+            if not dec.last and os.environ.get('AERO_CONVTR_STACK', '1') != '0':
                 # input-side form (all `stride` residue classes from one pass over the source rows), when Cout % 8 == 0
                 st = pack.convtr_stacked_spec(sd[f'{p}.conv_tr.weight'], sd[f'{p}.conv_tr.bias'], dec.stride, device, act=act)
                 if st is not None:
@@ -867,10 +868,7 @@ class HipEngine:
         act = {'snake': ACT_SNAKE, 'gelu': ACT_GELU}.get(dc.act_func, ACT_RELU)
         if (self.fuse_dconv_row and all('row' in L for L in layers) and len(layers) <= _lib.DCONV_MAX_DEPTH and x.is_contiguous()
                 and ops.dconv_row_fits(T, layers[0]['row']['C'], layers[0]['row']['hidden'], max(L['row']['dilation'] for L in layers))):
-            ops.tag = 'stack'
-            y = ops.dconv_row(x, [dict(L['row'], snake_a=L.get('snake_a')) for L in layers], act, Fo)
-            ops.tag = ''
-            return y
+            return ops.dconv_row(x, [dict(L['row'], snake_a=L.get('snake_a')) for L in layers], act, Fo)
         for L in layers:
             g1 = L['gn1']
             st1 = None
