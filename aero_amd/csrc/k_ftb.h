@@ -103,6 +103,63 @@ __global__ __launch_bounds__(256) void aero_freqfc_kernel(AeroFreqFcK p) {
     }
 }
 
+// Small F (the two deepest encoder levels: 16 and 8 frequency rows): the GEMM above runs one 64 x 128 tile per block with a
+// single k-chunk -- 48 000 blocks of staging, transposing and barriers for an 8 x 8 product (133 us for 197 MB).  Here a
+// thread owns 8 consecutive (t, c) positions (one 16-byte vector per row), keeps the F input rows in registers as fp32 and
+// produces the F output rows with plain FMAs against W (fp32 in LDS, broadcast reads): 16-byte loads and stores, no barrier
+// in the loop, 10-19 vector instructions per output.  HBM-bound: 4 bytes per element.
+template <int FT>
+__global__ __launch_bounds__(256) void aero_freqfc_small_kernel(AeroFreqFcK p) {
+    __shared__ AERO_LDS_ALIGN float Wf[FT * FT];
+    const aero_freqfc_desc& d = p.d;
+    const int F = d.F;
+    const int64_t N = p.N;
+    for (int i = threadIdx.x; i < FT * FT; i += 256) {
+        const int fo = i / FT, fi = i - fo * FT;
+        Wf[i] = (fo < F && fi < F) ? (float)((const h16*)d.w)[(int64_t)fo * p.Kp + fi] : 0.f;
+    }
+    __syncthreads();
+    const int64_t nv = N >> 3;                                    // vectors per (b, f) row (N % 8 == 0: host)
+    const int64_t total = (int64_t)d.B * nv;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+        const int b = (int)(v / nv);
+        const int64_t n = (v - (int64_t)b * nv) * 8;
+        const h16* x = (const h16*)d.x + (int64_t)b * F * N + n;
+        h16* dst = (h16*)d.dst + (int64_t)b * F * N + n;
+        const h16x8 gv = *(const h16x8*)((const h16*)d.gate + (int64_t)b * N + n);
+        float xf[FT][8];
+#pragma unroll
+        for (int fi = 0; fi < FT; ++fi) {
+            h16x8 xv = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (fi < F) xv = *(const h16x8*)(x + (int64_t)fi * N);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[fi][e] = (float)xv[e];
+        }
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (float)gv[e];
+#pragma unroll
+        for (int fo = 0; fo < FT; ++fo) {
+            if (fo >= F) break;
+            float a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = 0.f;
+#pragma unroll
+            for (int f4 = 0; f4 < FT; f4 += 4) {
+                const f32x4 w = *(const f32x4*)&Wf[fo * FT + f4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = fmaf(w[k], xf[f4 + k][e], a[e]);
+            }
+            h16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (h16)(a[e] * g[e]);
+            *(h16x8*)(dst + (int64_t)fo * N) = o;
+        }
+    }
+}
+
 static int aero_freqfc_launch(const aero_freqfc_desc* d, hipStream_t stream, const char** err) {
     if (!d || !d->x || !d->w || !d->gate || !d->dst) { *err = "freqfc: null pointer"; return AERO_ERR_ARG; }
     if (d->B < 1 || d->F < 1 || d->T < 1 || d->C < 1) { *err = "freqfc: bad geometry"; return AERO_ERR_ARG; }
@@ -116,6 +173,14 @@ static int aero_freqfc_launch(const aero_freqfc_desc* d, hipStream_t stream, con
     const long nwg = (long)d->B * p.nnt * p.nmt;
     if (nwg > 0x7fffffffL) { *err = "freqfc: grid too large"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)nwg), block(256);
+    if (d->F <= 16 && p.vec && (((uintptr_t)d->dst | (uintptr_t)d->gate) & 15) == 0) {
+        const int64_t total = (int64_t)d->B * (p.N >> 3);
+        const int64_t want = (total + 255) / 256;
+        dim3 sgrid((unsigned)(want < 256 * 16 ? want : 256 * 16));
+        if (d->F <= 8) AERO_LAUNCH(aero_freqfc_small_kernel<8>, sgrid, block, stream, p);
+        else AERO_LAUNCH(aero_freqfc_small_kernel<16>, sgrid, block, stream, p);
+        return AERO_OK;
+    }
     AERO_LAUNCH(aero_freqfc_kernel, grid, block, stream, p);
     return AERO_OK;
 }

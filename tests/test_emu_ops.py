@@ -145,7 +145,7 @@ def test_localstate(emu, kw):
     oc.case_localstate(emu, DEV, **kw)
 
 
-@pytest.mark.parametrize('kw', [dict(Fq=16, Cc=8, T=20), dict(Fq=70, Cc=12, T=11), dict(Fq=4, Cc=4, T=9, B=1)])
+@pytest.mark.parametrize('kw', [dict(Fq=16, Cc=8, T=20), dict(Fq=70, Cc=12, T=11), dict(Fq=4, Cc=4, T=9, B=1), dict(Fq=8, Cc=16, T=33), dict(Fq=13, Cc=8, T=7)])
 def test_freqfc(emu, kw):
     oc.case_freqfc(emu, DEV, **kw)
 

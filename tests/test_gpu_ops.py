@@ -111,7 +111,7 @@ def test_localstate(lib, kw):
     oc.case_localstate(lib, DEV, **kw)
 
 
-@pytest.mark.parametrize('kw', [dict(Fq=256, Cc=48, T=501, B=1), dict(Fq=64, Cc=48, T=501), dict(Fq=8, Cc=192, T=501), dict(Fq=4, Cc=4, T=9, B=1)])
+@pytest.mark.parametrize('kw', [dict(Fq=256, Cc=48, T=501, B=1), dict(Fq=64, Cc=48, T=501), dict(Fq=8, Cc=192, T=501), dict(Fq=16, Cc=96, T=501), dict(Fq=4, Cc=4, T=9, B=1)])
 def test_freqfc(lib, kw):
     oc.case_freqfc(lib, DEV, **kw)
 
