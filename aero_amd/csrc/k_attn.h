@@ -20,10 +20,9 @@
 #define AERO_ATTN_KC 256                 /* keys per LDS chunk (streaming form) */
 #define AERO_ATTN_KRES 512               /* keys held in LDS by the resident form (T <= 512: every reference config at 2-s clips) */
 
-// RES = true (T <= AERO_ATTN_KRES; option, off): the block stages K and V^T of its (row, head) ONCE and walks over all query
-// blocks of the row.  The streaming form (one block per 128 queries, keys in chunks of 256) re-stages the whole row's K/V
-// for each of the four query blocks (PMC: 729 MB fetched for a 107-MB tensor) -- but removing that re-fetch did not help,
-// see the launcher.
+// RES = false is the only instantiation: the streaming form (one block per 128 queries, keys in chunks of 256), used for rows
+// longer than AERO_ATTN_FOLD_T.  (RES = true -- K / V^T of a (row, head) staged once for all query blocks -- was measured
+// slower with this instruction-bound score loop (328 vs 290 us); the folded kernel below is what made the resident layout pay.)
 template <int DT, bool RES>  // DT = number of 16-row output tiles: head dim <= 16*DT
 __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
     constexpr int KC = RES ? AERO_ATTN_KRES : AERO_ATTN_KC;
@@ -536,12 +535,6 @@ static int aero_attn_launch(const aero_attn_desc* d, hipStream_t stream, const c
     if (d->R > 65535 || d->heads > 65535) { *err = "localstate: too many rows/heads for one launch"; return AERO_ERR_ARG; }
     const int dh = d->C / d->heads;
     if (dh > 32) { *err = "localstate: head dim > 32 unsupported"; return AERO_ERR_UNSUPPORTED; }
-    // AERO_ATTN_RES=1: the resident form.  Measured on MI355X (tools/bench_attn.py): 328 vs 290 us (C = 48), 182 vs 171 us
-    // (C = 96) -- SLOWER although it fetches a quarter of the bytes: the kernel is bound by instruction issue (PMC: ~2200
-    // instructions per wave, 12.7 vector instructions per score), not by the K/V request stream, and 2048 long-lived blocks
-    // balance worse than 8192 short ones.  Kept as a tested option; default off.
-    static int res = -1;
-    if (res < 0) { const char* e = getenv("AERO_ATTN_RES"); res = (e && e[0] == '1') ? 1 : 0; }
     dim3 block(512);
     // AERO_ATTN_FOLD=0: the streaming kernel also for short rows (A/B)
     static int fold = -1;
@@ -550,12 +543,6 @@ static int aero_attn_launch(const aero_attn_desc* d, hipStream_t stream, const c
         dim3 grid(1, (unsigned)d->heads, (unsigned)d->R);
         if (dh + 1 <= 16) AERO_LAUNCH((aero_attn_fold_kernel<1>), grid, block, stream, *d);
         else AERO_LAUNCH((aero_attn_fold_kernel<2>), grid, block, stream, *d);
-        return AERO_OK;
-    }
-    if (res && d->T <= AERO_ATTN_KRES) {
-        dim3 grid(1, (unsigned)d->heads, (unsigned)d->R);
-        if (dh <= 16) AERO_LAUNCH((aero_attn_kernel<1, true>), grid, block, stream, *d);
-        else AERO_LAUNCH((aero_attn_kernel<2, true>), grid, block, stream, *d);
         return AERO_OK;
     }
     dim3 grid((unsigned)((d->T + 127) / 128), (unsigned)d->heads, (unsigned)d->R);

@@ -1255,121 +1255,6 @@ __global__ __launch_bounds__(256) void aero_conv_tiny_kernel(AeroConvK p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// 3x3 (time-context) specialisation -- the decoder "rewrite" convs, 68 % of the model's FLOPs.
-// Same tiling as above (128 channels x 128 steps of one row), but a pipeline stage is (frequency tap df, 32-channel
-// chunk) and carries all THREE time taps: the activation slab [t0-1, t0+129) x 32ch is staged once and read at row
-// offsets 0/1/2, with three weight tiles.  Per barrier pair: 48 MFMAs per wave instead of 16, and activations are
-// fetched from HBM/L2 once instead of three times.
-__global__ __launch_bounds__(256) void aero_conv3x3_kernel(AeroConvK p) {
-    constexpr int MF = 4, WM = 2, WN = 2, NF = 4, BM = 128, BN = 128;
-    constexpr int SLAB = 136;                                   // >= BN + 2 rows
-    constexpr int CS = BM + 8;
-    constexpr int SMEM = 3 * BM * 32 + SLAB * 32 > 64 * CS ? 3 * BM * 32 + SLAB * 32 : 64 * CS;
-    __shared__ AERO_LDS_ALIGN h16 smem[SMEM];
-    h16* As = smem;                                             // [3][BM][32]
-    h16* Bs = smem + 3 * BM * 32;                               // [SLAB][32]
-    h16* Cs = smem;
-    const aero_conv_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
-    const int mt = id % p.nmt;
-    id /= p.nmt;
-    const int tt = id % p.ntt;
-    const int row = id / p.ntt;
-    const int b = row / d.Fout, fo = row % d.Fout;
-    const int fdst = fo - d.dst_f_off;
-    if (fdst < 0 || fdst >= d.dst_F) return;
-    const int m0 = mt * BM, t0 = tt * BN;
-    const h16* Wp = (const h16*)d.weight + (int64_t)m0 * p.Ktot;
-    const h16* s0 = (const h16*)d.src0;
-    const h16* s1 = (const h16*)d.src1;
-    const int C0 = d.C0, C1 = d.C1, T = d.T;
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int n = 0; n < NF; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    h16x8 ra[6], rb[3];
-    int jf = -1, cc = p.cpt - 1, fi = 0;                        // stage iterator: frequency tap jf (df = jf-1), chunk cc
-    auto next_stage = [&]() -> bool {
-        for (;;) {
-            ++cc;
-            if (cc == p.cpt) {
-                cc = 0;
-                ++jf;
-                while (jf < 3) {
-                    fi = fo + jf - 1;
-                    if (fi >= 0 && fi < d.Fin) break;
-                    ++jf;
-                }
-            }
-            if (jf >= 3) return false;
-            if (s0 == nullptr && (cc + 1) * 32 <= C0) continue;
-            return true;
-        }
-    };
-    auto load_stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {                           // 3 taps x 128 rows x 4 vectors = 1536 = 6 per thread
-            const int v = tid + 256 * i;
-            const int dtj = v >> 9, rem = v & 511;
-            ra[i] = *(const h16x8*)(Wp + (int64_t)(rem >> 2) * p.Ktot + (jf * 3 + dtj) * p.Cp + cc * 32 + (rem & 3) * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {                           // slab: 130 rows x 4 vectors
-            const int v = tid + 256 * i;
-            h16x8 z = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            const int t = t0 - 1 + (v >> 2);
-            const int c = cc * 32 + (v & 3) * 8;
-            if (v < (BN + 2) * 4 && t >= 0 && t < T) {
-                if (c < C0) {
-                    if (s0) z = *(const h16x8*)(s0 + (int64_t)b * d.s0_b + (int64_t)fi * d.s0_f + (int64_t)t * d.s0_t + c);
-                } else if (c - C0 < C1) {
-                    z = *(const h16x8*)(s1 + (int64_t)b * d.s1_b + (int64_t)fi * d.s1_f + (int64_t)t * d.s1_t + (c - C0));
-                }
-            }
-            rb[i] = z;
-        }
-    };
-
-    bool have = next_stage();
-    if (have) load_stage();
-    while (have) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int v = tid + 256 * i;
-            const int dtj = v >> 9, rem = v & 511;
-            *(h16x8*)&As[dtj * BM * 32 + aero_tile_off(rem >> 2, rem & 3)] = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int v = tid + 256 * i;
-            if (v < SLAB * 4) *(h16x8*)&Bs[aero_tile_off(v >> 2, v & 3)] = rb[i];
-        }
-        __syncthreads();
-        have = next_stage();
-        if (have) load_stage();
-#pragma unroll
-        for (int dtj = 0; dtj < 3; ++dtj) {
-            h16x8 af[MF], bf[NF];
-#pragma unroll
-            for (int i = 0; i < MF; ++i) af[i] = *(const h16x8*)&As[dtj * BM * 32 + aero_tile_off((wm * MF + i) * 16 + (lane & 15), lane >> 4)];
-#pragma unroll
-            for (int n = 0; n < NF; ++n) bf[n] = *(const h16x8*)&Bs[aero_tile_off((wn * NF + n) * 16 + (lane & 15) + dtj, lane >> 4)];
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[n], acc[i][n], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    aero_conv_epilogue<MF, WM, false>(p, acc, Cs, b, fo, fdst, m0, t0);
-}
-
 // taps on a regular (frequency x time) grid?  fills the grid parameters of AeroConvK
 static bool aero_conv_regular_taps(const aero_conv_desc* d, AeroConvK* p) {
     const int n = d->ntaps;
@@ -1390,13 +1275,6 @@ static bool aero_conv_regular_taps(const aero_conv_desc* d, AeroConvK* p) {
     p->f_step = f_step;
     p->t_lo = d->dt[0];
     p->t_step = t_step;
-    return true;
-}
-
-static bool aero_conv_is_3x3(const aero_conv_desc* d) {
-    if (d->ntaps != 9 || d->transposed || d->fstride != 1) return false;
-    for (int j = 0; j < 9; ++j)
-        if (d->df[j] != j / 3 - 1 || d->dt[j] != j % 3 - 1) return false;
     return true;
 }
 
@@ -1581,11 +1459,6 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         return AERO_OK;
     }
     if (d->scatter_M && !(p.staged && p.vec_in && p.glds)) { *err = "conv: row scatter needs aligned fp16 operands (direct-to-LDS pipeline)"; return AERO_ERR_UNSUPPORTED; }
-    if (bm == 128 && p.vec_in && !p.glds && !d->stat_mode && aero_conv_is_3x3(d)) {
-        if (name) snprintf(name, 96, "aero_conv3x3_kernel");
-        else AERO_LAUNCH(aero_conv3x3_kernel, grid, block, stream, p);
-        return AERO_OK;
-    }
     if (p.vec_in && p.glds && aero_conv_regular_taps(d, &p)) {
         // 64-channel chunks pay off only for the big compute-bound contractions (measured: +5 % on the decoder 3x3
         // convs, -2 % on the whole model if used everywhere because two 64-KiB stages halve the blocks per CU)

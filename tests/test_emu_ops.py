@@ -140,7 +140,7 @@ def test_blstm(emu, kw):
 
 
 @pytest.mark.parametrize('kw', [dict(Cc=8, heads=4, R=2, T=70), dict(Cc=48, heads=4, R=1, T=300), dict(Cc=4, heads=4, R=3, T=33),
-                                dict(Cc=96, heads=4, R=1, T=501), dict(Cc=16, heads=4, R=1, T=530)])    # resident form (T <= 512, 4 query blocks) / streaming form
+                                dict(Cc=96, heads=4, R=1, T=501), dict(Cc=16, heads=4, R=1, T=530)])    # folded two-pass form (T <= 512) / streaming form
 def test_localstate(emu, kw):
     oc.case_localstate(emu, DEV, **kw)
 
@@ -160,20 +160,6 @@ def test_localstate_streaming_form_for_short_rows():
             "oc.case_localstate(_lib.load(build()), 'cpu', Cc=48, heads=4, R=1, T=300)\nprint('ok')\n"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_ATTN_FOLD': '0'}, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
-
-
-def test_localstate_resident_form_option():
-    """AERO_ATTN_RES=1 (K/V of a row staged once for all query blocks; off by default: measured slower on MI355X) still
-    computes the same thing -- run in a fresh interpreter because the switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import op_cases as oc\nfrom aero_amd import _lib\nfrom emu.build_emu import build\n"
-            "oc.case_localstate(_lib.load(build()), 'cpu', Cc=48, heads=4, R=1, T=300)\nprint('ok')\n"
-            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
-    out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_ATTN_RES': '1', 'AERO_ATTN_FOLD': '0'}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
 
 
