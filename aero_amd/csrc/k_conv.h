@@ -1464,7 +1464,10 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         // convs, -2 % on the whole model if used everywhere because two 64-KiB stages halve the blocks per CU)
         const int mode = aero_conv_glds_mode();               // 0 auto, 1 = KC 32, 2 = KC 64 where legal
         const bool k64_ok = (p.Cp % 64 == 0);
-        const bool k64 = mode == 2 ? k64_ok : (mode == 1 ? false : (k64_ok && bm >= 96 && p.Ktot >= 1024));
+        // ... and for the long, thin contractions that cannot fill the chip (FTB Conv1d over time: 250 blocks x 360 chunks, one
+        // block per CU, each chunk a full copy -> barrier -> MFMA round trip): half as many, twice as long chunks (185 -> 150 us)
+        const bool thin = p.Ktot >= 2048 && (long)d->B * d->Fout * p.ntt * ((d->M + bm - 1) / bm) <= 512;
+        const bool k64 = mode == 2 ? k64_ok : (mode == 1 ? false : (k64_ok && ((bm >= 96 && p.Ktot >= 1024) || thin)));
         // 256-/192-row tiles (8 waves) for the wide compute-bound contractions; AERO_CONV_BM256=0 disables (A/B),
         // =1 only the 256-row tile.  KC 32 here: two 48-KiB blocks (16 waves) per CU measured 937 TF/s on the first
         // decoder layer vs 872 with one 96-KiB KC-64 block and 860 for the 128-row KC-64 tile.
