@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
                 ('stat_mode', i32), ('stat_G', i32), ('stat_per_row', i32), ('stat_eps', C.c_float),
                 ('gamma', fp), ('beta', fp), ('layer_scale', fp),
                 ('scatter_M', i32), ('scatter_stride', i32), ('scatter_off', i32), ('scatter_F', i32),
-                ('weight_tiled', vp), ('tiled_bm', i32)]
+                ('weight_tiled', vp), ('tiled_bm', i32), ('tap_split', i32), ('split_acc', fp)]
 
 
 class NormDesc(C.Structure):
@@ -100,6 +100,7 @@ _PROTOS = {
     'aero_spec_normalize': (i32, [fp, i32, i64, dp, vp, fp, vp]),
     'aero_istft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, fp, fp, i32, vp]),
     'aero_conv_fwd': (i32, [C.POINTER(ConvDesc), vp]),
+    'aero_split_finish': (i32, [fp, i32, fp, i32, vp, i64, i32, vp]),
     'aero_conv_tile_m': (i32, [i32]),
     'aero_conv_ring_bm': (i32, [i32, i32]),
     'aero_conv_kernel_name': (i32, [C.POINTER(ConvDesc), C.c_char_p, i32]),

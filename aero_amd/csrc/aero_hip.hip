@@ -160,6 +160,12 @@ int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream) {
     return aero_finish(rc, err);
 }
 
+int aero_split_finish(const float* acc, int32_t nsplit, const float* bias, int32_t act, void* dst, int64_t npos, int32_t M, void* stream) {
+    const char* err = "";
+    int rc = aero_split_finish_launch(acc, nsplit, bias, act, dst, npos, M, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 int aero_dconv_row_fwd(const aero_dconv_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_dconv_launch(d, (hipStream_t)stream, &err);

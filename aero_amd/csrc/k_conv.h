@@ -600,6 +600,8 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const int sp = id % p.tsplit;                   // tap group of this block (aero_conv_desc.tap_split; 1 group: sp = 0)
+    id /= p.tsplit;
     const int mt = id % p.nmt;
     id /= p.nmt;
     const int tt = id % p.ntt;
@@ -619,6 +621,7 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
     const int cpt = p.Cp / KC;
     const int cc_lo = (s0 == nullptr && C0 % KC == 0) ? C0 / KC : 0;
     const int nF = d.ntaps / p.nT;
+    const int jt_lo = sp * (p.nT / p.tsplit), jt_hi = jt_lo + p.nT / p.tsplit;     // this block's time taps
 
     // ---- lane-invariant parts of the copy addresses: full per-lane pointers (item, in-tile position and channel slice
     // folded in), so that a K-chunk only adds ONE block-uniform 32-bit element offset per source.  PMC: the loop used
@@ -665,7 +668,7 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
     const int nT = p.nT, f_step = p.f_step, t_step = p.t_step, Cpk = p.Cp;
     const int s0f = (int)d.s0_f, s1f = (int)d.s1_f;             // in-item row offsets fit 32 bits (checked on the host)
     const int t_base = t0 + p.t_lo;
-    int jf = -1, jt = nT - 1, cc = cpt - 1, fi = 0;
+    int jf = -1, jt = jt_hi - 1, cc = cpt - 1, fi = 0;
     int kofs = 0, tsh = 0, off0 = 0, off1 = 0;
     bool tin[NIB];                                              // source time of this lane's position inside [0, T): per tap
     auto next_chunk = [&]() -> bool {
@@ -674,8 +677,8 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
             return true;
         }
         cc = cc_lo;
-        if (++jt >= nT) {
-            jt = 0;
+        if (++jt >= jt_hi) {
+            jt = jt_lo;
             for (;;) {
                 if (++jf >= nF) return false;
                 fi = fbase + jf * f_step;
@@ -751,6 +754,22 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
             compute(buf);
             buf ^= 1;
         }
+    }
+    if (p.tsplit > 1) {                        // partial sums of this tap group -> fp32 accumulator (finished by aero_split_finish)
+        float* ws = d.split_acc + ((int64_t)((sp * d.B + b) * d.Fout + fo) * T) * d.M;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int t = t0 + (wn * NF + n) * 16 + (lane & 15);
+            if (t >= T) continue;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = m0 + (wm * MF + i) * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < d.M) ws[(int64_t)t * d.M + m + r] = acc[i][n][r];
+            }
+        }
+        return;
     }
     __syncthreads();                           // all waves done with the operand stages: smem becomes the output tile
     aero_conv_epilogue<MF, WM, STATS, NWV>(p, acc, Cs, b, fo, fdst, m0, t0);
@@ -1329,11 +1348,35 @@ static int aero_conv_pick_bm(int M, int Mpad) {
         else AERO_LAUNCH((K<A, B, false>), grid, block, stream, p);                                            \
     } while (0)
 
+// fp32 partial-sum accumulator of a tap-split conv -> fp16 activation: dst[pos][m] = act(acc[pos][m] + bias[m])
+__global__ __launch_bounds__(256) void aero_split_finish_kernel(const float* acc, int nsplit, const float* bias, int act, h16* dst, int64_t n, int M) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = acc[i];
+        for (int s = 1; s < nsplit; ++s) v += acc[(int64_t)s * n + i];
+        v += bias ? bias[(int)(i % M)] : 0.f;
+        if (act == AERO_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == AERO_ACT_GELU) v = aero_gelu(v);
+        dst[i] = (h16)v;
+    }
+}
+static int aero_split_finish_launch(const float* acc, int nsplit, const float* bias, int act, void* dst, int64_t npos, int M, hipStream_t stream, const char** err) {
+    if (!acc || !dst || npos < 1 || M < 1 || nsplit < 1) { *err = "split_finish: bad arguments"; return AERO_ERR_ARG; }
+    if (act != AERO_ACT_NONE && act != AERO_ACT_RELU && act != AERO_ACT_GELU) { *err = "split_finish: unsupported act"; return AERO_ERR_UNSUPPORTED; }
+    const int64_t n = npos * M;
+    const int64_t want = (n + 255) / 256;
+    AERO_LAUNCH(aero_split_finish_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), stream, acc, nsplit, bias, act, (h16*)dst, n, M);
+    return AERO_OK;
+}
+
 // k_conv_ring.h: the software-pipelined 8-wave kernel for the wide contractions; returns true if it took the launch
 static bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStream_t stream, char* name);
 
 static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const char** err, char* name = nullptr) {
-    if (!d || !d->weight || (!d->dst && d->stat_mode != 2)) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
+    if (!d || !d->weight || (!d->dst && d->stat_mode != 2 && d->tap_split <= 1)) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
+    if (d->tap_split > 1 && (!d->split_acc || d->M <= 16 || d->stat_mode || d->scatter_M || d->res || d->post_add || d->batch_scale)) {
+        *err = "conv: tap split needs split_acc, M > 16 and a plain epilogue";
+        return AERO_ERR_UNSUPPORTED;
+    }
     if (d->ntaps < 1 || d->ntaps > 9) { *err = "conv: ntaps must be 1..9"; return AERO_ERR_ARG; }
     if (d->C0 < 0 || d->C1 < 0 || d->C0 + d->C1 <= 0 || d->M <= 0) { *err = "conv: bad channel counts"; return AERO_ERR_ARG; }
     if (d->C1 > 0 && !d->src1) { *err = "conv: src1 NULL with C1>0"; return AERO_ERR_ARG; }
@@ -1357,6 +1400,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     }
     AeroConvK p;
     p.d = *d;
+    p.tsplit = 1;
     p.Cp = (d->C0 + d->C1 + 31) / 32 * 32;
     p.cpt = p.Cp / 32;
     p.Ktot = d->ntaps * p.Cp;
@@ -1471,10 +1515,15 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         // 256-/192-row tiles (8 waves) for the wide compute-bound contractions; AERO_CONV_BM256=0 disables (A/B),
         // =1 only the 256-row tile.  KC 32 here: two 48-KiB blocks (16 waves) per CU measured 937 TF/s on the first
         // decoder layer vs 872 with one 96-KiB KC-64 block and 860 for the 128-row KC-64 tile.
-        if (aero_conv_ring_try(d, p, stream, name)) return AERO_OK;
+        if (d->tap_split > 1) {                                 // (4-wave tiles only: the launch is block-starved by construction)
+            if (p.nT % d->tap_split) { *err = "conv: tap split must divide the time taps"; return AERO_ERR_UNSUPPORTED; }
+            p.tsplit = d->tap_split;
+            grid = dim3(grid.x * (unsigned)p.tsplit);
+        }
+        if (p.tsplit == 1 && aero_conv_ring_try(d, p, stream, name)) return AERO_OK;
         static int wide = -1;
         if (wide < 0) { const char* e = getenv("AERO_CONV_BM256"); wide = e ? atoi(e) : 2; }
-        const int wbm = (wide >= 1 && d->M % 256 == 0 && p.Ktot >= 1024) ? 256
+        const int wbm = p.tsplit > 1 ? 0 : (wide >= 1 && d->M % 256 == 0 && p.Ktot >= 1024) ? 256
                         : (wide >= 2 && d->M % 192 == 0 && p.Ktot >= 768) ? 192 : 0;
         if (wbm) {
             p.nmt = d->M / wbm;
@@ -1515,6 +1564,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         return AERO_OK;
     }
     if (d->scatter_M) { *err = "conv: row scatter needs a regular tap grid"; return AERO_ERR_UNSUPPORTED; }
+    if (d->tap_split > 1) { *err = "conv: tap split needs aligned fp16 operands on a regular tap grid"; return AERO_ERR_UNSUPPORTED; }
     switch (bm) {
         case 128: AERO_CONV_GO2(aero_conv_kernel, 4, 2); break;
         case 96: AERO_CONV_GO2(aero_conv_kernel, 3, 2); break;

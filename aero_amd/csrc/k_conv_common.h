@@ -6,6 +6,7 @@ struct AeroConvK {
     aero_conv_desc d;
     int Cp, cpt, Ktot, Mpad, nmt, ntt, vec_in, vec4, vec_out, staged, glds;
     int nT, f_lo, f_step, t_lo, t_step;      // regular tap grid: df = f_lo + (j / nT) * f_step, dt = t_lo + (j % nT) * t_step
+    int tsplit;                              // >= 1: groups the time taps are split into (aero_conv_desc.tap_split)
 };
 
 // LDS image of a [rows][KC] fp16 operand tile: 16-byte slot `slot` of row `row`, XOR-swizzled so that the ds_read_b128

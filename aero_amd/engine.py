@@ -89,10 +89,15 @@ class Ops:
     # -- convolution family --------------------------------------------------------------------
     def conv(self, spec, src0, src1, B, Fin, Fout, T, dst=None, dst_f32=False, dst_f_off=0, dst_F=None, res=None,
              post_add=None, batch_scale=None, batch_shift=None, act=None, dst_strides=None, src0_strides=None,
-             stat=None, scatter=None):
-        """src0/src1: channels-last [B,Fin,T,C] tensors (src0 may be None = zeros).  Returns dst."""
+             stat=None, scatter=None, tap_split=1):
+        """src0/src1: channels-last [B,Fin,T,C] tensors (src0 may be None = zeros).  Returns dst.
+        tap_split = S > 1 (aero_hip.h "tap split"): S x the blocks, partial sums into an fp32 accumulator, then aero_split_finish."""
         dev = spec.weight.device
         act = spec.act if act is None else act
+        split_acc = None
+        if tap_split > 1:
+            assert dst is None and stat is None and res is None and not dst_f32 and act != ACT_GLU
+            split_acc = torch.empty(tap_split, B, Fout, T, spec.M, dtype=torch.float32, device=dev)
         Mout = spec.M // 2 if act == ACT_GLU else spec.M
         dst_F = Fout if dst_F is None else dst_F
         no_store = stat is not None and stat['mode'] == 2
@@ -132,6 +137,8 @@ class Ops:
             d.r_b, d.r_f, d.r_t = _strides4(res)
         d.post_add = _ptr(post_add)
         d.batch_scale, d.batch_shift = _ptr(batch_scale), _ptr(batch_shift)
+        if split_acc is not None:
+            d.tap_split, d.split_acc = tap_split, _ptr(split_acc)
         ref_t = dst if dst is not None else spec.weight
         if self.prof is None:
             self.lib.call('aero_conv_fwd', C.byref(d), self.stream(ref_t))
@@ -146,6 +153,9 @@ class Ops:
             flops = 2.0 * pos * spec.M * len(spec.df) * cin_exec       # executed (NULL source skipped)
             nbytes = pos * (Mout * (dst.element_size() if dst is not None else 0)) + B * Fin * T * cin_exec * 2
             self._call('aero_conv_fwd', kname, flops, nbytes, C.byref(d), self.stream(ref_t))
+        if split_acc is not None:
+            self._call('aero_split_finish', 'aero_split_finish_kernel', 0.0, split_acc.numel() * 4 + dst.numel() * 2, _ptr(split_acc), tap_split,
+                       _ptr(spec.bias), act, _ptr(dst), B * Fout * T, spec.M, self.stream(dst))
         return dst
 
     def begin_step(self, device):
@@ -385,6 +395,7 @@ class HipEngine:
         self.ring_stats = os.environ.get('AERO_RING_STATS', '1') != '0'    # GroupNorm statistics in the ring conv kernel's epilogue
         self.fuse_lstm_proj = True         # W_ih x_t inside the recurrent kernel (no 8H-channel pre-activation tensor in HBM)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
+        self.split_taps = os.environ.get('AERO_TAP_SPLIT', '1') != '0'        # long thin FTB Conv1d: 3 x the blocks, partial sums summed in fixed order
         self.fuse_dconv_row = os.environ.get('AERO_DCONV_ROW', '1') != '0'    # DConv branches without LSTM / attention: one launch, the row stays in LDS (k_dconv.h)
         self.fuse_enc0 = os.environ.get('AERO_FUSE_ENC0', '1') != '0'     # ... and fused with the layer's strided conv (k_enc0.h)
 
@@ -668,7 +679,7 @@ class HipEngine:
         removes the per-launch Python / ctypes / runtime cost.  Inputs are copied into the graph's static buffer;
         outputs are cloned out of it (the graph's memory is reused by the next replay)."""
         key = ('graph', tuple(mix.shape), str(mix.device), want_spec, want_lr_spec,
-               self.fuse_dconv_tail, self.fuse_stats, self.collapse_first_ftb, self.fuse_lstm_proj, self.fuse_enc0, self.fuse_dconv_row)
+               self.fuse_dconv_tail, self.fuse_stats, self.collapse_first_ftb, self.fuse_lstm_proj, self.fuse_enc0, self.fuse_dconv_row, self.split_taps)
         self._prepare(mix.device)                       # (drops the captured graphs if the weights changed)
         ent = self._tables.get(key)
         if ent is None:
@@ -733,7 +744,7 @@ class HipEngine:
             # pad channels (rp > r) must read as zero; with rp == r the conv writes every element
             c1 = (torch.empty if rp == L['ftb0_c1'].M else torch.zeros)(B, T, Fq * rp, dtype=torch.float16, device=x.device)
             ops.conv(L['ftb0_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
-            gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)      # [B,1,T,Cc]
+            gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T, tap_split=self._tap_split(L['ftb_c1d'], B, T))      # [B,1,T,Cc]
             okey = ('ones', B, T, str(x.device))
             if okey not in self._tables:                # (setdefault would allocate and fill a fresh tensor on every forward)
                 self._tables[okey] = torch.ones(B, T, 2, dtype=torch.float16, device=x.device)
@@ -761,7 +772,7 @@ class HipEngine:
             Cc, rp = L['ftb_c2'].M, L['ftb_rp']
             c1 = (torch.empty if rp == L['ftb_c1'].M else torch.zeros)(B, T, Fq * rp, dtype=torch.float16, device=x.device)
             ops.conv(L['ftb_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
-            gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)      # [B,1,T,Cc]
+            gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T, tap_split=self._tap_split(L['ftb_c1d'], B, T))      # [B,1,T,Cc]
             fc = ops.freqfc(x, L['ftb_fc'], gate.view(B, T, Cc))
             x = ops.conv(L['ftb_c2'], fc, x, B, Fq, Fq, T)
         return x
@@ -924,6 +935,15 @@ class HipEngine:
             x = ops.norm_act(g, 1, True, g2[0] if g2 else None, g2[1] if g2 else None, ACT_GLU,
                              layer_scale=L['scale'], res=x, normalize=g2 is not None, stats=st2)
         return x
+
+    def _tap_split(self, spec, B, T):
+        """3-way split over the time taps for the long thin FTB Conv1d (aero_hip.h "tap split"): K >= 2048 on <= 512 tiles"""
+        ktot = spec.weight.shape[-1]                                 # ntaps * Cp
+        nT = len(set(spec.dt))
+        if (self.split_taps and nT == len(spec.dt) and nT % 3 == 0 and len(set(spec.df)) == 1 and 16 < spec.M <= 128 and ktot >= 2048
+                and B * ((T + 127) // 128) <= 512 and spec.act != ACT_GLU and not spec.transposed):
+            return 3
+        return 1
 
     def _want_stats(self, spec):
         return self.fuse_stats is True or (self.fuse_stats == 'auto' and spec is not None and len(spec.df) > 1)

@@ -112,8 +112,18 @@ typedef struct {
      * contiguous reads instead of 16 strided 64-byte pieces per wave instruction.  tiled_bm must equal
      * aero_conv_ring_bm(M, ntaps * Cp) or the image is ignored. */
     const void* weight_tiled; int32_t tiled_bm;
+    /* Tap split (0 or 1 = off) for long, thin contractions that cannot fill the chip (FTB Conv1d over time, modules.py:290:
+     * M = 48, K = 9 x 1280, 250 tiles): the nT time taps of a regular tap grid are divided into tap_split contiguous groups,
+     * the launch has tap_split x the blocks, and every block STORES the partial sums of its group -- no bias, no activation --
+     * into its own slab of split_acc, fp32 contiguous [tap_split][B][Fout][T][M] (every element is written; no atomics, so the
+     * result does not depend on block order); dst / bias / act are ignored.  nT % tap_split == 0; no statistics / scatter /
+     * residual.  aero_split_finish() adds the slabs in order and produces the fp16 activation. */
+    int32_t tap_split; float* split_acc;
 } aero_conv_desc;
 int aero_conv_fwd(const aero_conv_desc* d, void* stream);
+/* dst fp16 [npos][M] (contiguous) = act(sum_s acc[s][npos][M] + bias[M]), s = 0..nsplit-1 in that order; act NONE / RELU / GELU;
+ * bias may be NULL */
+int aero_split_finish(const float* acc, int32_t nsplit, const float* bias, int32_t act, void* dst, int64_t npos, int32_t M, void* stream);
 /* rows per block (16/32/48/64/128) of the kernel instantiation aero_conv_fwd picks for M output channels */
 int aero_conv_tile_m(int32_t M);
 /* rows per block (256/128/64) of the software-pipelined kernel for a contraction with M rows and Ktot = ntaps * Cp

@@ -416,3 +416,22 @@ def case_dconv_row(lib, dev, Cc, T, Fq=3, B=2, depth=2, act='gelu', norm=True, s
     assert y.shape == x.shape
     err = rel_l2(y.float().cpu(), want)
     assert err < TOL16, err
+
+
+def case_conv1d_split(lib, dev, Cin, Cout, k, R, T, S=3, seed=25):
+    """tap split (aero_conv_desc.tap_split): the same Conv1d with its time taps in S groups summed by aero_split_finish equals the
+    one-launch form up to fp32 summation order, and fp32 torch within the usual tolerance; two runs are bit-identical."""
+    ops = Ops(lib)
+    w = _rand((Cout, Cin, k), seed, 1.0 / math.sqrt(Cin * k))
+    b = _rand((Cout,), seed + 1)
+    x = _rand((R, Cin, T), seed + 2)
+    taps, df, dt = pack.conv1d_taps(q16(w), 1, k // 2)
+    spec = pack.make_conv_spec(taps, b, Cin, 0, df, dt, dev, act=_lib.ACT_RELU)
+    xc = x.permute(0, 2, 1).contiguous().half().view(1, R, T, Cin).to(dev)
+    ref = F.relu(F.conv1d(q16(x), q16(w), b, padding=k // 2))
+    y1 = ops.conv(spec, xc, None, 1, R, R, T, tap_split=S)
+    y2 = ops.conv(spec, xc, None, 1, R, R, T, tap_split=S)
+    y0 = ops.conv(spec, xc, None, 1, R, R, T)
+    assert torch.equal(y1, y2)
+    assert rel_l2(y1.float().cpu()[0].permute(0, 2, 1), ref) < TOL16
+    assert rel_l2(y1.float().cpu(), y0.float().cpu()) < 1e-3

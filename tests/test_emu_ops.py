@@ -175,3 +175,8 @@ def test_enc0_fused(emu, kw):
                                 dict(Cc=96, T=70, Fq=1, depth=3), dict(Cc=32, T=16, Fq=2, norm=False), dict(Cc=128, T=50, Fq=1, B=1)])
 def test_dconv_row(emu, kw):
     oc.case_dconv_row(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=64, Cout=48, k=9, R=2, T=150), dict(Cin=32, Cout=24, k=3, R=1, T=70)])
+def test_conv1d_tap_split(emu, kw):
+    oc.case_conv1d_split(emu, DEV, **kw)
