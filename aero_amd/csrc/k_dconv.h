@@ -51,13 +51,26 @@ static inline size_t aero_dconv_lds_bytes(int T, int C, int hidden, int maxdil) 
     return halves * 2 + floats * 4;
 }
 
+// (sum, sum of squares) of a row -> mean and 1/sqrt(var + eps).  fp64 only for the cancellation-prone E[x^2] - mean^2; a float rsqrt
+// with one Newton step instead of a double division and square root (those expand to ~100 instructions each, and EVERY thread
+// of the block runs them twice per layer: the first version spent 15 % of its vector instructions there)
+static __device__ __forceinline__ void aero_dconv_moments(float s1, float s2, float inv_n, float eps, float& mean, float& rstd) {
+    const float m = s1 * inv_n;
+    double var = (double)s2 * (double)inv_n - (double)m * (double)m;
+    const float vf = fmaxf((float)var, 0.f) + eps;
+    float r = aero_rsqrt(vf);
+    r = r * (1.5f - 0.5f * vf * r * r);
+    mean = m;
+    rstd = r;
+}
+
 // 8 waves (two blocks per CU when the row is small) or 16 (one block per CU, or more than 32 fragments); 4 fragments per wave
 static inline int aero_dconv_nw(size_t lds_bytes, int T) { return (lds_bytes > 80 * 1024 || T > 512) ? 16 : 8; }
 
 // HM = HP/16: M fragments of conv1 = k-steps of conv2;  NF2 = C/8 = M fragments of conv2;  NW waves, each owning at most MAXF
 // 16-step column fragments (cf = wave + f*NW): T <= 16 * NW * MAXF
 template <int HM, int NF2, int NW, int MAXF>
-__global__ __launch_bounds__(NW * 64) void aero_dconv_row_kernel(AeroDconvK p) {
+__global__ __launch_bounds__(NW * 64, 4) void aero_dconv_row_kernel(AeroDconvK p) {     // 4 waves per SIMD: <= 128 registers (two 8-wave blocks per CU)
     constexpr int C = NF2 * 8, HP = HM * 16, NK1 = (3 * C + 31) / 32, K1p = NK1 * 32, CU = NF2, NT = NW * 64;
     const aero_dconv_desc& d = p.d;
     const int T = d.T, hidden = d.hidden;
@@ -154,14 +167,10 @@ __global__ __launch_bounds__(NW * 64) void aero_dconv_row_kernel(AeroDconvK p) {
             s2 = aero_wave_sum(s2);
             if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
             __syncthreads();
-            double a = 0.0, b = 0.0;
+            float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) { a += (double)red[w * 2]; b += (double)red[w * 2 + 1]; }
-            const double n = (double)hidden * T, m = a / n;
-            double var = b / n - m * m;
-            var = var > 0.0 ? var : 0.0;
-            mean1 = (float)m;
-            rstd1 = (float)(1.0 / sqrt(var + (double)d.eps));
+            for (int w = 0; w < NW; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
+            aero_dconv_moments(a, b, 1.0f / ((float)hidden * (float)T), d.eps, mean1, rstd1);
         } else {
             __syncthreads();                                     // every wave is done READING its neighbours' x rows before pass C writes x
         }
@@ -198,6 +207,11 @@ __global__ __launch_bounds__(NW * 64) void aero_dconv_row_kernel(AeroDconvK p) {
         // (row fragment of W2 and its constants OUTER, the wave's column fragments inner: one LDS fetch serves MAXF fragments --
         //  with the column fragment outer the broadcast reads of the constants alone kept the LDS pipe 40 % busy)
         if (norm2) {
+            // sums per column fragment in PAIRS (v_pk_add_f32 / v_pk_fma_f32: four vector instructions per 4 values); the
+            // time mask depends on the fragment only and is applied once at the end
+            f32x2 p1[MAXF], p2[MAXF];
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) { p1[f] = (f32x2){0.f, 0.f}; p2[f] = (f32x2){0.f, 0.f}; }
 #pragma unroll
             for (int mf = 0; mf < NF2; ++mf) {
                 const f32x4 bias = *(const f32x4*)&c2[mf * 16 + g * 4];
@@ -210,9 +224,15 @@ __global__ __launch_bounds__(NW * 64) void aero_dconv_row_kernel(AeroDconvK p) {
                     f32x4 v = bias;
 #pragma unroll
                     for (int ks = 0; ks < HM; ++ks) v = __builtin_amdgcn_mfma_f32_16x16x16f16(wf[ks], hB[f][ks], v, 0, 0, 0);
-                    s1 = fmaf(msk[f], (v[0] + v[1]) + (v[2] + v[3]), s1);
-                    s2 = fmaf(msk[f], fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]), s2);
+                    const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+                    p1[f] += lo + hi;
+                    p2[f] = lo * lo + (hi * hi + p2[f]);
                 }
+            }
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) {
+                s1 = fmaf(msk[f], p1[f][0] + p1[f][1], s1);
+                s2 = fmaf(msk[f], p2[f][0] + p2[f][1], s2);
             }
         }
         float mean2 = 0.f, rstd2 = 1.f;
@@ -221,14 +241,10 @@ __global__ __launch_bounds__(NW * 64) void aero_dconv_row_kernel(AeroDconvK p) {
             s2 = aero_wave_sum(s2);
             if (lane == 0) { red[2 * NW + wave * 2] = s1; red[2 * NW + wave * 2 + 1] = s2; }
             __syncthreads();
-            double a = 0.0, b = 0.0;
+            float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) { a += (double)red[2 * NW + w * 2]; b += (double)red[2 * NW + w * 2 + 1]; }
-            const double n = (double)(2 * C) * T, m = a / n;
-            double var = b / n - m * m;
-            var = var > 0.0 ? var : 0.0;
-            mean2 = (float)m;
-            rstd2 = (float)(1.0 / sqrt(var + (double)d.eps));
+            for (int w = 0; w < NW; ++w) { a += red[2 * NW + w * 2]; b += red[2 * NW + w * 2 + 1]; }
+            aero_dconv_moments(a, b, 1.0f / ((float)(2 * C) * (float)T), d.eps, mean2, rstd2);
         }
         // GN2 folded into one FMA per value: v' = acc * A2 + B2, A2 = rstd*g2, B2 = be2 + (b2 - mean) * A2  (in place of g2 / be2)
         for (int m = tid; m < 2 * C; m += NT) {
