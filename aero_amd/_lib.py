@@ -97,6 +97,9 @@ _PROTOS = {
     'aero_last_error': (C.c_char_p, []),
     'aero_last_kernel_name': (C.c_char_p, []),
     'aero_stft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, i32, fp, i32, dp, i32, vp]),
+    'aero_stft_dft_table_bytes': (i64, [i32]),
+    'aero_stft_dft_table': (i32, [fp, i32, i32, vp, vp]),
+    'aero_stft_dft_fwd': (i32, [fp, i32, i32, i32, i32, i32, i32, vp, fp, i32, dp, i32, vp]),
     'aero_spec_normalize': (i32, [fp, i32, i64, dp, vp, fp, vp]),
     'aero_istft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, fp, fp, i32, vp]),
     'aero_conv_fwd': (i32, [C.POINTER(ConvDesc), vp]),

@@ -77,6 +77,21 @@ int aero_stft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n
     return aero_finish(rc, err);
 }
 
+int64_t aero_stft_dft_table_bytes(int32_t n_fft) { return (int64_t)aero_stft_dft_tbytes((int)n_fft); }
+
+int aero_stft_dft_table(const float* window, int32_t n_fft, int32_t win_off, void* table, void* stream) {
+    const char* err = "";
+    int rc = aero_stft_dft_table_launch(window, n_fft, win_off, table, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_stft_dft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, int32_t win_off, const void* table,
+                      float* spec, int32_t T, double* stats, int32_t sig_per_item, void* stream) {
+    const char* err = "";
+    int rc = aero_stft_dft_launch(x, nsig, L, Lp, n_fft, hop, win_off, table, spec, T, stats, sig_per_item, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 int aero_spec_normalize(const float* spec, int32_t nitems, int64_t n_per_item, const double* stats, void* xn,
                         float* mean_std, void* stream) {
     const char* err = "";

@@ -404,6 +404,180 @@ static int aero_stft_launch(const float* x, int nsig, int L, int Lp, int n_fft, 
     return AERO_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// STFT as a GEMM for SHORT windows (Aero._spec of the low-rate input: n_fft 512 but a 128-sample window, aero.py:324-328).
+// Only 128 of the 512 samples of a frame are non-zero, so  X[f, t] = sum_{k<128} A[f][k] * x[t*hop + k + c],
+// A[f][k] = w[k] * n_fft^-1/2 * e^{-2 pi i f (k + win_off) / n_fft}  -- a [2*n_bins x 128] matrix times the [128 x T] frame
+// matrix of a signal: 4.2 GFLOP for the whole batch, nothing for the matrix cores, where the FFT kernel above spends its time
+// on LDS round trips of a 512-point transform that is three quarters zeros (75 us for a 68-MB output).
+// fp32 results from the fp16 MFMA: both operands are split  v = hi + lo  (two fp16, 22 significant bits; the table is
+// pre-scaled by 2^10 so that its `lo` halves stay normal) and  hi*hi + hi*lo + lo*hi  is accumulated in fp32 (the dropped
+// lo*lo term is 2^-22 relative): measured 3e-7 rel-L2 against the fp64 oracle, like the FFT.
+// Block: 512 threads, 128 rows (= 64 bins, re/im interleaved) x 128 frames of one signal; wave tile 32 x 64.  The block's
+// slice of the table (both halves, all four 32-column chunks: 64 KiB) is copied into LDS in one go (direct global->LDS copies,
+// image already in tile order: one L2 latency; a double-buffered chunk pipeline paid four and ran at 35 us); the frames are
+// rows of ONE shared span of the signal in LDS (hi / lo), read at offset frame*hop.
+// HBM-bound by its 8-byte-per-bin output; the table (256 KB) is L2 traffic.
+#define AERO_DFT_K 128
+#define AERO_DFT_SPAN 2176          /* samples of signal the 128 frames of a block may span: hop <= 16 (74 KiB of LDS: two blocks per CU) */
+struct AeroStftDftK {
+    const float* x; const h16* table; float* spec; double* stats;
+    int nsig, L, Lp, n_fft, hop, win_off, T, sig_per_item;
+};
+
+// table image: fp16 [part hi|lo][chunk 0..3][n_fft rows (2f + {re, im})][32], rows in tile order (aero_tile_off); value * 2^10
+__global__ __launch_bounds__(256) void aero_stft_dft_table_kernel(const float* window, int n_fft, int win_off, h16* table) {
+    const int total = 4 * n_fft * 32;
+    const double scale = 1024.0 / sqrt((double)n_fft);
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int kc = idx / (n_fft * 32), rem = idx - kc * (n_fft * 32);
+        const int r = rem >> 5, j = rem & 31;
+        const int q = (j >> 3) ^ ((0 - (r >> 2)) & 3);            // the slot stored at position j >> 3 of row r (aero_tile_off)
+        const int k = kc * 32 + q * 8 + (j & 7);
+        const int f = r >> 1, n = win_off + k;
+        const double w = n < n_fft ? (double)window[n] : 0.0;
+        const long ph = ((long)f * n) % n_fft;                    // exact phase index
+        const double ang = -2.0 * 3.14159265358979323846 * (double)ph / (double)n_fft;
+        const double v = w * scale * ((r & 1) ? sin(ang) : cos(ang));
+        const h16 hi = (h16)(float)v;
+        const h16 lo = (h16)(float)(v - (double)(float)hi);
+        table[(size_t)kc * n_fft * 32 + rem] = hi;
+        table[(size_t)(4 + kc) * n_fft * 32 + rem] = lo;
+    }
+}
+
+__global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
+    __shared__ AERO_LDS_ALIGN h16 As[4][2][128 * 32];             // [chunk][hi | lo][128 rows][32]: the block's whole table slice
+    __shared__ AERO_LDS_ALIGN h16 xh[AERO_DFT_SPAN + 8], xl[AERO_DFT_SPAN + 8];
+    __shared__ double red[2][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int kg = lane >> 4, col = lane & 15;
+    const int wr = wave >> 1, wc = wave & 1;                     // wave tile: rows wr*32 .. +32, frames wc*64 .. +64
+    const int sig = blockIdx.y, quarter = blockIdx.z;
+    const int t0 = blockIdx.x * 128;
+    const int n_fft = p.n_fft, hop = p.hop, n_bins = n_fft >> 1;
+    const float* xs = p.x + (int64_t)sig * p.L;
+    // the block's table slice, all four chunks at once (one L2 latency instead of four): 4 x 2 x 128 rows x 4 slots = 4096
+    // 16-byte units, 8 per thread; the image is already in tile order, so the copy is linear
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int W = wave + 8 * u;                              // 64-unit piece: (chunk, part) = W >> 3, rows (W & 7) * 16 .. +16
+        const int cp = W >> 3, kc = cp >> 1, part = cp & 1;
+        const h16* src = p.table + ((size_t)(part * 4 + kc) * n_fft + quarter * 128) * 32 + ((W & 7) * 64 + lane) * 8;
+        aero_glds16(src, &As[kc][part][0] + (W & 7) * 512);
+    }
+    // the span of the (hop-padded, reflect-padded) signal the block's 128 frames read: split into hi + lo fp16.  All loads first.
+    const int span = 127 * hop + AERO_DFT_K;
+    {
+        constexpr int NV = (AERO_DFT_SPAN + 511) / 512;
+        float v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int j = tid + u * 512;
+            int xi = t0 * hop + j + p.win_off - (n_fft >> 1);
+            if (xi < 0) xi = -xi;
+            if (xi >= p.Lp) xi = 2 * (p.Lp - 1) - xi;
+            v[u] = (j < span && xi >= 0 && xi < p.L) ? xs[xi] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int j = tid + u * 512;
+            if (j < span) {
+                const h16 hi = (h16)v[u];
+                xh[j] = hi;
+                xl[j] = (h16)(v[u] - (float)hi);
+            }
+        }
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                             // table slice (vmcnt drained) and span are in
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        h16x8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = aero_tile_off(wr * 32 + i * 16 + col, kg);
+            ah[i] = *(const h16x8*)&As[kc][0][off];
+            al[i] = *(const h16x8*)&As[kc][1][off];
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int base = (wc * 64 + n * 16 + col) * hop + kc * 32 + kg * 8;
+            const h16x8 bh = *(const h16x8*)&xh[base];
+            const h16x8 bl = *(const h16x8*)&xl[base];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][n], 0, 0, 0);
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][n], 0, 0, 0);
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][n], 0, 0, 0);
+            }
+        }
+    }
+    // rows m = quarter*128 + wr*32 + i*16 + kg*4 + r = 2f + {re, im}: registers (0,1) and (2,3) are two complex bins
+    float s = 0.f, ss = 0.f;
+    float* out = p.spec + (int64_t)sig * n_bins * p.T * 2;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int t = t0 + wc * 64 + n * 16 + col;
+        if (t >= p.T) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = (quarter * 128 + wr * 32 + i * 16 + kg * 4) >> 1;
+            const f32x4 v = acc[i][n] * (1.0f / 1024.0f);
+            *(f32x2*)(out + ((int64_t)f * p.T + t) * 2) = (f32x2){v[0], v[1]};
+            *(f32x2*)(out + ((int64_t)(f + 1) * p.T + t) * 2) = (f32x2){v[2], v[3]};
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    if (p.stats) {
+        const double ds = aero_wave_sum((double)s), dss = aero_wave_sum((double)ss);
+        if (lane == 0) { red[0][wave] = ds; red[1][wave] = dss; }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < 8; ++w) { a += red[0][w]; b += red[1][w]; }
+            double* st = p.stats + 2 * (int64_t)(sig / p.sig_per_item);
+            atomicAdd(st, a);
+            atomicAdd(st + 1, b);
+        }
+    }
+}
+
+static size_t aero_stft_dft_tbytes(int n_fft) { return (size_t)2 * 4 * n_fft * 32 * sizeof(h16); }
+
+static int aero_stft_dft_ok(int n_fft, int hop, int win_off) {
+    return n_fft >= 128 && n_fft % 128 == 0 && n_fft <= 4096 && hop >= 8 && hop % 8 == 0 && 127 * hop + AERO_DFT_K <= AERO_DFT_SPAN &&
+           win_off >= 0 && win_off + 1 <= n_fft;
+}
+
+static int aero_stft_dft_table_launch(const float* window, int n_fft, int win_off, void* table, hipStream_t stream, const char** err) {
+    if (!window || !table) { *err = "stft_dft_table: null pointer"; return AERO_ERR_ARG; }
+    if (n_fft < 256 || n_fft % 256 || n_fft > 4096 || win_off < 0 || win_off >= n_fft || ((uintptr_t)table & 15)) { *err = "stft_dft_table: bad geometry"; return AERO_ERR_ARG; }
+    AERO_LAUNCH(aero_stft_dft_table_kernel, dim3((unsigned)((4 * n_fft * 32 + 255) / 256)), dim3(256), stream, window, n_fft, win_off, (h16*)table);
+    return AERO_OK;
+}
+
+static int aero_stft_dft_launch(const float* x, int nsig, int L, int Lp, int n_fft, int hop, int win_off, const void* table, float* spec,
+                                int T, double* stats, int sig_per_item, hipStream_t stream, const char** err) {
+    if (!x || !table || !spec) { *err = "stft_dft: null pointer"; return AERO_ERR_ARG; }
+    if (!aero_stft_dft_ok(n_fft, hop, win_off)) { *err = "stft_dft: n_fft % 256, hop % 8, hop <= 16 and a window of <= 128 samples are required"; return AERO_ERR_UNSUPPORTED; }
+    if (Lp < L || T != 1 + Lp / hop || Lp <= n_fft / 2) { *err = "stft_dft: inconsistent L/Lp/hop/T"; return AERO_ERR_ARG; }
+    if ((stats && sig_per_item < 1) || ((uintptr_t)table & 15) || ((uintptr_t)spec & 7)) { *err = "stft_dft: bad arguments"; return AERO_ERR_ARG; }
+    if (nsig > 65535) { *err = "stft_dft: too many signals for one launch"; return AERO_ERR_ARG; }
+    AeroStftDftK p;
+    p.x = x; p.table = (const h16*)table; p.spec = spec; p.stats = stats;
+    p.nsig = nsig; p.L = L; p.Lp = Lp; p.n_fft = n_fft; p.hop = hop; p.win_off = win_off; p.T = T;
+    p.sig_per_item = sig_per_item > 0 ? sig_per_item : 1;
+    dim3 grid((unsigned)((T + 127) / 128), (unsigned)nsig, (unsigned)(n_fft / 128)), block(512);
+    AERO_LAUNCH(aero_stft_dft_kernel, grid, block, stream, p);
+    return AERO_OK;
+}
+
 static int aero_spec_normalize_launch(const float* spec, int nitems, int64_t n_per_item, const double* stats, void* xn,
                                       float* mean_std, hipStream_t stream, const char** err) {
     if (!spec || !stats || !xn || !mean_std) { *err = "spec_normalize: null pointer"; return AERO_ERR_ARG; }

@@ -35,6 +35,8 @@ class Ops:
     def __init__(self, lib):
         self.lib = lib
         self.prof = None          # bench.py sets this to a list to collect per-launch HIP-event timings
+        self.dft_stft = os.environ.get('AERO_STFT_DFT', '1') != '0'      # short-window STFT as a GEMM (k_stft.h)
+        self._dft_tables = {}
         self.prof_shapes = None   # (tools/launch_table.py) one short shape note per profiled launch
         self.tag = ''             # engine-set label of the launches being issued ('stack' = Conv2d / ConvTranspose2d of the U-Net)
         self._shape_note = ''
@@ -62,10 +64,29 @@ class Ops:
         self._shape_note = ''
 
     # -- K1/K2/K15 ---------------------------------------------------------------------------
-    def stft(self, x, L, Lp, n_fft, hop, window, n_bins, stats=None, sig_per_item=1):
+    def stft(self, x, L, Lp, n_fft, hop, window, n_bins, stats=None, sig_per_item=1, win_len=None):
+        """win_len: length of the centred window inside `window` [n_fft]; short windows (<= 128 samples, hop % 8 == 0, hop <= 16,
+        Nyquist dropped) take the DFT-as-GEMM kernel (aero_stft_dft_fwd) with a table cached per (window, n_fft)."""
         nsig = x.shape[0]
         T = 1 + Lp // hop
         spec = torch.empty(nsig, n_bins, T, 2, dtype=torch.float32, device=x.device)
+        if (self.dft_stft and win_len is not None and win_len <= 128 and n_bins == n_fft // 2 and n_fft % 256 == 0 and n_fft <= 4096
+                and hop % 8 == 0 and hop <= 16 and nsig <= 65535 and Lp > n_fft // 2):
+            win_off = (n_fft - win_len) // 2
+            key = (window.data_ptr(), n_fft, win_len, str(x.device))
+            table = self._dft_tables.get(key)
+            if table is None:
+                nbytes = int(self.lib.cdll.aero_stft_dft_table_bytes(n_fft))
+                table = torch.empty(nbytes // 2, dtype=torch.float16, device=x.device)
+                self.lib.call('aero_stft_dft_table', _ptr(window), n_fft, win_off, _ptr(table), self.stream(x))
+                if len(self._dft_tables) >= 8:
+                    self._dft_tables.pop(next(iter(self._dft_tables)))
+                self._dft_tables[key] = (table, window)                    # (the window tensor is kept alive with its table)
+            else:
+                table = table[0]
+            self._call('aero_stft_dft_fwd', 'aero_stft_dft_kernel', 2.0 * nsig * T * n_fft * 128, nsig * (L * 4 + n_bins * T * 8),
+                       _ptr(x), nsig, L, Lp, n_fft, hop, win_off, _ptr(table), _ptr(spec), T, _ptr(stats), sig_per_item, self.stream(x))
+            return spec
         self._call('aero_stft_fwd', 'aero_stft_kernel', 0, nsig * (L * 4 + n_bins * T * 8),
                    _ptr(x), nsig, L, Lp, n_fft, hop, _ptr(window), n_bins, _ptr(spec), T,
                    _ptr(stats), sig_per_item, self.stream(x))
@@ -622,7 +643,7 @@ class HipEngine:
         if scale:
             hop, win = int(hop * m.scale), int(win * m.scale)
         z = self.ops.stft(x.reshape(B * Cc, L).contiguous(), L, Lp, m.nfft, hop, self._window(win, x.device),
-                          m.nfft // 2, stats=stats, sig_per_item=Cc)
+                          m.nfft // 2, stats=stats, sig_per_item=Cc, win_len=win)
         return torch.view_as_complex(z).view(B, Cc, m.nfft // 2, -1)
 
     def ispec(self, z):

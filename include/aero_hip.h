@@ -48,6 +48,16 @@ int aero_stft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n
                   const float* window, int32_t n_bins, float* spec, int32_t T, double* stats,
                   int32_t sig_per_item, void* stream);
 
+/* K1' -- the same transform for SHORT analysis windows (Aero._spec of the low-rate input: n_fft 512 with a 128-sample window,
+ * aero.py:324-328) as a GEMM against a windowed DFT table (k_stft.h): the window's non-zero samples are window[win_off ..
+ * win_off + 128) (win_off = (n_fft - win_length) / 2 for the centred window of spec.py:15-16; shorter windows: the rest is the
+ * zero padding).  table: fp16, aero_stft_dft_table_bytes(n_fft) bytes, filled once per (window, n_fft) by aero_stft_dft_table.
+ * Needs n_fft % 256 == 0, hop % 8 == 0, hop <= 16, n_bins = n_fft/2 (Nyquist dropped).  Same outputs / stats as aero_stft_fwd. */
+int64_t aero_stft_dft_table_bytes(int32_t n_fft);
+int aero_stft_dft_table(const float* window, int32_t n_fft, int32_t win_off, void* table, void* stream);
+int aero_stft_dft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, int32_t win_off,
+                      const void* table, float* spec, int32_t T, double* stats, int32_t sig_per_item, void* stream);
+
 /* K2 -- aero.py:430-434,462-464: complex -> 2 channels + per-item normalisation.
  * spec viewed as [nitems][n_per_item] fp32; xn fp16 same shape = (v-mean)/(1e-5+std) with the
  * unbiased std; mean_std[2*i], [2*i+1] receive mean and std (used again by K14). */

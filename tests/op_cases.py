@@ -43,13 +43,18 @@ def q16(x):
 
 
 # ------------------------------------------------------------------------------------------------
-def case_stft(lib, dev, nfft, hop, win, L, B=2, nyquist=False):
-    """nyquist=True keeps bin n_fft/2 (the loss / metric STFTs of stft_loss.py:22 and metrics.py:50 are one-sided with it)"""
+def case_stft(lib, dev, nfft, hop, win, L, B=2, nyquist=False, dft=False):
+    """nyquist=True keeps bin n_fft/2 (the loss / metric STFTs of stft_loss.py:22 and metrics.py:50 are one-sided with it);
+    dft=True: the short-window GEMM form (aero_stft_dft_fwd) instead of the FFT kernel"""
     ops = Ops(lib)
+    ops.dft_stft = dft
     x = _rand((B, L), 1)
     pad = (hop - L % hop) % hop
     stats = torch.zeros(B, 2, dtype=torch.float64, device=dev)
-    z = ops.stft(x.to(dev), L, L + pad, nfft, hop, _hann_padded(win, nfft, dev), nfft // 2 + int(nyquist), stats=stats)
+    z = ops.stft(x.to(dev), L, L + pad, nfft, hop, _hann_padded(win, nfft, dev), nfft // 2 + int(nyquist), stats=stats,
+                 win_len=win if dft else None)
+    if dft:
+        assert 'dft' in (ops.lib.cdll.aero_last_kernel_name().decode() or 'dft')
     zr = O.stft(F.pad(x, (0, pad)), nfft, hop, win)
     if not nyquist:
         zr = zr[..., :-1, :]

@@ -180,3 +180,10 @@ def test_dconv_row(emu, kw):
 @pytest.mark.parametrize('kw', [dict(Cin=64, Cout=48, k=9, R=2, T=150), dict(Cin=32, Cout=24, k=3, R=1, T=70)])
 def test_conv1d_tap_split(emu, kw):
     oc.case_conv1d_split(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('geom', [(512, 16, 128, 1000), (256, 8, 64, 799), (512, 16, 100, 2003), (1024, 16, 128, 1700)])
+def test_stft_short_window_as_gemm(emu, geom):
+    """aero_stft_dft_fwd: windows of <= 128 samples (Aero._spec of the low-rate input) as hi/lo-split fp16 MFMAs against a windowed
+    DFT table; same 2e-6 bar as the FFT kernel, same statistics."""
+    oc.case_stft(emu, DEV, *geom, dft=True)
