@@ -205,7 +205,7 @@ def main():
         # STFT / iSTFT against the HBM roofline (algorithmic bytes: SURVEY 8d)
         roof_stft = {}
         for kname, v in kernels.items():
-            if 'stft_kernel' in kname and v['ms'] > 0:
+            if 'stft' in kname and 'table' not in kname and v['ms'] > 0:
                 ach = v['bytes'] / (v['ms'] * 1e-3) / 1e9
                 roof_stft[kname] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                     'frac': round(ach / PEAK_HBM_GBS, 4), 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
