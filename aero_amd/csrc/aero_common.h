@@ -147,10 +147,21 @@ static __device__ __forceinline__ f32x2 aero_gelu2(f32x2 y) {
     return g - ay * (p * E);
 }
 
+// true if the predicate holds in any lane of the wave (one s_cmp on the vote mask; the emulator sums)
+static __device__ __forceinline__ bool aero_wave_any(bool pred);
+
 template <class T>
 static __device__ __forceinline__ T aero_wave_sum(T v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
+}
+
+static __device__ __forceinline__ bool aero_wave_any(bool pred) {
+#ifdef AERO_EMU
+    return aero_wave_sum(pred ? 1 : 0) != 0;
+#else
+    return __builtin_amdgcn_ballot_w64(pred) != 0;
+#endif
 }
 
 // LDS image of a [rows][32] fp16 tile (64-byte rows).  ds_read_b128 is serviced in four 16-lane

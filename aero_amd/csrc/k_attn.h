@@ -402,7 +402,11 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
             const float x = u + koff[e];
             sc[e] = ((e < 4) ? s0[e & 3] : s1[e & 3]) - fabsf(x) * Dq;
             if (x == 0.f) sc[e] = -100.f * L2E;                                          // self reference (modules.py:120)
-            if (tb + (int)koff[e] >= T) sc[e] = -1e30f;
+        }
+        if (tb + 32 > T) {                                                               // ragged last block only (block-uniform)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (tb + (int)koff[e] >= T) sc[e] = -1e30f;
         }
     };
     auto folded = [&](int tb, const h16x8& q, float* sc) {
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
         m = fmaxf(m, __shfl_xor(m, 32));
     }
     // the folded constants must stay inside fp16 (c = -+D*s - m); otherwise every block takes the general path
-    const bool fold_ok = aero_wave_sum((fabsf(m) < 2.0e4f) ? 1 : 0) == 64;
+    const bool fold_ok = !aero_wave_any(!(fabsf(m) < 2.0e4f));
 
     // ---- pass 2: probabilities against the fixed maximum, O += V^T P (row dh of V^T = ones: the denominator)
     f32x4 O[DT];
@@ -518,12 +522,16 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
         const float inv = 1.0f / lsum;
         h16* op = (h16*)d.out + ((int64_t)row * T + s) * C + h * dh;
 #pragma unroll
-        for (int i = 0; i < DT; ++i)
+        for (int i = 0; i < DT; ++i) {
+            const int dd = i * 16 + g * 4;                       // this lane's four consecutive output channels
+            if (vec4 && (((uintptr_t)d.out) & 7) == 0) {         // (dh % 4 == 0: all four real or all four padding)
+                if (dd < dh) *(h16x4*)(op + dd) = (h16x4){(h16)(O[i][0] * inv), (h16)(O[i][1] * inv), (h16)(O[i][2] * inv), (h16)(O[i][3] * inv)};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int dd = i * 16 + g * 4 + r;
-                if (dd < dh) op[dd] = (h16)(O[i][r] * inv);
+                for (int r = 0; r < 4; ++r)
+                    if (dd + r < dh) op[dd + r] = (h16)(O[i][r] * inv);
             }
+        }
     }
   }
 }
