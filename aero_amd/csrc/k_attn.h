@@ -246,7 +246,6 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
     constexpr int VS = KC + 4;
     __shared__ AERO_LDS_ALIGN h16 Ks[KC * 32];
     __shared__ AERO_LDS_ALIGN h16 Vt[DT * 16 * VS];
-    __shared__ AERO_LDS_ALIGN h16 Qs[128 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int g = lane >> 4, col = lane & 15;
     const int h = blockIdx.y, row = blockIdx.z;
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
     constexpr float L2E = 1.4426950408889634f;
     const float qscale = L2E / sqrtf((float)dh);
     const int kn32 = (T + 31) & ~31;
-    const int nqb = (T + 127) / 128;                             // the block walks over all query blocks of its (row, head)
+    const int nqb = (T + 255) / 256;                             // the block walks over all query blocks (256 queries: 8 waves x 32) of its (row, head)
     // ---- staging: queries (scaled), keys + bias slots, V^T + the row of ones
     const bool vec4 = (dh % 4 == 0) && (d.ld % 4 == 0) && (C % 4 == 0) && (((uintptr_t)d.qkvd & 7) == 0);
     const int nc4 = (dh + 3) >> 2;                               // 8-byte pieces per head slice
@@ -335,49 +334,51 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
             Vt[dd * VS + tl] = v;
         }
     }
-  for (int qb = 0; qb < nqb; ++qb) {
-    const int s_blk = qb * 128;
-    if (qb) __syncthreads();                                     // every wave has taken its query fragment of the previous block
-    if (vec4) {
-        for (int idx = tid; idx < 128 * 8; idx += 512) {
-            const int sl = idx >> 3, c4 = idx & 7;
-            const int sq = s_blk + sl;
-            h16x4 v = (h16x4){0, 0, 0, 0};
-            if (sq < T && c4 * 4 < dh) {
-                const h16x4 x = *(const h16x4*)(base + (int64_t)sq * d.ld + h * dh + c4 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (h16)((float)x[e] * qscale);
-            }
-            *(h16x4*)&Qs[aero_tile_off(sl, c4 >> 1) + (c4 & 1) * 4] = v;
-        }
-    } else {
-        for (int idx = tid; idx < 128 * 32; idx += 512) {
-            const int sl = idx >> 5, c = idx & 31;
-            const int sq = s_blk + sl;
-            float v = 0.f;
-            if (sq < T && c < dh) v = (float)base[(int64_t)sq * d.ld + h * dh + c] * qscale;
-            Qs[aero_tile_off(sl, c >> 3) + (c & 7)] = (h16)v;
-        }
-    }
-    __syncthreads();                                             // K, V^T (first trip) and the queries are in
-    // this lane's query and its decay slope
-    const int s = s_blk + wave * 16 + col;
-    float Dq = 0.f;
-    if (s < T) {
-        const h16* dp = base + (int64_t)s * d.ld + 3 * C + h * d.ndecay;
-        for (int f = 0; f < d.ndecay; ++f) Dq += (float)(f + 1) * aero_sigmoid((float)dp[f]);
-        Dq *= L2E * 0.5f / sqrtf((float)(d.ndecay > 0 ? d.ndecay : 1));
-    }
-    const int sw_lo = s_blk + wave * 16, sw_hi = sw_lo + 16;    // this wave's queries
-    const h16x8 qf = *(const h16x8*)&Qs[aero_tile_off(wave * 16 + col, g)];
+    __syncthreads();                                             // K and V^T of the (row, head) are in
     float koff[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) koff[e] = (float)(((e >> 2) << 4) + g * 4 + (e & 3));
-    // query fragment with the four bias slots filled in: sign = +1 for key blocks before the queries, -1 after; cc = c
-    auto with_bias = [&](float sign, float cc) {
-        h16x8 q = qf;
+    constexpr int NQ = 2;                                        // query fragments per wave: K / V^T fragments are fetched once for both
+  for (int qb = 0; qb < nqb; ++qb) {
+    const int sw_lo = qb * 256 + wave * 32;                      // this wave's 32 queries (two fragments of 16): a multiple of 32
+    if (sw_lo >= T) continue;                                    // (wave-uniform; nothing below synchronises the block)
+    // this lane's queries (fragment j: sw_lo + 16j + col), straight from global memory into MFMA B fragments (dims g*8 .. +7,
+    // pre-scaled), and their decay slopes
+    int sq[NQ];
+    float Dq[NQ];
+    h16x8 qf[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        sq[j] = sw_lo + j * 16 + col;
+        Dq[j] = 0.f;
+        qf[j] = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (sq[j] < T) {
+            const h16* qp = base + (int64_t)sq[j] * d.ld + h * dh;
+            if (vec4) {
+#pragma unroll
+                for (int hv = 0; hv < 2; ++hv) {
+                    const int c = g * 8 + hv * 4;
+                    if (c < dh) {
+                        const h16x4 x = *(const h16x4*)(qp + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) qf[j][hv * 4 + e] = (h16)((float)x[e] * qscale);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (g * 8 + e < dh) qf[j][e] = (h16)((float)qp[g * 8 + e] * qscale);
+            }
+            const h16* dp = base + (int64_t)sq[j] * d.ld + 3 * C + h * d.ndecay;
+            for (int f = 0; f < d.ndecay; ++f) Dq[j] += (float)(f + 1) * aero_sigmoid((float)dp[f]);
+            Dq[j] *= L2E * 0.5f / sqrtf((float)(d.ndecay > 0 ? d.ndecay : 1));
+        }
+    }
+    // query fragment with the bias slots filled in: sign = +1 for key blocks before the queries, -1 after; cc = c
+    auto with_bias = [&](int j, float sign, float cc) {
+        h16x8 q = qf[j];
         if (g == gx) {
-            const float Ds = sign * Dq;
+            const float Ds = sign * Dq[j];
             const h16 d_hi = (h16)Ds, d_lo = (h16)(Ds - (float)d_hi);
             const h16 c_hi = (h16)cc, c_lo = (h16)(cc - (float)c_hi);
             if (e0 == 0) { q[0] = d_hi; q[1] = d_lo; q[2] = c_hi; q[3] = c_lo; }
@@ -389,147 +390,135 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
         }
         return q;
     };
-    // general path (blocks around the diagonal, ragged end): as in the streaming kernel
-    auto scores = [&](int tb, float* sc) {
+    // scores of one 32-key block for both fragments, K fragments fetched once.  GENERAL = the block on the diagonal (and every
+    // block when the folded constants would leave fp16): |t - s|, the self reference and the ragged end are applied per score
+    auto block = [&](int tb, const h16x8 (&q)[NQ], bool general, float (&sc)[NQ][8]) {
         const h16x8 k0 = *(const h16x8*)&Ks[aero_tile_off(tb + col, g)];
         const h16x8 k1 = *(const h16x8*)&Ks[aero_tile_off(tb + 16 + col, g)];
         const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf, z4, 0, 0, 0);   // (qf: bias slots zero)
-        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf, z4, 0, 0, 0);
-        const float u = (float)(tb - s);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = u + koff[e];
-            sc[e] = ((e < 4) ? s0[e & 3] : s1[e & 3]) - fabsf(x) * Dq;
-            if (x == 0.f) sc[e] = -100.f * L2E;                                          // self reference (modules.py:120)
+        for (int j = 0; j < NQ; ++j) {
+            const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, q[j], z4, 0, 0, 0);
+            const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, q[j], z4, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc[j][e] = s0[e]; sc[j][4 + e] = s1[e]; }
         }
-        if (tb + 32 > T) {                                                               // ragged last block only (block-uniform)
+        if (general) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (tb + (int)koff[e] >= T) sc[e] = -1e30f;
+            for (int j = 0; j < NQ; ++j) {
+                const float u = (float)(tb - sq[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = u + koff[e];
+                    sc[j][e] -= fabsf(x) * Dq[j];
+                    if (x == 0.f) sc[j][e] = -100.f * L2E;                               // self reference (modules.py:120)
+                    if (tb + (int)koff[e] >= T) sc[j][e] = -1e30f;
+                }
+            }
         }
-    };
-    auto folded = [&](int tb, const h16x8& q, float* sc) {
-        const h16x8 k0 = *(const h16x8*)&Ks[aero_tile_off(tb + col, g)];
-        const h16x8 k1 = *(const h16x8*)&Ks[aero_tile_off(tb + 16 + col, g)];
-        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, q, z4, 0, 0, 0);
-        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, q, z4, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; }
     };
     auto max8 = [](const float* sc) {
         return fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
     };
-    // The key range splits at the 32-key block that holds the wave's 16 queries (sw_lo is a multiple of 16): blocks before it
-    // run with the "before" query fragment, the diagonal block takes the general path, blocks after it the "after" fragment
-    // -- three straight loops, no per-block selection.  Ranges are walked two independent blocks at a time.
-    const int tdiag = sw_lo & ~31;
-    auto walk = [&](int lo, int hi, auto&& two, auto&& one) {    // [lo, hi) in steps of 32
-        int tb = lo;
-        for (; tb + 64 <= hi; tb += 64) two(tb);
-        if (tb < hi) one(tb);
-    };
+    // The key range splits at the 32-key block that holds the wave's 32 queries: blocks before it run with the "before" query
+    // fragments, the diagonal block takes the general path, blocks after it the "after" fragments -- three straight loops.
+    const int tdiag = sw_lo;
 
     // ---- pass 1: the maximum of every query's scores
-    float m = -1e30f;
+    float m[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) m[j] = -1e30f;
     {
-        const h16x8 qb = with_bias(1.f, -Dq * (float)s), qa = with_bias(-1.f, Dq * (float)s);
-        auto run = [&](int lo, int hi, const h16x8& q) {
-            walk(lo, hi,
-                 [&](int tb) { float sa[8], sb[8]; folded(tb, q, sa); folded(tb + 32, q, sb); m = fmaxf(m, fmaxf(max8(sa), max8(sb))); },
-                 [&](int tb) { float sa[8]; folded(tb, q, sa); m = fmaxf(m, max8(sa)); });
+        h16x8 qbv[NQ], qav[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) { qbv[j] = with_bias(j, 1.f, -Dq[j] * (float)sq[j]); qav[j] = with_bias(j, -1.f, Dq[j] * (float)sq[j]); }
+        auto run = [&](int lo, int hi, const h16x8 (&q)[NQ]) {
+            for (int tb = lo; tb < hi; tb += 32) {
+                float sc[NQ][8];
+                block(tb, q, false, sc);
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) m[j] = fmaxf(m[j], max8(sc[j]));
+            }
         };
-        run(0, tdiag < kn32 ? tdiag : kn32, qb);
+        run(0, tdiag < kn32 ? tdiag : kn32, qbv);
         if (tdiag < kn32) {
-            float sc[8];
-            scores(tdiag, sc);
-            m = fmaxf(m, max8(sc));
-            run(tdiag + 32, kn32, qa);
+            float sc[NQ][8];
+            block(tdiag, qf, true, sc);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) m[j] = fmaxf(m[j], max8(sc[j]));
+            run(tdiag + 32, kn32, qav);
         }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            m[j] = fmaxf(m[j], __shfl_xor(m[j], 16));
+            m[j] = fmaxf(m[j], __shfl_xor(m[j], 32));
+        }
     }
     // the folded constants must stay inside fp16 (c = -+D*s - m); otherwise every block takes the general path
-    const bool fold_ok = !aero_wave_any(!(fabsf(m) < 2.0e4f));
+    const bool fold_ok = !aero_wave_any(!(fabsf(m[0]) < 2.0e4f && fabsf(m[1]) < 2.0e4f));
 
     // ---- pass 2: probabilities against the fixed maximum, O += V^T P (row dh of V^T = ones: the denominator)
-    f32x4 O[DT];
+    f32x4 O[NQ][DT];
 #pragma unroll
-    for (int i = 0; i < DT; ++i) O[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int i = 0; i < DT; ++i) O[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-        const h16x8 qb = with_bias(1.f, -Dq * (float)s - m), qa = with_bias(-1.f, Dq * (float)s - m);
-        auto pv = [&](int tb, const h16x8& pf) {
+        h16x8 qbv[NQ], qav[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) { qbv[j] = with_bias(j, 1.f, -Dq[j] * (float)sq[j] - m[j]); qav[j] = with_bias(j, -1.f, Dq[j] * (float)sq[j] - m[j]); }
+        auto step = [&](int tb, const h16x8 (&q)[NQ], bool general) {
+            float sc[NQ][8];
+            block(tb, q, general, sc);
+            h16x8 pf[NQ];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[j][e] = (h16)aero_exp2(general ? sc[j][e] - m[j] : sc[j][e]);
 #pragma unroll
             for (int i = 0; i < DT; ++i) {
                 const h16* vr = &Vt[(i * 16 + col) * VS + tb + g * 4];
                 const h16x4 va = *(const h16x4*)vr;
                 const h16x4 vb = *(const h16x4*)(vr + 16);
                 const h16x8 vf = (h16x8){va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-                O[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, O[i], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) O[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[j], O[j][i], 0, 0, 0);
             }
-        };
-        auto probs = [&](const float* sc, h16x8& pf) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pf[e] = (h16)aero_exp2(sc[e]);
-        };
-        auto general = [&](int tb) {
-            float sc[8];
-            h16x8 pf;
-            scores(tb, sc);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sc[e] -= m;
-            probs(sc, pf);
-            pv(tb, pf);
-        };
-        auto run = [&](int lo, int hi, const h16x8& q) {
-            walk(lo, hi,
-                 [&](int tb) {
-                     float sa[8], sb[8];
-                     h16x8 pa, pb;
-                     folded(tb, q, sa);
-                     folded(tb + 32, q, sb);
-                     probs(sa, pa);
-                     probs(sb, pb);
-                     pv(tb, pa);
-                     pv(tb + 32, pb);
-                 },
-                 [&](int tb) { float sa[8]; h16x8 pa; folded(tb, q, sa); probs(sa, pa); pv(tb, pa); });
         };
         if (fold_ok) {
-            run(0, tdiag < kn32 ? tdiag : kn32, qb);
+            for (int tb = 0; tb < (tdiag < kn32 ? tdiag : kn32); tb += 32) step(tb, qbv, false);
             if (tdiag < kn32) {
-                general(tdiag);
-                run(tdiag + 32, kn32, qa);
+                step(tdiag, qf, true);
+                for (int tb = tdiag + 32; tb < kn32; tb += 32) step(tb, qav, false);
             }
         } else {
-            for (int tb = 0; tb < kn32; tb += 32) general(tb);
+            for (int tb = 0; tb < kn32; tb += 32) step(tb, qf, true);
         }
     }
     // the denominator: row dh of O, held by lane group (dh % 16) / 4 in register dh % 4 of tile dh / 16
-    float lsum = 0.f;
-    {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
         const int li = dh >> 4, lr = dh & 3, lg = (dh & 15) >> 2;
         float mine = 0.f;
 #pragma unroll
         for (int i = 0; i < DT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (i == li && r == lr) mine = O[i][r];
-        lsum = __shfl(mine, lg * 16 + col);
-    }
-    if (s < T) {
-        const float inv = 1.0f / lsum;
-        h16* op = (h16*)d.out + ((int64_t)row * T + s) * C + h * dh;
+                if (i == li && r == lr) mine = O[j][i][r];
+        const float lsum = __shfl(mine, lg * 16 + col);
+        if (sq[j] < T) {
+            const float inv = 1.0f / lsum;
+            h16* op = (h16*)d.out + ((int64_t)row * T + sq[j]) * C + h * dh;
 #pragma unroll
-        for (int i = 0; i < DT; ++i) {
-            const int dd = i * 16 + g * 4;                       // this lane's four consecutive output channels
-            if (vec4 && (((uintptr_t)d.out) & 7) == 0) {         // (dh % 4 == 0: all four real or all four padding)
-                if (dd < dh) *(h16x4*)(op + dd) = (h16x4){(h16)(O[i][0] * inv), (h16)(O[i][1] * inv), (h16)(O[i][2] * inv), (h16)(O[i][3] * inv)};
-            } else {
+            for (int i = 0; i < DT; ++i) {
+                const int dd = i * 16 + g * 4;                   // this lane's four consecutive output channels
+                if (vec4 && (((uintptr_t)d.out) & 7) == 0) {     // (dh % 4 == 0: all four real or all four padding)
+                    if (dd < dh) *(h16x4*)(op + dd) = (h16x4){(h16)(O[j][i][0] * inv), (h16)(O[j][i][1] * inv), (h16)(O[j][i][2] * inv), (h16)(O[j][i][3] * inv)};
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (dd + r < dh) op[dd + r] = (h16)(O[i][r] * inv);
+                    for (int r = 0; r < 4; ++r)
+                        if (dd + r < dh) op[dd + r] = (h16)(O[j][i][r] * inv);
+                }
             }
         }
     }
