@@ -309,35 +309,49 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
 
     // cooperative x copy: vector L = tid + v*NT -> (step-in-group, sequence row, 8-channel slot); the addressing is
     // recomputed per group (a handful of integer ops every G steps) rather than held in VGPRs
+    // Everything about a thread's share of the group traffic that does not depend on the group is computed ONCE: which
+    // (step-in-group, sequence, channel slot) it copies, the frame arithmetic (a division by the run-time frame count), the
+    // LDS offsets.  PMC: the step loop ran 54 vector instructions per step and wave, 20 more than the gate math needs --
+    // integer divisions and 64-bit address arithmetic of these three helpers, redone every group; on the CUs that host two
+    // blocks the kernel is VALU-bound (76 % busy), so they were on the critical path.
     const bool xvec = (d.in_ch % 8 == 0) && (d.x_pitch % 8 == 0) && (((uintptr_t)xin & 15) == 0);
     h16x8 xr[NXV];
+    int lx_i[NXV], lx_tmax[NXV], lx_c[NXV], lx_dst[NXV];          // tmax: tau must stay below it (-1: this thread copies nothing)
+    int64_t lx_base[NXV];
+#pragma unroll
+    for (int v = 0; v < NXV; ++v) {
+        const int L = tid + v * NT;
+        const int i = L / (16 * SPR), rem = L - i * (16 * SPR);
+        const int row = rem / SPR, slot = rem - row * SPR;
+        const int seq = seq0 + row;
+        const bool ok = L < G * 16 * SPR && seq < d.nseq && slot * 8 < d.in_ch;
+        lx_i[v] = i;
+        lx_c[v] = slot * 8;
+        lx_dst[v] = (i * 16 + row) * XS + slot * 8;
+        if (d.in_mode == 1) {
+            const int r = seq / d.nframes, k = seq - r * d.nframes;
+            lx_tmax[v] = ok ? d.T - k * d.S : -1;
+            lx_base[v] = (int64_t)r * d.T + k * d.S;
+        } else {
+            lx_tmax[v] = ok ? W : -1;
+            lx_base[v] = (int64_t)seq * W;
+        }
+    }
     auto load_x = [&](int g) {          // global -> VGPR for group g (steps beyond W, padded frames, bad rows: zeros)
 #pragma unroll
         for (int v = 0; v < NXV; ++v) {
-            const int L = tid + v * NT;
-            const int i = L / (16 * SPR), rem = L - i * (16 * SPR);
-            const int row = rem / SPR, c = (rem - row * SPR) * 8;
-            const int seq = seq0 + row;
-            const int step = g * G + i;
+            const int step = g * G + lx_i[v];
             const int tau = dir ? W - 1 - step : step;
-            bool ok = L < G * 16 * SPR && step < W && seq < d.nseq && c < d.in_ch;
-            int64_t pos;
-            if (d.in_mode == 1) {
-                const int r = seq / d.nframes, k = seq - r * d.nframes;
-                ok = ok && (k * d.S + tau < d.T);
-                pos = (int64_t)r * d.T + k * d.S + tau;
-            } else {
-                pos = (int64_t)seq * W + tau;
-            }
+            const bool ok = step < W && tau < lx_tmax[v];
             h16x8 z = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
             if (ok) {
-                const h16* sp = xin + pos * d.x_pitch + c;
+                const h16* sp = xin + (lx_base[v] + tau) * d.x_pitch + lx_c[v];
                 if (xvec) {
                     z = *(const h16x8*)sp;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        if (c + e < d.in_ch) z[e] = sp[e];
+                        if (lx_c[v] + e < d.in_ch) z[e] = sp[e];
                 }
             }
             xr[v] = z;
@@ -345,19 +359,52 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
     };
     auto park_x = [&](int buf) {        // VGPR -> LDS ring buffer
 #pragma unroll
-        for (int v = 0; v < NXV; ++v) {
-            const int L = tid + v * NT;
-            const int i = L / (16 * SPR), rem = L - i * (16 * SPR);
-            const int row = rem / SPR, slot = rem - row * SPR;
-            if (L < G * 16 * SPR) *(h16x8*)(xring + buf * (G * 16 * XS) + (i * 16 + row) * XS + slot * 8) = xr[v];
-        }
+        for (int v = 0; v < NXV; ++v)
+            if (tid + v * NT < G * 16 * SPR) *(h16x8*)(xring + buf * (G * 16 * XS) + lx_dst[v]) = xr[v];
     };
     // write the h rows of group g (LDS ring slots) to the stitched output
     const int vecs = (H % 8 == 0 && (((uintptr_t)out & 15) == 0)) ? H / 8 : 0;
     const int per = vecs ? vecs : H;
+    constexpr int NSV = (G * 16 * KT * 4 + NT - 1) / NT;           // precomputed 16-byte pieces per thread (vecs <= KT * 4)
+    const bool sg_fast = vecs != 0;
+    int sg_pk[NSV], sg_tlo[NSV], sg_thi[NSV];                      // (step-in-group << 20 | LDS offset), valid range of tau (empty: thi = -1)
+    int64_t sg_base[NSV];
+#pragma unroll
+    for (int k2 = 0; k2 < NSV; ++k2) {
+        const int idx = tid + k2 * NT;
+        const int i = idx / (16 * per), rem = idx - i * (16 * per);
+        const int sl = rem / per, e = rem - sl * per;
+        const int s2 = seq0 + sl;
+        const bool ok = sg_fast && idx < G * 16 * per && s2 < d.nseq;
+        sg_pk[k2] = (i << 20) | (sl * HS + e * 8);
+        sg_tlo[k2] = 0;
+        sg_thi[k2] = ok ? W : -1;
+        if (d.out_mode == 1) {
+            const int r = s2 / d.nframes, kf = s2 - r * d.nframes;
+            const int lim = d.S / 2;
+            const int hi = (kf == d.nframes - 1 && kf != 0) ? W : W - lim;
+            const int tl = d.T - kf * d.S;                          // t = kf*S + tau must stay below T
+            sg_tlo[k2] = (kf == 0) ? 0 : lim;
+            sg_thi[k2] = ok ? (hi < tl ? hi : tl) : -1;
+            sg_base[k2] = ((int64_t)r * d.T + kf * d.S) * H2 + dir * H + e * 8;
+        } else {
+            sg_base[k2] = ((int64_t)s2 * W) * H2 + dir * H + e * 8;
+        }
+    }
     auto store_group = [&](int g) {
         const int s_base = g * G;
         const int nst = W - s_base < G ? W - s_base : G;
+        if (sg_fast) {
+#pragma unroll
+            for (int k2 = 0; k2 < NSV; ++k2) {
+                const int i = sg_pk[k2] >> 20;
+                const int step = s_base + i;
+                const int tau = dir ? W - 1 - step : step;
+                if (i >= nst || tau < sg_tlo[k2] || tau >= sg_thi[k2]) continue;
+                *(h16x8*)(out + sg_base[k2] + (int64_t)tau * H2) = *(const h16x8*)(hring + (step & (R - 1)) * 16 * HS + (sg_pk[k2] & 0xFFFFF));
+            }
+            return;
+        }
         for (int idx = tid; idx < nst * 16 * per; idx += NT) {
             const int i = idx / (16 * per), rem = idx - i * (16 * per);
             const int sl = rem / per, e = rem - sl * per;

@@ -13,7 +13,7 @@ from aero_amd.engine import Ops  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument("--iters", type=int, default=int(os.environ.get("ITERS", 10)))
     a = ap.parse_args()
     dev = 'cuda'
     lib = _lib.load()
