@@ -468,13 +468,13 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][kt], bf[kt], accs[t], 0, 0, 0);
+            // gate math of all the wave's tiles first, the h stores after it: with the store's `if (j < H)` inside the tile loop the
+            // compiler sank half of each tile's math into that branch and ran the tiles strictly one after the other -- two
+            // dependent exp -> rcp -> exp -> rcp chains back to back instead of interleaved
+            float hq[TPW];
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const f32x4 a = accs[t];
-                const int j = (wave * TPW + t) * 4 + q;
-                // exponents pre-scaled by log2(e): bare v_exp_f32.  Only the tanh-type exponents need a clamp (from above,
-                // 2x <= 60 in log2 units): an infinite e_i/e_f/e_o just drives its reciprocal to 0, which is the right limit,
-                // whereas e_g = inf would meet that 0 as inf * 0.
                 constexpr float L2E = 1.4426950408889634f, LIM = 60.f, NOLIM = -3.0e38f;
                 const float ei = aero_exp2(a[0] * -L2E);
                 const float ef = aero_exp2(a[1] * -L2E);
@@ -485,8 +485,16 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
                 c[t] = fmaf(aero_rcp(1.f + ef), c[t], igg);
                 const float ec = aero_exp2(aero_med3(c[t] * (2.f * L2E), NOLIM, LIM));
                 const float r2 = aero_rcp((1.f + eo) * (ec + 1.f));
-                const float h = fmaf(ec, r2, -r2);                                      // sigmoid(o) * tanh(c)
-                if (j < H) hnext[j] = (h16)h;
+                hq[t] = fmaf(ec, r2, -r2);                                              // sigmoid(o) * tanh(c)
+            }
+#ifndef AERO_EMU
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) asm volatile("" : "+v"(hq[t]));               // (keeps the math above out of the store's branch)
+#endif
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int j = (wave * TPW + t) * 4 + q;
+                if (j < H) hnext[j] = (h16)hq[t];
             }
             // input projection of the NEXT step (independent of h): issued before the barrier so its LDS reads and
             // MFMAs fill the pipes while the other waves finish their gate math
