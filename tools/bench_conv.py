@@ -22,9 +22,9 @@ PW = {  # pointwise (1x1) shapes of the path: name: (C, M, F)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--layers', default='d0,d1,d2,d3')
+    ap.add_argument('--layers', default=os.environ.get('LAYERS', 'd0,d1,d2,d3'))
     ap.add_argument('--batch', type=int, default=64)
-    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--iters', type=int, default=int(os.environ.get('ITERS', 20)))
     ap.add_argument('--T', type=int, default=501)
     ap.add_argument('--lib', default=None, help='alternative build of the C-ABI library (profiling variants)')
     ap.add_argument('--race', type=int, default=0, help='repeat each launch this many times and require bit-identical outputs')
