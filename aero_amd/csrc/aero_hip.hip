@@ -14,6 +14,7 @@
 #include "k_norm.h"
 #include "k_gram.h"
 #include "k_stft.h"
+#include "k_optim.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -172,6 +173,13 @@ int aero_localstate_fwd(const aero_attn_desc* d, void* stream) {
 int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_freqfc_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int32_t step,
+                   float grad_scale, void* stream) {
+    const char* err = "";
+    int rc = aero_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 

@@ -106,6 +106,17 @@ def count_ranks(device=None):
     return int(round(float(t.item())))
 
 
+def sum_gradients(flat_grad):
+    """One collective for the whole generator: all-reduce (SUM) of FlatAdam's flat gradient buffer over RCCL / xGMI (what
+    DistributedDataParallel does bucket by bucket, distrib.py:66).  Returns the factor the optimizer applies to turn the sum into
+    the mean (FlatAdam.step(grad_scale=...)): the division rides along in the fused step instead of a separate pass."""
+    if world_size == 1 or not is_initialized():
+        return 1.0
+    t = flat_grad if flat_grad.is_cuda or _dist().get_backend() != 'nccl' else flat_grad.cuda()
+    _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
+    return 1.0 / world_size
+
+
 def shard_indices(n, r=None, w=None):
     """Eval sharding rule of the reference: item i -> rank i mod world (distrib.py:100)."""
     r = rank if r is None else r

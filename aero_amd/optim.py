@@ -1,0 +1,72 @@
+"""Optimizer of the generator (reference train.py:83: `torch.optim.Adam(generator.parameters(), lr, betas=(0.9, beta2))`;
+stepped by solver.py:602-605) as ONE fused pass over a flat parameter buffer (aero_adam_step, csrc/k_optim.h).
+
+FlatAdam re-homes the parameters into a single contiguous fp32 buffer (each `p.data` becomes a view, as
+DistributedDataParallel does with its buckets) and gives every parameter a gradient view into a second flat buffer, so
+
+    * `zero_grad()` is one memset,
+    * a gradient all-reduce over RCCL is one collective on the flat buffer (`distrib.sum_gradients`; the 1 / world-size factor
+      is applied inside the fused step),
+    * `step()` is one kernel launch: 28 bytes of HBM traffic per parameter.
+
+The arithmetic and its order are torch's single-tensor Adam (no amsgrad, no weight decay): tests/test_optim.py compares
+against torch.optim.Adam step by step.  There is no CPU path: without the HIP library `step()` raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class FlatAdam:
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, lib=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('FlatAdam: no parameters')
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError('FlatAdam: parameters must be fp32 tensors on one device')
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.lib = lib
+        sizes = [p.numel() for p in self.params]
+        # every parameter starts on a 16-byte boundary of the flat buffer (4 floats): the kernel moves float4
+        offs, n = [], 0
+        for sz in sizes:
+            offs.append(n)
+            n += (sz + 3) // 4 * 4
+        self.n = n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o, sz in zip(self.params, offs, sizes):
+                self.flat_p[o:o + sz].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + sz].view_as(p)
+                p.grad = self.flat_g[o:o + sz].view_as(p)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        """(gradients stay views of the flat buffer: set_to_none is accepted for API compatibility and ignored)"""
+        self.flat_g.zero_()
+
+    def step(self, grad_scale=1.0):
+        lib = self.lib or _lib.load()
+        if not self.flat_p.is_cuda and self.lib is None:
+            raise RuntimeError('FlatAdam.step: parameters must live on the MI355X (no CPU path)')
+        self.step_count += 1
+        stream = torch.cuda.current_stream(self.flat_p.device).cuda_stream if self.flat_p.is_cuda else 0
+        lib.call('aero_adam_step', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                 self.n, C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), self.step_count,
+                 C.c_float(grad_scale), stream)
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr, 'betas': self.betas,
+                'eps': self.eps}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.lr, self.betas, self.eps = float(sd['lr']), tuple(sd['betas']), float(sd['eps'])

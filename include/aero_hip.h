@@ -291,6 +291,13 @@ typedef struct {
 int aero_dconv_row_fwd(const aero_dconv_desc* d, void* stream);
 int aero_dconv_row_fits(int T, int C, int hidden, int max_dilation);
 
+/* Optimizer step of the generator (train.py:83: torch.optim.Adam(params, lr, betas=(0.9, beta2)); solver.py:602-605), fused over a
+ * flat buffer: p, g, m, v fp32 [n], 16-byte aligned (parameters and gradients are views into p and g).  step >= 1 is the
+ * 1-based step count of the bias corrections; every gradient is multiplied by grad_scale first (1 / world size after a summing
+ * all-reduce, or 1).  Same arithmetic and operation order as torch's Adam without amsgrad / weight decay. */
+int aero_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   int32_t step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

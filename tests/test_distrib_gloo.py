@@ -58,3 +58,52 @@ def test_two_rank_batch_sharding():
     assert idx == [1, 3]
     assert tmax == 1.0
     assert avg == pytest.approx([(1 * 3 + 2 * 2) / 5.0])   # rank0 has 3 clips (weight 3), rank1 has 2
+
+
+def _opt_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from aero_amd import _lib, distrib
+    from aero_amd.optim import FlatAdam
+    from emu.build_emu import build
+    distrib.init_from_env(backend='gloo')
+    p = [torch.nn.Parameter(torch.arange(10, dtype=torch.float32)), torch.nn.Parameter(torch.ones(3, 5))]
+    opt = FlatAdam(p, lr=1e-2, lib=_lib.load(build()))
+    opt.zero_grad()
+    for t in p:
+        t.grad.fill_(float(rank + 1))                    # rank 0: 1, rank 1: 2 -> mean 1.5 on both
+    scale = distrib.sum_gradients(opt.flat_g)            # ONE all-reduce over the flat buffer
+    opt.step(grad_scale=scale)
+    distrib.barrier()
+    q.put((rank, scale, opt.flat_g[:4].tolist(), p[0].detach().clone()))
+    distrib.close()
+
+
+def test_two_rank_gradient_allreduce_and_fused_step():
+    """train.py ddp=true (config 5): gradients summed over the ranks with one collective on FlatAdam's flat buffer,
+    the 1 / world factor applied inside the fused optimizer step; both ranks end up with identical parameters, equal to a
+    single-process step on the mean gradient."""
+    from aero_amd import _lib
+    from aero_amd.optim import FlatAdam
+    from emu.build_emu import build
+    lib = _lib.load(build())
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_opt_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] == 0.5 and got[0][2] == [3.0] * 4          # summed gradient 1 + 2
+    assert torch.equal(got[0][3], got[1][3])
+    ref = [torch.nn.Parameter(torch.arange(10, dtype=torch.float32)), torch.nn.Parameter(torch.ones(3, 5))]
+    o = FlatAdam(ref, lr=1e-2, lib=lib)
+    for t in ref:
+        t.grad.fill_(1.5)
+    o.step()
+    assert torch.equal(ref[0].detach(), got[0][3])
