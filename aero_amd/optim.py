@@ -20,7 +20,10 @@ from . import _lib
 
 
 class FlatAdam:
-    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, lib=None):
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, lib=None, model=None):
+        """model: the `Aero` module these parameters belong to (optional).  The kernel writes the weights behind autograd's back, so
+        version counters do not move: after every step `model.repack()` tells the device engine to re-pack them."""
+        self.model = model
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('FlatAdam: no parameters')
@@ -60,6 +63,8 @@ class FlatAdam:
         lib.call('aero_adam_step', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                  self.n, C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), self.step_count,
                  C.c_float(grad_scale), stream)
+        if self.model is not None and hasattr(self.model, 'repack'):
+            self.model.repack()
 
     def state_dict(self):
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr, 'betas': self.betas,

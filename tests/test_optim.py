@@ -50,6 +50,20 @@ def test_grad_scale_is_the_mean_over_ranks():
     assert torch.equal(a[0].detach(), b[0].detach())
 
 
+def test_step_invalidates_the_engines_packed_weights():
+    class M:
+        n = 0
+
+        def repack(self):
+            self.n += 1
+    from emu.build_emu import build
+    m = M()
+    opt = FlatAdam([torch.nn.Parameter(torch.ones(8))], lib=_lib.load(build()), model=m)
+    opt.step()
+    opt.step()
+    assert m.n == 2
+
+
 def test_cpu_parameters_without_the_emulator_fail_loudly():
     with pytest.raises((RuntimeError, ImportError, OSError)):
         FlatAdam([torch.nn.Parameter(torch.ones(4))]).step()
