@@ -16,9 +16,12 @@ from conftest import build_model  # noqa: E402
 def run(m, B, L, lr_sr, steps=10, warmup=3):
     x = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(0)).cuda()
     with torch.no_grad():
-        for _ in range(warmup):
+        t0 = time.perf_counter()
+        n = 0
+        while n < warmup or time.perf_counter() - t0 < 0.3:      # also long enough for the clocks to come back up after host-side set-up
             m(x)
-        torch.cuda.synchronize()
+            n += 1
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             m(x)
