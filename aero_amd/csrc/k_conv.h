@@ -1275,6 +1275,175 @@ __global__ __launch_bounds__(256) void aero_conv_tiny_kernel(AeroConvK p) {
 }
 
 // taps on a regular (frequency x time) grid?  fills the grid parameters of AeroConvK
+// ------------------------------------------------------------------------------------------------------
+// Last decoder ConvTranspose ([2*fs, 1] kernel, stride [fs, 1], fs * M <= 8 output values per source row and tap half:
+// 96 channels -> 4 rows x (re, im)) from the input side with the second tap CARRIED in the accumulator, so that every
+// source row is read exactly once (the stream kernel above reads rows q and q-1 per item: 2x the source, 796 MB fetched
+// against 393 MB of activations).  A wave owns 64 time steps of one clip and walks source rows upwards:
+//   * the 16 MFMA rows hold both taps of the row: 8 "current" rows (tap 0 -> output rows fs*q .. fs*q+fs-1) and 8 "carry"
+//     rows (tap 1 -> output rows of q+1); the two weight images swap halves from one step to the next, so the carry rows of
+//     step q ARE the current rows of step q+1 -- the MFMA adds the new tap-0 products onto them, no cross-lane movement;
+//   * after a step the lanes holding the finished rows store them and clear their accumulators (next step's carry);
+//   * a wave stages its 64 steps x C channels of a row with direct global->LDS copies (quads of lanes read whole 64-byte
+//     sectors; the swizzle goes on the source address) into its own LDS tile -- no block barriers -- and issues the copy of
+//     the NEXT row as soon as this row's fragments are in registers, under this row's MFMAs and stores.
+//     (First version: fragments loaded straight from global memory in MFMA layout, lane = step: 16 lanes x 192-byte stride per
+//     request, 185 us -- slower than the 2x-traffic stream kernel at 176 us.)
+// Rows are cut into chunks of QC per wave for parallelism (one extra row read per chunk to start the carry).
+template <int NCH>
+__global__ __launch_bounds__(256) void aero_convtr_carry_kernel(AeroConvK p, int QC) {
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int M = d.M, T = d.T, FS = d.fstride;
+    const int NR = (d.Fout + FS - 1) / FS;
+    const int nseg = (T + 63) >> 6;
+    const int nch = (NR + QC - 1) / QC;
+    int item = aero_uniform((int)blockIdx.x * 4 + wave);
+    if (item >= d.B * nch * nseg) return;
+    const int seg = item % nseg;
+    item /= nseg;
+    const int ch = item % nch;
+    const int b = item / nch;
+    const int q_lo = ch * QC;
+    const int q_hi = q_lo + QC < NR ? q_lo + QC : NR;
+    // weight fragments of the two parities: parity 0 = rows 0-7 current (tap 0), rows 8-15 carry (tap 1); parity 1 swapped
+    h16x8 W[2][NCH];
+    {
+        const int row = lane & 15, R8 = row & 7;
+        const int r = R8 / M, m = R8 - r * M;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int tap = ((row < 8) == (par == 0)) ? 0 : 1;
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc) {
+                h16x8 w = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (r < FS) w = *(const h16x8*)((const h16*)d.weight + ((int64_t)r * p.Mpad + m) * p.Ktot + tap * p.Cp + cc * 32 + (lane >> 4) * 8);
+                W[par][cc] = w;
+            }
+        }
+    }
+    // per-lane output rows of a finished half: R8 = ((lane >> 4) & 1) * 4 + i
+    int o_r[4], o_m[4];
+    float bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R8 = ((lane >> 4) & 1) * 4 + i;
+        o_r[i] = R8 / M;
+        o_m[i] = R8 - o_r[i] * M;
+        bv[i] = (d.bias && o_r[i] < FS) ? d.bias[o_m[i]] : 0.f;
+    }
+    const float bsc = d.batch_scale ? d.batch_scale[b] : 1.f;
+    const float bsh = d.batch_scale ? d.batch_shift[b] : 0.f;
+    const int st = (int)d.s0_t;
+    const int tl = seg * 64 + (lane & 15);
+    __shared__ AERO_LDS_ALIGN h16 Xs[4][NCH * 2048];
+    h16* Xw = Xs[wave];
+    const h16* sb = (const h16*)d.src0 + (int64_t)b * d.s0_b;
+    const h16* zpv = aero_zero_page;
+    const bool full = seg * 64 + 64 <= T;
+    h16* dst16 = (h16*)d.dst;
+    float* dst32 = (float*)d.dst;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // copy instruction (cc, i): steps i*16 .. i*16+15, lane -> (step i*16 + lane/4, LDS slot lane%4); aero_tile_off's swizzle
+    // ((-(row >> 2)) & 3 = (-(lane >> 4)) & 3 for every i) is applied to the SOURCE slot
+    int c_off[4];
+    bool c_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int stp = i * 16 + (lane >> 2);
+        c_ok[i] = seg * 64 + stp < T;
+        c_off[i] = (seg * 64 + stp) * st + (((lane & 3) ^ ((0 - (lane >> 4)) & 3)) << 3);
+    }
+    auto copy = [&](int fi) {
+        if (fi < 0 || fi >= d.Fin) return;
+        const h16* rb = sb + (int64_t)fi * d.s0_f;
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aero_glds16((full || c_ok[i]) ? rb + (c_off[i] + cc * 32) : zpv, Xw + cc * 2048 + i * 512);
+    };
+    // fragments of the staged row -> registers, then the copy of row `nxt` may overwrite the tile
+    auto fetch = [&](h16x8* nb, int fi, int nxt) {
+        if (fi >= 0 && fi < d.Fin) {
+#ifndef AERO_EMU
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            aero_wave_sync();
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) nb[g * NCH + cc] = *(const h16x8*)&Xw[cc * 2048 + aero_tile_off(g * 16 + (lane & 15), lane >> 4)];
+#ifndef AERO_EMU
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            aero_wave_sync();
+        }
+        copy(nxt);
+    };
+    auto step = [&](const h16x8* nb, int fi, const int par) {
+        if (fi >= 0 && fi < d.Fin) {
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[par][cc], nb[g * NCH + cc], acc[g], 0, 0, 0);
+        }
+        const bool mine = (lane >= 32) == (par == 1);                 // this lane holds rows of the finished (current) half
+        if (mine) {
+            if (fi >= q_lo) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int t = tl + g * 16;
+                    if (!full && t >= T) continue;
+                    float x[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[g][i] + bv[i];
+                        if (d.act == AERO_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (d.act == AERO_ACT_GELU) v = aero_gelu(v);
+                        x[i] = v * bsc + bsh;
+                    }
+                    if (M == 2) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int fo = fi * FS + o_r[2 * h];
+                            const int fdst = fo - d.dst_f_off;
+                            if (o_r[2 * h] >= FS || fo >= d.Fout || fdst < 0 || fdst >= d.dst_F) continue;
+                            const int64_t E = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * 2;
+                            if (d.dst_f32) *(f32x2*)(dst32 + E) = (f32x2){x[2 * h], x[2 * h + 1]};
+                            else *(h16x2*)(dst16 + E) = (h16x2){(h16)x[2 * h], (h16)x[2 * h + 1]};
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int fo = fi * FS + o_r[i];
+                            const int fdst = fo - d.dst_f_off;
+                            if (o_r[i] >= FS || fo >= d.Fout || fdst < 0 || fdst >= d.dst_F) continue;
+                            const int64_t E = (int64_t)b * d.d_b + (int64_t)fdst * d.d_f + (int64_t)t * M + o_m[i];
+                            if (d.dst_f32) dst32[E] = x[i];
+                            else dst16[E] = (h16)x[i];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    const int r0 = q_lo - 1, ns = q_hi - r0;                          // source rows r0 .. q_hi-1 (row q_lo-1 only starts the carry)
+    h16x8 nb[4 * NCH];
+    copy(r0);
+    for (int s = 0; s < ns; s += 2) {
+        fetch(nb, r0 + s, s + 1 < ns ? r0 + s + 1 : -1);
+        step(nb, r0 + s, 0);
+        if (s + 1 < ns) {
+            fetch(nb, r0 + s + 1, s + 2 < ns ? r0 + s + 2 : -1);
+            step(nb, r0 + s + 1, 1);
+        }
+    }
+}
+
 static bool aero_conv_regular_taps(const aero_conv_desc* d, AeroConvK* p) {
     const int n = d->ntaps;
     int nT = 1;
@@ -1467,6 +1636,31 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
                            (int64_t)d->B * d->Fout * ((d->T + 63) / 64) < 0x7fffffffLL;
         if (stack * d->M <= 16 && nk <= AERO_STREAM_SLOTS && dense && small && p.Ktot + 8 <= AERO_SKINNY_WMAX &&
             aero_conv_regular_taps(d, &p) && (!d->transposed || (p.f_step == -1 && p.f_lo == 0))) {
+            // last decoder ConvTranspose: carried-tap form, every source row read once
+            static int carry_on = -1;
+            if (carry_on < 0) { const char* e = getenv("AERO_CONVTR_CARRY"); carry_on = (e && e[0] == '0') ? 0 : 1; }
+            if (carry_on && d->transposed && d->ntaps == 2 && p.nT == 1 && p.t_lo == 0 && d->fstride * d->M <= 8 && d->C0 % 32 == 0 && d->C0 <= 128 &&
+                d->C0 == p.Cp && (d->s0_t % 8) == 0 && (d->s0_f % 8) == 0 && (d->s0_b % 8) == 0 && (((uintptr_t)d->src0 & 15) == 0) &&
+                (d->M != 2 || ((d->d_b % 2) == 0 && (d->d_f % 2) == 0 && (((uintptr_t)d->dst & 7) == 0)))) {
+                const int NRq = (d->Fout + d->fstride - 1) / d->fstride;
+                const int nsegq = (d->T + 63) / 64;
+                // rows per wave: as few chunks as give every CU a block (each chunk re-reads one row to start its carry).  Measured at
+                // B = 64 (8 segments, 65 row groups): 2 chunks 104 us, 3: 108-114, 5: 121, 9: 107-120 -- more resident waves buy nothing,
+                // the kernel sits at ~4.4 TB/s either way, and partial last rounds cost
+                int nchq = (int)((256L * 4 + (long)d->B * nsegq - 1) / ((long)d->B * nsegq));
+                if (nchq > NRq / 4) nchq = NRq / 4;
+                if (nchq < 1) nchq = 1;
+                int QC = (NRq + nchq - 1) / nchq;
+                { const char* e = getenv("AERO_CARRY_QC"); if (e) QC = atoi(e); }
+                const long nitq = (long)d->B * nsegq * ((NRq + QC - 1) / QC);
+                const int ncc = d->C0 / 32;
+                if (name) snprintf(name, 96, "aero_convtr_carry_kernel<%d>", ncc);
+                else if (ncc == 1) AERO_LAUNCH(aero_convtr_carry_kernel<1>, dim3((unsigned)((nitq + 3) / 4)), block, stream, p, QC);
+                else if (ncc == 2) AERO_LAUNCH(aero_convtr_carry_kernel<2>, dim3((unsigned)((nitq + 3) / 4)), block, stream, p, QC);
+                else if (ncc == 3) AERO_LAUNCH(aero_convtr_carry_kernel<3>, dim3((unsigned)((nitq + 3) / 4)), block, stream, p, QC);
+                else AERO_LAUNCH(aero_convtr_carry_kernel<4>, dim3((unsigned)((nitq + 3) / 4)), block, stream, p, QC);
+                return AERO_OK;
+            }
             p.nmt = AERO_STREAM_SLOTS / nk;                       // segments per wave item
             const int nseg = (d->T + 63) / 64;
             const int NR = d->transposed ? (d->Fout + d->fstride - 1) / d->fstride : d->Fout;

@@ -209,6 +209,8 @@ def case_convtr(lib, dev, Cin, Cout, K, stride, Fin, T, trim=True, f32_affine=Fa
         ref = ref * sc.view(B, 1, 1, 1) + sh.view(B, 1, 1, 1)
     y = ops.conv(spec, cl(x).to(dev), None, B, Fin, Fu, T, dst_f_off=pad, dst_F=Fu - 2 * pad, **kw)
     assert y.shape == (B, Fu - 2 * pad, T, Cout)
+    if Cin % 32 == 0 and Cin <= 128 and K == 2 * stride and stride * Cout <= 8:      # the carried-tap kernel is the one that ran
+        assert 'carry' in ops.lib.cdll.aero_last_kernel_name().decode()
     assert rel_l2(uncl(y.cpu()), ref) < TOL16
 
 

@@ -108,6 +108,9 @@ def test_conv1d(emu, kw):
 
 @pytest.mark.parametrize('kw', [dict(Cin=32, Cout=16, K=8, stride=2, Fin=4, T=40), dict(Cin=16, Cout=8, K=8, stride=4, Fin=5, T=33),
                                 dict(Cin=16, Cout=2, K=8, stride=4, Fin=6, T=70, f32_affine=True),
+                                dict(Cin=96, Cout=2, K=8, stride=4, Fin=21, T=70, f32_affine=True),   # carried-tap kernel, row chunks
+                                dict(Cin=96, Cout=2, K=8, stride=4, Fin=5, T=64), dict(Cin=32, Cout=1, K=8, stride=4, Fin=9, T=33, trim=False),
+                                dict(Cin=64, Cout=2, K=4, stride=2, Fin=18, T=130, B=3),
                                 dict(Cin=8, Cout=4, K=4, stride=2, Fin=3, T=20), dict(Cin=8, Cout=4, K=2, stride=2, Fin=2, T=20),
                                 dict(Cin=16, Cout=8, K=8, stride=2, Fin=4, T=30, trim=False),
                                 dict(Cin=256, Cout=192, K=8, stride=2, Fin=3, T=70)])     # 192-row 8-wave tile, weight sets

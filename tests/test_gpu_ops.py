@@ -77,6 +77,9 @@ def test_conv1d(lib, kw):
 
 @pytest.mark.parametrize('kw', [dict(Cin=768, Cout=192, K=8, stride=2, Fin=4, T=501), dict(Cin=192, Cout=48, K=8, stride=4, Fin=16, T=501),
                                 dict(Cin=96, Cout=2, K=8, stride=4, Fin=64, T=501, f32_affine=True),
+                                dict(Cin=96, Cout=2, K=8, stride=4, Fin=21, T=70, f32_affine=True),   # carried-tap kernel, row chunks
+                                dict(Cin=96, Cout=2, K=8, stride=4, Fin=5, T=64), dict(Cin=32, Cout=1, K=8, stride=4, Fin=9, T=33, trim=False),
+                                dict(Cin=64, Cout=2, K=4, stride=2, Fin=18, T=130, B=3),
                                 dict(Cin=8, Cout=4, K=2, stride=2, Fin=2, T=20), dict(Cin=384, Cout=96, K=8, stride=2, Fin=8, T=501, trim=False)])
 def test_convtr(lib, kw):
     oc.case_convtr(lib, DEV, **kw)
