@@ -43,6 +43,24 @@ class NormDesc(C.Structure):
                 ('dst', vp), ('d_b', i64), ('d_f', i64), ('d_t', i64)]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [('dy', vp), ('dy_b', i64), ('dy_f', i64), ('dy_t', i64),
+                ('x', vp), ('x_b', i64), ('x_f', i64), ('x_t', i64),
+                ('dw', fp), ('db', fp),
+                ('B', i32), ('Fin', i32), ('Fout', i32), ('T', i32), ('M', i32), ('C', i32), ('ntaps', i32), ('fstride', i32),
+                ('df', i32 * 9), ('dt', i32 * 9)]
+
+
+class NormBwdDesc(C.Structure):
+    _fields_ = [('x', vp), ('x_b', i64), ('x_f', i64), ('x_t', i64),
+                ('dy', vp), ('dy_b', i64), ('dy_f', i64), ('dy_t', i64),
+                ('dx', vp), ('dx_b', i64), ('dx_f', i64), ('dx_t', i64),
+                ('B', i32), ('F', i32), ('T', i32), ('C', i32), ('G', i32), ('per_row', i32),
+                ('eps', C.c_float), ('stats', dp), ('stat_count', C.c_double),
+                ('gamma', fp), ('beta', fp), ('layer_scale', fp), ('act', i32),
+                ('sums', dp), ('dgamma', fp), ('dbeta', fp), ('dlayer_scale', fp)]
+
+
 class GramDesc(C.Structure):
     _fields_ = [('x', vp), ('s_b', i64), ('s_f', i64), ('s_t', i64),
                 ('B', i32), ('F', i32), ('T', i32), ('C', i32),
@@ -105,6 +123,9 @@ _PROTOS = {
     'aero_conv_fwd': (i32, [C.POINTER(ConvDesc), vp]),
     'aero_split_finish': (i32, [fp, i32, fp, i32, vp, i64, i32, vp]),
     'aero_adam_step': (i32, [fp, fp, fp, fp, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float, vp]),
+    'aero_conv_wgrad': (i32, [C.POINTER(WgradDesc), vp]),
+    'aero_norm_bwd_reduce': (i32, [C.POINTER(NormBwdDesc), vp]),
+    'aero_norm_bwd_apply': (i32, [C.POINTER(NormBwdDesc), vp]),
     'aero_conv_tile_m': (i32, [i32]),
     'aero_conv_ring_bm': (i32, [i32, i32]),
     'aero_conv_kernel_name': (i32, [C.POINTER(ConvDesc), C.c_char_p, i32]),

@@ -1,0 +1,101 @@
+"""Backward of the generator's building blocks on the MI355X (reference: `loss.backward()` in
+src/solver.py:602-605 over the modules of src/models/aero.py / modules.py).
+
+Data gradients of every convolution kind of the path are themselves convolutions of the forward family, so they run on the
+forward kernels (`aero_conv_fwd`) with a re-packed weight image -- nothing here touches ATen for arithmetic:
+
+    Conv2d, stride 1 (aero.py:95,172 rewrite; modules.py FTB)        dX = conv2d(dY, W^T flipped, pad k-1-p)
+    Conv1d, dilated (modules.py:206-210 DConv)                        dX[t] = sum_j W_j^T dY[t + p - j d]
+    Conv2d [K,1] / stride [s,1] (aero.py:86 encoder conv)             dX = conv_transpose2d(dY, W, stride s), rows p.. kept
+    ConvTranspose2d [K,1] / stride [s,1] (aero.py:179 decoder)        dX[q] = sum_kk W[:, :, kk] dY[q s + kk - p]   (strided conv)
+
+Weight gradients are a GEMM over positions (`aero_conv_wgrad`, k_bwd.h); GroupNorm + activation backward is
+`aero_norm_bwd_*` (k_bwd.h).  LSTM, attention, FTB and STFT backward are not built yet.
+"""
+import torch
+
+from . import _lib, pack
+
+
+def dgrad_conv2d(w, pad_f, pad_t, device):
+    """w: nn.Conv2d weight [M, C, kF, kT] of a stride-1 conv with zero padding (pad_f, pad_t).  Spec of dY [.., M] -> dX [.., C]."""
+    M, Cc, kF, kT = w.shape
+    wt = w.detach().float().transpose(0, 1).flip(2, 3)
+    taps, df, dt = pack.conv2d_taps(wt, kF - 1 - pad_f, kT - 1 - pad_t)
+    return pack.make_conv_spec(taps, None, M, 0, df, dt, device)
+
+
+def dgrad_conv1d(w, dilation, padding, device):
+    """w: nn.Conv1d weight [M, C, k] over time (dilation, zero padding)."""
+    M, Cc, k = w.shape
+    taps = w.detach().float().permute(1, 2, 0).reshape(1, Cc, k, M)
+    return pack.make_conv_spec(taps, None, M, 0, [0] * k, [padding - j * dilation for j in range(k)], device)
+
+
+def dgrad_conv_fstride(w, stride, device):
+    """w: nn.Conv2d weight [M, C, K, 1], stride (s, 1), padding (p, 0): dX is the ConvTranspose of dY by the same weight;
+    run with Fin = rows of dY, Fout = (Fin-1)*s + K, dst_f_off = p, dst_F = rows of X."""
+    taps, df, dt = pack.convtr_taps(w.detach().float(), stride)
+    return pack.make_conv_spec(taps, None, w.shape[0], 0, df, dt, device, transposed=1, fstride=stride)
+
+
+def dgrad_convtr(w, stride, pad, device):
+    """w: nn.ConvTranspose2d weight [Cin, Cout, K, 1], stride (s, 1), output rows cropped by `pad` on both sides: dX is a
+    strided conv of dY (zero outside its rows); run with Fin = rows of dY, Fout = rows of X."""
+    Cin, Cout, K, kT = w.shape
+    assert kT == 1
+    taps = w.detach().float()[:, :, :, 0].permute(0, 2, 1).reshape(1, Cin, K, Cout)
+    return pack.make_conv_spec(taps, None, Cout, 0, [kk - pad for kk in range(K)], [0] * K, device, fstride=stride)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# kernel wrappers (k_bwd.h)
+import ctypes as C  # noqa: E402
+
+from .engine import _ptr, _strides4  # noqa: E402
+
+
+def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True):
+    """dy fp16 [B,Fout,T,M], x fp16 [B,Fin,T,C] (channels-last) -> (dw fp32 [ntaps, M, C], db fp32 [M] or None):
+    dw[j][m][c] = sum dy[b,fo,t,m] * x[b, fo*fstride + df[j], t + dt[j], c]  (aero_conv_wgrad)."""
+    B, Fout, T, M = dy.shape
+    Bx, Fin, Tx, Cc = x.shape
+    assert B == Bx and T == Tx and len(df) == len(dt)
+    d = _lib.WgradDesc()
+    d.dy, d.x = _ptr(dy), _ptr(x)
+    d.dy_b, d.dy_f, d.dy_t = _strides4(dy)
+    d.x_b, d.x_f, d.x_t = _strides4(x)
+    dw = torch.zeros(len(df), M, Cc, dtype=torch.float32, device=dy.device)
+    db = torch.zeros(M, dtype=torch.float32, device=dy.device) if bias else None
+    d.dw, d.db = _ptr(dw), _ptr(db)
+    d.B, d.Fin, d.Fout, d.T, d.M, d.C, d.ntaps, d.fstride = B, Fin, Fout, T, M, Cc, len(df), fstride
+    for i, (a, b_) in enumerate(zip(df, dt)):
+        d.df[i], d.dt[i] = a, b_
+    ops.lib.call('aero_conv_wgrad', C.byref(d), ops.stream(dy))
+    return dw, db
+
+
+def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, eps=1e-5):
+    """Backward of aero_norm_apply (GroupNorm + GELU / GLU(+LayerScale) / identity).  x: the norm's input fp16 [B,F,T,C]; stats: the
+    forward statistics (fp64 sum / sum of squares per (item, group)); dy: gradient of the output.  Returns
+    (dx fp16 [B,F,T,C], dgamma, dbeta fp32 [C], dlayer_scale fp32 [C/2] or None)."""
+    B, F, T, Cc = x.shape
+    d = _lib.NormBwdDesc()
+    d.x, d.dy = _ptr(x), _ptr(dy)
+    d.x_b, d.x_f, d.x_t = _strides4(x)
+    d.dy_b, d.dy_f, d.dy_t = _strides4(dy)
+    dx = torch.empty(B, F, T, Cc, dtype=torch.float16, device=x.device)
+    d.dx = _ptr(dx)
+    d.dx_b, d.dx_f, d.dx_t = _strides4(dx)
+    d.B, d.F, d.T, d.C, d.G, d.per_row, d.eps = B, F, T, Cc, G, int(per_row), eps
+    d.stats = _ptr(stats)
+    d.stat_count = float((1 if per_row == 1 else F) * T * (Cc // G))
+    d.gamma, d.beta, d.layer_scale, d.act = _ptr(gamma), _ptr(beta), _ptr(layer_scale), act
+    sums = torch.zeros_like(stats)
+    dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+    dbeta = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+    dls = torch.zeros(Cc // 2, dtype=torch.float32, device=x.device) if (layer_scale is not None and act == _lib.ACT_GLU) else None
+    d.sums, d.dgamma, d.dbeta, d.dlayer_scale = _ptr(sums), _ptr(dgamma), _ptr(dbeta), _ptr(dls)
+    ops.lib.call('aero_norm_bwd_reduce', C.byref(d), ops.stream(x))
+    ops.lib.call('aero_norm_bwd_apply', C.byref(d), ops.stream(x))
+    return dx, dgamma, dbeta, dls

@@ -15,6 +15,7 @@
 #include "k_gram.h"
 #include "k_stft.h"
 #include "k_optim.h"
+#include "k_bwd.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -200,6 +201,24 @@ int aero_dconv_row_fits(int T, int C, int hidden, int max_dilation) { return aer
 int aero_enc0_fwd(const aero_enc0_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_enc0_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_conv_wgrad_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_norm_bwd_reduce(const aero_norm_bwd_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_norm_bwd_launch(d, 0, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_norm_bwd_apply(const aero_norm_bwd_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_norm_bwd_launch(d, 1, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 

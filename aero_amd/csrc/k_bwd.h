@@ -1,0 +1,359 @@
+// k_bwd.h -- backward kernels of the generator's building blocks (reference: loss.backward() in
+// src/solver.py:602-605 through nn.Conv2d / Conv1d / ConvTranspose2d / GroupNorm + GELU / GLU of src/models/aero.py:86-101,
+// 172-179 and modules.py:206-210).  Data gradients of the convolutions run on the FORWARD kernels with re-packed weights
+// (aero_amd/backward.py); here are the two things that are not convolutions of that family:
+//   * aero_conv_wgrad  -- weight (and bias) gradient: a GEMM whose contraction runs over POSITIONS, the slow index of both
+//                         channels-last operands;
+//   * aero_norm_bwd    -- GroupNorm + activation backward (two streaming passes: group sums, then dx).
+#pragma once
+#include "aero_common.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient.   dw[j][m][c] += sum_{b, fo, t} dy[b, fo, t, m] * x[b, fo*fstride + df[j], t + dt[j], c]   (x = 0 outside)
+// Both operands are channels-last, so the contraction index (t) is the SLOW one in memory, while an MFMA lane wants 8
+// consecutive k of one row.  Transposing through LDS would cost 2-byte scattered accesses; instead:
+//   * a thread loads an 8 (positions) x 8 (channels) block -- eight aligned 16-byte loads -- and transposes it in registers
+//     (32 dword merges): it now holds, for each of its 8 channels j, the fragment "8 consecutive positions of channel 8*o + j";
+//   * MFMA number (j, j') multiplies the fragments of channel set {8*o + j} (16 lanes o) with those of {8*o' + j'}: the matrix
+//     rows an MFMA covers are a STRIDED set of channels -- any row permutation is as good as any other for a GEMM -- so the
+//     64 (j, j') products tile a 128 x 128 block of dw with no further data movement;
+//   * fragments are exchanged between the four waves through LDS in fragment order (16-byte conflict-free writes / reads).
+// Block: 256 threads, a 128 (m) x 128 (c) tile of one tap, 64 positions per step (threads 0-127 stage dy, 128-255 stage x),
+// wave w owns channels j = 2w, 2w+1 of the m side against all eight j'.  Partial sums of a block's row chunk are added to dw
+// with fp32 atomics (the sum order across chunks is not fixed: results differ in the last bits from run to run, as
+// torch's own weight gradients do).
+struct AeroWgradK {
+    aero_wgrad_desc d;
+    int nmt, nct, RC, nchunk;
+};
+
+static __device__ __forceinline__ void aero_transpose8x8(const h16x8* r, h16x8* c) {
+    // r[i] = 8 channels of position i  ->  c[j] = 8 positions of channel j
+    uint32_t in[8][4], out[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        union { h16x8 h; uint32_t u[4]; } cv;
+        cv.h = r[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) in[i][q] = cv.u[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t a = in[2 * e][q], b = in[2 * e + 1][q];
+            out[2 * q][e] = (a & 0xffffu) | (b << 16);
+            out[2 * q + 1][e] = (a >> 16) | (b & 0xffff0000u);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        union { h16x8 h; uint32_t u[4]; } cv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cv.u[e] = out[j][e];
+        c[j] = cv.h;
+    }
+}
+
+__global__ __launch_bounds__(256) void aero_conv_wgrad_kernel(AeroWgradK p) {
+    __shared__ AERO_LDS_ALIGN h16 FR[2][2][8][64 * 8];        // [operand][k half][j][lane * 8]: 32 KiB
+    const aero_wgrad_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    int id = (int)blockIdx.x;
+    const int mt = id % p.nmt; id /= p.nmt;
+    const int ct = id % p.nct; id /= p.nct;
+    const int tap = id % d.ntaps;
+    const int chunk = id / d.ntaps;
+    const int m0 = mt * 128, c0 = ct * 128;
+    const int opnd = tid >> 7, o = tid & 15, g8 = (tid >> 4) & 7;
+    const int dtj = d.dt[tap], dfj = d.df[tap];
+    const int nrows = d.B * d.Fout;
+    const int r_lo = chunk * p.RC;
+    const int r_hi = r_lo + p.RC < nrows ? r_lo + p.RC : nrows;
+    const int nT = (d.T + 63) >> 6;
+    const h16* zpv = aero_zero_page;
+    const int ch = (opnd ? c0 : m0) + 8 * o;                  // first of this thread's 8 channels
+    const bool ch_ok = ch < (opnd ? d.C : d.M);
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    const bool do_bias = d.db != nullptr && ct == 0 && tap == 0 && opnd == 0;
+    h16x8 r[8];
+    auto load = [&](int it) {
+        const int row = r_lo + it / nT, t0 = (it % nT) * 64;
+        const int b = row / d.Fout, fo = row - b * d.Fout;
+        const int fi = fo * d.fstride + dfj;
+        const bool row_ok = fi >= 0 && fi < d.Fin;
+        const h16* base = opnd ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f + ch
+                               : (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)fo * d.dy_f + ch;
+        const int64_t st = opnd ? d.x_t : d.dy_t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = t0 + 8 * g8 + i;
+            const int tt = opnd ? t + dtj : t;
+            const bool ok = ch_ok && t < d.T && (!opnd || (row_ok && tt >= 0 && tt < d.T));   // (dy unmasked by the tap: x is zero there, and db sums all of dy)
+            r[i] = *(const h16x8*)(ok ? base + (int64_t)tt * st : zpv);
+        }
+    };
+    const int nit = (r_hi - r_lo) * nT;
+    if (nit > 0) load(0);
+    for (int it = 0; it < nit; ++it) {
+        h16x8 c[8];
+        aero_transpose8x8(r, c);
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[j] += (float)c[j][e];
+        }
+        if (it) __syncthreads();                               // the previous step's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(h16x8*)&FR[opnd][g8 >> 2][j][(o + 16 * (g8 & 3)) * 8] = c[j];
+        __syncthreads();
+        if (it + 1 < nit) load(it + 1);                        // next step's loads fly under the MFMAs
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const h16x8 a0 = *(const h16x8*)&FR[0][kh][2 * wave][lane * 8];
+            const h16x8 a1 = *(const h16x8*)&FR[0][kh][2 * wave + 1][lane * 8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const h16x8 bf = *(const h16x8*)&FR[1][kh][j][lane * 8];
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf, acc[1][j], 0, 0, 0);
+            }
+        }
+    }
+    // accumulator (a, j')[i] of lane l: m = m0 + 8 * ((l >> 4) * 4 + i) + 2 * wave + a,  c = c0 + 8 * (l & 15) + j'
+    float* dw = d.dw + (int64_t)tap * d.M * d.C;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 8 * ((lane >> 4) * 4 + i) + 2 * wave + a;
+                const int cc = c0 + 8 * (lane & 15) + j;
+                if (m < d.M && cc < d.C) atomicAdd(dw + (int64_t)m * d.C + cc, acc[a][j][i]);
+            }
+    if (do_bias && ch_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (ch + j < d.M) atomicAdd(d.db + ch + j, bsum[j]);
+    }
+}
+
+static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, const char** err) {
+    if (!d || !d->dy || !d->x || !d->dw) { *err = "wgrad: null pointer"; return AERO_ERR_ARG; }
+    if (d->ntaps < 1 || d->ntaps > 9 || d->B < 1 || d->Fin < 1 || d->Fout < 1 || d->T < 1 || d->M < 1 || d->C < 1 || d->fstride < 1) {
+        *err = "wgrad: bad geometry"; return AERO_ERR_ARG;
+    }
+    if ((d->M % 8) || (d->C % 8) || (d->dy_b % 8) || (d->dy_f % 8) || (d->dy_t % 8) || (d->x_b % 8) || (d->x_f % 8) || (d->x_t % 8) ||
+        ((uintptr_t)d->dy & 15) || ((uintptr_t)d->x & 15)) {
+        *err = "wgrad: channel counts and strides must be multiples of 8 (16-byte aligned channel vectors)"; return AERO_ERR_UNSUPPORTED;
+    }
+    AeroWgradK p;
+    p.d = *d;
+    p.nmt = (d->M + 127) / 128;
+    p.nct = (d->C + 127) / 128;
+    const long tiles = (long)p.nmt * p.nct * d->ntaps;
+    const int nrows = d->B * d->Fout;
+    long nchunk = (4096 + tiles - 1) / tiles;                 // enough blocks to fill the chip a few times over
+    if (nchunk > nrows) nchunk = nrows;
+    if (nchunk < 1) nchunk = 1;
+    p.RC = (int)((nrows + nchunk - 1) / nchunk);
+    p.nchunk = (nrows + p.RC - 1) / p.RC;
+    const long nb = tiles * p.nchunk;
+    if (nb > 0x7fffffffL) { *err = "wgrad: grid too large"; return AERO_ERR_ARG; }
+    AERO_LAUNCH(aero_conv_wgrad_kernel, dim3((unsigned)nb), dim3(256), stream, p);
+    return AERO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GroupNorm + activation backward.   forward (aero_norm_apply):  xh = (x - mean) * rstd,  u = xh * gamma + beta,
+//   y = GELU(u)   |   y[c] = u[c] * sigmoid(u[c + C/2]) * layer_scale[c]  (GLU)   |   y = u
+// backward:  du = dy * act'(u);  dgamma[c] += sum du * xh;  dbeta[c] += sum du;  dxh = du * gamma;
+//   dx = rstd * (dxh - S1/N - xh * S2/N)   with   S1 = sum_group dxh,  S2 = sum_group dxh * xh   over the (item, group).
+// Two streaming passes over (x, dy): `reduce` adds S1, S2 (fp64) and dgamma / dbeta / dlayer_scale (fp32) with one atomic per
+// block and channel; `apply` recomputes du and writes dx (fp16).  Thread (v, ty): channel vector v (8 channels; for GLU also the
+// matching 8 gate channels) of time steps ty, ty + TY, ...  Groups must be at least 8 channels wide (a vector then spans at
+// most two groups); per_row 0 / 1 as in aero_norm_desc.
+struct AeroNormBwdK {
+    aero_norm_bwd_desc d;
+    int tchunk, apply;
+};
+
+__global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
+    __shared__ float red_c[3][2048];                           // dgamma, dbeta (all C channels), dlayer_scale (C/2)
+    __shared__ float red_g[2][256];                            // S1, S2 per group
+    const aero_norm_bwd_desc& d = p.d;
+    const bool glu = d.act == AERO_ACT_GLU;
+    const int Cout = glu ? d.C / 2 : d.C;
+    const int vpp = Cout / 8;
+    const int TY = 256 / vpp;
+    const int tid = threadIdx.x;
+    const int v = tid % vpp, ty = tid / vpp;
+    const int b = blockIdx.z, f = blockIdx.y;
+    const int item = d.per_row == 1 ? b * d.F + f : b;
+    const int gs = d.C / d.G;
+    const bool apply = p.apply != 0;
+    if (!apply) {
+        for (int i = tid; i < d.C; i += 256) { red_c[0][i] = 0.f; red_c[1][i] = 0.f; }
+        for (int i = tid; i < Cout; i += 256) red_c[2][i] = 0.f;
+        for (int i = tid; i < d.G; i += 256) { red_g[0][i] = 0.f; red_g[1][i] = 0.f; }
+        __syncthreads();
+    }
+    const int nh = glu ? 2 : 1;
+    const double inv_count = 1.0 / d.stat_count;
+    // per owned channel (both halves): A = rstd * gamma, Bc = beta - mean * rstd * gamma  (u = x * A + Bc),  rstd, -mean * rstd,
+    // gamma, group index, and for `apply` the group terms  S1/N, S2/N
+    float rs[2][8], mr[2][8], gm[2][8], bt[2][8], k1[2][8], k2[2][8];
+    int grp[2][8];
+    if (ty < TY) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h >= nh) continue;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = h * Cout + v * 8 + i;
+                const int g = c / gs;
+                const double* st = d.stats + ((int64_t)item * d.G + g) * 2;
+                const double mean = st[0] * inv_count;
+                double var = st[1] * inv_count - mean * mean;
+                if (var < 0) var = 0;
+                const float r = (float)(1.0 / sqrt(var + (double)d.eps));
+                rs[h][i] = r;
+                mr[h][i] = -(float)mean * r;
+                gm[h][i] = d.gamma ? d.gamma[c] : 1.f;
+                bt[h][i] = d.beta ? d.beta[c] : 0.f;
+                grp[h][i] = g;
+                k1[h][i] = k2[h][i] = 0.f;
+                if (apply) {
+                    const double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
+                    k1[h][i] = (float)(sm[0] * inv_count);
+                    k2[h][i] = (float)(sm[1] * inv_count);
+                }
+            }
+        }
+    }
+    float dgam[2][8], dbet[2][8], dls[8], s1[2][8], s2[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dgam[h][i] = dbet[h][i] = s1[h][i] = s2[h][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dls[i] = 0.f;
+    const int t0 = blockIdx.x * p.tchunk;
+    const int t1 = t0 + p.tchunk < d.T ? t0 + p.tchunk : d.T;
+    const h16* xs = (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)f * d.x_f + v * 8;
+    const h16* dys = (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)f * d.dy_f + v * 8;
+    h16* dxs = (h16*)d.dx + (int64_t)b * d.dx_b + (int64_t)f * d.dx_f + v * 8;
+    if (ty < TY) {
+        for (int t = t0 + ty; t < t1; t += TY) {
+            const h16x8 xa = *(const h16x8*)(xs + (int64_t)t * d.x_t);
+            h16x8 xg = xa;
+            if (glu) xg = *(const h16x8*)(xs + (int64_t)t * d.x_t + Cout);
+            const h16x8 dyv = *(const h16x8*)(dys + (int64_t)t * d.dy_t);
+            h16x8 oa, og;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh0 = (float)xa[i] * rs[0][i] + mr[0][i];
+                const float u0 = xh0 * gm[0][i] + bt[0][i];
+                const float g_out = (float)dyv[i];
+                float du0, du1 = 0.f, xh1 = 0.f;
+                if (glu) {
+                    xh1 = (float)xg[i] * rs[1][i] + mr[1][i];
+                    const float u1 = xh1 * gm[1][i] + bt[1][i];
+                    const float sg = aero_sigmoid(u1);
+                    const float ls = d.layer_scale ? d.layer_scale[v * 8 + i] : 1.f;
+                    const float gy = g_out * ls;
+                    du0 = gy * sg;
+                    du1 = gy * u0 * sg * (1.f - sg);
+                    dls[i] += g_out * u0 * sg;
+                } else if (d.act == AERO_ACT_GELU) {
+                    const float cdf = 0.5f * (1.0f + aero_erf(u0 * 0.70710678118654752f));
+                    const float pdf = 0.3989422804014327f * aero_fast_exp(-0.5f * u0 * u0);
+                    du0 = g_out * (cdf + u0 * pdf);
+                } else if (d.act == AERO_ACT_RELU) {
+                    du0 = u0 > 0.f ? g_out : 0.f;
+                } else {
+                    du0 = g_out;
+                }
+                const float dxh0 = du0 * gm[0][i], dxh1 = du1 * gm[1][i];
+                if (!apply) {
+                    dgam[0][i] += du0 * xh0; dbet[0][i] += du0;
+                    s1[0][i] += dxh0; s2[0][i] += dxh0 * xh0;
+                    if (glu) {
+                        dgam[1][i] += du1 * xh1; dbet[1][i] += du1;
+                        s1[1][i] += dxh1; s2[1][i] += dxh1 * xh1;
+                    }
+                } else {
+                    oa[i] = (h16)(rs[0][i] * (dxh0 - k1[0][i] - xh0 * k2[0][i]));
+                    if (glu) og[i] = (h16)(rs[1][i] * (dxh1 - k1[1][i] - xh1 * k2[1][i]));
+                }
+            }
+            if (apply) {
+                *(h16x8*)(dxs + (int64_t)t * d.dx_t) = oa;
+                if (glu) *(h16x8*)(dxs + (int64_t)t * d.dx_t + Cout) = og;
+            }
+        }
+    }
+    if (apply) return;
+    if (ty < TY) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h >= nh) continue;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = h * Cout + v * 8 + i;
+                atomicAdd(&red_c[0][c], dgam[h][i]);
+                atomicAdd(&red_c[1][c], dbet[h][i]);
+                atomicAdd(&red_g[0][grp[h][i]], s1[h][i]);
+                atomicAdd(&red_g[1][grp[h][i]], s2[h][i]);
+            }
+        }
+        if (glu && d.dlayer_scale) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) atomicAdd(&red_c[2][v * 8 + i], dls[i]);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < d.C; c += 256) {
+        if (d.dgamma) atomicAdd(d.dgamma + c, red_c[0][c]);
+        if (d.dbeta) atomicAdd(d.dbeta + c, red_c[1][c]);
+    }
+    if (glu && d.dlayer_scale)
+        for (int c = tid; c < Cout; c += 256) atomicAdd(d.dlayer_scale + c, red_c[2][c]);
+    for (int g = tid; g < d.G; g += 256) {
+        double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
+        atomicAdd(sm, (double)red_g[0][g]);
+        atomicAdd(sm + 1, (double)red_g[1][g]);
+    }
+}
+
+static int aero_norm_bwd_launch(const aero_norm_bwd_desc* d, int apply, hipStream_t stream, const char** err) {
+    if (!d || !d->x || !d->dy || !d->stats || !d->sums || (apply && !d->dx)) { *err = "norm_bwd: null pointer"; return AERO_ERR_ARG; }
+    if (d->B < 1 || d->F < 1 || d->T < 1 || d->C < 8 || d->G < 1 || d->C % d->G || d->stat_count <= 0) { *err = "norm_bwd: bad geometry"; return AERO_ERR_ARG; }
+    const bool glu = d->act == AERO_ACT_GLU;
+    const int Cout = glu ? d->C / 2 : d->C;
+    if (d->per_row != 0 && d->per_row != 1) { *err = "norm_bwd: per_row must be 0 or 1 (batch statistics are not supported)"; return AERO_ERR_UNSUPPORTED; }
+    if (d->act != AERO_ACT_NONE && d->act != AERO_ACT_GELU && d->act != AERO_ACT_GLU && d->act != AERO_ACT_RELU) { *err = "norm_bwd: activation not supported"; return AERO_ERR_UNSUPPORTED; }
+    if ((Cout % 8) || Cout / 8 > 256 || d->C > 2048 || d->G > 256 || (d->C / d->G) < 8 || (d->x_b % 8) || (d->x_f % 8) || (d->x_t % 8) || (d->dy_b % 8) || (d->dy_f % 8) ||
+        (d->dy_t % 8) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->dy & 15)) {
+        *err = "norm_bwd: needs 8-channel aligned fp16 rows, C <= 2048, groups of >= 8 channels"; return AERO_ERR_UNSUPPORTED;
+    }
+    if (apply && ((d->dx_b % 8) || (d->dx_f % 8) || (d->dx_t % 8) || ((uintptr_t)d->dx & 15))) { *err = "norm_bwd: dx must be 16-byte aligned"; return AERO_ERR_UNSUPPORTED; }
+    AeroNormBwdK p;
+    p.d = *d;
+    p.apply = apply;
+    const int TY = 256 / (Cout / 8);
+    int tchunk = TY * 16;                                      // 16 time steps per thread
+    if (tchunk > d->T) tchunk = d->T;
+    p.tchunk = tchunk;
+    dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)d->F, (unsigned)d->B);
+    AERO_LAUNCH(aero_norm_bwd_kernel, grid, dim3(256), stream, p);
+    return AERO_OK;
+}

@@ -298,6 +298,45 @@ int aero_dconv_row_fits(int T, int C, int hidden, int max_dilation);
 int aero_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    int32_t step, float grad_scale, void* stream);
 
+/* ---- backward (loss.backward() of src/solver.py:602-605 through the modules of aero.py / modules.py).
+ * Data gradients of the convolutions are aero_conv_fwd calls with re-packed weights (aero_amd/backward.py). */
+
+/* weight gradient of any convolution of the aero_conv_desc family (nn.Conv2d aero.py:86,95,172; nn.Conv1d modules.py:206-210;
+ * nn.ConvTranspose2d aero.py:179 with the roles of x and dy swapped):
+ *   dw[j][m][c] += sum_{b, fo, t} dy[b, fo, t, m] * x[b, fo*fstride + df[j], t + dt[j], c]      (x = 0 outside its rows / steps)
+ *   db[m]       += sum_{b, fo, t} dy[b, fo, t, m]                                                (db may be NULL)
+ * dy fp16 [B, Fout, T, M], x fp16 [B, Fin, T, C] (element strides; M, C and strides multiples of 8); dw fp32 [ntaps][M][C] and
+ * db fp32 [M] are ACCUMULATED (the caller zeroes them) with fp32 atomics. */
+typedef struct {
+    const void* dy; int64_t dy_b, dy_f, dy_t;
+    const void* x; int64_t x_b, x_f, x_t;
+    float* dw; float* db;
+    int32_t B, Fin, Fout, T, M, C, ntaps, fstride;
+    int32_t df[9], dt[9];
+} aero_wgrad_desc;
+int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream);
+
+/* nn.GroupNorm + GELU / GLU(+LayerScale) backward (aero.py:56,127,133,148,198,214; modules.py:189,232-236).  x is the saved INPUT
+ * of the norm (fp16 [B,F,T,C]), stats / stat_count the forward statistics (aero_norm_stats / the conv epilogues), dy the gradient
+ * of the activation output (fp16 [B,F,T,C] or [B,F,T,C/2] for GLU).  aero_norm_bwd_reduce ADDS the group sums
+ * (sum dxh, sum dxh*xh: fp64 pairs, laid out as stats) to `sums` and the parameter gradients to dgamma / dbeta [C] /
+ * dlayer_scale [C/2] (fp32, may be NULL; the caller zeroes all of them); aero_norm_bwd_apply then writes
+ * dx = rstd * (dxh - S1/N - xh * S2/N) as fp16.  per_row 0 / 1 as in aero_norm_desc. */
+typedef struct {
+    const void* x; int64_t x_b, x_f, x_t;
+    const void* dy; int64_t dy_b, dy_f, dy_t;
+    void* dx; int64_t dx_b, dx_f, dx_t;
+    int32_t B, F, T, C, G, per_row;
+    float eps;
+    const double* stats; double stat_count;
+    const float* gamma; const float* beta; const float* layer_scale;
+    int32_t act;
+    double* sums;
+    float* dgamma; float* dbeta; float* dlayer_scale;
+} aero_norm_bwd_desc;
+int aero_norm_bwd_reduce(const aero_norm_bwd_desc* d, void* stream);
+int aero_norm_bwd_apply(const aero_norm_bwd_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -442,3 +442,173 @@ def case_conv1d_split(lib, dev, Cin, Cout, k, R, T, S=3, seed=25):
     assert torch.equal(y1, y2)
     assert rel_l2(y1.float().cpu()[0].permute(0, 2, 1), ref) < TOL16
     assert rel_l2(y1.float().cpu(), y0.float().cpu()) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# backward (aero_amd/backward.py): data gradients on the forward conv kernels, checked against torch.autograd of the
+# same op in fp32 on fp16-rounded operands
+def _autograd_dx(fn, x, dy):
+    xr = q16(x).clone().requires_grad_(True)
+    y = fn(xr)
+    assert y.shape == dy.shape, (y.shape, dy.shape)
+    return torch.autograd.grad(y, xr, q16(dy))[0]
+
+
+def case_dgrad_conv2d(lib, dev, Cin, Cout, kF, kT, Fr, T, B=2, seed=70):
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    w = _rand((Cout, Cin, kF, kT), seed, 1.0 / math.sqrt(Cout * kF * kT))
+    x = _rand((B, Cin, Fr, T), seed + 1)
+    dy = _rand((B, Cout, Fr, T), seed + 2)
+    ref = _autograd_dx(lambda v: F.conv2d(v, q16(w), None, padding=(kF // 2, kT // 2)), x, dy)
+    spec = bw.dgrad_conv2d(q16(w), kF // 2, kT // 2, dev)
+    dx = ops.conv(spec, cl(dy).to(dev), None, B, Fr, Fr, T)
+    assert rel_l2(uncl(dx.cpu()), ref) < TOL16
+
+
+def case_dgrad_conv1d(lib, dev, Cin, Cout, k, dil, R, T, seed=73):
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    w = _rand((Cout, Cin, k), seed, 1.0 / math.sqrt(Cout * k))
+    x = _rand((R, Cin, T), seed + 1)
+    dy = _rand((R, Cout, T), seed + 2)
+    pad = dil * (k // 2)
+    ref = _autograd_dx(lambda v: F.conv1d(v, q16(w), None, dilation=dil, padding=pad), x, dy)
+    spec = bw.dgrad_conv1d(q16(w), dil, pad, dev)
+    dycl = dy.permute(0, 2, 1).contiguous().half().view(1, R, T, Cout).to(dev)
+    dx = ops.conv(spec, dycl, None, 1, R, R, T)
+    assert rel_l2(dx.cpu().float()[0].permute(0, 2, 1), ref) < TOL16
+
+
+def case_dgrad_conv_fstride(lib, dev, Cin, Cout, K, stride, Fin, T, B=2, seed=76):
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    pad = (K - stride) // 2
+    w = _rand((Cout, Cin, K, 1), seed, 1.0 / math.sqrt(Cout * K / stride))
+    x = _rand((B, Cin, Fin, T), seed + 1)
+    Fo = (Fin + 2 * pad - K) // stride + 1
+    dy = _rand((B, Cout, Fo, T), seed + 2)
+    ref = _autograd_dx(lambda v: F.conv2d(v, q16(w), None, stride=(stride, 1), padding=(pad, 0)), x, dy)
+    spec = bw.dgrad_conv_fstride(q16(w), stride, dev)
+    Fu = (Fo - 1) * stride + K
+    dx = ops.conv(spec, cl(dy).to(dev), None, B, Fo, Fu, T, dst_f_off=pad, dst_F=Fin)
+    assert rel_l2(uncl(dx.cpu()), ref) < TOL16
+
+
+def case_dgrad_convtr(lib, dev, Cin, Cout, K, stride, Fin, T, B=2, seed=79):
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    pad = (K - stride) // 2
+    w = _rand((Cin, Cout, K, 1), seed, 1.0 / math.sqrt(Cout * K / stride))
+    x = _rand((B, Cin, Fin, T), seed + 1)
+    Fu = (Fin - 1) * stride + K
+    Fy = Fu - 2 * pad
+    dy = _rand((B, Cout, Fy, T), seed + 2)
+    ref = _autograd_dx(lambda v: F.conv_transpose2d(v, q16(w), None, stride=(stride, 1))[:, :, pad:Fu - pad], x, dy)
+    spec = bw.dgrad_convtr(q16(w), stride, pad, dev)
+    dx = ops.conv(spec, cl(dy).to(dev), None, B, Fy, Fin, T)
+    assert rel_l2(uncl(dx.cpu()), ref) < TOL16
+
+
+def _autograd_dw(fn, w, b, dy):
+    wr = q16(w).clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y = fn(wr, br)
+    assert y.shape == dy.shape, (y.shape, dy.shape)
+    return torch.autograd.grad(y, [wr, br], q16(dy))
+
+
+def case_wgrad_conv2d(lib, dev, Cin, Cout, kF, kT, Fr, T, B=2, seed=82):
+    """weight / bias gradient of a stride-1 Conv2d (aero_conv_wgrad) against torch.autograd"""
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    w = _rand((Cout, Cin, kF, kT), seed, 1.0 / math.sqrt(Cin * kF * kT))
+    b = _rand((Cout,), seed + 3)
+    x = _rand((B, Cin, Fr, T), seed + 1)
+    dy = _rand((B, Cout, Fr, T), seed + 2)
+    gw, gb = _autograd_dw(lambda ww, bb: F.conv2d(q16(x), ww, bb, padding=(kF // 2, kT // 2)), w, b, dy)
+    _, df, dt = pack.conv2d_taps(w, kF // 2, kT // 2)
+    dw, db = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt)
+    got = dw.cpu().view(kF, kT, Cout, Cin).permute(2, 3, 0, 1)
+    assert rel_l2(got, gw) < TOL16, rel_l2(got, gw)
+    assert rel_l2(db.cpu(), gb) < TOL16
+
+
+def case_wgrad_conv1d(lib, dev, Cin, Cout, k, dil, R, T, seed=85):
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    w = _rand((Cout, Cin, k), seed, 1.0 / math.sqrt(Cin * k))
+    b = _rand((Cout,), seed + 3)
+    x = _rand((R, Cin, T), seed + 1)
+    dy = _rand((R, Cout, T), seed + 2)
+    pad = dil * (k // 2)
+    gw, gb = _autograd_dw(lambda ww, bb: F.conv1d(q16(x), ww, bb, dilation=dil, padding=pad), w, b, dy)
+    _, df, dt = pack.conv1d_taps(w, dil, pad)
+    to_cl = lambda v: v.permute(0, 2, 1).contiguous().half().view(1, R, T, v.shape[1]).to(dev)   # noqa: E731
+    dw, db = bw.conv_wgrad(ops, to_cl(dy), to_cl(x), df, dt)
+    assert rel_l2(dw.cpu().permute(1, 2, 0), gw) < TOL16
+    assert rel_l2(db.cpu(), gb) < TOL16
+
+
+def case_wgrad_conv_fstride(lib, dev, Cin, Cout, K, stride, Fin, T, B=2, seed=88):
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    pad = (K - stride) // 2
+    w = _rand((Cout, Cin, K, 1), seed, 1.0 / math.sqrt(Cin * K))
+    b = _rand((Cout,), seed + 3)
+    x = _rand((B, Cin, Fin, T), seed + 1)
+    Fo = (Fin + 2 * pad - K) // stride + 1
+    dy = _rand((B, Cout, Fo, T), seed + 2)
+    gw, gb = _autograd_dw(lambda ww, bb: F.conv2d(q16(x), ww, bb, stride=(stride, 1), padding=(pad, 0)), w, b, dy)
+    _, df, dt = pack.conv2d_taps(w, pad, 0)
+    dw, db = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt, fstride=stride)
+    assert rel_l2(dw.cpu().permute(1, 2, 0).unsqueeze(-1), gw) < TOL16
+    assert rel_l2(db.cpu(), gb) < TOL16
+
+
+def case_wgrad_convtr(lib, dev, Cin, Cout, K, stride, Fin, T, B=2, seed=91):
+    """ConvTranspose2d weight gradient: the same kernel with the roles of x and dy swapped"""
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    pad = (K - stride) // 2
+    w = _rand((Cin, Cout, K, 1), seed, 1.0 / math.sqrt(Cin * K / stride))
+    b = _rand((Cout,), seed + 3)
+    x = _rand((B, Cin, Fin, T), seed + 1)
+    Fu = (Fin - 1) * stride + K
+    dy = _rand((B, Cout, Fu - 2 * pad, T), seed + 2)
+    gw, gb = _autograd_dw(lambda ww, bb: F.conv_transpose2d(q16(x), ww, bb, stride=(stride, 1))[:, :, pad:Fu - pad], w, b, dy)
+    # dw[ci, co, kk] = sum_q x[q][ci] * dy[q*s + kk - pad][co]
+    dw, _ = bw.conv_wgrad(ops, cl(x).to(dev), cl(dy).to(dev), [kk - pad for kk in range(K)], [0] * K, fstride=stride, bias=False)
+    assert rel_l2(dw.cpu().permute(1, 2, 0).unsqueeze(-1), gw) < TOL16
+
+
+def case_norm_bwd(lib, dev, C_, G, per_row, act, Fr, T, B=2, layer_scale=False, seed=94):
+    """GroupNorm + activation backward (aero_norm_bwd_*) against torch.autograd of the fp32 composition"""
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    x = _rand((B, C_, Fr, T), seed, 1.5) + 0.3
+    gamma, beta = _rand((C_,), seed + 1) * 0.5 + 1.0, _rand((C_,), seed + 2) * 0.3
+    Cout = C_ // 2 if act == 'glu' else C_
+    ls = (_rand((Cout,), seed + 4).abs() + 0.2) if layer_scale else None
+    dy = _rand((B, Cout, Fr, T), seed + 3)
+    xr = q16(x).clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    lr = ls.clone().requires_grad_(True) if ls is not None else None
+    if per_row:
+        u = F.group_norm(xr.permute(0, 2, 1, 3).reshape(B * Fr, C_, T), G, gr, br).view(B, Fr, C_, T).permute(0, 2, 1, 3)
+    else:
+        u = F.group_norm(xr, G, gr, br)
+    y = {'none': lambda v: v, 'gelu': F.gelu, 'glu': lambda v: F.glu(v, dim=1)}[act](u)
+    if lr is not None:
+        y = y * lr.view(1, -1, 1, 1)
+    grads = torch.autograd.grad(y, [xr, gr, br] + ([lr] if lr is not None else []), q16(dy))
+    actc = {'none': _lib.ACT_NONE, 'gelu': _lib.ACT_GELU, 'glu': _lib.ACT_GLU}[act]
+    xd = cl(x).to(dev)
+    ops.norm_act(xd, G, per_row, gamma.to(dev), beta.to(dev), actc, layer_scale=None if ls is None else ls.to(dev))
+    stats = ops._last_stats
+    dx, dg, dbt, dls = bw.norm_bwd(ops, xd, cl(dy).to(dev), stats, G, per_row, gamma.to(dev), beta.to(dev), actc,
+                                   layer_scale=None if ls is None else ls.to(dev))
+    assert rel_l2(uncl(dx.cpu()), grads[0]) < 2 * TOL16, rel_l2(uncl(dx.cpu()), grads[0])
+    assert rel_l2(dg.cpu(), grads[1]) < TOL16 and rel_l2(dbt.cpu(), grads[2]) < TOL16
+    if lr is not None:
+        assert rel_l2(dls.cpu(), grads[3]) < TOL16

@@ -190,3 +190,53 @@ def test_stft_short_window_as_gemm(emu, geom):
     """aero_stft_dft_fwd: windows of <= 128 samples (Aero._spec of the low-rate input) as hi/lo-split fp16 MFMAs against a windowed
     DFT table; same 2e-6 bar as the FFT kernel, same statistics."""
     oc.case_stft(emu, DEV, *geom, dft=True)
+
+
+# ---- backward: data gradients on the forward kernels (aero_amd/backward.py)
+@pytest.mark.parametrize('kw', [dict(Cin=32, Cout=64, kF=3, kT=3, Fr=4, T=40), dict(Cin=16, Cout=32, kF=1, kT=1, Fr=3, T=50)])
+def test_dgrad_conv2d(emu, kw):
+    oc.case_dgrad_conv2d(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=48, Cout=16, k=3, dil=2, R=3, T=70), dict(Cin=16, Cout=96, k=1, dil=1, R=2, T=40)])
+def test_dgrad_conv1d(emu, kw):
+    oc.case_dgrad_conv1d(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=16, Cout=32, K=8, stride=4, Fin=16, T=40), dict(Cin=32, Cout=32, K=8, stride=2, Fin=8, T=33)])
+def test_dgrad_conv_fstride(emu, kw):
+    oc.case_dgrad_conv_fstride(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=32, Cout=16, K=8, stride=4, Fin=4, T=40), dict(Cin=64, Cout=32, K=8, stride=2, Fin=3, T=33)])
+def test_dgrad_convtr(emu, kw):
+    oc.case_dgrad_convtr(emu, DEV, **kw)
+
+
+# ---- backward: weight gradients and GroupNorm + activation backward (k_bwd.h)
+@pytest.mark.parametrize('kw', [dict(Cin=32, Cout=64, kF=3, kT=3, Fr=3, T=70), dict(Cin=136, Cout=144, kF=1, kT=1, Fr=2, T=50),
+                                dict(Cin=8, Cout=16, kF=3, kT=1, Fr=5, T=33, B=3)])
+def test_wgrad_conv2d(emu, kw):
+    oc.case_wgrad_conv2d(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=48, Cout=16, k=3, dil=2, R=5, T=70), dict(Cin=16, Cout=96, k=1, dil=1, R=2, T=40)])
+def test_wgrad_conv1d(emu, kw):
+    oc.case_wgrad_conv1d(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=16, Cout=32, K=8, stride=4, Fin=16, T=40)])
+def test_wgrad_conv_fstride(emu, kw):
+    oc.case_wgrad_conv_fstride(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=32, Cout=16, K=8, stride=4, Fin=4, T=40), dict(Cin=64, Cout=32, K=8, stride=2, Fin=3, T=33)])
+def test_wgrad_convtr(emu, kw):
+    oc.case_wgrad_convtr(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(C_=48, G=4, per_row=0, act='gelu', Fr=4, T=50), dict(C_=96, G=1, per_row=1, act='glu', Fr=3, T=37, layer_scale=True),
+                                dict(C_=32, G=1, per_row=1, act='gelu', Fr=2, T=20), dict(C_=64, G=4, per_row=0, act='glu', Fr=3, T=33),
+                                dict(C_=48, G=4, per_row=0, act='none', Fr=2, T=300)])
+def test_norm_bwd(emu, kw):
+    oc.case_norm_bwd(emu, DEV, **kw)

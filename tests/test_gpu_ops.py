@@ -168,3 +168,51 @@ def test_stft_short_window_as_gemm(lib, geom):
     """aero_stft_dft_fwd: windows of <= 128 samples (Aero._spec of the low-rate input) as hi/lo-split fp16 MFMAs against a windowed
     DFT table; same 2e-6 bar as the FFT kernel, same statistics."""
     oc.case_stft(lib, DEV, *geom, dft=True)
+
+
+# ---- backward (aero_amd/backward.py, k_bwd.h): data gradients on the forward kernels, weight gradients, GroupNorm backward
+@pytest.mark.parametrize('kw', [dict(Cin=192, Cout=384, kF=3, kT=3, Fr=4, T=501), dict(Cin=48, Cout=96, kF=1, kT=1, Fr=8, T=501)])
+def test_dgrad_conv2d(lib, kw):
+    oc.case_dgrad_conv2d(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=192, Cout=48, k=3, dil=2, R=16, T=501), dict(Cin=48, Cout=384, k=1, dil=1, R=8, T=501)])
+def test_dgrad_conv1d(lib, kw):
+    oc.case_dgrad_conv1d(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=48, Cout=96, K=8, stride=4, Fin=64, T=501), dict(Cin=192, Cout=384, K=8, stride=2, Fin=8, T=501)])
+def test_dgrad_conv_fstride(lib, kw):
+    oc.case_dgrad_conv_fstride(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=192, Cout=96, K=8, stride=4, Fin=4, T=501), dict(Cin=768, Cout=192, K=8, stride=2, Fin=4, T=501)])
+def test_dgrad_convtr(lib, kw):
+    oc.case_dgrad_convtr(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=192, Cout=384, kF=3, kT=3, Fr=4, T=501), dict(Cin=136, Cout=144, kF=1, kT=1, Fr=2, T=50),
+                                dict(Cin=8, Cout=16, kF=3, kT=1, Fr=5, T=33, B=3)])
+def test_wgrad_conv2d(lib, kw):
+    oc.case_wgrad_conv2d(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=192, Cout=48, k=3, dil=2, R=16, T=501), dict(Cin=16, Cout=96, k=1, dil=1, R=2, T=40)])
+def test_wgrad_conv1d(lib, kw):
+    oc.case_wgrad_conv1d(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=48, Cout=96, K=8, stride=4, Fin=64, T=501)])
+def test_wgrad_conv_fstride(lib, kw):
+    oc.case_wgrad_conv_fstride(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cin=192, Cout=96, K=8, stride=4, Fin=4, T=501), dict(Cin=64, Cout=32, K=8, stride=2, Fin=3, T=33)])
+def test_wgrad_convtr(lib, kw):
+    oc.case_wgrad_convtr(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(C_=48, G=4, per_row=0, act='gelu', Fr=64, T=501), dict(C_=96, G=1, per_row=1, act='glu', Fr=16, T=501, layer_scale=True),
+                                dict(C_=384, G=4, per_row=0, act='glu', Fr=4, T=501), dict(C_=48, G=4, per_row=0, act='none', Fr=2, T=300)])
+def test_norm_bwd(lib, kw):
+    oc.case_norm_bwd(lib, DEV, **kw)
