@@ -1,0 +1,141 @@
+"""torch.autograd glue for the backward kernels: one Function per building block of the generator,
+forward AND backward on the HIP kernels -- conv (aero_conv_fwd) -> GroupNorm -> GELU / GLU (aero_norm_stats/apply), then
+aero_norm_bwd_* -> data gradient (aero_conv_fwd on re-packed weights) + aero_conv_wgrad.  Tensors are channels-last fp16
+[B, F, T, C] on the device; parameters and their gradients are fp32 in the nn.Module layout (aero.py:86-101,172-179).
+
+First version: the weight image is re-packed on every call, and LSTM / attention / FTB / STFT have no backward yet, so this does
+not train the whole model."""
+import torch
+
+from . import _lib, backward as bw, pack
+from .engine import Ops
+
+_ACT = {'none': _lib.ACT_NONE, 'gelu': _lib.ACT_GELU, 'glu': _lib.ACT_GLU}
+
+
+class ConvNormAct(torch.autograd.Function):
+    """y = act(GroupNorm_G(conv(x)))   --  HEncLayer conv+norm1+gelu, rewrite+norm2+glu, HDecLayer conv_tr+norm2+gelu.
+    kind: ('conv2d', pad_f, pad_t) | ('fstride', stride) [kernel [K,1], padding (K-stride)//2] | ('convtr', stride) [cropped]"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, lib, kind, G, act):
+        ops = Ops(lib)
+        dev = x.device
+        B, Fin, T, Cin = x.shape
+        w = weight.detach().float().cpu()
+        if kind[0] == 'conv2d':
+            taps, df, dt = pack.conv2d_taps(w, kind[1], kind[2])
+            spec = pack.make_conv_spec(taps, bias.detach(), Cin, 0, df, dt, dev)
+            Fout, kw = Fin, {}
+        elif kind[0] == 'fstride':
+            K, s = w.shape[2], kind[1]
+            pad = (K - s) // 2
+            taps, df, dt = pack.conv2d_taps(w, pad, 0)
+            spec = pack.make_conv_spec(taps, bias.detach(), Cin, 0, df, dt, dev, fstride=s)
+            Fout, kw = (Fin + 2 * pad - K) // s + 1, {}
+        else:
+            K, s = w.shape[2], kind[1]
+            pad = (K - s) // 2
+            taps, df, dt = pack.convtr_taps(w, s)
+            spec = pack.make_conv_spec(taps, bias.detach(), Cin, 0, df, dt, dev, transposed=1, fstride=s)
+            Fu = (Fin - 1) * s + K
+            Fout, kw = Fu, dict(dst_f_off=pad, dst_F=Fu - 2 * pad)
+        h = ops.conv(spec, x, None, B, Fin, Fout, T, **kw)
+        y = ops.norm_act(h, G, 0, gamma.detach(), beta.detach(), _ACT[act])
+        ctx.save_for_backward(x, weight, gamma, beta, h, ops._last_stats)
+        ctx.cfg = (lib, kind, G, act, df, dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, gamma, beta, h, stats = ctx.saved_tensors
+        lib, kind, G, act, df, dt = ctx.cfg
+        ops = Ops(lib)
+        dev = x.device
+        B, Fin, T, Cin = x.shape
+        Fh = h.shape[1]
+        dh, dgamma, dbeta, _ = bw.norm_bwd(ops, h, dy.contiguous(), stats, G, 0, gamma.detach(), beta.detach(), _ACT[act])
+        w = weight.detach().float().cpu()
+        if kind[0] == 'conv2d':
+            dx = ops.conv(bw.dgrad_conv2d(w, kind[1], kind[2], dev), dh, None, B, Fh, Fin, T)
+            dw, db = bw.conv_wgrad(ops, dh, x, df, dt)
+            kF, kT = w.shape[2], w.shape[3]
+            dweight = dw.view(kF, kT, w.shape[0], Cin).permute(2, 3, 0, 1)
+        elif kind[0] == 'fstride':
+            K, s = w.shape[2], kind[1]
+            pad = (K - s) // 2
+            dx = ops.conv(bw.dgrad_conv_fstride(w, s, dev), dh, None, B, Fh, (Fh - 1) * s + K, T, dst_f_off=pad, dst_F=Fin)
+            dw, db = bw.conv_wgrad(ops, dh, x, df, dt, fstride=s)
+            dweight = dw.permute(1, 2, 0).unsqueeze(-1)
+        else:
+            K, s = w.shape[2], kind[1]
+            pad = (K - s) // 2
+            dx = ops.conv(bw.dgrad_convtr(w, s, pad, dev), dh, None, B, Fh, Fin, T)
+            dw, _ = bw.conv_wgrad(ops, x, dh, [kk - pad for kk in range(K)], [0] * K, fstride=s, bias=False)
+            dweight = dw.permute(1, 2, 0).unsqueeze(-1)
+            db = _bias_grad(ops, dh)
+        return dx, dweight.contiguous(), db, dgamma, dbeta, None, None, None, None
+
+
+def _bias_grad(ops, dh):
+    """db[m] = sum of dh over positions, for the ConvTranspose block whose weight-gradient call has x and dy swapped: the bias
+    reduction of aero_conv_wgrad on a 1-tap, 8-channel problem (the [M, 8] dw it also produces is discarded)."""
+    _, db = bw.conv_wgrad(ops, dh, dh[..., :8], [0], [0], bias=True)
+    return db
+
+
+def _pad0(t, n, dim=0):
+    """zero-pad dimension `dim` of a parameter to n entries"""
+    if t.shape[dim] == n:
+        return t
+    shape = list(t.shape)
+    shape[dim] = n - t.shape[dim]
+    return torch.cat([t, torch.zeros(shape, dtype=t.dtype, device=t.device)], dim)
+
+
+class DConvLayer(torch.autograd.Function):
+    """One residual DConv layer without LSTM / attention (modules.py:206-244):
+        y = x + scale * GLU(GroupNorm1(conv1x1(GELU(GroupNorm1(conv1d_k,dilation(x))))))       on rows [B*F, C, T]
+    x fp16 [B,F,T,C]; w1 [H, C, k], w2 [2C, H, 1] (H = C / compress).  The hidden width is zero-padded to a multiple of 8 for the
+    16-byte channel vectors of the kernels (zero weights, gamma = beta = 0 there; the statistics count stays T * H)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, scale, lib, dilation):
+        ops = Ops(lib)
+        dev = x.device
+        B, Fr, T, Cc = x.shape
+        H, _, k = w1.shape
+        Hp = (H + 7) // 8 * 8
+        pad = dilation * (k // 2)
+        w1p, b1p = _pad0(w1.detach().float().cpu(), Hp), _pad0(b1.detach().float(), Hp)
+        g1p, be1p = _pad0(g1.detach().float(), Hp), _pad0(be1.detach().float(), Hp)
+        w2p = _pad0(w2.detach().float().cpu(), Hp, 1)
+        t1, df1, dt1 = pack.conv1d_taps(w1p, dilation, pad)
+        h1 = ops.conv(pack.make_conv_spec(t1, b1p, Cc, 0, df1, dt1, dev), x, None, B, Fr, Fr, T)
+        a = ops.norm_act(h1, 1, 1, g1p, be1p, _lib.ACT_GELU, stat_count=T * H)
+        st1 = ops._last_stats
+        t2, df2, dt2 = pack.conv1d_taps(w2p, 1, 0)
+        h2 = ops.conv(pack.make_conv_spec(t2, b2.detach(), Hp, 0, df2, dt2, dev), a, None, B, Fr, Fr, T)
+        y = ops.norm_act(h2, 1, 1, g2.detach(), be2.detach(), _lib.ACT_GLU, layer_scale=scale.detach(), res=x)
+        st2 = ops._last_stats
+        ctx.save_for_backward(x, h1, a, h2, st1, st2, w1p, w2p, g1p, be1p, g2, be2, scale)
+        ctx.cfg = (lib, dilation, H, df1, dt1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h1, a, h2, st1, st2, w1p, w2p, g1p, be1p, g2, be2, scale = ctx.saved_tensors
+        lib, dilation, H, df1, dt1 = ctx.cfg
+        ops = Ops(lib)
+        dev = x.device
+        B, Fr, T, Cc = x.shape
+        k = w1p.shape[2]
+        dy = dy.contiguous()
+        dh2, dg2, dbe2, dls = bw.norm_bwd(ops, h2, dy, st2, 1, 1, g2.detach(), be2.detach(), _lib.ACT_GLU, layer_scale=scale.detach())
+        dw2, db2 = bw.conv_wgrad(ops, dh2, a, [0], [0])
+        da = ops.conv(bw.dgrad_conv1d(w2p, 1, 0, dev), dh2, None, B, Fr, Fr, T)
+        dh1, dg1, dbe1, _ = bw.norm_bwd(ops, h1, da, st1, 1, 1, g1p, be1p, _lib.ACT_GELU, stat_count=T * H)
+        dw1, db1 = bw.conv_wgrad(ops, dh1, x, df1, dt1)
+        dx = ops.conv(bw.dgrad_conv1d(w1p, dilation, dilation * (k // 2), dev), dh1, None, B, Fr, Fr, T, res=dy)   # + the skip path
+        return (dx, dw1.permute(1, 2, 0)[:H].contiguous(), db1[:H], dg1[:H], dbe1[:H],
+                dw2.permute(1, 2, 0)[:, :H].contiguous(), db2, dg2, dbe2, dls, None, None)

@@ -75,7 +75,7 @@ def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True):
     return dw, db
 
 
-def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, eps=1e-5):
+def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, eps=1e-5, stat_count=None):
     """Backward of aero_norm_apply (GroupNorm + GELU / GLU(+LayerScale) / identity).  x: the norm's input fp16 [B,F,T,C]; stats: the
     forward statistics (fp64 sum / sum of squares per (item, group)); dy: gradient of the output.  Returns
     (dx fp16 [B,F,T,C], dgamma, dbeta fp32 [C], dlayer_scale fp32 [C/2] or None)."""
@@ -89,7 +89,7 @@ def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, 
     d.dx_b, d.dx_f, d.dx_t = _strides4(dx)
     d.B, d.F, d.T, d.C, d.G, d.per_row, d.eps = B, F, T, Cc, G, int(per_row), eps
     d.stats = _ptr(stats)
-    d.stat_count = float((1 if per_row == 1 else F) * T * (Cc // G))
+    d.stat_count = float((1 if per_row == 1 else F) * T * (Cc // G)) if stat_count is None else float(stat_count)
     d.gamma, d.beta, d.layer_scale, d.act = _ptr(gamma), _ptr(beta), _ptr(layer_scale), act
     sums = torch.zeros_like(stats)
     dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device)

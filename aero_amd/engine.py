@@ -211,7 +211,7 @@ class Ops:
 
     # -- GroupNorm + activation ----------------------------------------------------------------
     def norm_act(self, x, G, per_row, gamma, beta, act, snake_a=None, layer_scale=None, res=None, normalize=True,
-                 f_lo=0, f_cnt=None, eps=1e-5, dst=None, stats=None, dst_strides=None):
+                 f_lo=0, f_cnt=None, eps=1e-5, dst=None, stats=None, dst_strides=None, stat_count=None):
         """x [B,F,T,C] fp16.  Statistics over all F rows; output only rows [f_lo, f_lo+f_cnt).
         per_row: 0 = per (b, group), 1 = per (b, f) row and group, 2 = per group over the whole batch (BatchNorm, training)."""
         B, F, T, Cc = x.shape
@@ -221,6 +221,8 @@ class Ops:
         d.B, d.F, d.T, d.C, d.G, d.per_row, d.eps = B, F, T, Cc, G, int(per_row), eps
         if normalize:
             d.stat_count = float((1 if per_row == 1 else (B * F if per_row == 2 else F)) * T * (Cc // G))
+            if stat_count is not None:              # elements per (item, group) when some channels are zero padding
+                d.stat_count = float(stat_count)
             if stats is None:                       # not already accumulated by the producing conv's epilogue
                 stats = self.new_stats(B, F, G, per_row, x.device)
                 d.stats = _ptr(stats)

@@ -612,3 +612,67 @@ def case_norm_bwd(lib, dev, C_, G, per_row, act, Fr, T, B=2, layer_scale=False, 
     assert rel_l2(dg.cpu(), grads[1]) < TOL16 and rel_l2(dbt.cpu(), grads[2]) < TOL16
     if lr is not None:
         assert rel_l2(dls.cpu(), grads[3]) < TOL16
+
+
+def case_block_autograd(lib, dev, kind, Cin, Cout, G, act, Fin, T, B=2, seed=100):
+    """conv -> GroupNorm -> GELU / GLU as ONE torch.autograd.Function on the HIP kernels (aero_amd/autograd.py): loss.backward()
+    through it gives the same input / parameter gradients as the fp32 torch composition (HEncLayer / HDecLayer blocks)."""
+    from aero_amd.autograd import ConvNormAct
+    if kind[0] == 'conv2d':
+        w = _rand((Cout, Cin, 2 * kind[1] + 1, 2 * kind[2] + 1), seed, 1.0 / math.sqrt(Cin * (2 * kind[1] + 1) * (2 * kind[2] + 1)))
+        ref_conv = lambda v, ww, bb: F.conv2d(v, ww, bb, padding=(kind[1], kind[2]))                      # noqa: E731
+    elif kind[0] == 'fstride':
+        K, s = 2 * kind[1], kind[1]
+        w = _rand((Cout, Cin, K, 1), seed, 1.0 / math.sqrt(Cin * K))
+        ref_conv = lambda v, ww, bb: F.conv2d(v, ww, bb, stride=(s, 1), padding=((K - s) // 2, 0))        # noqa: E731
+    else:
+        K, s = 2 * kind[1], kind[1]
+        w = _rand((Cin, Cout, K, 1), seed, 1.0 / math.sqrt(Cin * K / s))
+        p_ = (K - s) // 2
+        ref_conv = lambda v, ww, bb: F.conv_transpose2d(v, ww, bb, stride=(s, 1))[:, :, p_:-p_]         # noqa: E731
+    w = q16(w)
+    b = _rand((Cout,), seed + 1) * 0.1
+    gamma, beta = _rand((Cout,), seed + 2) * 0.3 + 1.0, _rand((Cout,), seed + 3) * 0.2
+    x = q16(_rand((B, Cin, Fin, T), seed + 4))
+    actf = {'gelu': F.gelu, 'glu': lambda v: F.glu(v, dim=1)}[act]
+    # reference: fp32 autograd
+    pr = [t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta)]
+    yr = actf(F.group_norm(ref_conv(pr[0], pr[1], pr[2]), G, pr[3], pr[4]))
+    gy = q16(_rand(tuple(yr.shape), seed + 5))
+    (yr * gy).sum().backward()
+    # device: the Function
+    pd = [cl(x).to(dev).requires_grad_(True)] + [t.clone().to(dev).requires_grad_(True) for t in (w, b, gamma, beta)]
+    yd = ConvNormAct.apply(pd[0], pd[1], pd[2], pd[3], pd[4], lib, kind, G, act)
+    assert rel_l2(uncl(yd.detach().cpu()), yr.detach()) < TOL16
+    (yd.float() * cl(gy).to(dev).float()).sum().backward()
+    assert rel_l2(uncl(pd[0].grad.cpu()), pr[0].grad) < 3 * TOL16, rel_l2(uncl(pd[0].grad.cpu()), pr[0].grad)
+    for got, ref, nm in zip(pd[1:], pr[1:], ('weight', 'bias', 'gamma', 'beta')):
+        assert rel_l2(got.grad.cpu(), ref.grad) < 3 * TOL16, (nm, rel_l2(got.grad.cpu(), ref.grad))
+
+
+def case_dconv_autograd(lib, dev, Cc, k, dil, Fr, T, B=2, compress=4, seed=110):
+    """a residual DConv layer (modules.py:206-244, no LSTM / attention) as one Function on the HIP kernels vs fp32 torch autograd"""
+    from aero_amd.autograd import DConvLayer
+    H = Cc // compress
+    w1 = q16(_rand((H, Cc, k), seed, 1.0 / math.sqrt(Cc * k)))
+    w2 = q16(_rand((2 * Cc, H, 1), seed + 1, 1.0 / math.sqrt(H)))
+    b1, b2 = _rand((H,), seed + 2) * 0.1, _rand((2 * Cc,), seed + 3) * 0.1
+    g1, be1 = _rand((H,), seed + 4) * 0.3 + 1.0, _rand((H,), seed + 5) * 0.2
+    g2, be2 = _rand((2 * Cc,), seed + 6) * 0.3 + 1.0, _rand((2 * Cc,), seed + 7) * 0.2
+    scale = _rand((Cc,), seed + 8).abs() * 0.5 + 0.1
+    x = q16(_rand((B, Cc, Fr, T), seed + 9))
+    params = (w1, b1, g1, be1, w2, b2, g2, be2, scale)
+    pr = [t.clone().requires_grad_(True) for t in (x,) + params]
+    xr = pr[0].permute(0, 2, 1, 3).reshape(B * Fr, Cc, T)
+    hr = F.gelu(F.group_norm(F.conv1d(xr, pr[1], pr[2], dilation=dil, padding=dil * (k // 2)), 1, pr[3], pr[4]))
+    hr = F.glu(F.group_norm(F.conv1d(hr, pr[5], pr[6]), 1, pr[7], pr[8]), dim=1)
+    yr = (xr + pr[9].view(1, -1, 1) * hr).view(B, Fr, Cc, T).permute(0, 2, 1, 3)
+    gy = q16(_rand(tuple(yr.shape), seed + 10))
+    (yr * gy).sum().backward()
+    pd = [cl(x).to(dev).requires_grad_(True)] + [t.clone().to(dev).requires_grad_(True) for t in params]
+    yd = DConvLayer.apply(*pd, lib, dil)
+    assert rel_l2(uncl(yd.detach().cpu()), yr.detach()) < TOL16
+    (yd.float() * cl(gy).to(dev).float()).sum().backward()
+    assert rel_l2(uncl(pd[0].grad.cpu()), pr[0].grad) < 3 * TOL16, rel_l2(uncl(pd[0].grad.cpu()), pr[0].grad)
+    for got, ref, nm in zip(pd[1:], pr[1:], ('w1', 'b1', 'g1', 'be1', 'w2', 'b2', 'g2', 'be2', 'scale')):
+        assert rel_l2(got.grad.cpu(), ref.grad) < 3 * TOL16, (nm, rel_l2(got.grad.cpu(), ref.grad))

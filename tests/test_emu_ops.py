@@ -240,3 +240,15 @@ def test_wgrad_convtr(emu, kw):
                                 dict(C_=48, G=4, per_row=0, act='none', Fr=2, T=300)])
 def test_norm_bwd(emu, kw):
     oc.case_norm_bwd(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(kind=('conv2d', 1, 1), Cin=16, Cout=32, G=4, act='glu', Fin=4, T=40),
+                                dict(kind=('fstride', 4), Cin=16, Cout=32, G=4, act='gelu', Fin=16, T=33),
+                                dict(kind=('convtr', 4), Cin=32, Cout=32, G=4, act='gelu', Fin=4, T=33)])
+def test_block_autograd(emu, kw):
+    oc.case_block_autograd(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=48, k=3, dil=1, Fr=3, T=40), dict(Cc=96, k=3, dil=2, Fr=2, T=33)])
+def test_dconv_autograd(emu, kw):
+    oc.case_dconv_autograd(emu, DEV, **kw)

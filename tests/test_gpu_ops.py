@@ -216,3 +216,15 @@ def test_wgrad_convtr(lib, kw):
                                 dict(C_=384, G=4, per_row=0, act='glu', Fr=4, T=501), dict(C_=48, G=4, per_row=0, act='none', Fr=2, T=300)])
 def test_norm_bwd(lib, kw):
     oc.case_norm_bwd(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(kind=('conv2d', 1, 1), Cin=96, Cout=192, G=4, act='glu', Fin=4, T=501),
+                                dict(kind=('fstride', 4), Cin=48, Cout=96, G=4, act='gelu', Fin=16, T=501),
+                                dict(kind=('convtr', 4), Cin=96, Cout=48, G=4, act='gelu', Fin=4, T=501)])
+def test_block_autograd(lib, kw):
+    oc.case_block_autograd(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(Cc=48, k=3, dil=1, Fr=16, T=501), dict(Cc=96, k=3, dil=2, Fr=8, T=501)])
+def test_dconv_autograd(lib, kw):
+    oc.case_dconv_autograd(lib, DEV, **kw)
