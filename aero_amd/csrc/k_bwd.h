@@ -186,6 +186,7 @@ struct AeroNormBwdK {
     int tchunk, apply;
 };
 
+template <bool APPLY>
 __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     __shared__ float red_c[3][2048];                           // dgamma, dbeta (all C channels), dlayer_scale (C/2)
     __shared__ float red_g[2][256];                            // S1, S2 per group
@@ -196,112 +197,181 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     const int TY = 256 / vpp;
     const int tid = threadIdx.x;
     const int v = tid % vpp, ty = tid / vpp;
-    const int b = blockIdx.z, f = blockIdx.y;
-    const int item = d.per_row == 1 ? b * d.F + f : b;
     const int gs = d.C / d.G;
-    const bool apply = p.apply != 0;
-    if (!apply) {
+    const int nh = glu ? 2 : 1;
+    if (!APPLY) {
         for (int i = tid; i < d.C; i += 256) { red_c[0][i] = 0.f; red_c[1][i] = 0.f; }
         for (int i = tid; i < Cout; i += 256) red_c[2][i] = 0.f;
+    }
+    float dgam[2][8], dbet[2][8], dls[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dgam[h][i] = dbet[h][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dls[i] = 0.f;
+    // work items (b, f, time chunk), grid-strided: the parameter gradients stay in registers across a block's items and reach
+    // memory once per block (one block per item made 8192 blocks x 2C same-line atomics: 12 ms for the last decoder's norm)
+    const int ntch = (d.T + p.tchunk - 1) / p.tchunk;
+    const int nwork = d.B * d.F * ntch;
+    for (int work = (int)blockIdx.x; work < nwork; work += (int)gridDim.x) {
+    const int tch = work % ntch;
+    const int f = (work / ntch) % d.F;
+    const int b = work / (ntch * d.F);
+    const int item = d.per_row == 1 ? b * d.F + f : b;
+    if (!APPLY) {
+        __syncthreads();                                       // the previous item's group sums have been flushed
         for (int i = tid; i < d.G; i += 256) { red_g[0][i] = 0.f; red_g[1][i] = 0.f; }
         __syncthreads();
     }
-    const int nh = glu ? 2 : 1;
-    const double inv_count = 1.0 / d.stat_count;
-    // per owned channel (both halves): A = rstd * gamma, Bc = beta - mean * rstd * gamma  (u = x * A + Bc),  rstd, -mean * rstd,
-    // gamma, group index, and for `apply` the group terms  S1/N, S2/N
-    float rs[2][8], mr[2][8], gm[2][8], bt[2][8], k1[2][8], k2[2][8];
+    const float inv_count = (float)(1.0 / d.stat_count);
+    // per owned channel (both halves): xh = x * rs + mr,  u = xh * gm + bt;  for APPLY the group terms k1 = S1/N, k2 = S2/N.
+    // The statistics become (rstd, -mean * rstd) once per GROUP the vector touches (at most two per half): fp64 only for
+    // E[x^2] - mean^2, then a float rsqrt with one Newton step (as aero_norm_apply_kernel)
+    float rs[2][8], mr[2][8], gm[2][8], bt[2][8], k1[2][8], k2[2][8], ls[8];
     int grp[2][8];
     if (ty < TY) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h >= nh) continue;
+            int g_prev = -1;
+            float g_r = 0.f, g_m = 0.f, g_k1 = 0.f, g_k2 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = h * Cout + v * 8 + i;
                 const int g = c / gs;
-                const double* st = d.stats + ((int64_t)item * d.G + g) * 2;
-                const double mean = st[0] * inv_count;
-                double var = st[1] * inv_count - mean * mean;
-                if (var < 0) var = 0;
-                const float r = (float)(1.0 / sqrt(var + (double)d.eps));
-                rs[h][i] = r;
-                mr[h][i] = -(float)mean * r;
+                if (g != g_prev) {
+                    g_prev = g;
+                    const double* st = d.stats + ((int64_t)item * d.G + g) * 2;
+                    const double mean = st[0] / d.stat_count;
+                    double var = st[1] / d.stat_count - mean * mean;
+                    if (var < 0) var = 0;
+                    const float vf = (float)var + d.eps;
+                    float r = aero_rsqrt(vf);
+                    r = r * (1.5f - 0.5f * vf * r * r);
+                    g_r = r;
+                    g_m = -(float)mean * r;
+                    if (APPLY) {
+                        const double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
+                        g_k1 = (float)sm[0] * inv_count;
+                        g_k2 = (float)sm[1] * inv_count;
+                    }
+                }
+                rs[h][i] = g_r;
+                mr[h][i] = g_m;
+                k1[h][i] = g_k1;
+                k2[h][i] = g_k2;
                 gm[h][i] = d.gamma ? d.gamma[c] : 1.f;
                 bt[h][i] = d.beta ? d.beta[c] : 0.f;
                 grp[h][i] = g;
-                k1[h][i] = k2[h][i] = 0.f;
-                if (apply) {
-                    const double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
-                    k1[h][i] = (float)(sm[0] * inv_count);
-                    k2[h][i] = (float)(sm[1] * inv_count);
-                }
             }
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ls[i] = (glu && d.layer_scale) ? d.layer_scale[v * 8 + i] : 1.f;
     }
-    float dgam[2][8], dbet[2][8], dls[8], s1[2][8], s2[2][8];
+    float s1[2][8], s2[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dgam[h][i] = dbet[h][i] = s1[h][i] = s2[h][i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dls[i] = 0.f;
-    const int t0 = blockIdx.x * p.tchunk;
+        for (int i = 0; i < 8; ++i) s1[h][i] = s2[h][i] = 0.f;
+    const int t0 = tch * p.tchunk;
     const int t1 = t0 + p.tchunk < d.T ? t0 + p.tchunk : d.T;
     const h16* xs = (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)f * d.x_f + v * 8;
     const h16* dys = (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)f * d.dy_f + v * 8;
     h16* dxs = (h16*)d.dx + (int64_t)b * d.dx_b + (int64_t)f * d.dx_f + v * 8;
-    if (ty < TY) {
-        for (int t = t0 + ty; t < t1; t += TY) {
-            const h16x8 xa = *(const h16x8*)(xs + (int64_t)t * d.x_t);
-            h16x8 xg = xa;
-            if (glu) xg = *(const h16x8*)(xs + (int64_t)t * d.x_t + Cout);
-            const h16x8 dyv = *(const h16x8*)(dys + (int64_t)t * d.dy_t);
-            h16x8 oa, og;
+    // one time step
+    auto elem = [&](const h16x8& xa, const h16x8& xg, const h16x8& dyv, h16x8& oa, h16x8& og) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float xh0 = (float)xa[i] * rs[0][i] + mr[0][i];
-                const float u0 = xh0 * gm[0][i] + bt[0][i];
-                const float g_out = (float)dyv[i];
-                float du0, du1 = 0.f, xh1 = 0.f;
-                if (glu) {
-                    xh1 = (float)xg[i] * rs[1][i] + mr[1][i];
-                    const float u1 = xh1 * gm[1][i] + bt[1][i];
-                    const float sg = aero_sigmoid(u1);
-                    const float ls = d.layer_scale ? d.layer_scale[v * 8 + i] : 1.f;
-                    const float gy = g_out * ls;
-                    du0 = gy * sg;
-                    du1 = gy * u0 * sg * (1.f - sg);
-                    dls[i] += g_out * u0 * sg;
-                } else if (d.act == AERO_ACT_GELU) {
-                    const float cdf = 0.5f * (1.0f + aero_erf(u0 * 0.70710678118654752f));
-                    const float pdf = 0.3989422804014327f * aero_fast_exp(-0.5f * u0 * u0);
-                    du0 = g_out * (cdf + u0 * pdf);
-                } else if (d.act == AERO_ACT_RELU) {
-                    du0 = u0 > 0.f ? g_out : 0.f;
-                } else {
-                    du0 = g_out;
-                }
-                const float dxh0 = du0 * gm[0][i], dxh1 = du1 * gm[1][i];
-                if (!apply) {
-                    dgam[0][i] += du0 * xh0; dbet[0][i] += du0;
-                    s1[0][i] += dxh0; s2[0][i] += dxh0 * xh0;
-                    if (glu) {
-                        dgam[1][i] += du1 * xh1; dbet[1][i] += du1;
-                        s1[1][i] += dxh1; s2[1][i] += dxh1 * xh1;
-                    }
-                } else {
-                    oa[i] = (h16)(rs[0][i] * (dxh0 - k1[0][i] - xh0 * k2[0][i]));
-                    if (glu) og[i] = (h16)(rs[1][i] * (dxh1 - k1[1][i] - xh1 * k2[1][i]));
-                }
+        for (int i = 0; i < 8; ++i) {
+            const float xh0 = (float)xa[i] * rs[0][i] + mr[0][i];
+            const float u0 = xh0 * gm[0][i] + bt[0][i];
+            const float g_out = (float)dyv[i];
+            float du0, du1 = 0.f, xh1 = 0.f;
+            if (glu) {
+                xh1 = (float)xg[i] * rs[1][i] + mr[1][i];
+                const float u1 = xh1 * gm[1][i] + bt[1][i];
+                const float sg = aero_sigmoid(u1);
+                const float gy = g_out * ls[i];
+                du0 = gy * sg;
+                du1 = gy * u0 * sg * (1.f - sg);
+                if (!APPLY) dls[i] += g_out * u0 * sg;
+            } else if (d.act == AERO_ACT_GELU) {
+                const float cdf = 0.5f * (1.0f + aero_erf(u0 * 0.70710678118654752f));
+                const float pdf = 0.3989422804014327f * aero_fast_exp(-0.5f * u0 * u0);
+                du0 = g_out * (cdf + u0 * pdf);
+            } else if (d.act == AERO_ACT_RELU) {
+                du0 = u0 > 0.f ? g_out : 0.f;
+            } else {
+                du0 = g_out;
             }
-            if (apply) {
-                *(h16x8*)(dxs + (int64_t)t * d.dx_t) = oa;
-                if (glu) *(h16x8*)(dxs + (int64_t)t * d.dx_t + Cout) = og;
+            const float dxh0 = du0 * gm[0][i], dxh1 = du1 * gm[1][i];
+            if (!APPLY) {
+                dgam[0][i] += du0 * xh0; dbet[0][i] += du0;
+                s1[0][i] += dxh0; s2[0][i] += dxh0 * xh0;
+                if (glu) {
+                    dgam[1][i] += du1 * xh1; dbet[1][i] += du1;
+                    s1[1][i] += dxh1; s2[1][i] += dxh1 * xh1;
+                }
+            } else {
+                oa[i] = (h16)(rs[0][i] * (dxh0 - k1[0][i] - xh0 * k2[0][i]));
+                if (glu) og[i] = (h16)(rs[1][i] * (dxh1 - k1[1][i] - xh1 * k2[1][i]));
+            }
+        }
+    };
+    if (ty < TY) {
+        // UNR steps per trip, every load issued before the first use
+        constexpr int UNR = 4;
+        for (int tb = t0 + ty; tb < t1; tb += UNR * TY) {
+            h16x8 xa[UNR], xg[UNR], dyv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int t = tb + u * TY;
+                const int tc = t < t1 ? t : t1 - 1;           // clamped address; the result of a step past the end is dropped
+                xa[u] = *(const h16x8*)(xs + (int64_t)tc * d.x_t);
+                xg[u] = glu ? *(const h16x8*)(xs + (int64_t)tc * d.x_t + Cout) : xa[u];
+                dyv[u] = *(const h16x8*)(dys + (int64_t)tc * d.dy_t);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int t = tb + u * TY;
+                if (t >= t1) break;
+                h16x8 oa, og;
+                elem(xa[u], xg[u], dyv[u], oa, og);
+                if (APPLY) {
+                    *(h16x8*)(dxs + (int64_t)t * d.dx_t) = oa;
+                    if (glu) *(h16x8*)(dxs + (int64_t)t * d.dx_t + Cout) = og;
+                }
             }
         }
     }
-    if (apply) return;
+    if (APPLY) continue;
+    if (ty < TY) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h >= nh) continue;
+            // the vector's group sums: one LDS atomic per group it touches, not per channel
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a1 += s1[h][i];
+                a2 += s2[h][i];
+                if (i == 7 || grp[h][i + 1 < 8 ? i + 1 : 7] != grp[h][i]) {
+                    atomicAdd(&red_g[0][grp[h][i]], a1);
+                    atomicAdd(&red_g[1][grp[h][i]], a2);
+                    a1 = a2 = 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int g = tid; g < d.G; g += 256) {
+        double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
+        atomicAdd(sm, (double)red_g[0][g]);
+        atomicAdd(sm + 1, (double)red_g[1][g]);
+    }
+    }   // work items
+    if (APPLY) return;
+    __syncthreads();
     if (ty < TY) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -311,8 +381,6 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
                 const int c = h * Cout + v * 8 + i;
                 atomicAdd(&red_c[0][c], dgam[h][i]);
                 atomicAdd(&red_c[1][c], dbet[h][i]);
-                atomicAdd(&red_g[0][grp[h][i]], s1[h][i]);
-                atomicAdd(&red_g[1][grp[h][i]], s2[h][i]);
             }
         }
         if (glu && d.dlayer_scale) {
@@ -327,11 +395,6 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     }
     if (glu && d.dlayer_scale)
         for (int c = tid; c < Cout; c += 256) atomicAdd(d.dlayer_scale + c, red_c[2][c]);
-    for (int g = tid; g < d.G; g += 256) {
-        double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
-        atomicAdd(sm, (double)red_g[0][g]);
-        atomicAdd(sm + 1, (double)red_g[1][g]);
-    }
 }
 
 static int aero_norm_bwd_launch(const aero_norm_bwd_desc* d, int apply, hipStream_t stream, const char** err) {
@@ -350,10 +413,13 @@ static int aero_norm_bwd_launch(const aero_norm_bwd_desc* d, int apply, hipStrea
     p.d = *d;
     p.apply = apply;
     const int TY = 256 / (Cout / 8);
-    int tchunk = TY * 16;                                      // 16 time steps per thread
+    int tchunk = TY * 16;                                      // 16 time steps per thread (four trips of four)
     if (tchunk > d->T) tchunk = d->T;
     p.tchunk = tchunk;
-    dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)d->F, (unsigned)d->B);
-    AERO_LAUNCH(aero_norm_bwd_kernel, grid, dim3(256), stream, p);
+    const long nwork = (long)((d->T + tchunk - 1) / tchunk) * d->F * d->B;
+    if (nwork > 0x7fffffffL) { *err = "norm_bwd: too many work items"; return AERO_ERR_ARG; }
+    dim3 grid((unsigned)(apply ? nwork : (nwork < 1024 ? nwork : 1024)));
+    if (apply) AERO_LAUNCH(aero_norm_bwd_kernel<true>, grid, dim3(256), stream, p);
+    else AERO_LAUNCH(aero_norm_bwd_kernel<false>, grid, dim3(256), stream, p);
     return AERO_OK;
 }

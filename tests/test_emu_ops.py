@@ -237,7 +237,8 @@ def test_wgrad_convtr(emu, kw):
 
 @pytest.mark.parametrize('kw', [dict(C_=48, G=4, per_row=0, act='gelu', Fr=4, T=50), dict(C_=96, G=1, per_row=1, act='glu', Fr=3, T=37, layer_scale=True),
                                 dict(C_=32, G=1, per_row=1, act='gelu', Fr=2, T=20), dict(C_=64, G=4, per_row=0, act='glu', Fr=3, T=33),
-                                dict(C_=48, G=4, per_row=0, act='none', Fr=2, T=300)])
+                                dict(C_=48, G=4, per_row=0, act='none', Fr=2, T=300),
+                                dict(C_=32, G=1, per_row=1, act='glu', Fr=650, T=8)])     # > 1024 work items: blocks loop over several
 def test_norm_bwd(emu, kw):
     oc.case_norm_bwd(emu, DEV, **kw)
 
