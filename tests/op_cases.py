@@ -676,3 +676,66 @@ def case_dconv_autograd(lib, dev, Cc, k, dil, Fr, T, B=2, compress=4, seed=110):
     assert rel_l2(uncl(pd[0].grad.cpu()), pr[0].grad) < 3 * TOL16, rel_l2(uncl(pd[0].grad.cpu()), pr[0].grad)
     for got, ref, nm in zip(pd[1:], pr[1:], ('w1', 'b1', 'g1', 'be1', 'w2', 'b2', 'g2', 'be2', 'scale')):
         assert rel_l2(got.grad.cpu(), ref.grad) < 3 * TOL16, (nm, rel_l2(got.grad.cpu(), ref.grad))
+
+
+def case_train_steps(lib, dev, steps=4, B=2, Fin=16, T=48, seed=120):
+    """f1 pieces together: a strided-conv block -> residual DConv layer -> 1x1 rewrite block (an encoder layer of aero.py:86-101
+    without FTB / LSTM / attention), trained for a few steps -- forward and backward through aero_amd.autograd on the HIP kernels,
+    fused FlatAdam step -- against the fp32 torch modules under torch.optim.Adam: same loss trajectory, same parameters."""
+    from aero_amd.autograd import ConvNormAct, DConvLayer
+    from aero_amd.optim import FlatAdam
+    C0, C1 = 16, 32
+    H = C1 // 4
+    shapes = dict(w_a=(C1, C0, 8, 1), b_a=(C1,), g_a=(C1,), be_a=(C1,),
+                  w1=(H, C1, 3), b1=(H,), g1=(H,), be1=(H,), w2=(2 * C1, H, 1), b2=(2 * C1,), g2=(2 * C1,), be2=(2 * C1,), sc=(C1,),
+                  w_r=(2 * C1, C1, 1, 1), b_r=(2 * C1,), g_r=(2 * C1,), be_r=(2 * C1,))
+    init = {}
+    for i, (k, shp) in enumerate(shapes.items()):
+        if k.startswith('g'):
+            init[k] = _rand(shp, seed + i) * 0.1 + 1.0
+        elif k == 'sc':
+            init[k] = _rand(shp, seed + i).abs() * 0.3 + 0.2
+        elif k.startswith('w'):
+            init[k] = q16(_rand(shp, seed + i, 1.0 / math.sqrt(shp[1] * shp[2])))
+        else:
+            init[k] = _rand(shp, seed + i) * 0.1
+    x = q16(_rand((B, C0, Fin, T), seed + 50))
+    tgt = _rand((B, C1, Fin // 4, T), seed + 51)
+
+    def ref_net(P, v):
+        h = F.gelu(F.group_norm(F.conv2d(v, P['w_a'], P['b_a'], stride=(4, 1), padding=(2, 0)), 4, P['g_a'], P['be_a']))
+        Bq, Cq, Fq, Tq = h.shape
+        r = h.permute(0, 2, 1, 3).reshape(Bq * Fq, Cq, Tq)
+        u = F.gelu(F.group_norm(F.conv1d(r, P['w1'], P['b1'], padding=1), 1, P['g1'], P['be1']))
+        u = F.glu(F.group_norm(F.conv1d(u, P['w2'], P['b2']), 1, P['g2'], P['be2']), dim=1)
+        h = (r + P['sc'].view(1, -1, 1) * u).view(Bq, Fq, Cq, Tq).permute(0, 2, 1, 3)
+        return F.glu(F.group_norm(F.conv2d(h, P['w_r'], P['b_r']), 4, P['g_r'], P['be_r']), dim=1)
+
+    def dev_net(P, v):
+        h = ConvNormAct.apply(v, P['w_a'], P['b_a'], P['g_a'], P['be_a'], lib, ('fstride', 4), 4, 'gelu')
+        h = DConvLayer.apply(h, P['w1'], P['b1'], P['g1'], P['be1'], P['w2'], P['b2'], P['g2'], P['be2'], P['sc'], lib, 1)
+        return ConvNormAct.apply(h, P['w_r'], P['b_r'], P['g_r'], P['be_r'], lib, ('conv2d', 0, 0), 4, 'glu')
+
+    Pr = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+    Pd = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in init.items()}
+    opt_r = torch.optim.Adam(list(Pr.values()), lr=2e-3, betas=(0.9, 0.999))
+    opt_d = FlatAdam(list(Pd.values()), lr=2e-3, betas=(0.9, 0.999), lib=lib)
+    xd, tgd = cl(x).to(dev), cl(tgt).to(dev).float()
+    losses = []
+    for it in range(steps):
+        opt_r.zero_grad()
+        lr_ = ((ref_net(Pr, x) - tgt) ** 2).mean()
+        lr_.backward()
+        opt_r.step()
+        opt_d.zero_grad()
+        ld = ((dev_net(Pd, xd).float() - tgd) ** 2).mean()          # (the loss itself is host-side code, as in the reference's solver)
+        ld.backward()
+        opt_d.step()
+        losses.append((float(lr_.detach()), float(ld.detach())))
+    for a, b_ in losses:
+        assert abs(a - b_) <= 2e-2 * abs(a), losses
+    assert losses[-1][0] < losses[0][0] and losses[-1][1] < losses[0][1], losses
+    for k in init:
+        moved = (Pr[k].detach() - init[k]).norm()
+        err = (Pd[k].detach().cpu() - Pr[k].detach()).norm()
+        assert err <= 0.15 * moved + 1e-6, (k, float(err), float(moved))       # the UPDATE agrees, not just the (mostly unchanged) value

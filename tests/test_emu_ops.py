@@ -253,3 +253,7 @@ def test_block_autograd(emu, kw):
 @pytest.mark.parametrize('kw', [dict(Cc=48, k=3, dil=1, Fr=3, T=40), dict(Cc=96, k=3, dil=2, Fr=2, T=33)])
 def test_dconv_autograd(emu, kw):
     oc.case_dconv_autograd(emu, DEV, **kw)
+
+
+def test_train_steps_match_torch(emu):
+    oc.case_train_steps(emu, DEV)

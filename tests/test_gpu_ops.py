@@ -228,3 +228,7 @@ def test_block_autograd(lib, kw):
 @pytest.mark.parametrize('kw', [dict(Cc=48, k=3, dil=1, Fr=16, T=501), dict(Cc=96, k=3, dil=2, Fr=8, T=501)])
 def test_dconv_autograd(lib, kw):
     oc.case_dconv_autograd(lib, DEV, **kw)
+
+
+def test_train_steps_match_torch(lib):
+    oc.case_train_steps(lib, DEV)
