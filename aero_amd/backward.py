@@ -55,7 +55,7 @@ import ctypes as C  # noqa: E402
 from .engine import _ptr, _strides4  # noqa: E402
 
 
-def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True):
+def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None):
     """dy fp16 [B,Fout,T,M], x fp16 [B,Fin,T,C] (channels-last) -> (dw fp32 [ntaps, M, C], db fp32 [M] or None):
     dw[j][m][c] = sum dy[b,fo,t,m] * x[b, fo*fstride + df[j], t + dt[j], c]  (aero_conv_wgrad)."""
     B, Fout, T, M = dy.shape
@@ -71,6 +71,12 @@ def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True):
     d.B, d.Fin, d.Fout, d.T, d.M, d.C, d.ntaps, d.fstride = B, Fin, Fout, T, M, Cc, len(df), fstride
     for i, (a, b_) in enumerate(zip(df, dt)):
         d.df[i], d.dt[i] = a, b_
+    if nslab is None:                           # as many row chunks as the kernel would like (4096 blocks / tiles), within 1 GiB
+        tiles = ((M + 127) // 128) * ((Cc + 127) // 128) * len(df)
+        nslab = max(1, min(-(-4096 // tiles), 256, B * Fout, (1 << 30) // (len(df) * M * Cc * 4)))
+    if nslab:                                   # per-chunk partial slabs added in fixed order (deterministic); nslab = 0: fp32 atomics
+        slabs = torch.empty(nslab, len(df), M, Cc, dtype=torch.float32, device=dy.device)
+        d.slabs, d.nslab = _ptr(slabs), nslab
     ops.lib.call('aero_conv_wgrad', C.byref(d), ops.stream(dy))
     return dw, db
 

@@ -24,7 +24,7 @@
 // torch's own weight gradients do).
 struct AeroWgradK {
     aero_wgrad_desc d;
-    int nmt, nct, RC, nchunk;
+    int nmt, nct, RC, nchunk, noswz;
 };
 
 static __device__ __forceinline__ void aero_transpose8x8(const h16x8* r, h16x8* c) {
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void aero_conv_wgrad_kernel(AeroWgradK p) {
     __shared__ AERO_LDS_ALIGN h16 FR[2][2][8][64 * 8];        // [operand][k half][j][lane * 8]: 32 KiB
     const aero_wgrad_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
-    int id = (int)blockIdx.x;
+    // consecutive tiles of a row chunk share dy / x slices: give each XCD (private L2) a contiguous run of them
+    int id = (p.noswz & 1) ? (int)blockIdx.x : aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const int mt = id % p.nmt; id /= p.nmt;
     const int ct = id % p.nct; id /= p.nct;
     const int tap = id % d.ntaps;
@@ -128,6 +129,22 @@ __global__ __launch_bounds__(256) void aero_conv_wgrad_kernel(AeroWgradK p) {
         }
     }
     // accumulator (a, j')[i] of lane l: m = m0 + 8 * ((l >> 4) * 4 + i) + 2 * wave + a,  c = c0 + 8 * (l & 15) + j'
+    if (d.slabs) {
+        // this chunk's partial tile -> its own slab with plain 16-byte stores (a lane's eight j' are eight consecutive c);
+        // aero_wgrad_finish_kernel adds the slabs in chunk order: deterministic, and no scattered 4-byte atomics
+        float* sl = d.slabs + ((int64_t)chunk * d.ntaps + tap) * d.M * d.C;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 8 * ((lane >> 4) * 4 + i) + 2 * wave + a;
+                const int cc = c0 + 8 * (lane & 15);
+                if (m < d.M && cc < d.C) {
+                    *(f32x4*)(sl + (int64_t)m * d.C + cc) = (f32x4){acc[a][0][i], acc[a][1][i], acc[a][2][i], acc[a][3][i]};
+                    *(f32x4*)(sl + (int64_t)m * d.C + cc + 4) = (f32x4){acc[a][4][i], acc[a][5][i], acc[a][6][i], acc[a][7][i]};
+                }
+            }
+    } else {
     float* dw = d.dw + (int64_t)tap * d.M * d.C;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -137,12 +154,140 @@ __global__ __launch_bounds__(256) void aero_conv_wgrad_kernel(AeroWgradK p) {
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + 8 * ((lane >> 4) * 4 + i) + 2 * wave + a;
                 const int cc = c0 + 8 * (lane & 15) + j;
-                if (m < d.M && cc < d.C) atomicAdd(dw + (int64_t)m * d.C + cc, acc[a][j][i]);
+                if (m < d.M && cc < d.C && !(p.noswz & 2)) atomicAdd(dw + (int64_t)m * d.C + cc, acc[a][j][i]);
             }
+    }
     if (do_bias && ch_ok) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if (ch + j < d.M) atomicAdd(d.db + ch + j, bsum[j]);
+    }
+}
+
+// 256 (m) x 256 (c) tile on eight waves for the wide layers: the 128 x 128 tile moves 32 KB of operands per 2.1 MFLOP step
+// (64 flop/B: the first decoder's weight gradient would pull 42 GB through L2 -- it ran at 6.6 TB/s of fragment traffic, 427 TF/s);
+// this one moves 64 KB per 8.4 MFLOP.  Same scheme: 512 threads stage one 8 x 8 block each (threads 0-255 dy, 256-511 x; channel
+// half = bit 4 of the octet index), wave w = (m half, c half, j quad) owns j = 4*jq .. 4*jq+3 against all eight j'.
+__global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p) {
+    h16* FR = (h16*)AERO_DYN_SMEM;                             // [operand][half][k half][j][lane * 8]: 64 KiB
+    const aero_wgrad_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    // consecutive tiles of a row chunk share dy / x slices: give each XCD (private L2) a contiguous run of them
+    int id = (p.noswz & 1) ? (int)blockIdx.x : aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const int mt = id % p.nmt; id /= p.nmt;
+    const int ct = id % p.nct; id /= p.nct;
+    const int tap = id % d.ntaps;
+    const int chunk = id / d.ntaps;
+    const int m0 = mt * 256, c0 = ct * 256;
+    const int opnd = tid >> 8, o32 = tid & 31, g8 = (tid >> 5) & 7;
+    const int half = o32 >> 4, o = o32 & 15;
+    const int dtj = d.dt[tap], dfj = d.df[tap];
+    const int nrows = d.B * d.Fout;
+    const int r_lo = chunk * p.RC;
+    const int r_hi = r_lo + p.RC < nrows ? r_lo + p.RC : nrows;
+    const int nT = (d.T + 63) >> 6;
+    const h16* zpv = aero_zero_page;
+    const int ch = (opnd ? c0 : m0) + 128 * half + 8 * o;
+    const bool ch_ok = ch < (opnd ? d.C : d.M);
+    const int mh = wave >> 2, chh = (wave >> 1) & 1, jq = wave & 1;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    const bool do_bias = d.db != nullptr && ct == 0 && tap == 0 && opnd == 0;
+    h16x8 r[8];
+    auto load = [&](int it) {
+        const int row = r_lo + it / nT, t0 = (it % nT) * 64;
+        const int b = row / d.Fout, fo = row - b * d.Fout;
+        const int fi = fo * d.fstride + dfj;
+        const bool row_ok = fi >= 0 && fi < d.Fin;
+        const h16* base = opnd ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f + ch
+                               : (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)fo * d.dy_f + ch;
+        const int64_t st = opnd ? d.x_t : d.dy_t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = t0 + 8 * g8 + i;
+            const int tt = opnd ? t + dtj : t;
+            const bool ok = ch_ok && t < d.T && (!opnd || (row_ok && tt >= 0 && tt < d.T));
+            r[i] = *(const h16x8*)(ok ? base + (int64_t)tt * st : zpv);
+        }
+    };
+    // fragment (operand, half, kh, j) at FR + ((((operand * 2 + half) * 2 + kh) * 8 + j) * 64 + lane) * 8
+    h16* wr = FR + ((((opnd * 2 + half) * 2 + (g8 >> 2)) * 8) * 64 + (o + 16 * (g8 & 3))) * 8;
+    const h16* ra = FR + (((0 * 2 + mh) * 2) * 8 * 64 + lane) * 8;
+    const h16* rb = FR + (((1 * 2 + chh) * 2) * 8 * 64 + lane) * 8;
+    const int nit = (r_hi - r_lo) * nT;
+    if (nit > 0) load(0);
+    for (int it = 0; it < nit; ++it) {
+        h16x8 c[8];
+        aero_transpose8x8(r, c);
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[j] += (float)c[j][e];
+        }
+        if (it) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(h16x8*)(wr + j * 512) = c[j];
+        __syncthreads();
+        if (it + 1 < nit && !(p.noswz & 4)) load(it + 1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            h16x8 af[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = *(const h16x8*)(ra + (kh * 8 + 4 * jq + a) * 512);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const h16x8 bf = *(const h16x8*)(rb + (kh * 8 + j) * 512);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a], bf, acc[a][j], 0, 0, 0);
+            }
+        }
+    }
+    if (d.slabs) {
+        float* sl = d.slabs + ((int64_t)chunk * d.ntaps + tap) * d.M * d.C;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 128 * mh + 8 * ((lane >> 4) * 4 + i) + 4 * jq + a;
+                const int cc = c0 + 128 * chh + 8 * (lane & 15);
+                if (m < d.M && cc < d.C) {
+                    *(f32x4*)(sl + (int64_t)m * d.C + cc) = (f32x4){acc[a][0][i], acc[a][1][i], acc[a][2][i], acc[a][3][i]};
+                    *(f32x4*)(sl + (int64_t)m * d.C + cc + 4) = (f32x4){acc[a][4][i], acc[a][5][i], acc[a][6][i], acc[a][7][i]};
+                }
+            }
+    } else {
+    float* dw = d.dw + (int64_t)tap * d.M * d.C;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 128 * mh + 8 * ((lane >> 4) * 4 + i) + 4 * jq + a;
+                const int cc = c0 + 128 * chh + 8 * (lane & 15) + j;
+                if (m < d.M && cc < d.C && !(p.noswz & 2)) atomicAdd(dw + (int64_t)m * d.C + cc, acc[a][j][i]);
+            }
+    }
+    if (do_bias && ch_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (ch + j < d.M) atomicAdd(d.db + ch + j, bsum[j]);
+    }
+}
+
+// dw[e] += slab_0[e] + slab_1[e] + ... in chunk order (n = ntaps * M * C, a multiple of 4)
+__global__ __launch_bounds__(256) void aero_wgrad_finish_kernel(const float* slabs, int nslab, float* dw, int64_t n) {
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (int64_t)gridDim.x * 1024) {
+        f32x4 v = *(const f32x4*)(dw + e);
+        for (int sidx = 0; sidx < nslab; ++sidx) v += *(const f32x4*)(slabs + (int64_t)sidx * n + e);
+        *(f32x4*)(dw + e) = v;
     }
 }
 
@@ -151,24 +296,40 @@ static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, 
     if (d->ntaps < 1 || d->ntaps > 9 || d->B < 1 || d->Fin < 1 || d->Fout < 1 || d->T < 1 || d->M < 1 || d->C < 1 || d->fstride < 1) {
         *err = "wgrad: bad geometry"; return AERO_ERR_ARG;
     }
+    if (d->slabs && (d->nslab < 1 || ((uintptr_t)d->slabs & 15) || ((uintptr_t)d->dw & 15))) { *err = "wgrad: slabs / dw must be 16-byte aligned, nslab >= 1"; return AERO_ERR_ARG; }
     if ((d->M % 8) || (d->C % 8) || (d->dy_b % 8) || (d->dy_f % 8) || (d->dy_t % 8) || (d->x_b % 8) || (d->x_f % 8) || (d->x_t % 8) ||
         ((uintptr_t)d->dy & 15) || ((uintptr_t)d->x & 15)) {
         *err = "wgrad: channel counts and strides must be multiples of 8 (16-byte aligned channel vectors)"; return AERO_ERR_UNSUPPORTED;
     }
     AeroWgradK p;
     p.d = *d;
-    p.nmt = (d->M + 127) / 128;
-    p.nct = (d->C + 127) / 128;
+    { const char* e = getenv("AERO_WGRAD_ABL"); p.noswz = e ? atoi(e) : 0; }       // ablation bits (timing experiments): 1 no XCD swizzle, 2 no atomics, 4 no loads after the first step
+    // AERO_WGRAD_256: 0 never, 2 whenever both sides are >= 192 channels (tests), default: only the widest layers -- measured
+    // D0 (1536 x 768) 427 -> 510 TF/s, D1 (768 x 384) 380 -> 366: with one 8-wave block per CU the smaller problem has too few tiles
+    const char* e256 = getenv("AERO_WGRAD_256");
+    const int mode = e256 ? atoi(e256) : 1;
+    const bool big = mode && d->M >= 192 && d->C >= 192 && (mode == 2 || (long)d->M * d->C >= 768L * 1024);
+    const int TS = big ? 256 : 128;
+    p.nmt = (d->M + TS - 1) / TS;
+    p.nct = (d->C + TS - 1) / TS;
     const long tiles = (long)p.nmt * p.nct * d->ntaps;
     const int nrows = d->B * d->Fout;
-    long nchunk = (4096 + tiles - 1) / tiles;                 // enough blocks to fill the chip a few times over
+    long nchunk = ((big ? 1024 : 4096) + tiles - 1) / tiles;  // enough blocks to fill the chip a few times over
     if (nchunk > nrows) nchunk = nrows;
+    if (d->slabs && nchunk > d->nslab) nchunk = d->nslab;
     if (nchunk < 1) nchunk = 1;
     p.RC = (int)((nrows + nchunk - 1) / nchunk);
     p.nchunk = (nrows + p.RC - 1) / p.RC;
     const long nb = tiles * p.nchunk;
     if (nb > 0x7fffffffL) { *err = "wgrad: grid too large"; return AERO_ERR_ARG; }
-    AERO_LAUNCH(aero_conv_wgrad_kernel, dim3((unsigned)nb), dim3(256), stream, p);
+    if (big) AERO_LAUNCH_DYN(aero_conv_wgrad256_kernel, dim3((unsigned)nb), dim3(512), (size_t)64 * 1024, stream, p);
+    else AERO_LAUNCH(aero_conv_wgrad_kernel, dim3((unsigned)nb), dim3(256), stream, p);
+    if (d->slabs) {
+        const int64_t n = (int64_t)d->ntaps * d->M * d->C;
+        int64_t fb = (n / 4 + 255) / 256;
+        if (fb > 2048) fb = 2048;
+        AERO_LAUNCH(aero_wgrad_finish_kernel, dim3((unsigned)fb), dim3(256), stream, (const float*)d->slabs, p.nchunk, d->dw, n);
+    }
     return AERO_OK;
 }
 

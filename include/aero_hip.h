@@ -306,13 +306,17 @@ int aero_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
  *   dw[j][m][c] += sum_{b, fo, t} dy[b, fo, t, m] * x[b, fo*fstride + df[j], t + dt[j], c]      (x = 0 outside its rows / steps)
  *   db[m]       += sum_{b, fo, t} dy[b, fo, t, m]                                                (db may be NULL)
  * dy fp16 [B, Fout, T, M], x fp16 [B, Fin, T, C] (element strides; M, C and strides multiples of 8); dw fp32 [ntaps][M][C] and
- * db fp32 [M] are ACCUMULATED (the caller zeroes them) with fp32 atomics. */
+ * db fp32 [M] are ACCUMULATED (the caller zeroes them).  The positions are cut into row chunks for parallelism: with
+ * slabs == NULL the chunks add their partial tiles to dw with fp32 atomics (sum order not fixed); with a workspace
+ * slabs fp32 [nslab][ntaps][M][C] each chunk (at most nslab of them) stores its partial with plain vector stores and a second
+ * kernel adds them to dw in chunk order -- deterministic, and faster (no scattered 4-byte atomics). */
 typedef struct {
     const void* dy; int64_t dy_b, dy_f, dy_t;
     const void* x; int64_t x_b, x_f, x_t;
     float* dw; float* db;
     int32_t B, Fin, Fout, T, M, C, ntaps, fstride;
     int32_t df[9], dt[9];
+    float* slabs; int32_t nslab;
 } aero_wgrad_desc;
 int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream);
 

@@ -528,7 +528,18 @@ def case_wgrad_conv2d(lib, dev, Cin, Cout, kF, kT, Fr, T, B=2, seed=82):
     dy = _rand((B, Cout, Fr, T), seed + 2)
     gw, gb = _autograd_dw(lambda ww, bb: F.conv2d(q16(x), ww, bb, padding=(kF // 2, kT // 2)), w, b, dy)
     _, df, dt = pack.conv2d_taps(w, kF // 2, kT // 2)
-    dw, db = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt)
+    import os
+    os.environ['AERO_WGRAD_256'] = '2'                        # the 256 x 256 tile wherever it is legal (read per call)
+    try:
+        dwa, _ = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt, nslab=0)        # chunks added with atomics
+        if Cin >= 192 and Cout >= 192:
+            assert 'wgrad256' in ops.lib.cdll.aero_last_kernel_name().decode()
+        dw, db = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt)                 # per-chunk slabs, added in order
+        dw2, _ = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt)
+    finally:
+        del os.environ['AERO_WGRAD_256']
+    assert torch.equal(dw, dw2)                                  # the slab form is deterministic
+    assert rel_l2(dwa.cpu(), dw.cpu()) < 1e-5
     got = dw.cpu().view(kF, kT, Cout, Cin).permute(2, 3, 0, 1)
     assert rel_l2(got, gw) < TOL16, rel_l2(got, gw)
     assert rel_l2(db.cpu(), gb) < TOL16

@@ -215,7 +215,8 @@ def test_dgrad_convtr(emu, kw):
 
 # ---- backward: weight gradients and GroupNorm + activation backward (k_bwd.h)
 @pytest.mark.parametrize('kw', [dict(Cin=32, Cout=64, kF=3, kT=3, Fr=3, T=70), dict(Cin=136, Cout=144, kF=1, kT=1, Fr=2, T=50),
-                                dict(Cin=8, Cout=16, kF=3, kT=1, Fr=5, T=33, B=3)])
+                                dict(Cin=8, Cout=16, kF=3, kT=1, Fr=5, T=33, B=3),
+                                dict(Cin=200, Cout=264, kF=3, kT=1, Fr=3, T=70)])       # 256 x 256 tile, ragged in both directions
 def test_wgrad_conv2d(emu, kw):
     oc.case_wgrad_conv2d(emu, DEV, **kw)
 
