@@ -193,7 +193,8 @@ def test_dgrad_convtr(lib, kw):
 
 @pytest.mark.parametrize('kw', [dict(Cin=192, Cout=384, kF=3, kT=3, Fr=4, T=501), dict(Cin=136, Cout=144, kF=1, kT=1, Fr=2, T=50),
                                 dict(Cin=8, Cout=16, kF=3, kT=1, Fr=5, T=33, B=3),
-                                dict(Cin=200, Cout=264, kF=3, kT=1, Fr=3, T=70)])       # 256 x 256 tile, ragged in both directions
+                                dict(Cin=200, Cout=264, kF=3, kT=1, Fr=3, T=70),        # 256 x 256 tile, ragged in both directions
+                                dict(Cin=768, Cout=1536, kF=3, kT=3, Fr=4, T=250, B=1)])  # first decoder's rewrite conv
 def test_wgrad_conv2d(lib, kw):
     oc.case_wgrad_conv2d(lib, DEV, **kw)
 
