@@ -10,15 +10,17 @@ import torch
 from . import _lib, backward as bw, pack
 from .engine import Ops
 
-_ACT = {'none': _lib.ACT_NONE, 'gelu': _lib.ACT_GELU, 'glu': _lib.ACT_GLU}
+_ACT = {'none': _lib.ACT_NONE, 'gelu': _lib.ACT_GELU, 'glu': _lib.ACT_GLU, 'snake': _lib.ACT_SNAKE}
 
 
 class ConvNormAct(torch.autograd.Function):
-    """y = act(GroupNorm_G(conv(x)))   --  HEncLayer conv+norm1+gelu, rewrite+norm2+glu, HDecLayer conv_tr+norm2+gelu.
+    """y = act(GroupNorm_G(conv(x)))   --  HEncLayer conv+norm1+act, rewrite+norm2+glu, HDecLayer conv_tr+norm2+act, with act = GELU
+    or Snake (act_func of the config; `alpha` = Snake's per-frequency-row parameter [F_out], snake.py:67) and G = 0 for the layers
+    before norm_starts (identity norm; gamma = beta = None).
     kind: ('conv2d', pad_f, pad_t) | ('fstride', stride) [kernel [K,1], padding (K-stride)//2] | ('convtr', stride) [cropped]"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, lib, kind, G, act):
+    def forward(ctx, x, weight, bias, gamma, beta, lib, kind, G, act, alpha=None):
         ops = Ops(lib)
         dev = x.device
         B, Fin, T, Cin = x.shape
@@ -41,20 +43,29 @@ class ConvNormAct(torch.autograd.Function):
             Fu = (Fin - 1) * s + K
             Fout, kw = Fu, dict(dst_f_off=pad, dst_F=Fu - 2 * pad)
         h = ops.conv(spec, x, None, B, Fin, Fout, T, **kw)
-        y = ops.norm_act(h, G, 0, gamma.detach(), beta.detach(), _ACT[act])
-        ctx.save_for_backward(x, weight, gamma, beta, h, ops._last_stats)
+        sa = None if alpha is None else alpha.detach().float()
+        if G:
+            y = ops.norm_act(h, G, 0, gamma.detach(), beta.detach(), _ACT[act], snake_a=sa)
+            stats = ops._last_stats
+        else:
+            y = ops.norm_act(h, 1, 0, None, None, _ACT[act], snake_a=sa, normalize=False)
+            stats = None
+        ctx.save_for_backward(x, weight, gamma, beta, h, stats, alpha)
         ctx.cfg = (lib, kind, G, act, df, dt)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, gamma, beta, h, stats = ctx.saved_tensors
+        x, weight, gamma, beta, h, stats, alpha = ctx.saved_tensors
         lib, kind, G, act, df, dt = ctx.cfg
         ops = Ops(lib)
         dev = x.device
         B, Fin, T, Cin = x.shape
         Fh = h.shape[1]
-        dh, dgamma, dbeta, _ = bw.norm_bwd(ops, h, dy.contiguous(), stats, G, 0, gamma.detach(), beta.detach(), _ACT[act])
+        res = bw.norm_bwd(ops, h, dy.contiguous(), stats, G if G else 1, 0, gamma.detach() if G else None, beta.detach() if G else None,
+                          _ACT[act], snake_a=None if alpha is None else alpha.detach().float())
+        dh, dgamma, dbeta = res[0], res[1], res[2]
+        dalpha = res[4] if alpha is not None else None
         w = weight.detach().float().cpu()
         if kind[0] == 'conv2d':
             dx = ops.conv(bw.dgrad_conv2d(w, kind[1], kind[2], dev), dh, None, B, Fh, Fin, T)
@@ -74,7 +85,7 @@ class ConvNormAct(torch.autograd.Function):
             dw, _ = bw.conv_wgrad(ops, x, dh, [kk - pad for kk in range(K)], [0] * K, fstride=s, bias=False)
             dweight = dw.permute(1, 2, 0).unsqueeze(-1)
             db = _bias_grad(ops, dh)
-        return dx, dweight.contiguous(), db, dgamma, dbeta, None, None, None, None
+        return dx, dweight.contiguous(), db, dgamma, dbeta, None, None, None, None, dalpha
 
 
 def _bias_grad(ops, dh):

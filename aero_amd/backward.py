@@ -81,10 +81,11 @@ def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None):
     return dw, db
 
 
-def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, eps=1e-5, stat_count=None):
+def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, eps=1e-5, stat_count=None, snake_a=None):
     """Backward of aero_norm_apply (GroupNorm + GELU / GLU(+LayerScale) / identity).  x: the norm's input fp16 [B,F,T,C]; stats: the
     forward statistics (fp64 sum / sum of squares per (item, group)); dy: gradient of the output.  Returns
-    (dx fp16 [B,F,T,C], dgamma, dbeta fp32 [C], dlayer_scale fp32 [C/2] or None)."""
+    (dx fp16 [B,F,T,C], dgamma, dbeta fp32 [C], dlayer_scale fp32 [C/2] or None) -- and, for Snake (act 4, snake_a fp32 [F]), the
+    gradient of snake_a as a fifth item.  stats None = identity norm (the layers before norm_starts)."""
     B, F, T, Cc = x.shape
     d = _lib.NormBwdDesc()
     d.x, d.dy = _ptr(x), _ptr(dy)
@@ -97,11 +98,15 @@ def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, 
     d.stats = _ptr(stats)
     d.stat_count = float((1 if per_row == 1 else F) * T * (Cc // G)) if stat_count is None else float(stat_count)
     d.gamma, d.beta, d.layer_scale, d.act = _ptr(gamma), _ptr(beta), _ptr(layer_scale), act
-    sums = torch.zeros_like(stats)
-    dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device)
-    dbeta = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+    sums = None if stats is None else torch.zeros_like(stats)
+    dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device) if gamma is not None else None
+    dbeta = torch.zeros(Cc, dtype=torch.float32, device=x.device) if beta is not None else None
+    dsn = torch.zeros(F, dtype=torch.float32, device=x.device) if snake_a is not None else None
+    d.snake_a, d.dsnake_a = _ptr(snake_a), _ptr(dsn)
     dls = torch.zeros(Cc // 2, dtype=torch.float32, device=x.device) if (layer_scale is not None and act == _lib.ACT_GLU) else None
     d.sums, d.dgamma, d.dbeta, d.dlayer_scale = _ptr(sums), _ptr(dgamma), _ptr(dbeta), _ptr(dls)
     ops.lib.call('aero_norm_bwd_reduce', C.byref(d), ops.stream(x))
     ops.lib.call('aero_norm_bwd_apply', C.byref(d), ops.stream(x))
+    if snake_a is not None:
+        return dx, dgamma, dbeta, dls, dsn
     return dx, dgamma, dbeta, dls

@@ -351,6 +351,7 @@ template <bool APPLY>
 __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     __shared__ float red_c[3][2048];                           // dgamma, dbeta (all C channels), dlayer_scale (C/2)
     __shared__ float red_g[2][256];                            // S1, S2 per group
+    __shared__ float red_a;                                    // d snake_a[f] of the current item
     const aero_norm_bwd_desc& d = p.d;
     const bool glu = d.act == AERO_ACT_GLU;
     const int Cout = glu ? d.C / 2 : d.C;
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     if (!APPLY) {
         __syncthreads();                                       // the previous item's group sums have been flushed
         for (int i = tid; i < d.G; i += 256) { red_g[0][i] = 0.f; red_g[1][i] = 0.f; }
+        if (tid == 0) red_a = 0.f;
         __syncthreads();
     }
     const float inv_count = (float)(1.0 / d.stat_count);
@@ -401,7 +403,9 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
             for (int i = 0; i < 8; ++i) {
                 const int c = h * Cout + v * 8 + i;
                 const int g = c / gs;
-                if (g != g_prev) {
+                if (!d.stats) {                                 // identity norm (layers before norm_starts, aero.py:56,148)
+                    g_r = 1.f;
+                } else if (g != g_prev) {
                     g_prev = g;
                     const double* st = d.stats + ((int64_t)item * d.G + g) * 2;
                     const double mean = st[0] / d.stat_count;
@@ -440,6 +444,8 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     const h16* xs = (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)f * d.x_f + v * 8;
     const h16* dys = (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)f * d.dy_f + v * 8;
     h16* dxs = (h16*)d.dx + (int64_t)b * d.dx_b + (int64_t)f * d.dx_f + v * 8;
+    const float sn_a = d.act == AERO_ACT_SNAKE ? d.snake_a[f] : 1.f, sn_ia = 1.f / sn_a;
+    float dsn = 0.f;
     // one time step
     auto elem = [&](const h16x8& xa, const h16x8& xg, const h16x8& dyv, h16x8& oa, h16x8& og) {
 #pragma unroll
@@ -462,6 +468,10 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
                 du0 = g_out * (cdf + u0 * pdf);
             } else if (d.act == AERO_ACT_RELU) {
                 du0 = u0 > 0.f ? g_out : 0.f;
+            } else if (d.act == AERO_ACT_SNAKE) {               // y = u + sin^2(a u) / a  (snake.py:67), a = snake_a[f]
+                const float sn = sinf(sn_a * u0), cs = cosf(sn_a * u0);
+                du0 = g_out * (1.f + 2.f * sn * cs);
+                if (!APPLY) dsn += g_out * (2.f * u0 * sn * cs - sn * sn * sn_ia) * sn_ia;
             } else {
                 du0 = g_out;
             }
@@ -524,12 +534,19 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
             }
         }
     }
-    __syncthreads();
-    for (int g = tid; g < d.G; g += 256) {
-        double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
-        atomicAdd(sm, (double)red_g[0][g]);
-        atomicAdd(sm + 1, (double)red_g[1][g]);
+    if (d.act == AERO_ACT_SNAKE && d.dsnake_a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dsn += __shfl_xor(dsn, o);
+        if ((tid & 63) == 0) atomicAdd(&red_a, dsn);
     }
+    __syncthreads();
+    if (d.stats)
+        for (int g = tid; g < d.G; g += 256) {
+            double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
+            atomicAdd(sm, (double)red_g[0][g]);
+            atomicAdd(sm + 1, (double)red_g[1][g]);
+        }
+    if (tid == 0 && d.act == AERO_ACT_SNAKE && d.dsnake_a) atomicAdd(d.dsnake_a + f, red_a);
     }   // work items
     if (APPLY) return;
     __syncthreads();
@@ -559,12 +576,13 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
 }
 
 static int aero_norm_bwd_launch(const aero_norm_bwd_desc* d, int apply, hipStream_t stream, const char** err) {
-    if (!d || !d->x || !d->dy || !d->stats || !d->sums || (apply && !d->dx)) { *err = "norm_bwd: null pointer"; return AERO_ERR_ARG; }
-    if (d->B < 1 || d->F < 1 || d->T < 1 || d->C < 8 || d->G < 1 || d->C % d->G || d->stat_count <= 0) { *err = "norm_bwd: bad geometry"; return AERO_ERR_ARG; }
+    if (!d || !d->x || !d->dy || (d->stats && !d->sums) || (apply && !d->dx)) { *err = "norm_bwd: null pointer"; return AERO_ERR_ARG; }
+    if (d->act == AERO_ACT_SNAKE && !d->snake_a) { *err = "norm_bwd: Snake needs snake_a"; return AERO_ERR_ARG; }
+    if (d->B < 1 || d->F < 1 || d->T < 1 || d->C < 8 || d->G < 1 || d->C % d->G || (d->stats && d->stat_count <= 0)) { *err = "norm_bwd: bad geometry"; return AERO_ERR_ARG; }
     const bool glu = d->act == AERO_ACT_GLU;
     const int Cout = glu ? d->C / 2 : d->C;
     if (d->per_row != 0 && d->per_row != 1) { *err = "norm_bwd: per_row must be 0 or 1 (batch statistics are not supported)"; return AERO_ERR_UNSUPPORTED; }
-    if (d->act != AERO_ACT_NONE && d->act != AERO_ACT_GELU && d->act != AERO_ACT_GLU && d->act != AERO_ACT_RELU) { *err = "norm_bwd: activation not supported"; return AERO_ERR_UNSUPPORTED; }
+    if (d->act != AERO_ACT_NONE && d->act != AERO_ACT_GELU && d->act != AERO_ACT_GLU && d->act != AERO_ACT_RELU && d->act != AERO_ACT_SNAKE) { *err = "norm_bwd: activation not supported"; return AERO_ERR_UNSUPPORTED; }
     if ((Cout % 8) || Cout / 8 > 256 || d->C > 2048 || d->G > 256 || (d->C / d->G) < 8 || (d->x_b % 8) || (d->x_f % 8) || (d->x_t % 8) || (d->dy_b % 8) || (d->dy_f % 8) ||
         (d->dy_t % 8) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->dy & 15)) {
         *err = "norm_bwd: needs 8-channel aligned fp16 rows, C <= 2048, groups of >= 8 channels"; return AERO_ERR_UNSUPPORTED;

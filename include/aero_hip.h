@@ -325,7 +325,8 @@ int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream);
  * of the activation output (fp16 [B,F,T,C] or [B,F,T,C/2] for GLU).  aero_norm_bwd_reduce ADDS the group sums
  * (sum dxh, sum dxh*xh: fp64 pairs, laid out as stats) to `sums` and the parameter gradients to dgamma / dbeta [C] /
  * dlayer_scale [C/2] (fp32, may be NULL; the caller zeroes all of them); aero_norm_bwd_apply then writes
- * dx = rstd * (dxh - S1/N - xh * S2/N) as fp16.  per_row 0 / 1 as in aero_norm_desc. */
+ * dx = rstd * (dxh - S1/N - xh * S2/N) as fp16.  per_row 0 / 1 as in aero_norm_desc.  stats == NULL: identity norm (the layers
+ * before norm_starts), dx = dxh.  Snake (snake.py:67): y = u + sin^2(a_f u) / a_f, with d a_f accumulated into dsnake_a. */
 typedef struct {
     const void* x; int64_t x_b, x_f, x_t;
     const void* dy; int64_t dy_b, dy_f, dy_t;
@@ -337,6 +338,7 @@ typedef struct {
     int32_t act;
     double* sums;
     float* dgamma; float* dbeta; float* dlayer_scale;
+    const float* snake_a; float* dsnake_a;      /* Snake (act 4): a per frequency row [F], its gradient (accumulated, may be NULL) */
 } aero_norm_bwd_desc;
 int aero_norm_bwd_reduce(const aero_norm_bwd_desc* d, void* stream);
 int aero_norm_bwd_apply(const aero_norm_bwd_desc* d, void* stream);

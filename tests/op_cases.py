@@ -750,3 +750,50 @@ def case_train_steps(lib, dev, steps=4, B=2, Fin=16, T=48, seed=120):
         moved = (Pr[k].detach() - init[k]).norm()
         err = (Pd[k].detach().cpu() - Pr[k].detach()).norm()
         assert err <= 0.15 * moved + 1e-6, (k, float(err), float(moved))       # the UPDATE agrees, not just the (mostly unchanged) value
+
+
+def _snake_ref(u, a):
+    """snake.py:67 with the per-frequency-row parameter: u [B, C, F, T], a [F]"""
+    av = a.view(1, 1, -1, 1)
+    return u + torch.sin(av * u) ** 2 / av
+
+
+def case_block_autograd_snake(lib, dev, kind, Cin, Cout, G, Fin, T, B=2, seed=130):
+    """the flagship config's blocks (act_func snake; G = 0: the layers before norm_starts have no GroupNorm): conv -> [GroupNorm] ->
+    Snake through aero_amd.autograd.ConvNormAct, gradients incl. Snake's alpha against fp32 torch autograd"""
+    from aero_amd.autograd import ConvNormAct
+    if kind[0] == 'fstride':
+        K, s_ = 2 * kind[1], kind[1]
+        w = q16(_rand((Cout, Cin, K, 1), seed, 1.0 / math.sqrt(Cin * K)))
+        ref_conv = lambda v, ww, bb: F.conv2d(v, ww, bb, stride=(s_, 1), padding=((K - s_) // 2, 0))      # noqa: E731
+        Fo = Fin // s_
+    else:
+        K, s_ = 2 * kind[1], kind[1]
+        w = q16(_rand((Cin, Cout, K, 1), seed, 1.0 / math.sqrt(Cin * K / s_)))
+        p_ = (K - s_) // 2
+        ref_conv = lambda v, ww, bb: F.conv_transpose2d(v, ww, bb, stride=(s_, 1))[:, :, p_:-p_]         # noqa: E731
+        Fo = Fin * s_
+    b = _rand((Cout,), seed + 1) * 0.1
+    alpha = _rand((Fo,), seed + 6).abs() * 0.8 + 0.4
+    x = q16(_rand((B, Cin, Fin, T), seed + 4))
+    names = ['x', 'weight', 'bias']
+    pr = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    ar = alpha.clone().requires_grad_(True)
+    hr = ref_conv(pr[0], pr[1], pr[2])
+    if G:
+        gamma, beta = _rand((Cout,), seed + 2) * 0.3 + 1.0, _rand((Cout,), seed + 3) * 0.2
+        pr += [gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)]
+        names += ['gamma', 'beta']
+        hr = F.group_norm(hr, G, pr[3], pr[4])
+    yr = _snake_ref(hr, ar)
+    gy = q16(_rand(tuple(yr.shape), seed + 5))
+    (yr * gy).sum().backward()
+    pd = [cl(x).to(dev).requires_grad_(True)] + [t.detach().clone().to(dev).requires_grad_(True) for t in pr[1:]]
+    ad = alpha.clone().to(dev).requires_grad_(True)
+    yd = ConvNormAct.apply(pd[0], pd[1], pd[2], pd[3] if G else None, pd[4] if G else None, lib, kind, G, 'snake', ad)
+    assert rel_l2(uncl(yd.detach().cpu()), yr.detach()) < TOL16
+    (yd.float() * cl(gy).to(dev).float()).sum().backward()
+    assert rel_l2(uncl(pd[0].grad.cpu()), pr[0].grad) < 3 * TOL16, rel_l2(uncl(pd[0].grad.cpu()), pr[0].grad)
+    for got, ref, nm in zip(pd[1:], pr[1:], names[1:]):
+        assert rel_l2(got.grad.cpu(), ref.grad) < 3 * TOL16, (nm, rel_l2(got.grad.cpu(), ref.grad))
+    assert rel_l2(ad.grad.cpu(), ar.grad) < 3 * TOL16, rel_l2(ad.grad.cpu(), ar.grad)

@@ -258,3 +258,10 @@ def test_dconv_autograd(emu, kw):
 
 def test_train_steps_match_torch(emu):
     oc.case_train_steps(emu, DEV)
+
+
+@pytest.mark.parametrize('kw', [dict(kind=('fstride', 4), Cin=16, Cout=32, G=0, Fin=16, T=33),
+                                dict(kind=('fstride', 2), Cin=16, Cout=32, G=4, Fin=8, T=40),
+                                dict(kind=('convtr', 2), Cin=32, Cout=32, G=4, Fin=4, T=33)])
+def test_block_autograd_snake(emu, kw):
+    oc.case_block_autograd_snake(emu, DEV, **kw)

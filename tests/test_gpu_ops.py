@@ -234,3 +234,10 @@ def test_dconv_autograd(lib, kw):
 
 def test_train_steps_match_torch(lib):
     oc.case_train_steps(lib, DEV)
+
+
+@pytest.mark.parametrize('kw', [dict(kind=('fstride', 4), Cin=48, Cout=96, G=0, Fin=16, T=501),
+                                dict(kind=('fstride', 2), Cin=96, Cout=192, G=4, Fin=8, T=501),
+                                dict(kind=('convtr', 2), Cin=192, Cout=96, G=4, Fin=4, T=501)])
+def test_block_autograd_snake(lib, kw):
+    oc.case_block_autograd_snake(lib, DEV, **kw)
