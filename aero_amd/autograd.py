@@ -16,60 +16,72 @@ _ACT = {'none': _lib.ACT_NONE, 'gelu': _lib.ACT_GELU, 'glu': _lib.ACT_GLU, 'snak
 class ConvNormAct(torch.autograd.Function):
     """y = act(GroupNorm_G(conv(x)))   --  HEncLayer conv+norm1+act, rewrite+norm2+glu, HDecLayer conv_tr+norm2+act, with act = GELU
     or Snake (act_func of the config; `alpha` = Snake's per-frequency-row parameter [F_out], snake.py:67) and G = 0 for the layers
-    before norm_starts (identity norm; gamma = beta = None).
+    before norm_starts (identity norm; gamma = beta = None); act 'none' with G = 0 is the bare conv (the last decoder layer).
+    skip: a second input ADDED to x before the conv (HDecLayer.forward: x = x + skip, aero.py:195) -- run as a two-source conv with
+    the weights seen twice, so no separate add pass exists in either direction.
     kind: ('conv2d', pad_f, pad_t) | ('fstride', stride) [kernel [K,1], padding (K-stride)//2] | ('convtr', stride) [cropped]"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, lib, kind, G, act, alpha=None):
+    def forward(ctx, x, weight, bias, gamma, beta, lib, kind, G, act, alpha=None, skip=None):
         ops = Ops(lib)
         dev = x.device
         B, Fin, T, Cin = x.shape
         w = weight.detach().float().cpu()
+        two = skip is not None
+        dup = (lambda t: torch.cat([t, t], -1)) if two else (lambda t: t)
+        C1 = Cin if two else 0
         if kind[0] == 'conv2d':
             taps, df, dt = pack.conv2d_taps(w, kind[1], kind[2])
-            spec = pack.make_conv_spec(taps, bias.detach(), Cin, 0, df, dt, dev)
+            spec = pack.make_conv_spec(dup(taps), bias.detach(), Cin, C1, df, dt, dev)
             Fout, kw = Fin, {}
         elif kind[0] == 'fstride':
             K, s = w.shape[2], kind[1]
             pad = (K - s) // 2
             taps, df, dt = pack.conv2d_taps(w, pad, 0)
-            spec = pack.make_conv_spec(taps, bias.detach(), Cin, 0, df, dt, dev, fstride=s)
+            spec = pack.make_conv_spec(dup(taps), bias.detach(), Cin, C1, df, dt, dev, fstride=s)
             Fout, kw = (Fin + 2 * pad - K) // s + 1, {}
         else:
             K, s = w.shape[2], kind[1]
             pad = (K - s) // 2
             taps, df, dt = pack.convtr_taps(w, s)
-            spec = pack.make_conv_spec(taps, bias.detach(), Cin, 0, df, dt, dev, transposed=1, fstride=s)
+            spec = pack.make_conv_spec(dup(taps), bias.detach(), Cin, C1, df, dt, dev, transposed=1, fstride=s)
             Fu = (Fin - 1) * s + K
             Fout, kw = Fu, dict(dst_f_off=pad, dst_F=Fu - 2 * pad)
-        h = ops.conv(spec, x, None, B, Fin, Fout, T, **kw)
+        h = ops.conv(spec, x, skip, B, Fin, Fout, T, **kw)
         sa = None if alpha is None else alpha.detach().float()
         if G:
             y = ops.norm_act(h, G, 0, gamma.detach(), beta.detach(), _ACT[act], snake_a=sa)
             stats = ops._last_stats
+        elif act == 'none':
+            y, stats = h, None
         else:
             y = ops.norm_act(h, 1, 0, None, None, _ACT[act], snake_a=sa, normalize=False)
             stats = None
-        ctx.save_for_backward(x, weight, gamma, beta, h, stats, alpha)
+        ctx.save_for_backward(x, weight, gamma, beta, h, stats, alpha, skip)
         ctx.cfg = (lib, kind, G, act, df, dt)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, gamma, beta, h, stats, alpha = ctx.saved_tensors
+        x, weight, gamma, beta, h, stats, alpha, skip = ctx.saved_tensors
         lib, kind, G, act, df, dt = ctx.cfg
         ops = Ops(lib)
         dev = x.device
         B, Fin, T, Cin = x.shape
         Fh = h.shape[1]
-        res = bw.norm_bwd(ops, h, dy.contiguous(), stats, G if G else 1, 0, gamma.detach() if G else None, beta.detach() if G else None,
-                          _ACT[act], snake_a=None if alpha is None else alpha.detach().float())
-        dh, dgamma, dbeta = res[0], res[1], res[2]
-        dalpha = res[4] if alpha is not None else None
+        if not G and act == 'none':
+            dh, dgamma, dbeta, dalpha = dy.contiguous(), None, None, None
+        else:
+            res = bw.norm_bwd(ops, h, dy.contiguous(), stats, G if G else 1, 0, gamma.detach() if G else None, beta.detach() if G else None,
+                              _ACT[act], snake_a=None if alpha is None else alpha.detach().float())
+            dh, dgamma, dbeta = res[0], res[1], res[2]
+            dalpha = res[4] if alpha is not None else None
         w = weight.detach().float().cpu()
         if kind[0] == 'conv2d':
             dx = ops.conv(bw.dgrad_conv2d(w, kind[1], kind[2], dev), dh, None, B, Fh, Fin, T)
             dw, db = bw.conv_wgrad(ops, dh, x, df, dt)
+            if skip is not None:
+                dw, _ = bw.conv_wgrad(ops, dh, skip, df, dt, bias=False, dw_acc=dw)
             kF, kT = w.shape[2], w.shape[3]
             dweight = dw.view(kF, kT, w.shape[0], Cin).permute(2, 3, 0, 1)
         elif kind[0] == 'fstride':
@@ -77,15 +89,19 @@ class ConvNormAct(torch.autograd.Function):
             pad = (K - s) // 2
             dx = ops.conv(bw.dgrad_conv_fstride(w, s, dev), dh, None, B, Fh, (Fh - 1) * s + K, T, dst_f_off=pad, dst_F=Fin)
             dw, db = bw.conv_wgrad(ops, dh, x, df, dt, fstride=s)
+            if skip is not None:
+                dw, _ = bw.conv_wgrad(ops, dh, skip, df, dt, fstride=s, bias=False, dw_acc=dw)
             dweight = dw.permute(1, 2, 0).unsqueeze(-1)
         else:
             K, s = w.shape[2], kind[1]
             pad = (K - s) // 2
             dx = ops.conv(bw.dgrad_convtr(w, s, pad, dev), dh, None, B, Fh, Fin, T)
             dw, _ = bw.conv_wgrad(ops, x, dh, [kk - pad for kk in range(K)], [0] * K, fstride=s, bias=False)
+            if skip is not None:
+                dw, _ = bw.conv_wgrad(ops, skip, dh, [kk - pad for kk in range(K)], [0] * K, fstride=s, bias=False, dw_acc=dw)
             dweight = dw.permute(1, 2, 0).unsqueeze(-1)
             db = _bias_grad(ops, dh)
-        return dx, dweight.contiguous(), db, dgamma, dbeta, None, None, None, None, dalpha
+        return dx, dweight.contiguous(), db, dgamma, dbeta, None, None, None, None, dalpha, (dx if skip is not None else None)
 
 
 def _bias_grad(ops, dh):

@@ -55,17 +55,29 @@ import ctypes as C  # noqa: E402
 from .engine import _ptr, _strides4  # noqa: E402
 
 
-def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None):
+def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None, dw_acc=None):
     """dy fp16 [B,Fout,T,M], x fp16 [B,Fin,T,C] (channels-last) -> (dw fp32 [ntaps, M, C], db fp32 [M] or None):
-    dw[j][m][c] = sum dy[b,fo,t,m] * x[b, fo*fstride + df[j], t + dt[j], c]  (aero_conv_wgrad)."""
+    dw[j][m][c] = sum dy[b,fo,t,m] * x[b, fo*fstride + df[j], t + dt[j], c]  (aero_conv_wgrad).  dw_acc: an earlier result to accumulate
+    into (the kernel adds to dw), e.g. the second source of a two-source conv."""
     B, Fout, T, M = dy.shape
     Bx, Fin, Tx, Cc = x.shape
     assert B == Bx and T == Tx and len(df) == len(dt)
+    if M % 8 or Cc % 8:
+        # narrow sides (the last decoder's 2 output channels, the FTB's 5): zero-padded copies to the kernel's 8-channel vectors
+        # (data movement only), the padding rows / columns of the result dropped
+        pad = lambda t: torch.nn.functional.pad(t, (0, -t.shape[-1] % 8))       # noqa: E731
+        dw, db = conv_wgrad(ops, pad(dy), pad(x), df, dt, fstride, bias, nslab, dw_acc=None)
+        dw, db = dw[:, :M, :Cc], (None if db is None else db[:M])
+        if dw_acc is not None:
+            dw_acc += dw
+            return dw_acc, db
+        return dw.contiguous(), db
     d = _lib.WgradDesc()
     d.dy, d.x = _ptr(dy), _ptr(x)
     d.dy_b, d.dy_f, d.dy_t = _strides4(dy)
     d.x_b, d.x_f, d.x_t = _strides4(x)
-    dw = torch.zeros(len(df), M, Cc, dtype=torch.float32, device=dy.device)
+    dw = torch.zeros(len(df), M, Cc, dtype=torch.float32, device=dy.device) if dw_acc is None else dw_acc
+    assert dw.shape == (len(df), M, Cc) and dw.is_contiguous()
     db = torch.zeros(M, dtype=torch.float32, device=dy.device) if bias else None
     d.dw, d.db = _ptr(dw), _ptr(db)
     d.B, d.Fin, d.Fout, d.T, d.M, d.C, d.ntaps, d.fstride = B, Fin, Fout, T, M, Cc, len(df), fstride

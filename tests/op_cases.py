@@ -797,3 +797,48 @@ def case_block_autograd_snake(lib, dev, kind, Cin, Cout, G, Fin, T, B=2, seed=13
     for got, ref, nm in zip(pd[1:], pr[1:], names[1:]):
         assert rel_l2(got.grad.cpu(), ref.grad) < 3 * TOL16, (nm, rel_l2(got.grad.cpu(), ref.grad))
     assert rel_l2(ad.grad.cpu(), ar.grad) < 3 * TOL16, rel_l2(ad.grad.cpu(), ar.grad)
+
+
+def case_decoder_autograd(lib, dev, C=64, Fin=4, T=40, B=2, seed=140):
+    """two HDecLayers as the flagship config builds them (aero.py:148-216): x + skip -> 3x3 rewrite -> [GroupNorm] -> GLU -> ConvTranspose
+    -> [GroupNorm] -> Snake, the last one without norm / activation and with 2 output channels -- every gradient (inputs, both skips,
+    all parameters) through aero_amd.autograd against fp32 torch autograd."""
+    from aero_amd.autograd import ConvNormAct
+    P = dict(w_r1=q16(_rand((2 * C, C, 3, 3), seed, 1.0 / math.sqrt(C * 9))), b_r1=_rand((2 * C,), seed + 1) * 0.1,
+             g_r1=_rand((2 * C,), seed + 2) * 0.3 + 1.0, be_r1=_rand((2 * C,), seed + 3) * 0.2,
+             w_t1=q16(_rand((C, C // 2, 4, 1), seed + 4, 1.0 / math.sqrt(C * 2))), b_t1=_rand((C // 2,), seed + 5) * 0.1,
+             g_t1=_rand((C // 2,), seed + 6) * 0.3 + 1.0, be_t1=_rand((C // 2,), seed + 7) * 0.2,
+             al1=_rand((2 * Fin,), seed + 8).abs() * 0.8 + 0.4,
+             w_r2=q16(_rand((C, C // 2, 3, 3), seed + 9, 1.0 / math.sqrt(C * 4.5))), b_r2=_rand((C,), seed + 10) * 0.1,
+             w_t2=q16(_rand((C // 2, 2, 8, 1), seed + 11, 1.0 / math.sqrt(C))), b_t2=_rand((2,), seed + 12) * 0.1)
+    x = q16(_rand((B, C, Fin, T), seed + 20))
+    s1 = q16(_rand((B, C, Fin, T), seed + 21))
+    s2 = q16(_rand((B, C // 2, 2 * Fin, T), seed + 22))
+
+    def ref(P, x, s1, s2):
+        h = F.glu(F.group_norm(F.conv2d(x + s1, P['w_r1'], P['b_r1'], padding=1), 4, P['g_r1'], P['be_r1']), dim=1)
+        h = F.group_norm(F.conv_transpose2d(h, P['w_t1'], P['b_t1'], stride=(2, 1))[:, :, 1:-1], 4, P['g_t1'], P['be_t1'])
+        h = _snake_ref(h, P['al1'])
+        h = F.glu(F.conv2d(h + s2, P['w_r2'], P['b_r2'], padding=1), dim=1)
+        return F.conv_transpose2d(h, P['w_t2'], P['b_t2'], stride=(4, 1))[:, :, 2:-2]
+
+    def devnet(P, x, s1, s2):
+        h = ConvNormAct.apply(x, P['w_r1'], P['b_r1'], P['g_r1'], P['be_r1'], lib, ('conv2d', 1, 1), 4, 'glu', None, s1)
+        h = ConvNormAct.apply(h, P['w_t1'], P['b_t1'], P['g_t1'], P['be_t1'], lib, ('convtr', 2), 4, 'snake', P['al1'])
+        h = ConvNormAct.apply(h, P['w_r2'], P['b_r2'], None, None, lib, ('conv2d', 1, 1), 0, 'glu', None, s2)
+        return ConvNormAct.apply(h, P['w_t2'], P['b_t2'], None, None, lib, ('convtr', 4), 0, 'none')
+
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ir = [t.clone().requires_grad_(True) for t in (x, s1, s2)]
+    yr = ref(Pr, *ir)
+    gy = q16(_rand(tuple(yr.shape), seed + 30))
+    (yr * gy).sum().backward()
+    Pd = {k: v.clone().to(dev).requires_grad_(True) for k, v in P.items()}
+    idv = [cl(t).to(dev).requires_grad_(True) for t in (x, s1, s2)]
+    yd = devnet(Pd, *idv)
+    assert rel_l2(uncl(yd.detach().cpu()), yr.detach()) < 2 * TOL16
+    (yd.float() * cl(gy).to(dev).float()).sum().backward()
+    for got, ref_t, nm in zip(idv, ir, ('x', 'skip1', 'skip2')):
+        assert rel_l2(uncl(got.grad.cpu()), ref_t.grad) < 4 * TOL16, (nm, rel_l2(uncl(got.grad.cpu()), ref_t.grad))
+    for k in P:
+        assert rel_l2(Pd[k].grad.cpu(), Pr[k].grad) < 4 * TOL16, (k, rel_l2(Pd[k].grad.cpu(), Pr[k].grad))

@@ -265,3 +265,7 @@ def test_train_steps_match_torch(emu):
                                 dict(kind=('convtr', 2), Cin=32, Cout=32, G=4, Fin=4, T=33)])
 def test_block_autograd_snake(emu, kw):
     oc.case_block_autograd_snake(emu, DEV, **kw)
+
+
+def test_decoder_autograd(emu):
+    oc.case_decoder_autograd(emu, DEV)

@@ -241,3 +241,7 @@ def test_train_steps_match_torch(lib):
                                 dict(kind=('convtr', 2), Cin=192, Cout=96, G=4, Fin=4, T=501)])
 def test_block_autograd_snake(lib, kw):
     oc.case_block_autograd_snake(lib, DEV, **kw)
+
+
+def test_decoder_autograd(lib):
+    oc.case_decoder_autograd(lib, DEV, C=96, Fin=8, T=501)
