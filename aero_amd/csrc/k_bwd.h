@@ -54,7 +54,7 @@ static __device__ __forceinline__ void aero_transpose8x8(const h16x8* r, h16x8* 
     }
 }
 
-__global__ __launch_bounds__(256) void aero_conv_wgrad_kernel(AeroWgradK p) {
+__global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
     __shared__ AERO_LDS_ALIGN h16 FR[2][2][8][64 * 8];        // [operand][k half][j][lane * 8]: 32 KiB
     const aero_wgrad_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
@@ -84,11 +84,26 @@ __global__ __launch_bounds__(256) void aero_conv_wgrad_kernel(AeroWgradK p) {
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
     const bool do_bias = d.db != nullptr && ct == 0 && tap == 0 && opnd == 0;
     h16x8 r[8];
+    // per-lane element offsets inside a 64-step segment, fixed for the whole kernel: an interior step (all 64 positions and the
+    // shifted ones inside [0, T)) then costs no vector address arithmetic at all -- block-uniform row pointer + 32-bit lane offset.
+    // (PMC on the first version: 7 vector + 6 scalar instructions per MFMA, the 64-bit per-load address / mask arithmetic twice
+    // the transposes; the kernel was VALU-bound at 2x the MFMA time.)
+    const int opu = aero_uniform(opnd);
+    const int st_e = (int)(opu ? d.x_t : d.dy_t);
+    const int coff = ch + 8 * g8 * st_e;                      // (the eight positions of a lane add block-uniform multiples of the step stride)
     auto load = [&](int it) {
         const int row = r_lo + it / nT, t0 = (it % nT) * 64;
         const int b = row / d.Fout, fo = row - b * d.Fout;
         const int fi = fo * d.fstride + dfj;
         const bool row_ok = fi >= 0 && fi < d.Fin;
+        const int sh = opu ? dtj : 0;
+        if (t0 + 64 <= d.T && t0 + sh >= 0 && t0 + 64 + sh <= d.T && (!opu || row_ok)) {
+            const h16* rowp = (opu ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f
+                                   : (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)fo * d.dy_f) + (int64_t)(t0 + sh) * st_e;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = ch_ok ? *(const h16x8*)(rowp + (int64_t)i * st_e + coff) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            return;
+        }
         const h16* base = opnd ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f + ch
                                : (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)fo * d.dy_f + ch;
         const int64_t st = opnd ? d.x_t : d.dy_t;
@@ -200,11 +215,26 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
     const bool do_bias = d.db != nullptr && ct == 0 && tap == 0 && opnd == 0;
     h16x8 r[8];
+    // per-lane element offsets inside a 64-step segment, fixed for the whole kernel: an interior step (all 64 positions and the
+    // shifted ones inside [0, T)) then costs no vector address arithmetic at all -- block-uniform row pointer + 32-bit lane offset.
+    // (PMC on the first version: 7 vector + 6 scalar instructions per MFMA, the 64-bit per-load address / mask arithmetic twice
+    // the transposes; the kernel was VALU-bound at 2x the MFMA time.)
+    const int opu = aero_uniform(opnd);
+    const int st_e = (int)(opu ? d.x_t : d.dy_t);
+    const int coff = ch + 8 * g8 * st_e;                      // (the eight positions of a lane add block-uniform multiples of the step stride)
     auto load = [&](int it) {
         const int row = r_lo + it / nT, t0 = (it % nT) * 64;
         const int b = row / d.Fout, fo = row - b * d.Fout;
         const int fi = fo * d.fstride + dfj;
         const bool row_ok = fi >= 0 && fi < d.Fin;
+        const int sh = opu ? dtj : 0;
+        if (t0 + 64 <= d.T && t0 + sh >= 0 && t0 + 64 + sh <= d.T && (!opu || row_ok)) {
+            const h16* rowp = (opu ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f
+                                   : (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)fo * d.dy_f) + (int64_t)(t0 + sh) * st_e;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = ch_ok ? *(const h16x8*)(rowp + (int64_t)i * st_e + coff) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            return;
+        }
         const h16* base = opnd ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f + ch
                                : (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)fo * d.dy_f + ch;
         const int64_t st = opnd ? d.x_t : d.dy_t;
@@ -301,6 +331,7 @@ static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, 
         ((uintptr_t)d->dy & 15) || ((uintptr_t)d->x & 15)) {
         *err = "wgrad: channel counts and strides must be multiples of 8 (16-byte aligned channel vectors)"; return AERO_ERR_UNSUPPORTED;
     }
+    if ((int64_t)(d->T + 64) * d->dy_t + d->M + 256 > 0x7fffffffLL || (int64_t)(d->T + 64) * d->x_t + d->C + 256 > 0x7fffffffLL) { *err = "wgrad: rows too long for 32-bit in-row offsets"; return AERO_ERR_UNSUPPORTED; }
     AeroWgradK p;
     p.d = *d;
     { const char* e = getenv("AERO_WGRAD_ABL"); p.noswz = e ? atoi(e) : 0; }       // ablation bits (timing experiments): 1 no XCD swizzle, 2 no atomics, 4 no loads after the first step
