@@ -55,7 +55,7 @@ static __device__ __forceinline__ void aero_transpose8x8(const h16x8* r, h16x8* 
 }
 
 __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
-    __shared__ AERO_LDS_ALIGN h16 FR[2][2][8][64 * 8];        // [operand][k half][j][lane * 8]: 32 KiB
+    __shared__ AERO_LDS_ALIGN h16 FR2[2][2][2][8][64 * 8];    // [step parity][operand][k half][j][lane * 8]: 2 x 32 KiB (one barrier per step)
     const aero_wgrad_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     // consecutive tiles of a row chunk share dy / x slices: give each XCD (private L2) a contiguous run of them
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bsum[j] += (float)c[j][e];
         }
-        if (it) __syncthreads();                               // the previous step's fragment reads are done
+        auto& FR = FR2[it & 1];                                // (the readers of this half finished before the previous step's barrier)
 #pragma unroll
         for (int j = 0; j < 8; ++j) *(h16x8*)&FR[opnd][g8 >> 2][j][(o + 16 * (g8 & 3)) * 8] = c[j];
         __syncthreads();
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
 // this one moves 64 KB per 8.4 MFLOP.  Same scheme: 512 threads stage one 8 x 8 block each (threads 0-255 dy, 256-511 x; channel
 // half = bit 4 of the octet index), wave w = (m half, c half, j quad) owns j = 4*jq .. 4*jq+3 against all eight j'.
 __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p) {
-    h16* FR = (h16*)AERO_DYN_SMEM;                             // [operand][half][k half][j][lane * 8]: 64 KiB
+    h16* FR = (h16*)AERO_DYN_SMEM;                             // [step parity][operand][half][k half][j][lane * 8]: 2 x 64 KiB
     const aero_wgrad_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     // consecutive tiles of a row chunk share dy / x slices: give each XCD (private L2) a contiguous run of them
@@ -261,19 +261,19 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bsum[j] += (float)c[j][e];
         }
-        if (it) __syncthreads();
+        const int par = (it & 1) * 32768;                      // halves: the other 64-KiB image (one barrier per step)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *(h16x8*)(wr + j * 512) = c[j];
+        for (int j = 0; j < 8; ++j) *(h16x8*)(wr + par + j * 512) = c[j];
         __syncthreads();
         if (it + 1 < nit && !(p.noswz & 4)) load(it + 1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             h16x8 af[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) af[a] = *(const h16x8*)(ra + (kh * 8 + 4 * jq + a) * 512);
+            for (int a = 0; a < 4; ++a) af[a] = *(const h16x8*)(ra + par + (kh * 8 + 4 * jq + a) * 512);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const h16x8 bf = *(const h16x8*)(rb + (kh * 8 + j) * 512);
+                const h16x8 bf = *(const h16x8*)(rb + par + (kh * 8 + j) * 512);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a], bf, acc[a][j], 0, 0, 0);
             }
@@ -353,7 +353,7 @@ static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, 
     p.nchunk = (nrows + p.RC - 1) / p.RC;
     const long nb = tiles * p.nchunk;
     if (nb > 0x7fffffffL) { *err = "wgrad: grid too large"; return AERO_ERR_ARG; }
-    if (big) AERO_LAUNCH_DYN(aero_conv_wgrad256_kernel, dim3((unsigned)nb), dim3(512), (size_t)64 * 1024, stream, p);
+    if (big) AERO_LAUNCH_DYN(aero_conv_wgrad256_kernel, dim3((unsigned)nb), dim3(512), (size_t)128 * 1024, stream, p);
     else AERO_LAUNCH(aero_conv_wgrad_kernel, dim3((unsigned)nb), dim3(256), stream, p);
     if (d->slabs) {
         const int64_t n = (int64_t)d->ntaps * d->M * d->C;
