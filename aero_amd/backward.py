@@ -108,9 +108,9 @@ def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, 
     d.dx_b, d.dx_f, d.dx_t = _strides4(dx)
     d.B, d.F, d.T, d.C, d.G, d.per_row, d.eps = B, F, T, Cc, G, int(per_row), eps
     d.stats = _ptr(stats)
-    d.stat_count = float((1 if per_row == 1 else F) * T * (Cc // G)) if stat_count is None else float(stat_count)
+    d.stat_count = float((1 if per_row == 1 else (B * F if per_row == 2 else F)) * T * (Cc // G)) if stat_count is None else float(stat_count)
     d.gamma, d.beta, d.layer_scale, d.act = _ptr(gamma), _ptr(beta), _ptr(layer_scale), act
-    sums = None if stats is None else torch.zeros_like(stats)
+    sums = None if (stats is None or per_row == 2) else torch.zeros_like(stats)
     dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device) if gamma is not None else None
     dbeta = torch.zeros(Cc, dtype=torch.float32, device=x.device) if beta is not None else None
     dsn = torch.zeros(F, dtype=torch.float32, device=x.device) if snake_a is not None else None

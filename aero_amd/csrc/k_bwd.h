@@ -411,10 +411,11 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     const int tch = work % ntch;
     const int f = (work / ntch) % d.F;
     const int b = work / (ntch * d.F);
-    const int item = d.per_row == 1 ? b * d.F + f : b;
+    const int item = d.per_row == 1 ? b * d.F + f : (d.per_row == 2 ? 0 : b);
+    const bool bn = d.per_row == 2;                            // BatchNorm on batch statistics: group = channel over the whole batch
     if (!APPLY) {
         __syncthreads();                                       // the previous item's group sums have been flushed
-        for (int i = tid; i < d.G; i += 256) { red_g[0][i] = 0.f; red_g[1][i] = 0.f; }
+        for (int i = tid; i < (bn ? 0 : d.G); i += 256) { red_g[0][i] = 0.f; red_g[1][i] = 0.f; }
         if (tid == 0) red_a = 0.f;
         __syncthreads();
     }
@@ -447,10 +448,14 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
                     r = r * (1.5f - 0.5f * vf * r * r);
                     g_r = r;
                     g_m = -(float)mean * r;
-                    if (APPLY) {
+                    if (APPLY && !bn) {
                         const double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
                         g_k1 = (float)sm[0] * inv_count;
                         g_k2 = (float)sm[1] * inv_count;
+                    } else if (APPLY) {
+                        // per-channel groups: S1 = gamma * dbeta, S2 = gamma * dgamma -- the reduce pass's parameter gradients ARE the sums
+                        g_k1 = d.gamma[c] * d.dbeta[c] * inv_count;
+                        g_k2 = d.gamma[c] * d.dgamma[c] * inv_count;
                     }
                 }
                 rs[h][i] = g_r;
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
             for (int i = 0; i < 8; ++i) {
                 a1 += s1[h][i];
                 a2 += s2[h][i];
-                if (i == 7 || grp[h][i + 1 < 8 ? i + 1 : 7] != grp[h][i]) {
+                if (!bn && (i == 7 || grp[h][i + 1 < 8 ? i + 1 : 7] != grp[h][i])) {
                     atomicAdd(&red_g[0][grp[h][i]], a1);
                     atomicAdd(&red_g[1][grp[h][i]], a2);
                     a1 = a2 = 0.f;
@@ -571,7 +576,7 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
         if ((tid & 63) == 0) atomicAdd(&red_a, dsn);
     }
     __syncthreads();
-    if (d.stats)
+    if (d.stats && !bn)
         for (int g = tid; g < d.G; g += 256) {
             double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
             atomicAdd(sm, (double)red_g[0][g]);
@@ -607,14 +612,18 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
 }
 
 static int aero_norm_bwd_launch(const aero_norm_bwd_desc* d, int apply, hipStream_t stream, const char** err) {
-    if (!d || !d->x || !d->dy || (d->stats && !d->sums) || (apply && !d->dx)) { *err = "norm_bwd: null pointer"; return AERO_ERR_ARG; }
+    if (!d || !d->x || !d->dy || (d->stats && !d->sums && d->per_row != 2) || (apply && !d->dx)) { *err = "norm_bwd: null pointer"; return AERO_ERR_ARG; }
     if (d->act == AERO_ACT_SNAKE && !d->snake_a) { *err = "norm_bwd: Snake needs snake_a"; return AERO_ERR_ARG; }
     if (d->B < 1 || d->F < 1 || d->T < 1 || d->C < 8 || d->G < 1 || d->C % d->G || (d->stats && d->stat_count <= 0)) { *err = "norm_bwd: bad geometry"; return AERO_ERR_ARG; }
     const bool glu = d->act == AERO_ACT_GLU;
     const int Cout = glu ? d->C / 2 : d->C;
-    if (d->per_row != 0 && d->per_row != 1) { *err = "norm_bwd: per_row must be 0 or 1 (batch statistics are not supported)"; return AERO_ERR_UNSUPPORTED; }
+    if (d->per_row < 0 || d->per_row > 2) { *err = "norm_bwd: per_row must be 0, 1 or 2"; return AERO_ERR_ARG; }
+    const bool bn = d->per_row == 2;
+    if (bn && (d->G != d->C || !d->stats || !d->gamma || !d->dgamma || !d->dbeta || glu || d->act == AERO_ACT_SNAKE)) {
+        *err = "norm_bwd: batch statistics (per_row 2) need G == C, stats, gamma and the dgamma / dbeta buffers; no GLU / Snake"; return AERO_ERR_UNSUPPORTED;
+    }
     if (d->act != AERO_ACT_NONE && d->act != AERO_ACT_GELU && d->act != AERO_ACT_GLU && d->act != AERO_ACT_RELU && d->act != AERO_ACT_SNAKE) { *err = "norm_bwd: activation not supported"; return AERO_ERR_UNSUPPORTED; }
-    if ((Cout % 8) || Cout / 8 > 256 || d->C > 2048 || d->G > 256 || (d->C / d->G) < 8 || (d->x_b % 8) || (d->x_f % 8) || (d->x_t % 8) || (d->dy_b % 8) || (d->dy_f % 8) ||
+    if ((Cout % 8) || Cout / 8 > 256 || d->C > 2048 || (!bn && (d->G > 256 || (d->C / d->G) < 8)) || (d->x_b % 8) || (d->x_f % 8) || (d->x_t % 8) || (d->dy_b % 8) || (d->dy_f % 8) ||
         (d->dy_t % 8) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->dy & 15)) {
         *err = "norm_bwd: needs 8-channel aligned fp16 rows, C <= 2048, groups of >= 8 channels"; return AERO_ERR_UNSUPPORTED;
     }

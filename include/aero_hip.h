@@ -326,7 +326,8 @@ int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream);
  * (sum dxh, sum dxh*xh: fp64 pairs, laid out as stats) to `sums` and the parameter gradients to dgamma / dbeta [C] /
  * dlayer_scale [C/2] (fp32, may be NULL; the caller zeroes all of them); aero_norm_bwd_apply then writes
  * dx = rstd * (dxh - S1/N - xh * S2/N) as fp16.  per_row 0 / 1 as in aero_norm_desc.  stats == NULL: identity norm (the layers
- * before norm_starts), dx = dxh.  Snake (snake.py:67): y = u + sin^2(a_f u) / a_f, with d a_f accumulated into dsnake_a. */
+ * before norm_starts), dx = dxh.  per_row 2 (G == C): nn.BatchNorm on batch statistics (the FTB's three BatchNorms in training mode,
+ * modules.py:287,293,300): the per-channel sums are gamma * dbeta and gamma * dgamma, so `sums` is not used and dgamma / dbeta are required.  Snake (snake.py:67): y = u + sin^2(a_f u) / a_f, with d a_f accumulated into dsnake_a. */
 typedef struct {
     const void* x; int64_t x_b, x_f, x_t;
     const void* dy; int64_t dy_b, dy_f, dy_t;

@@ -842,3 +842,24 @@ def case_decoder_autograd(lib, dev, C=64, Fin=4, T=40, B=2, seed=140):
         assert rel_l2(uncl(got.grad.cpu()), ref_t.grad) < 4 * TOL16, (nm, rel_l2(uncl(got.grad.cpu()), ref_t.grad))
     for k in P:
         assert rel_l2(Pd[k].grad.cpu(), Pr[k].grad) < 4 * TOL16, (k, rel_l2(Pd[k].grad.cpu(), Pr[k].grad))
+
+
+def case_batchnorm_bwd(lib, dev, C_, act, Fr, T, B=3, seed=150):
+    """training-mode BatchNorm (+ ReLU) backward -- the FTB's norms (modules.py:287,293,300) -- through aero_norm_bwd_* with per_row 2"""
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    x = _rand((B, C_, Fr, T), seed, 1.5) + 0.3
+    gamma, beta = _rand((C_,), seed + 1) * 0.5 + 1.0, _rand((C_,), seed + 2) * 0.3
+    dy = _rand((B, C_, Fr, T), seed + 3)
+    xr = q16(x).clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    u = F.batch_norm(xr, None, None, gr, br, training=True)
+    y = F.relu(u) if act == 'relu' else u
+    grads = torch.autograd.grad(y, [xr, gr, br], q16(dy))
+    actc = _lib.ACT_RELU if act == 'relu' else _lib.ACT_NONE
+    xd = cl(x).to(dev)
+    ops.norm_act(xd, C_, 2, gamma.to(dev), beta.to(dev), actc)
+    stats = ops._last_stats
+    dx, dg, dbt, _ = bw.norm_bwd(ops, xd, cl(dy).to(dev), stats, C_, 2, gamma.to(dev), beta.to(dev), actc)
+    assert rel_l2(uncl(dx.cpu()), grads[0]) < 2 * TOL16, rel_l2(uncl(dx.cpu()), grads[0])
+    assert rel_l2(dg.cpu(), grads[1]) < TOL16 and rel_l2(dbt.cpu(), grads[2]) < TOL16

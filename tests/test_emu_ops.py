@@ -269,3 +269,8 @@ def test_block_autograd_snake(emu, kw):
 
 def test_decoder_autograd(emu):
     oc.case_decoder_autograd(emu, DEV)
+
+
+@pytest.mark.parametrize('kw', [dict(C_=16, act='relu', Fr=5, T=40), dict(C_=8, act='none', Fr=3, T=33)])
+def test_batchnorm_bwd(emu, kw):
+    oc.case_batchnorm_bwd(emu, DEV, **kw)

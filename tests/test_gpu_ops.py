@@ -245,3 +245,8 @@ def test_block_autograd_snake(lib, kw):
 
 def test_decoder_autograd(lib):
     oc.case_decoder_autograd(lib, DEV, C=96, Fin=8, T=501)
+
+
+@pytest.mark.parametrize('kw', [dict(C_=48, act='relu', Fr=64, T=501), dict(C_=8, act='none', Fr=3, T=501)])
+def test_batchnorm_bwd(lib, kw):
+    oc.case_batchnorm_bwd(lib, DEV, **kw)
