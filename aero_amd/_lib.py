@@ -126,6 +126,8 @@ _PROTOS = {
     'aero_conv_wgrad': (i32, [C.POINTER(WgradDesc), vp]),
     'aero_norm_bwd_reduce': (i32, [C.POINTER(NormBwdDesc), vp]),
     'aero_norm_bwd_apply': (i32, [C.POINTER(NormBwdDesc), vp]),
+    'aero_istft_bwd_prep': (i32, [fp, fp, fp, i32, i32, i32, i32, i32, vp]),
+    'aero_istft_bwd_pack': (i32, [fp, fp, i32, i32, i32, i32, i32, vp]),
     'aero_conv_tile_m': (i32, [i32]),
     'aero_conv_ring_bm': (i32, [i32, i32]),
     'aero_conv_kernel_name': (i32, [C.POINTER(ConvDesc), C.c_char_p, i32]),

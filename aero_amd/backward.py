@@ -122,3 +122,18 @@ def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, 
     if snake_a is not None:
         return dx, dgamma, dbeta, dls, dsn
     return dx, dgamma, dbeta, dls
+
+
+def istft_bwd(ops, dy, n_fft, hop, window, inv_env, T):
+    """Gradient of aero_istft_fwd's input spectrogram: dy fp32 [nsig, Lout] -> dz fp32 [nsig, n_fft/2, T, 2] (interleaved complex, the
+    Nyquist bin the forward treats as zero has none).  The adjoint is the forward STFT kernel on dy * inv_env (k_bwd.h)."""
+    nsig, L = dy.shape
+    off = n_fft // 2 + hop
+    Ls = -(-(off + L + n_fft + hop) // hop) * hop
+    s = torch.empty(nsig, Ls, dtype=torch.float32, device=dy.device)
+    ops.lib.call('aero_istft_bwd_prep', _ptr(dy), _ptr(inv_env), _ptr(s), nsig, L, Ls, off, n_fft // 2, ops.stream(dy))
+    spec = ops.stft(s, Ls, Ls, n_fft, hop, window, n_fft // 2)
+    Tsrc = spec.shape[2]
+    dz = torch.empty(nsig, n_fft // 2, T, 2, dtype=torch.float32, device=dy.device)
+    ops.lib.call('aero_istft_bwd_pack', _ptr(spec), _ptr(dz), nsig, n_fft // 2, Tsrc, T, off // hop, ops.stream(dy))
+    return dz

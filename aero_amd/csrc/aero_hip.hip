@@ -222,6 +222,18 @@ int aero_norm_bwd_apply(const aero_norm_bwd_desc* d, void* stream) {
     return aero_finish(rc, err);
 }
 
+int aero_istft_bwd_prep(const float* dy, const float* inv_env, float* s, int32_t nsig, int32_t L, int32_t Ls, int32_t off, int32_t env_off, void* stream) {
+    const char* err = "";
+    int rc = aero_istft_bwd_prep_launch(dy, inv_env, s, nsig, L, Ls, off, env_off, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_istft_bwd_pack(const float* spec, float* dz, int32_t nsig, int32_t nbins, int32_t Tsrc, int32_t T, int32_t t_off, void* stream) {
+    const char* err = "";
+    int rc = aero_istft_bwd_pack_launch(spec, dz, nsig, nbins, Tsrc, T, t_off, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_ftb_first_launch(d, (hipStream_t)stream, &err);

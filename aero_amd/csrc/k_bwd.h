@@ -642,3 +642,45 @@ static int aero_norm_bwd_launch(const aero_norm_bwd_desc* d, int apply, hipStrea
     else AERO_LAUNCH(aero_norm_bwd_kernel<false>, grid, dim3(256), stream, p);
     return AERO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// iSTFT backward (the adjoint of aero_istft_fwd; aero.py:423-428, spec.py:30-37).  With g = dy * inv_env the gradient of frame t,
+// bin k is  c_k * n_fft^-1/2 * sum_m w[m] g_full[t*hop + m] e^{-2 pi i k m / n_fft}  (c_0 = 1, c_k = 2: the Hermitian half of irfft;
+// the imaginary part of DC has no gradient) -- i.e. the EXISTING forward STFT kernel applied to g, zero-padded by n_fft/2 + hop in
+// front (the reflect padding of the centred STFT then mirrors zeros) and read at frame t + (n_fft/2 + hop)/hop.  Two small
+// streaming kernels bracket that call: `prep` builds the padded g, `pack` applies c_k and the frame shift.
+__global__ __launch_bounds__(256) void aero_istft_bwd_prep_kernel(const float* dy, const float* inv_env, float* s, int L, int Ls, int off, int env_off) {
+    const int sig = blockIdx.y;
+    for (int n = (int)blockIdx.x * 256 + threadIdx.x; n < Ls; n += (int)gridDim.x * 256) {
+        const int j = n - off;
+        s[(int64_t)sig * Ls + n] = (j >= 0 && j < L) ? dy[(int64_t)sig * L + j] * inv_env[j + env_off] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void aero_istft_bwd_pack_kernel(const f32x2* spec, f32x2* dz, int nbins, int Tsrc, int T, int t_off) {
+    const int sig = blockIdx.z, k = blockIdx.y;
+    const f32x2* src = spec + ((int64_t)sig * nbins + k) * Tsrc + t_off;
+    f32x2* dst = dz + ((int64_t)sig * nbins + k) * T;
+    for (int t = (int)blockIdx.x * 256 + threadIdx.x; t < T; t += (int)gridDim.x * 256) {
+        const f32x2 v = src[t];
+        dst[t] = k == 0 ? (f32x2){v[0], 0.f} : (f32x2){2.f * v[0], 2.f * v[1]};
+    }
+}
+
+static int aero_istft_bwd_prep_launch(const float* dy, const float* inv_env, float* s, int nsig, int L, int Ls, int off, int env_off,
+                                      hipStream_t stream, const char** err) {
+    if (!dy || !inv_env || !s) { *err = "istft_bwd_prep: null pointer"; return AERO_ERR_ARG; }
+    if (nsig < 1 || nsig > 65535 || L < 1 || off < 0 || env_off < 0 || Ls < off + L) { *err = "istft_bwd_prep: bad geometry"; return AERO_ERR_ARG; }
+    int nb = (Ls + 255) / 256;
+    if (nb > 64) nb = 64;
+    AERO_LAUNCH(aero_istft_bwd_prep_kernel, dim3((unsigned)nb, (unsigned)nsig), dim3(256), stream, dy, inv_env, s, L, Ls, off, env_off);
+    return AERO_OK;
+}
+
+static int aero_istft_bwd_pack_launch(const float* spec, float* dz, int nsig, int nbins, int Tsrc, int T, int t_off, hipStream_t stream, const char** err) {
+    if (!spec || !dz) { *err = "istft_bwd_pack: null pointer"; return AERO_ERR_ARG; }
+    if (nsig < 1 || nsig > 65535 || nbins < 1 || nbins > 65535 || T < 1 || t_off < 0 || t_off + T > Tsrc) { *err = "istft_bwd_pack: bad geometry"; return AERO_ERR_ARG; }
+    int nb = (T + 255) / 256;
+    AERO_LAUNCH(aero_istft_bwd_pack_kernel, dim3((unsigned)nb, (unsigned)nbins, (unsigned)nsig), dim3(256), stream, (const f32x2*)spec, (f32x2*)dz, nbins, Tsrc, T, t_off);
+    return AERO_OK;
+}

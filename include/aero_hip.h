@@ -344,6 +344,15 @@ typedef struct {
 int aero_norm_bwd_reduce(const aero_norm_bwd_desc* d, void* stream);
 int aero_norm_bwd_apply(const aero_norm_bwd_desc* d, void* stream);
 
+/* iSTFT backward (adjoint of aero_istft_fwd; aero.py:423-428, spec.py:30-37) = aero_stft_fwd on g = dy * inv_env, bracketed by:
+ *   aero_istft_bwd_prep: s[sig][off + n] = dy[sig][n] * inv_env[n + env_off] (n < L), zero elsewhere (s: Ls samples per signal;
+ *                        off = n_fft/2 + hop so that the centred STFT's reflect padding mirrors zeros, env_off = n_fft/2);
+ *   aero_istft_bwd_pack: dz[sig][k][t] = c_k * spec[sig][k][t + t_off]  (c_0 = 1 with zero imaginary part, c_k = 2;
+ *                        t_off = off / hop), spec / dz interleaved complex fp32 [nsig][nbins][Tsrc | T].
+ * aero_amd/backward.py: istft_bwd(). */
+int aero_istft_bwd_prep(const float* dy, const float* inv_env, float* s, int32_t nsig, int32_t L, int32_t Ls, int32_t off, int32_t env_off, void* stream);
+int aero_istft_bwd_pack(const float* spec, float* dz, int32_t nsig, int32_t nbins, int32_t Tsrc, int32_t T, int32_t t_off, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -863,3 +863,21 @@ def case_batchnorm_bwd(lib, dev, C_, act, Fr, T, B=3, seed=150):
     dx, dg, dbt, _ = bw.norm_bwd(ops, xd, cl(dy).to(dev), stats, C_, 2, gamma.to(dev), beta.to(dev), actc)
     assert rel_l2(uncl(dx.cpu()), grads[0]) < 2 * TOL16, rel_l2(uncl(dx.cpu()), grads[0])
     assert rel_l2(dg.cpu(), grads[1]) < TOL16 and rel_l2(dbt.cpu(), grads[2]) < TOL16
+
+
+def case_istft_bwd(lib, dev, nfft, hop, T, crop=5, B=2, seed=160):
+    """iSTFT backward (backward.istft_bwd: prep -> the forward STFT kernel -> pack) against autograd through the oracle's istft"""
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    z = torch.complex(_rand((B, nfft // 2, T), seed), _rand((B, nfft // 2, T), seed + 1)).requires_grad_(True)
+    Lout = hop * (T - 1) - crop
+    y = O.istft(F.pad(z, (0, 0, 0, 1)), hop, nfft)[..., :Lout]
+    gy = _rand(tuple(y.shape), seed + 2)
+    (y * gy).sum().backward()
+    w = _hann_padded(nfft, nfft, 'cpu')
+    env = torch.zeros(nfft + hop * (T - 1), dtype=torch.float64)
+    for t in range(T):
+        env[t * hop:t * hop + nfft] += (w * w).double()
+    dz = bw.istft_bwd(ops, gy.reshape(B, Lout).contiguous().to(dev), nfft, hop, w.to(dev), (1 / env).float().to(dev), T)
+    got = torch.view_as_complex(dz.cpu().contiguous())
+    assert rel_l2(torch.view_as_real(got), torch.view_as_real(z.grad)) < 5 * TOL32, rel_l2(torch.view_as_real(got), torch.view_as_real(z.grad))

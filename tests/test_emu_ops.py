@@ -274,3 +274,8 @@ def test_decoder_autograd(emu):
 @pytest.mark.parametrize('kw', [dict(C_=16, act='relu', Fr=5, T=40), dict(C_=8, act='none', Fr=3, T=33)])
 def test_batchnorm_bwd(emu, kw):
     oc.case_batchnorm_bwd(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(nfft=512, hop=64, T=24), dict(nfft=64, hop=16, T=13, crop=0)])
+def test_istft_bwd(emu, kw):
+    oc.case_istft_bwd(emu, DEV, **kw)

@@ -250,3 +250,8 @@ def test_decoder_autograd(lib):
 @pytest.mark.parametrize('kw', [dict(C_=48, act='relu', Fr=64, T=501), dict(C_=8, act='none', Fr=3, T=501)])
 def test_batchnorm_bwd(lib, kw):
     oc.case_batchnorm_bwd(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(nfft=512, hop=64, T=501, B=8), dict(nfft=64, hop=16, T=13, crop=0)])
+def test_istft_bwd(lib, kw):
+    oc.case_istft_bwd(lib, DEV, **kw)
