@@ -13,6 +13,7 @@
 #define aero_fast_exp(x) expf(x)
 #define aero_rcp(x) (1.0f / (x))
 #define aero_fast_sin(x) sinf(x)
+#define aero_fast_cos(x) cosf(x)
 #define aero_exp2(x) exp2f(x)
 #define aero_rsqrt(x) (1.0f / sqrtf(x))
 #define aero_med3(x, lo, hi) fminf(fmaxf((x), (lo)), (hi))
@@ -20,6 +21,7 @@
 #define aero_fast_exp(x) __expf(x)
 #define aero_rcp(x) __builtin_amdgcn_rcpf(x)
 #define aero_fast_sin(x) __sinf(x)
+#define aero_fast_cos(x) __cosf(x)
 #define aero_exp2(x) __builtin_amdgcn_exp2f(x)              /* bare v_exp_f32 */
 #define aero_rsqrt(x) __builtin_amdgcn_rsqf(x)
 #define aero_med3(x, lo, hi) __builtin_amdgcn_fmed3f((x), (lo), (hi))   /* one-instruction clamp */

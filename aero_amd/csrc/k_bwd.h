@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
             } else if (d.act == AERO_ACT_RELU) {
                 du0 = u0 > 0.f ? g_out : 0.f;
             } else if (d.act == AERO_ACT_SNAKE) {               // y = u + sin^2(a u) / a  (snake.py:67), a = snake_a[f]
-                const float sn = sinf(sn_a * u0), cs = cosf(sn_a * u0);
+                const float sn = aero_fast_sin(sn_a * u0), cs = aero_fast_cos(sn_a * u0);     // (hardware sin / cos as in the forward: the libm forms cost 70 registers)
                 du0 = g_out * (1.f + 2.f * sn * cs);
                 if (!APPLY) dsn += g_out * (2.f * u0 * sn * cs - sn * sn * sn_ia) * sn_ia;
             } else {

@@ -47,6 +47,24 @@ def main():
         nbytes = dy.numel() * 2 * 3 + g2.numel() * 2 * 2
         print(f'{name}: GroupNorm+GLU backward {ms:8.3f} ms {nbytes / ms / 1e6:7.1f} GB/s', flush=True)
 
+    # iSTFT backward (prep -> forward STFT kernel -> pack) at the model's output geometry, and the FTB's training-mode BatchNorm + ReLU
+    nfft, hop, T = 512, 64, 501
+    w = torch.hann_window(nfft, device=dev)
+    env = torch.zeros(nfft + hop * (T - 1), dtype=torch.float64)
+    for t in range(T):
+        env[t * hop:t * hop + nfft] += (w.cpu() * w.cpu()).double()
+    inv_env = (1 / env).float().to(dev)
+    dyw = torch.randn(B, hop * (T - 1), device=dev)
+    ms = timeit(lambda: bw.istft_bwd(ops, dyw, nfft, hop, w, inv_env, T))
+    print(f'iSTFT backward (B={B}, {hop * (T - 1)} samples): {ms * 1e3:8.1f} us', flush=True)
+    xb = torch.randn(B, 64, T, 48, device=dev).half()
+    gamma, beta = torch.ones(48, device=dev), torch.zeros(48, device=dev)
+    ops.norm_act(xb, 48, 2, gamma, beta, _lib.ACT_RELU)
+    stats = ops._last_stats
+    gb = torch.randn_like(xb)
+    ms = timeit(lambda: bw.norm_bwd(ops, xb, gb, stats, 48, 2, gamma, beta, _lib.ACT_RELU))
+    print(f'BatchNorm(train) + ReLU backward [B,48,64,{T}]: {ms:8.3f} ms {xb.numel() * 2 * 5 / ms / 1e6:7.1f} GB/s', flush=True)
+
 
 if __name__ == '__main__':
     main()
