@@ -378,13 +378,13 @@ struct AeroNormBwdK {
     int tchunk, apply;
 };
 
-template <bool APPLY>
+template <bool APPLY, int ACT>
 __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     __shared__ float red_c[3][2048];                           // dgamma, dbeta (all C channels), dlayer_scale (C/2)
     __shared__ float red_g[2][256];                            // S1, S2 per group
     __shared__ float red_a;                                    // d snake_a[f] of the current item
     const aero_norm_bwd_desc& d = p.d;
-    const bool glu = d.act == AERO_ACT_GLU;
+    constexpr bool glu = ACT == AERO_ACT_GLU;                 // (one instantiation per activation: the unused halves and paths cost registers)
     const int Cout = glu ? d.C / 2 : d.C;
     const int vpp = Cout / 8;
     const int TY = 256 / vpp;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     const h16* xs = (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)f * d.x_f + v * 8;
     const h16* dys = (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)f * d.dy_f + v * 8;
     h16* dxs = (h16*)d.dx + (int64_t)b * d.dx_b + (int64_t)f * d.dx_f + v * 8;
-    const float sn_a = d.act == AERO_ACT_SNAKE ? d.snake_a[f] : 1.f, sn_ia = 1.f / sn_a;
+    const float sn_a = ACT == AERO_ACT_SNAKE ? d.snake_a[f] : 1.f, sn_ia = 1.f / sn_a;
     float dsn = 0.f;
     // one time step
     auto elem = [&](const h16x8& xa, const h16x8& xg, const h16x8& dyv, h16x8& oa, h16x8& og) {
@@ -498,13 +498,13 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
                 du0 = gy * sg;
                 du1 = gy * u0 * sg * (1.f - sg);
                 if (!APPLY) dls[i] += g_out * u0 * sg;
-            } else if (d.act == AERO_ACT_GELU) {
+            } else if (ACT == AERO_ACT_GELU) {
                 const float cdf = 0.5f * (1.0f + aero_erf(u0 * 0.70710678118654752f));
                 const float pdf = 0.3989422804014327f * aero_fast_exp(-0.5f * u0 * u0);
                 du0 = g_out * (cdf + u0 * pdf);
-            } else if (d.act == AERO_ACT_RELU) {
+            } else if (ACT == AERO_ACT_RELU) {
                 du0 = u0 > 0.f ? g_out : 0.f;
-            } else if (d.act == AERO_ACT_SNAKE) {               // y = u + sin^2(a u) / a  (snake.py:67), a = snake_a[f]
+            } else if (ACT == AERO_ACT_SNAKE) {               // y = u + sin^2(a u) / a  (snake.py:67), a = snake_a[f]
                 const float sn = aero_fast_sin(sn_a * u0), cs = aero_fast_cos(sn_a * u0);     // (hardware sin / cos as in the forward: the libm forms cost 70 registers)
                 du0 = g_out * (1.f + 2.f * sn * cs);
                 if (!APPLY) dsn += g_out * (2.f * u0 * sn * cs - sn * sn * sn_ia) * sn_ia;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
             }
         }
     }
-    if (d.act == AERO_ACT_SNAKE && d.dsnake_a) {
+    if (ACT == AERO_ACT_SNAKE && d.dsnake_a) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dsn += __shfl_xor(dsn, o);
         if ((tid & 63) == 0) atomicAdd(&red_a, dsn);
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
             atomicAdd(sm, (double)red_g[0][g]);
             atomicAdd(sm + 1, (double)red_g[1][g]);
         }
-    if (tid == 0 && d.act == AERO_ACT_SNAKE && d.dsnake_a) atomicAdd(d.dsnake_a + f, red_a);
+    if (tid == 0 && ACT == AERO_ACT_SNAKE && d.dsnake_a) atomicAdd(d.dsnake_a + f, red_a);
     }   // work items
     if (APPLY) return;
     __syncthreads();
@@ -638,8 +638,19 @@ static int aero_norm_bwd_launch(const aero_norm_bwd_desc* d, int apply, hipStrea
     const long nwork = (long)((d->T + tchunk - 1) / tchunk) * d->F * d->B;
     if (nwork > 0x7fffffffL) { *err = "norm_bwd: too many work items"; return AERO_ERR_ARG; }
     dim3 grid((unsigned)(apply ? nwork : (nwork < 1024 ? nwork : 1024)));
-    if (apply) AERO_LAUNCH(aero_norm_bwd_kernel<true>, grid, dim3(256), stream, p);
-    else AERO_LAUNCH(aero_norm_bwd_kernel<false>, grid, dim3(256), stream, p);
+#define AERO_NB_LAUNCH(A)                                                                               \
+    do {                                                                                                \
+        if (apply) AERO_LAUNCH((aero_norm_bwd_kernel<true, A>), grid, dim3(256), stream, p);            \
+        else AERO_LAUNCH((aero_norm_bwd_kernel<false, A>), grid, dim3(256), stream, p);                 \
+    } while (0)
+    switch (d->act) {
+        case AERO_ACT_RELU: AERO_NB_LAUNCH(AERO_ACT_RELU); break;
+        case AERO_ACT_GELU: AERO_NB_LAUNCH(AERO_ACT_GELU); break;
+        case AERO_ACT_GLU: AERO_NB_LAUNCH(AERO_ACT_GLU); break;
+        case AERO_ACT_SNAKE: AERO_NB_LAUNCH(AERO_ACT_SNAKE); break;
+        default: AERO_NB_LAUNCH(AERO_ACT_NONE); break;
+    }
+#undef AERO_NB_LAUNCH
     return AERO_OK;
 }
 
