@@ -71,7 +71,18 @@ class LstmDesc(C.Structure):
     _fields_ = [('xproj', vp), ('xbias', vp), ('whh', vp), ('out', vp),
                 ('H', i32), ('nseq', i32), ('W', i32), ('in_mode', i32), ('out_mode', i32),
                 ('nframes', i32), ('S', i32), ('T', i32),
-                ('x', vp), ('wih', vp), ('bias', fp), ('in_ch', i32), ('x_pitch', i32)]
+                ('x', vp), ('wih', vp), ('bias', fp), ('in_ch', i32), ('x_pitch', i32),
+                ('save_gates', vp), ('save_c', fp)]
+
+
+class LstmBwdDesc(C.Structure):
+    _fields_ = [('dout', vp), ('whh_t', vp), ('save_gates', vp), ('save_c', fp), ('da', vp),
+                ('H', i32), ('nseq', i32), ('W', i32), ('out_mode', i32), ('nframes', i32), ('S', i32), ('T', i32)]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [('qkvd', vp), ('ld', i64), ('out', vp), ('dout', vp), ('dqkvd', vp), ('qstats', fp),
+                ('R', i32), ('T', i32), ('C', i32), ('heads', i32), ('ndecay', i32)]
 
 
 class AttnDesc(C.Structure):
@@ -143,6 +154,20 @@ _PROTOS = {
     'aero_enc0_fwd': (i32, [C.POINTER(Enc0Desc), vp]),
     'aero_dconv_row_fwd': (i32, [C.POINTER(DconvDesc), vp]),
     'aero_dconv_row_fits': (i32, [i32, i32, i32, i32]),
+    'aero_lstm_bwd': (i32, [C.POINTER(LstmBwdDesc), vp]),
+    'aero_lstm_bwd_k4p': (i32, [i32]),
+    'aero_localstate_bwd': (i32, [C.POINTER(AttnBwdDesc), vp]),
+    'aero_freqfc_wgrad': (i32, [vp, vp, vp, fp, fp, i32, i32, i32, i32, i32, vp]),
+    'aero_ftb_gate_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'aero_sum_bt': (i32, [vp, fp, i32, i32, i32, i32, C.c_float, vp]),
+    'aero_frames_op': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'aero_stft_loss_sums': (i32, [fp, fp, i64, C.c_float, dp, i32, dp, vp]),
+    'aero_stft_loss_bwd': (i32, [fp, fp, i64, C.c_float, dp, C.c_float, C.c_float, fp, fp, vp]),
+    'aero_irfft_frames': (i32, [fp, i32, i32, i32, i32, fp, fp, vp]),
+    'aero_stft_adj_fold': (i32, [fp, fp, i32, i32, i32, i32, i32, i32, vp]),
+    'aero_add_f16': (i32, [vp, vp, vp, i64, vp]),
+    'aero_scale_cast': (i32, [fp, i32, i64, fp, vp, C.c_float, vp, fp, vp]),
+    'aero_scale_f32': (i32, [fp, i64, fp, vp]),
 }
 
 EXPORTS = tuple(_PROTOS)

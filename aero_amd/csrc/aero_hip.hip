@@ -16,6 +16,7 @@
 #include "k_stft.h"
 #include "k_optim.h"
 #include "k_bwd.h"
+#include "k_train.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -237,6 +238,92 @@ int aero_istft_bwd_pack(const float* spec, float* dz, int32_t nsig, int32_t nbin
 int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_ftb_first_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_lstm_bwd(const aero_lstm_bwd_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_lstm_bwd_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_lstm_bwd_k4p(int32_t H) { const int k = aero_lstm_bwd_kt4(H); return k < 0 ? -1 : 32 * k; }
+
+int aero_localstate_bwd(const aero_attn_bwd_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_attn_bwd_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_freqfc_wgrad(const void* dfc, const void* x, const void* gate, float* dw, float* slabs, int32_t nslab, int32_t B, int32_t F,
+                      int32_t T, int32_t C, void* stream) {
+    const char* err = "";
+    int rc = aero_freqfc_wgrad_launch(dfc, x, gate, dw, slabs, nslab, B, F, T, C, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_ftb_gate_bwd(const void* v, const void* x, const void* gate, const void* add, void* dx, void* dgate, int32_t B, int32_t F,
+                      int32_t T, int32_t C, void* stream) {
+    const char* err = "";
+    int rc = aero_ftb_gate_bwd_launch(v, x, gate, add, dx, dgate, B, F, T, C, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_sum_bt(const void* x, float* out, int32_t B, int32_t F, int32_t T, int32_t C, float scale, void* stream) {
+    const char* err = "";
+    int rc = aero_sum_bt_launch(x, out, B, F, T, C, scale, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_frames_op(const void* src, void* dst, int32_t mode, int32_t R, int32_t T, int32_t C, int32_t nframes, int32_t W, int32_t S,
+                   void* stream) {
+    const char* err = "";
+    int rc = aero_frames_launch(src, dst, mode, R, T, C, nframes, W, S, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_stft_loss_sums(const float* zx, const float* zy, int64_t n, float pscale, double* part, int32_t npart, double* sums, void* stream) {
+    const char* err = "";
+    int rc = aero_stft_loss_sums_launch(zx, zy, n, pscale, part, npart, sums, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_stft_loss_bwd(const float* zx, const float* zy, int64_t n, float pscale, const double* sums, float w_sc, float w_mag,
+                       const float* gout, float* g, void* stream) {
+    const char* err = "";
+    int rc = aero_stft_loss_bwd_launch(zx, zy, n, pscale, sums, w_sc, w_mag, gout, g, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_irfft_frames(const float* g, int32_t nsig, int32_t nb, int32_t T, int32_t n_fft, const float* window, float* frames, void* stream) {
+    const char* err = "";
+    int rc = aero_irfft_frames_launch(g, nsig, nb, T, n_fft, window, frames, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_stft_adj_fold(const float* frames, float* dx, int32_t nsig, int32_t T, int32_t n_fft, int32_t hop, int32_t L, int32_t accumulate,
+                       void* stream) {
+    const char* err = "";
+    int rc = aero_stft_adj_fold_launch(frames, dx, nsig, T, n_fft, hop, L, accumulate, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_add_f16(const void* a, const void* b, void* dst, int64_t n, void* stream) {
+    const char* err = "";
+    int rc = aero_axpy_f16_launch(a, b, dst, n, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const float* item_scale, void* amax, float target, void* dst,
+                    float* scale_out, void* stream) {
+    const char* err = "";
+    int rc = aero_scale_cast_launch(x, nitems, n_per_item, item_scale, (unsigned int*)amax, target, dst, scale_out, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream) {
+    const char* err = "";
+    int rc = aero_scale_f32_launch(x, n, scale, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 

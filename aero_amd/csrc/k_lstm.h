@@ -221,6 +221,11 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
             c[i] = fg * c[i] + ig * gg;
             const float h = og * aero_tanh(c[i]);
             if (j < H) hbuf[cur ^ 1][col * KP + j] = (h16)h;
+            if (d.save_gates && j < H) {                       // training-mode forward: what aero_lstm_bwd needs (k_train.h)
+                const int64_t sb = ((int64_t)blockIdx.x * 2 + dir) * W + tau;
+                *(h16x4*)((h16*)d.save_gates + sb * H * 64 + ((int64_t)j * 16 + col) * 4) = (h16x4){(h16)ig, (h16)fg, (h16)gg, (h16)og};
+                d.save_c[sb * H * 16 + j * 16 + col] = c[i];
+            }
         }
         if (KTI > 0 && step + 1 < W) {
             // projection of the NEXT step (independent of h): fills the matrix pipe while other waves reach the barrier
@@ -539,7 +544,8 @@ static int aero_lstm_launch(const aero_lstm_desc* d, hipStream_t stream, const c
         AERO_LAUNCH_DYN((aero_lstm_ring_kernel<NW_, TPW_, KT_, KTI_, G_>), grid, block,                                 \
                         (AeroLstmRingGeom<KT_, KTI_, G_>::BYTES), stream, p);                                           \
     } while (0)
-    if (fused && ring) {
+    if ((d->save_gates == nullptr) != (d->save_c == nullptr)) { *err = "lstm: save_gates and save_c go together"; return AERO_ERR_ARG; }
+    if (fused && ring && !d->save_gates) {
         if (nw == 4 && tpw == 1) AERO_LSTM_RING_GO(4, 1, 1, 1, 4);
         else if (nw == 4 && tpw == 2) { if (kti == 1) AERO_LSTM_RING_GO(4, 2, 1, 1, 4); else AERO_LSTM_RING_GO(4, 2, 1, 2, 4); }
         else if (nw == 6) {

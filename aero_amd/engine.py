@@ -261,10 +261,13 @@ class Ops:
         return stats
 
     # -- LSTM / attention / FTB ----------------------------------------------------------------
-    def lstm(self, xproj, xbias, whh, H, nseq, W, in_mode, out_mode, nframes, S, T, out, x=None, fused=None):
+    def lstm(self, xproj, xbias, whh, H, nseq, W, in_mode, out_mode, nframes, S, T, out, x=None, fused=None, save=None):
         """one bidirectional layer.  Either (xproj, xbias) = precomputed input projection, or (x, fused=(wih, bias, in_ch)):
-        the projection is computed inside the recurrent kernel from the raw input rows x [npos, in_ch]."""
+        the projection is computed inside the recurrent kernel from the raw input rows x [npos, in_ch].
+        save = (gates fp16, c fp32) buffers (train_ops.lstm_save_buffers): the training-mode forward keeps what BPTT needs."""
         d = _lib.LstmDesc()
+        if save is not None:
+            d.save_gates, d.save_c = _ptr(save[0]), _ptr(save[1])
         d.xproj, d.xbias, d.whh, d.out = _ptr(xproj), _ptr(xbias), _ptr(whh), _ptr(out)
         d.H, d.nseq, d.W, d.in_mode, d.out_mode, d.nframes, d.S, d.T = H, nseq, W, in_mode, out_mode, nframes, S, T
         flops, nbytes = 2.0 * nseq * W * 2 * 4 * H * H, out.numel() * 2

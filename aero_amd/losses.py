@@ -7,7 +7,8 @@
 The transforms run through `aero_stft_fwd` (aero_amd/csrc/k_stft.h: n_fft up to 2048, any hop, any window length
 zero-padded to n_fft exactly as torch.stft does); the reductions on the magnitude tensors are a few device-side
 reductions.  The reference's `torch.stft(..., return_complex unset)` raises on torch >= 2; these restate it.
-No autograd: there are no backward kernels, so these are metric / validation values, not a trainable criterion.
+`STFTLoss` / `MultiResolutionSTFTLoss` are differentiable w.r.t. the predicted signal: their backward runs on the kernels of
+csrc/k_train.h (aero_stft_loss_bwd, aero_irfft_frames, aero_stft_adj_fold), so they are the training criterion of solver.py:560-584.
 """
 import torch
 
@@ -25,6 +26,12 @@ def _get_ops():
     return _ops
 
 
+def use_library(lib):
+    """tests: run the losses on an explicitly loaded library (the CPU-emulated test double); product code never calls this"""
+    global _ops
+    _ops = Ops(lib) if lib is not None else None
+
+
 def _window(win_length, n_fft, device):
     key = (win_length, n_fft, str(device))
     if key not in _windows:
@@ -35,11 +42,11 @@ def _window(win_length, n_fft, device):
 def stft_power(x, fft_size, hop_size, win_length):
     """|STFT|^2 of x [B, T] (float32 on the MI355X), un-normalised like torch.stft's default: [B, fft/2+1, frames].
     The kernel computes the `normalized=True` transform (aero.py's convention); the factor n_fft restores the scale."""
-    if not x.is_cuda:
+    ops = _get_ops()
+    if not x.is_cuda and not ops.lib.is_emulator:
         raise RuntimeError('aero_amd.losses runs on the MI355X: move the signals to "cuda"')
     x = x.contiguous().float()
     B, L = x.shape
-    ops = _get_ops()
     z = ops.stft(x, L, L, fft_size, hop_size, _window(win_length, fft_size, x.device), fft_size // 2 + 1)
     z = z[:, :, :1 + L // hop_size]                      # torch.stft(center=True): 1 + L // hop frames
     return (z[..., 0].square() + z[..., 1].square()) * float(fft_size)
@@ -50,20 +57,49 @@ def stft_magnitude(x, fft_size, hop_size, win_length):
     return torch.sqrt(torch.clamp(stft_power(x, fft_size, hop_size, win_length), min=1e-7)).transpose(2, 1)
 
 
+class _STFTLossFn(torch.autograd.Function):
+    """(spectral convergence, log-magnitude L1) of one resolution with its gradient w.r.t. the predicted signal, all on the HIP
+    kernels: aero_stft_fwd -> aero_stft_loss_sums; backward aero_stft_loss_bwd -> aero_irfft_frames + aero_stft_adj_fold (k_train.h)."""
+
+    @staticmethod
+    def forward(ctx, x, y, fft_size, hop, win):
+        from . import train_ops as TO
+        ops = _get_ops()
+        if not x.is_cuda and not ops.lib.is_emulator:
+            raise RuntimeError('aero_amd.losses runs on the MI355X: move the signals to "cuda"')
+        x, y = x.detach().contiguous().float(), y.detach().contiguous().float()
+        B, L = x.shape
+        wpad = _window(win, fft_size, x.device)
+        zx = ops.stft(x, L, L, fft_size, hop, wpad, fft_size // 2 + 1)
+        zy = ops.stft(y, L, L, fft_size, hop, wpad, fft_size // 2 + 1)
+        sums = TO.stft_loss_sums(ops, zx, zy, float(fft_size))
+        ctx.save_for_backward(zx, zy, sums)
+        ctx.geom = (fft_size, hop, win, L)
+        sc = (sums[0] / sums[1]).sqrt().float()                  # three device scalars: stft_loss.py:47,64
+        mag = (sums[2] / (zx.numel() // 2)).float()
+        return sc, mag
+
+    @staticmethod
+    def backward(ctx, gsc, gmag):
+        from . import train_ops as TO
+        ops = _get_ops()
+        zx, zy, sums = ctx.saved_tensors
+        fft_size, hop, win, L = ctx.geom
+        gout = torch.stack([gsc.reshape(()), gmag.reshape(())]).float().contiguous()
+        g = TO.stft_loss_bwd(ops, zx, zy, float(fft_size), sums, 1.0, 1.0, gout)
+        dx = TO.stft_adjoint(ops, g, fft_size, hop, _window(win, fft_size, zx.device), L)
+        return dx, None, None, None, None
+
+
 class STFTLoss(torch.nn.Module):
-    """stft_loss.py:84-117: spectral convergence and log-magnitude L1 of one resolution."""
+    """stft_loss.py:84-117: spectral convergence and log-magnitude L1 of one resolution (differentiable w.r.t. x)."""
 
     def __init__(self, fft_size=1024, shift_size=120, win_length=600):
         super().__init__()
         self.fft_size, self.shift_size, self.win_length = fft_size, shift_size, win_length
 
     def forward(self, x, y):
-        with torch.no_grad():
-            x_mag = stft_magnitude(x, self.fft_size, self.shift_size, self.win_length)
-            y_mag = stft_magnitude(y, self.fft_size, self.shift_size, self.win_length)
-            sc = torch.norm(y_mag - x_mag, p='fro') / torch.norm(y_mag, p='fro')
-            mag = torch.nn.functional.l1_loss(torch.log(y_mag), torch.log(x_mag))
-        return sc, mag
+        return _STFTLossFn.apply(x, y, self.fft_size, self.shift_size, self.win_length)
 
 
 class MultiResolutionSTFTLoss(torch.nn.Module):

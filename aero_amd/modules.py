@@ -288,15 +288,24 @@ class Aero(nn.Module):
             object.__setattr__(self, '_engine', HipEngine(self))
         return self._engine
 
+    def _get_train_engine(self):
+        from .train import TrainEngine
+        if getattr(self, '_train_engine', None) is None:
+            object.__setattr__(self, '_train_engine', TrainEngine(self, lib=self._get_engine().lib))
+        return self._train_engine
+
     def repack(self):
         """Tell the device engine that the weights were edited in a way version counters cannot see (writes through
         `.data`, as `rescale_module` and many EMA helpers do): the next forward repacks them."""
         if self._engine is not None:
             self._engine.invalidate()
+        if getattr(self, '_train_engine', None) is not None:
+            self._train_engine.invalidate()
 
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_engine'] = None
+        st.pop('_train_engine', None)
         return st
 
     def _spec(self, x, scale=False):
@@ -310,9 +319,18 @@ class Aero(nn.Module):
     def forward(self, mix, return_spec=False, return_lr_spec=False):
         """aero.py:446-523.  `mix` [B, in_channels, L] float32 on the MI355X device."""
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('aero_amd: the training-mode FORWARD runs on the MI355X (batch-statistics BatchNorm, '
-                                      'running-stat update), but there are no HIP backward kernels yet -- call it under '
-                                      'torch.no_grad() (or freeze the parameters); autograd through forward is not built')
+            # autograd through forward (solver.py:296-305, 602-605): the layer-by-layer training engine keeps what the HIP backward
+            # pass needs (aero_amd/train.py).  The waveform output carries the gradient; the spectrogram outputs are detached views
+            # (the reference's losses act on the waveform: solver.py:560-584).
+            from .train import AeroFunction
+            names, params = zip(*self.named_parameters())
+            if any(not p.requires_grad for p in params):
+                raise NotImplementedError('aero_amd: partially frozen generators are not supported by the HIP backward pass')
+            x, spec_r, lr_spec = AeroFunction.apply(self._get_train_engine(), names, mix, *params)
+            spec = torch.view_as_complex(spec_r).view(mix.shape[0], 1, spec_r.shape[1], spec_r.shape[2])
+            if return_spec:
+                return (x, spec, lr_spec) if return_lr_spec else (x, spec)
+            return x
         x, spec, lr_spec = self._get_engine().forward(mix, want_spec=return_spec, want_lr_spec=return_lr_spec,
                                                       train=self.training)
         if return_spec:

@@ -43,7 +43,7 @@ def glu_interleave(t):
     accumulator quad holds both halves of two GLU outputs (k_conv.h epilogue)."""
     n = t.shape[0] // 2
     idx = torch.stack([torch.arange(n), torch.arange(n) + n], 1).reshape(-1)
-    return t[idx]
+    return t[idx.to(t.device)]
 
 
 def make_conv_spec(w_taps, bias, C0, C1, df, dt, device, transposed=0, fstride=1, act=_lib.ACT_NONE):
@@ -56,8 +56,8 @@ def make_conv_spec(w_taps, bias, C0, C1, df, dt, device, transposed=0, fstride=1
             bias = glu_interleave(bias)
     Cp = _round_up(Ct, 32)
     Mpad = _round_up(M, 128)
-    img = torch.zeros(nw, Mpad, nt, Cp, dtype=torch.float32)
-    img[:, :M, :, :Ct] = w_taps
+    img = torch.zeros(nw, Mpad, nt, Cp, dtype=torch.float32, device=w_taps.device)     # (packed where the weights live: the
+    img[:, :M, :, :Ct] = w_taps                                                         #  training step re-packs on the device)
     spec = ConvSpec(weight=img.reshape(nw, Mpad, nt * Cp).to(device=device, dtype=torch.float16).contiguous(),
                     bias=None if bias is None else bias.detach().float().to(device).contiguous(),
                     M=M, C0=C0, C1=C1, df=list(df), dt=list(dt), transposed=transposed, fstride=fstride, act=act)
@@ -82,8 +82,8 @@ def tile_weights(w, bm):
     nw, M, K = w.shape
     assert M % bm == 0 and K % 32 == 0
     t = w.reshape(nw, M // bm, bm, K // 32, 4, 8).permute(0, 1, 3, 2, 4, 5)          # [nw, mt, kc, row, q_src, 8]
-    row = torch.arange(bm)
-    q = torch.arange(4)
+    row = torch.arange(bm, device=w.device)
+    q = torch.arange(4, device=w.device)
     src = q[None, :] ^ ((-(row[:, None] >> 2)) & 3)                                    # unit q of `row` reads source slot src
     idx = src[None, None, None, :, :, None].expand(nw, M // bm, K // 32, bm, 4, 8)
     return torch.gather(t, 4, idx).reshape(nw, M // bm, K // 32, bm * 32)
@@ -117,7 +117,7 @@ def convtr_taps(w, stride):
     Cin, Cout, K, kT = w.shape
     assert kT == 1
     nt = math.ceil(K / stride)
-    taps = torch.zeros(stride, Cout, nt, Cin)
+    taps = torch.zeros(stride, Cout, nt, Cin, device=w.device)
     for r in range(stride):
         for j in range(nt):
             kk = r + j * stride
@@ -164,7 +164,7 @@ def lstm_gate_perm(H):
 
 def pack_lstm_layer(lib, sd, prefix, layer, H, device):
     """-> (ConvSpec for the input projection of both directions, xbias fp16 [8H], whh fp16 [2,MP,KP])."""
-    perm = lstm_gate_perm(H)
+    perm = lstm_gate_perm(H).to(sd[f'{prefix}.weight_ih_l{layer}'].device)
     w_ih, b, w_hh = [], [], []
     for sfx in ('', '_reverse'):
         w_ih.append(sd[f'{prefix}.weight_ih_l{layer}{sfx}'].float()[perm])
@@ -174,14 +174,14 @@ def pack_lstm_layer(lib, sd, prefix, layer, H, device):
     b = torch.cat(b, 0)
     spec = make_conv_spec(w_ih[None, :, None, :], b, w_ih.shape[1], 0, [0], [0], device)
     MP, KP = lib.lstm_geometry(H)
-    whh = torch.zeros(2, MP, KP)
+    whh = torch.zeros(2, MP, KP, device=w_ih.device)
     for dr in range(2):
         whh[dr, :4 * H, :H] = w_hh[dr]
     fused = None
     in_ch = w_ih.shape[1]
     KPI = lib.lstm_geometry_in(H, in_ch)
     if KPI is not None:                                          # W_ih x_t computed inside the recurrent kernel
-        wih = torch.zeros(2, MP, KPI)
+        wih = torch.zeros(2, MP, KPI, device=w_ih.device)
         for dr in range(2):
             wih[dr, :4 * H, :in_ch] = w_ih[dr * 4 * H:(dr + 1) * 4 * H]
         fused = (wih.to(device=device, dtype=torch.float16).contiguous(), b.float().to(device).contiguous(), in_ch)

@@ -1,0 +1,756 @@
+"""One training step of the generator on the MI355X: the training-mode forward of `Aero` with everything the backward needs
+kept on the device, and the hand-written reverse pass -- reference `loss.backward()` of src/solver.py:602-605 through
+src/models/aero.py:108-135 (HEncLayer), :189-215 (HDecLayer), :446-523 (Aero.forward) and src/models/modules.py:32-65 (BLSTM),
+:94-127 (LocalState), :221-249 (DConv), :304-325 (FTB).
+
+Host plumbing only: every arithmetic step is a C-ABI kernel call (include/aero_hip.h) -- the forward family (`aero_conv_fwd`,
+`aero_norm_*`, `aero_lstm_fwd`, `aero_localstate_fwd`, `aero_freqfc_fwd`, STFT / iSTFT), the backward kernels of csrc/k_bwd.h
+(`aero_conv_wgrad`, `aero_norm_bwd_*`, iSTFT adjoint; data gradients are forward convolutions on re-packed weights,
+aero_amd/backward.py) and of csrc/k_train.h (LSTM BPTT, LocalState, FTB gate / freq_fc, frequency embedding, the fp16 boundary).
+torch supplies device memory, views / permutes of parameter-sized tensors (layout changes, no arithmetic) and the autograd
+hook (`AeroFunction`).  There is no CPU / eager fallback.
+
+Layer by layer rather than on the fused inference kernels: the backward needs the pre-normalisation and pre-activation tensors
+the fused forms never write.  Activations and their gradients are fp16 (fp32 accumulation); the gradient enters the fp16 domain
+multiplied by a power-of-two loss scale chosen from its own maximum (`aero_scale_cast`) and every parameter gradient is
+un-scaled in fp32 at the end (`aero_scale_f32`), so nothing depends on the magnitude of the loss.
+"""
+import math
+
+import torch
+
+from . import _lib, backward as bw, pack, train_ops as TO
+from ._lib import ACT_GELU, ACT_GLU, ACT_NONE, ACT_RELU, ACT_SNAKE
+from .engine import Ops, _hann_padded
+
+GRAD_TARGET = 4096.0        # the activation gradient enters fp16 with its largest magnitude in [2048, 4096]
+
+
+def _r8(n):
+    return (n + 7) // 8 * 8
+
+
+def lstm_param_grads(ops, da, x, out, sd, layer, H, nseq, W, in_ch, dev):
+    """Parameter and input gradients of one bidirectional nn.LSTM layer from da = d(gate pre-activations) (aero_lstm_bwd):
+    da fp16 [nseq*W, 2, 4H] (column 4j + gate), x fp16 [nseq, W, in_ch] the layer input, out fp16 [nseq, W, 2H] its output;
+    sd: the nn.LSTM state dict (`weight_ih_l{layer}[_reverse]`, ...).  Returns {parameter name: fp32 gradient, 'dx': fp16 [nseq, W, in_ch]}."""
+    npos = nseq * W
+    H4 = 4 * H
+    perm = pack.lstm_gate_perm(H).to(dev)                       # kernel row 4j+g <- nn.LSTM row g*H+j
+    g = {}
+    dw, db = bw.conv_wgrad(ops, da.view(1, 1, npos, 2 * H4), x.reshape(1, 1, npos, in_ch), [0], [0])      # [1, 8H, in_ch], [8H]
+    w_t = []
+    for dr, sfx in enumerate(('', '_reverse')):
+        gi = torch.empty(H4, in_ch, dtype=torch.float32, device=dev)
+        gi[perm] = dw[0, dr * H4:(dr + 1) * H4]
+        g[f'weight_ih_l{layer}{sfx}'] = gi
+        gb = torch.empty(H4, dtype=torch.float32, device=dev)
+        gb[perm] = db[dr * H4:(dr + 1) * H4]
+        g[f'bias_ih_l{layer}{sfx}'] = gb
+        g[f'bias_hh_l{layer}{sfx}'] = gb
+        dav = da.view(nseq, W, 2, H4)[:, :, dr, :].unsqueeze(1)                       # [nseq, 1, W, 4H] strided
+        hv = out.view(nseq, W, 2 * H)[:, :, dr * H:(dr + 1) * H].unsqueeze(1)         # h of this direction
+        if H % 8:
+            dav, hv = dav.contiguous(), hv.contiguous()
+        dwh, _ = bw.conv_wgrad(ops, dav, hv, [0], [1 if dr else -1], bias=False)      # h_{prev}: the step before in this direction
+        gh = torch.empty(H4, H, dtype=torch.float32, device=dev)
+        gh[perm] = dwh[0]
+        g[f'weight_hh_l{layer}{sfx}'] = gh
+        w_t.append(sd[f'weight_ih_l{layer}{sfx}'].detach().float().to(dev)[perm])   # [4H, in] kernel row order
+    wt = torch.cat(w_t, 0).t().contiguous()                                          # [in_ch, 8H]
+    spec = pack.make_conv_spec(wt[None, :, None, :], None, 2 * H4, 0, [0], [0], dev)
+    g['dx'] = ops.conv(spec, da.view(1, 1, npos, 2 * H4), None, 1, 1, 1, npos).view(nseq, W, in_ch)
+    return g
+
+
+class _Ctx:
+    """what one forward keeps for its backward"""
+    pass
+
+
+class TrainEngine:
+    def __init__(self, model, lib=None):
+        self.model = model
+        self.lib = lib if lib is not None else _lib.load()
+        self.ops = Ops(self.lib)
+        self._cache, self._key = {}, None
+        self._tables = {}
+        self._epoch = 0
+
+    # ------------------------------------------------------------------ weights (packed on the device, per parameter version)
+    def invalidate(self):
+        self._epoch += 1
+
+    def _sync_weights(self, dev):
+        key = (str(dev), self._epoch) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        if key != self._key:
+            self._cache, self._key = {}, key
+            self.sd = {k: v.detach() for k, v in self.model.state_dict(keep_vars=True).items()}
+
+    def w(self, name):
+        return self.sd[name].float()
+
+    def spec(self, key, build):
+        s = self._cache.get(key)
+        if s is None:
+            s = self._cache[key] = build()
+        return s
+
+    def _window(self, win, dev):
+        key = ('win', win, str(dev))
+        if key not in self._tables:
+            self._tables[key] = _hann_padded(win, self.model.nfft, dev)
+        return self._tables[key]
+
+    def _inv_env(self, win, hop, T, dev):
+        from .engine import HipEngine
+        key = ('env', win, hop, T, str(dev))
+        if key not in self._tables:
+            if len(self._tables) > 32:
+                self._tables.clear()
+            fake = HipEngine.__new__(HipEngine)
+            fake.model, fake._tables = self.model, {}
+            self._tables[key] = HipEngine._inv_env(fake, win, hop, T, dev)
+        return self._tables[key]
+
+    # ------------------------------------------------------------------ small helpers over Ops
+    def _norm(self, x, G, per_row, gamma, beta, act, **kw):
+        """aero_norm_stats + aero_norm_apply; returns (y, stats)"""
+        y = self.ops.norm_act(x, G, per_row, gamma, beta, act, **kw)
+        return y, (self.ops._last_stats if kw.get('normalize', True) else None)
+
+    def _bn_relu(self, y, bnmod, prefix, dst=None, dst_strides=None):
+        """training-mode BatchNorm + ReLU (modules.py:287,293,300) and the running-statistics bookkeeping of nn.BatchNorm"""
+        Bq, Fy, Ty, Cy = y.shape
+        gamma, beta = self.w(prefix + '.weight'), self.w(prefix + '.bias')
+        if Cy > gamma.numel():                                  # zero-padded channels (r_channel 5 -> 8): gamma = beta = 0 there
+            gamma = torch.cat([gamma, gamma.new_zeros(Cy - gamma.numel())])
+            beta = torch.cat([beta, beta.new_zeros(Cy - beta.numel())])
+        out = self.ops.norm_act(y, Cy, 2, gamma, beta, ACT_RELU, eps=bnmod.eps, dst=dst, dst_strides=dst_strides)
+        st = self.ops._last_stats
+        n = float(Bq * Fy * Ty)
+        nc = bnmod.running_mean.numel()
+        with torch.no_grad():                                   # buffer bookkeeping of nn.BatchNorm (not the data path)
+            mean = st[:nc, 0] / n
+            var = (st[:nc, 1] / n - mean * mean).clamp_min(0)
+            mom = bnmod.momentum
+            bnmod.running_mean.mul_(1 - mom).add_(mean.to(bnmod.running_mean.dtype), alpha=mom)
+            bnmod.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(bnmod.running_var.dtype), alpha=mom)
+            bnmod.num_batches_tracked.add_(1)
+        return out, st, gamma, beta
+
+    # ================================================================== forward
+    def forward(self, mix):
+        """-> (y fp32 [B,1,Lout], spec_out fp32 [B,F0,T,2], lr_spec complex64, ctx)"""
+        m, ops = self.model, self.ops
+        if m.in_channels != 1 or m.out_channels != 1:
+            raise NotImplementedError('only in_channels = out_channels = 1 (all reference configs)')
+        if not self.lib.is_emulator and not mix.is_cuda:
+            raise RuntimeError('aero_amd trains on the MI355X only: move the model and the input to "cuda"')
+        dev = mix.device
+        self._sync_weights(dev)
+        B, _, L = mix.shape
+        mix = mix.contiguous()
+        ops.begin_step(dev)
+        ops._cur = None                                          # statistics are kept for the backward: no shared arena
+        ctx = _Ctx()
+        hop, win = m.hop_length, m.win_length
+        padn = (hop - L % hop) % hop
+        stats = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+        z = ops.stft(mix.reshape(B, L), L, L + padn, m.nfft, hop, self._window(win, dev), m.nfft // 2, stats=stats, sig_per_item=1, win_len=win)
+        F0, T = z.shape[1], z.shape[2]
+        x, mean_std = ops.spec_normalize(z, B, stats)
+        ctx.mean, ctx.std = mean_std[:, 0].contiguous(), mean_std[:, 1].contiguous()
+        ctx.B, ctx.T, ctx.F0, ctx.L = B, T, F0, L
+        ctx.enc, ctx.dec = [], []
+        saved = []
+        Fq = F0
+        for i, enc in enumerate(m.encoder):
+            x, Fq, rec = self._enc_fwd(i, enc, x, B, Fq, T)
+            ctx.enc.append(rec)
+            saved.append((x, Fq))
+        x = None
+        for j, dec in enumerate(m.decoder):
+            skip, Fs = saved.pop()
+            x, rec = self._dec_fwd(j, dec, x, skip, B, Fs, T, ctx)
+            ctx.dec.append(rec)
+        spec_out = x
+        hop_o, win_o = int(m.hop_length * m.scale), int(m.win_length * m.scale)
+        Lout = min(hop_o * (T - 1), int(L * m.scale))
+        y = ops.istft(spec_out, m.nfft, hop_o, self._window(win_o, dev), self._inv_env(win_o, hop_o, T, dev), Lout)
+        ctx.Lout, ctx.hop_o, ctx.win_o = Lout, hop_o, win_o
+        return y.view(B, 1, Lout), spec_out, torch.view_as_complex(z).view(B, 1, F0, T), ctx
+
+    # ------------------------------------------------------------------ encoder layer
+    def _enc_fwd(self, i, enc, x, B, Fq, T):
+        ops, dev = self.ops, x.device
+        p = f'encoder.{i}'
+        mk = pack.make_conv_spec
+        r = _Ctx()
+        r.Fq = Fq
+        if enc.is_first:
+            r.x_in = x
+
+            def b_pre():
+                w, df, dt = pack.conv2d_taps(self.w(f'{p}.pre_conv.weight'), 0, 0)
+                return mk(w, self.w(f'{p}.pre_conv.bias'), w.shape[-1], 0, df, dt, dev)
+            x = ops.conv(self.spec(p + '.pre', b_pre), x, None, B, Fq, Fq, T)
+        r.ftb = None
+        if enc.freq_attn:
+            x, r.ftb = self._ftb_fwd(p + '.freq_attn_block', enc.freq_attn_block, x, B, Fq, T)
+        r.x_conv = x
+        Fo = (Fq + 2 * enc.pad - enc.kernel_size) // enc.stride + 1
+
+        def b_conv():
+            w, df, dt = pack.conv2d_taps(self.w(f'{p}.conv.weight'), enc.pad, 0)
+            return mk(w, self.w(f'{p}.conv.bias'), w.shape[-1], 0, df, dt, dev, fstride=enc.stride)
+        r.yc = ops.conv(self.spec(p + '.conv', b_conv), x, None, B, Fq, Fo, T)
+        if enc.norm:
+            x, r.stc = self._norm(r.yc, enc.norm_groups, 0, self.w(f'{p}.norm1.weight'), self.w(f'{p}.norm1.bias'), ACT_GELU)
+        else:
+            x, r.stc = self._norm(r.yc, 1, 0, None, None, ACT_GELU, normalize=False)
+        r.dconv = []
+        if enc.dconv is not None:
+            for d_ in range(enc.dconv.depth):
+                x, rec = self._dconv_layer_fwd(f'{p}.dconv.layers.{d_}', enc.dconv, d_, x, B, Fo, T)
+                r.dconv.append(rec)
+        r.x_rw = x
+        if enc.rewrite is None:
+            raise NotImplementedError('encoder layer without rewrite conv')
+
+        def b_rw():
+            w, df, dt = pack.conv2d_taps(self.w(f'{p}.rewrite.weight'), enc.context, enc.context)
+            return mk(w, self.w(f'{p}.rewrite.bias'), w.shape[-1], 0, df, dt, dev)
+        r.r = ops.conv(self.spec(p + '.rewrite', b_rw), x, None, B, Fo, Fo, T)
+        emb = None
+        if i == 0 and self.model.freq_emb is not None:
+            fe = self.model.freq_emb
+            e = (self.w('freq_emb.embedding.weight') * (fe.scale * self.model.freq_emb_scale)).half().contiguous()      # [Fo, C]
+            emb = e[None, :, None, :].expand(B, Fo, T, e.shape[1])
+        if enc.norm:
+            x, r.st_rw = self._norm(r.r, enc.norm_groups, 0, self.w(f'{p}.norm2.weight'), self.w(f'{p}.norm2.bias'), ACT_GLU, res=emb)
+        else:
+            x, r.st_rw = self._norm(r.r, 1, 0, None, None, ACT_GLU, normalize=False, res=emb)
+        r.Fo = Fo
+        return x, Fo, r
+
+    def _ftb_fwd(self, q, ftb, x, B, Fq, T):
+        """FTB in training mode (modules.py:304-325): conv1 (r_channel 5, run at 8 channels with zero rows) -> BN -> ReLU ->
+        [B,T,F*8] image -> Conv1d k=9 -> BN -> ReLU = gate; freq_fc(x * gate); conv2 on cat(att, x) -> BN -> ReLU."""
+        ops, dev = self.ops, x.device
+        mk = pack.make_conv_spec
+        Fd, Cc, rch = ftb.input_dim, ftb.in_channel, ftb.r_channel
+        assert Fd == Fq
+        rp = _r8(rch)
+        r = _Ctx()
+        r.x, r.rp = x, rp
+
+        def b_c1():
+            w = self.w(f'{q}.conv1.0.weight')[:, :, 0, 0]                       # [r, C]
+            wp = torch.zeros(rp, Cc, device=dev)
+            wp[:rch] = w
+            bp = torch.zeros(rp, device=dev)
+            bp[:rch] = self.w(f'{q}.conv1.0.bias')
+            return mk(wp[None, :, None, :], bp, Cc, 0, [0], [0], dev)
+        r.y1 = ops.conv(self.spec(q + '.c1', b_c1), x, None, B, Fq, Fq, T)                                  # [B,F,T,rp]
+        r.c1 = torch.empty(B, T, Fq * rp, dtype=torch.float16, device=dev)
+        _, r.st1, r.g1, r.b1 = self._bn_relu(r.y1, ftb.conv1[1], f'{q}.conv1.1', dst=r.c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
+
+        def b_c1d():
+            w = self.w(f'{q}.conv1d.0.weight')                                  # [C, r*F, 9], input channel c*F + f (modules.py:311)
+            k9 = w.shape[-1]
+            w = w.view(Cc, rch, Fd, k9).permute(0, 3, 2, 1)                     # [M, k, F, r]
+            wp = torch.zeros(Cc, k9, Fd, rp, device=dev)
+            wp[..., :rch] = w
+            return mk(wp.reshape(1, Cc, k9, Fd * rp), self.w(f'{q}.conv1d.0.bias'), Fd * rp, 0, [0] * k9, [j - (k9 // 2) for j in range(k9)], dev)
+        r.y2 = ops.conv(self.spec(q + '.c1d', b_c1d), r.c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T)          # [B,1,T,C]
+        gate, r.st2, r.g2, r.b2 = self._bn_relu(r.y2, ftb.conv1d[1], f'{q}.conv1d.1')
+        r.gate = gate.view(B, T, Cc)
+
+        def b_fc():
+            wfc = self.w(f'{q}.freq_fc.weight')
+            img = torch.zeros(pack._round_up(Fd, 128), pack._round_up(Fd, 32), device=dev)
+            img[:Fd, :Fd] = wfc
+            imt = torch.zeros_like(img)
+            imt[:Fd, :Fd] = wfc.t()
+            return img.half().contiguous(), imt.half().contiguous()
+        r.fc = ops.freqfc(x, self.spec(q + '.fc', b_fc)[0], r.gate)
+
+        def b_c2():
+            w, df, dt = pack.conv2d_taps(self.w(f'{q}.conv2.0.weight'), 0, 0)
+            return mk(w, self.w(f'{q}.conv2.0.bias'), Cc, Cc, df, dt, dev)
+        r.y3 = ops.conv(self.spec(q + '.c2', b_c2), r.fc, x, B, Fq, Fq, T)
+        out, r.st3, r.g3, r.b3 = self._bn_relu(r.y3, ftb.conv2[1], f'{q}.conv2.1')
+        return out, r
+
+    # ------------------------------------------------------------------ DConv layer
+    def _dconv_layer_fwd(self, q, dc, d_, x, B, Fo, T):
+        ops, dev = self.ops, x.device
+        mk = pack.make_conv_spec
+        Cc, hid = dc.channels, dc.hidden
+        hp = _r8(hid)
+        dil = 2 ** d_ if dc.dilate else 1
+        k = dc.kernel
+        r = _Ctx()
+        r.x, r.hp, r.dil = x, hp, dil
+        if not dc.norm:
+            raise NotImplementedError('DConv without GroupNorm is not used by any reference config')
+
+        def b_c1():
+            w = self.w(f'{q}.conv1.0.weight')                                   # [hid, C, k]
+            wp = torch.zeros(hp, Cc, k, device=dev)
+            wp[:hid] = w
+            bp = torch.zeros(hp, device=dev)
+            bp[:hid] = self.w(f'{q}.conv1.0.bias')
+            t, df, dt = pack.conv1d_taps(wp, dil, dil * (k // 2))
+            return mk(t, bp, Cc, 0, df, dt, dev), wp
+        r.h1 = ops.conv(self.spec(q + '.c1', b_c1)[0], x, None, B, Fo, Fo, T)
+
+        def padded(name):
+            v = self.w(name)
+            out = torch.zeros(hp, device=dev)
+            out[:hid] = v
+            return out
+        r.g1, r.be1 = padded(f'{q}.conv1.1.weight'), padded(f'{q}.conv1.1.bias')
+        act = {'snake': ACT_SNAKE, 'gelu': ACT_GELU}.get(dc.act_func, ACT_RELU)
+        r.act = act
+        r.snake_a = self.w(f'{q}.act.a').reshape(-1).contiguous() if act == ACT_SNAKE else None
+        a, r.st1 = self._norm(r.h1, 1, 1, r.g1, r.be1, act, snake_a=r.snake_a, stat_count=T * hid)
+        r.lstm = r.attn = None
+        if dc.lstm:
+            a, r.lstm = self._blstm_fwd(q + '.lstm', hid, hp, a, B, Fo, T)
+        if dc.time_attn:
+            a, r.attn = self._attn_fwd(q + '.time_attn', dc.layers[d_]['time_attn'], hid, hp, a, B, Fo, T)
+        r.a = a
+
+        def b_c2():
+            w = self.w(f'{q}.conv2.0.weight')                                   # [2C, hid, 1]
+            wp = torch.zeros(2 * Cc, hp, 1, device=dev)
+            wp[:, :hid] = w
+            t, df, dt = pack.conv1d_taps(wp, 1, 0)
+            return mk(t, self.w(f'{q}.conv2.0.bias'), hp, 0, df, dt, dev), wp
+        r.h2 = ops.conv(self.spec(q + '.c2', b_c2)[0], a, None, B, Fo, Fo, T)
+        y, r.st2 = self._norm(r.h2, 1, 1, self.w(f'{q}.conv2.1.weight'), self.w(f'{q}.conv2.1.bias'), ACT_GLU,
+                              layer_scale=self.w(f'{q}.conv2.3.scale'), res=x)
+        return y, r
+
+    def _lstm_specs(self, q, H, dev):
+        def b():
+            sd = {k[len(q) + 1:]: v for k, v in self.sd.items() if k.startswith(q + '.')}
+            sdf = {k: v.float() for k, v in sd.items()}
+            layers = [pack.pack_lstm_layer(self.lib, sdf, 'lstm', l, H, dev) for l in range(2)]
+            whh_t = [TO.pack_whh_t(self.lib, [sdf[f'lstm.weight_hh_l{l}'], sdf[f'lstm.weight_hh_l{l}_reverse']], H, dev) for l in range(2)]
+            w = sdf['linear.weight']
+            lin = pack.make_conv_spec(w[None, :, None, :], sdf['linear.bias'], w.shape[1], 0, [0], [0], dev)
+            return layers, whh_t, lin, {k[5:]: v for k, v in sdf.items() if k.startswith('lstm.')}
+        return self.spec(q + '.specs', b)
+
+    def _blstm_fwd(self, q, H, hp, a, B, Fo, T):
+        """BLSTM (modules.py:32-65): frames by aero_frames_op, two bidirectional layers with their gates / cell states kept, the stitch,
+        Linear(2H -> H) + skip.  `a` [B,Fo,T,hp] with H live channels (hp = H unless H % 8)."""
+        if hp != H:
+            raise NotImplementedError('BLSTM training path needs a hidden size that is a multiple of 8')
+        ops, dev = self.ops, a.device
+        layers, whh_t, lin, _ = self._lstm_specs(q, H, dev)
+        R = B * Fo
+        r = _Ctx()
+        framed = T > 200
+        if framed:
+            W, S = 200, 100
+            nf = math.ceil(T / S)
+            fr0 = TO.frames_op(ops, a.view(R, T, H), 0, R, T, H, nf, W, S)
+        else:
+            W, S, nf = T, 1, 1
+            fr0 = a.view(R, T, H)
+        nseq = R * nf
+        r.framed, r.W, r.S, r.nf, r.nseq, r.a = framed, W, S, nf, nseq, a
+        outs, saves, xin = [], [], fr0
+        for l in range(2):
+            pj, xb, whh, fz = layers[l]
+            out = torch.empty(nseq, W, 2 * H, dtype=torch.float16, device=dev)
+            save = TO.lstm_save_buffers(nseq, W, H, dev)
+            in_ch = xin.shape[-1]
+            if fz is not None:
+                ops.lstm(None, None, whh, H, nseq, W, 0, 0, 1, 1, W, out, x=xin.reshape(nseq, W, in_ch), fused=fz, save=save)
+            else:
+                xp = ops.conv(pj, xin.reshape(1, 1, nseq * W, in_ch), None, 1, 1, 1, nseq * W)
+                ops.lstm(xp, xb, whh, H, nseq, W, 0, 0, 1, 1, W, out, save=save)
+            outs.append(out)
+            saves.append(save)
+            xin = out
+        r.fr0, r.outs, r.saves = fr0, outs, saves
+        r.out1s = TO.frames_op(ops, outs[1], 2, R, T, 2 * H, nf, W, S) if framed else outs[1]
+        y = ops.conv(lin, r.out1s.view(B, Fo, T, 2 * H), None, B, Fo, Fo, T, res=a)
+        return y, r
+
+    def _attn_fwd(self, q, mod, Cc, hp, a, B, Fo, T):
+        if hp != Cc:
+            raise NotImplementedError('LocalState training path needs a channel count that is a multiple of 8')
+        ops, dev = self.ops, a.device
+
+        def b():
+            names = ('query', 'key', 'content', 'query_decay')
+            w = torch.cat([self.w(f'{q}.{n}.weight')[:, :, 0] for n in names], 0)
+            bb = torch.cat([self.w(f'{q}.{n}.bias') for n in names], 0)
+            qk = pack.make_conv_spec(w[None, :, None, :], bb, w.shape[1], 0, [0], [0], dev)
+            wp = self.w(f'{q}.proj.weight')[:, :, 0]
+            pj = pack.make_conv_spec(wp[None, :, None, :], self.w(f'{q}.proj.bias'), wp.shape[1], 0, [0], [0], dev)
+            return qk, pj, w, wp
+        qk, pj, _, _ = self.spec(q + '.specs', b)
+        r = _Ctx()
+        r.a = a
+        r.heads, r.ndecay = mod.heads, mod.ndecay
+        r.qkvd = ops.conv(qk, a, None, B, Fo, Fo, T)
+        r.att = ops.localstate(r.qkvd, B * Fo, T, Cc, mod.heads, mod.ndecay)
+        y = ops.conv(pj, r.att.view(B, Fo, T, Cc), None, B, Fo, Fo, T, res=a)
+        return y, r
+
+    # ------------------------------------------------------------------ decoder layer
+    def _dec_fwd(self, j, dec, x, skip, B, Fq, T, ctx):
+        ops, dev = self.ops, skip.device
+        p = f'decoder.{j}'
+        mk = pack.make_conv_spec
+        half = dec.chin // 2
+        r = _Ctx()
+        r.x, r.skip, r.Fq = x, skip, Fq
+        if dec.rewrite is None or dec.dconv is not None:
+            raise NotImplementedError('decoder without rewrite conv / with DConv is not used by any reference config')
+
+        def b_rw():
+            w, df, dt = pack.conv2d_taps(self.w(f'{p}.rewrite.weight'), dec.context, dec.context)
+            return mk(w, self.w(f'{p}.rewrite.bias'), half, half, df, dt, dev)
+        r.r = ops.conv(self.spec(p + '.rewrite', b_rw), x, skip, B, Fq, Fq, T)
+        if dec.norm:
+            y, r.st1 = self._norm(r.r, dec.norm_groups, 0, self.w(f'{p}.norm1.weight'), self.w(f'{p}.norm1.bias'), ACT_GLU)
+        else:
+            y, r.st1 = self._norm(r.r, 1, 0, None, None, ACT_GLU, normalize=False)
+        r.y = y
+        Fu = (Fq - 1) * dec.stride + dec.kernel_size
+        Ft = Fu - 2 * dec.pad
+        r.Fu, r.Ft = Fu, Ft
+
+        def b_tr():
+            w, df, dt = pack.convtr_taps(self.w(f'{p}.conv_tr.weight'), dec.stride)
+            return mk(w, self.w(f'{p}.conv_tr.bias'), w.shape[-1], 0, df, dt, dev, transposed=1, fstride=dec.stride)
+        tr = self.spec(p + '.conv_tr', b_tr)
+        if dec.last:
+            if dec.norm:
+                raise NotImplementedError('GroupNorm on the last decoder layer (norm_starts = 0)')
+            out = ops.conv(tr, y, None, B, Fq, Fu, T, dst_f32=True, dst_f_off=dec.pad, dst_F=Ft, batch_scale=ctx.std, batch_shift=ctx.mean)
+            return out, r
+        r.z = ops.conv(tr, y, None, B, Fq, Fu, T)                                                  # untrimmed rows: norm2 sees them (aero.py:206)
+        if dec.norm:
+            out, r.st2 = self._norm(r.z, dec.norm_groups, 0, self.w(f'{p}.norm2.weight'), self.w(f'{p}.norm2.bias'), ACT_GELU, f_lo=dec.pad, f_cnt=Ft)
+        else:
+            out, r.st2 = self._norm(r.z, 1, 0, None, None, ACT_GELU, normalize=False, f_lo=dec.pad, f_cnt=Ft)
+        return out, r
+
+    # ================================================================== backward
+    def backward(self, ctx, dy, grads):
+        """dy fp32 [B,1,Lout]: gradient of the waveform.  `grads`: {state-dict name: fp32 view of the flat gradient buffer} -- every
+        parameter gradient is WRITTEN there, still multiplied by the loss scale; returns the device tensor {S, 1/S}."""
+        m, ops = self.model, self.ops
+        dev = dy.device
+        B, T, F0 = ctx.B, ctx.T, ctx.F0
+        self.g = grads
+        dz = bw.istft_bwd(ops, dy.reshape(B, ctx.Lout).contiguous().float(), m.nfft, ctx.hop_o, self._window(ctx.win_o, dev),
+                          self._inv_env(ctx.win_o, ctx.hop_o, T, dev), T)                               # fp32 [B,F0,T,2]
+        # adjoint of x * std + mean (aero.py:497-498) and the fp32 -> fp16 boundary with the loss scale
+        d16, scale = TO.scale_cast(ops, dz, ctx.std, GRAD_TARGET)
+        dx = d16
+        dskips = []
+        for j in reversed(range(len(m.decoder))):
+            dx, dskip = self._dec_bwd(j, m.decoder[j], ctx.dec[j], dx, B, T)
+            dskips.append(dskip)                                 # decoder j used the output of encoder len-1-j
+        dskips.reverse()                                         # dskips[j] <-> encoder len-1-j
+        dx = None
+        n = len(m.encoder)
+        for i in reversed(range(n)):
+            dsk = dskips[n - 1 - i]
+            dout = dsk if dx is None else TO.add_f16(ops, dsk, dx)
+            dx = self._enc_bwd(i, m.encoder[i], ctx.enc[i], dout, B, T)
+        return scale
+
+    def _put(self, name, t):
+        self.g[name].copy_(t.reshape(self.g[name].shape))
+
+    # ------------------------------------------------------------------ decoder layer
+    def _dec_bwd(self, j, dec, r, dout, B, T):
+        ops, dev = self.ops, dout.device
+        p = f'decoder.{j}'
+        s, K, pad = dec.stride, dec.kernel_size, dec.pad
+        w_tr = self.w(f'{p}.conv_tr.weight')
+        Fq = r.Fq
+        if dec.last:
+            dz, pad_eff, Fz = dout.contiguous(), pad, r.Ft
+        else:
+            M = r.z.shape[-1]
+            if dec.norm:
+                dfull = torch.zeros(B, r.Fu, T, M, dtype=torch.float16, device=dev)      # dL/d(GELU output) is zero on the trimmed rows
+                dfull[:, pad:pad + r.Ft].copy_(dout)
+                res = bw.norm_bwd(ops, r.z, dfull, r.st2, dec.norm_groups, 0, self.w(f'{p}.norm2.weight'), self.w(f'{p}.norm2.bias'), ACT_GELU)
+                self._put(f'{p}.norm2.weight', res[1])
+                self._put(f'{p}.norm2.bias', res[2])
+                dz, pad_eff, Fz = res[0], 0, r.Fu
+            else:
+                zt = r.z[:, pad:pad + r.Ft]
+                dz = bw.norm_bwd(ops, zt, dout.contiguous(), None, 1, 0, None, None, ACT_GELU)[0]
+                pad_eff, Fz = pad, r.Ft
+        dyv = ops.conv(self.spec(p + f'.tr_dgrad{pad_eff}', lambda: bw.dgrad_convtr(w_tr, s, pad_eff, dev)), dz, None, B, Fz, Fq, T)
+        dw, _ = bw.conv_wgrad(ops, r.y, dz, [kk - pad_eff for kk in range(K)], [0] * K, fstride=s, bias=False)
+        self._put(f'{p}.conv_tr.weight', dw.permute(1, 2, 0))
+        _, db = bw.conv_wgrad(ops, dz, dz[..., :8] if dz.shape[-1] >= 8 else dz, [0], [0], bias=True)
+        self._put(f'{p}.conv_tr.bias', db)
+        # norm1 + GLU
+        if dec.norm:
+            res = bw.norm_bwd(ops, r.r, dyv, r.st1, dec.norm_groups, 0, self.w(f'{p}.norm1.weight'), self.w(f'{p}.norm1.bias'), ACT_GLU)
+            self._put(f'{p}.norm1.weight', res[1])
+            self._put(f'{p}.norm1.bias', res[2])
+            dr = res[0]
+        else:
+            dr = bw.norm_bwd(ops, r.r, dyv, None, 1, 0, None, None, ACT_GLU)[0]
+        # rewrite 3x3 over cat(x, skip) (aero.py:195-198)
+        w_rw = self.w(f'{p}.rewrite.weight')
+        half = dec.chin // 2
+        ctxp = dec.context
+        spec_rw = self.spec(p + '.rewrite', None)
+        dws, db = bw.conv_wgrad(ops, dr, r.skip, spec_rw.df, spec_rw.dt)
+        kF = kT = 1 + 2 * ctxp
+        gw = self.g[f'{p}.rewrite.weight']                        # [2chin, chin, kF, kT]
+        gw[:, half:].copy_(dws.view(kF, kT, dws.shape[1], half).permute(2, 3, 0, 1))
+        if r.x is not None:
+            dwx, _ = bw.conv_wgrad(ops, dr, r.x, spec_rw.df, spec_rw.dt, bias=False)
+            gw[:, :half].copy_(dwx.view(kF, kT, dwx.shape[1], half).permute(2, 3, 0, 1))
+        else:
+            gw[:, :half].zero_()                                 # the first decoder's x is zeros (aero.py:484)
+        self._put(f'{p}.rewrite.bias', db)
+        dskip = ops.conv(self.spec(p + '.rw_dgrad_s', lambda: bw.dgrad_conv2d(w_rw[:, half:], ctxp, ctxp, dev)), dr, None, B, Fq, Fq, T)
+        dxp = None
+        if r.x is not None:
+            dxp = ops.conv(self.spec(p + '.rw_dgrad_x', lambda: bw.dgrad_conv2d(w_rw[:, :half], ctxp, ctxp, dev)), dr, None, B, Fq, Fq, T)
+        return dxp, dskip
+
+    # ------------------------------------------------------------------ encoder layer
+    def _enc_bwd(self, i, enc, r, dout, B, T):
+        ops, dev, m = self.ops, dout.device, self.model
+        p = f'encoder.{i}'
+        Fq, Fo = r.Fq, r.Fo
+        if i == 0 and m.freq_emb is not None:
+            ge = self.g['freq_emb.embedding.weight']
+            ge.zero_()
+            TO.sum_bt(ops, dout.contiguous(), ge, float(m.freq_emb.scale * m.freq_emb_scale))
+        # norm2 + GLU, rewrite
+        if enc.norm:
+            res = bw.norm_bwd(ops, r.r, dout, r.st_rw, enc.norm_groups, 0, self.w(f'{p}.norm2.weight'), self.w(f'{p}.norm2.bias'), ACT_GLU)
+            self._put(f'{p}.norm2.weight', res[1])
+            self._put(f'{p}.norm2.bias', res[2])
+            dr = res[0]
+        else:
+            dr = bw.norm_bwd(ops, r.r, dout, None, 1, 0, None, None, ACT_GLU)[0]
+        w_rw = self.w(f'{p}.rewrite.weight')
+        c = enc.context
+        spec_rw = self.spec(p + '.rewrite', None)
+        dw, db = bw.conv_wgrad(ops, dr, r.x_rw, spec_rw.df, spec_rw.dt)
+        kk = 1 + 2 * c
+        self._put(f'{p}.rewrite.weight', dw.view(kk, kk, dw.shape[1], dw.shape[2]).permute(2, 3, 0, 1))
+        self._put(f'{p}.rewrite.bias', db)
+        dx = ops.conv(self.spec(p + '.rw_dgrad', lambda: bw.dgrad_conv2d(w_rw, c, c, dev)), dr, None, B, Fo, Fo, T)
+        # DConv residual branch
+        if enc.dconv is not None:
+            for d_ in reversed(range(enc.dconv.depth)):
+                dx = self._dconv_layer_bwd(f'{p}.dconv.layers.{d_}', enc.dconv, d_, r.dconv[d_], dx, B, Fo, T)
+        # norm1 + GELU, the strided frequency conv
+        if enc.norm:
+            res = bw.norm_bwd(ops, r.yc, dx, r.stc, enc.norm_groups, 0, self.w(f'{p}.norm1.weight'), self.w(f'{p}.norm1.bias'), ACT_GELU)
+            self._put(f'{p}.norm1.weight', res[1])
+            self._put(f'{p}.norm1.bias', res[2])
+            dyc = res[0]
+        else:
+            dyc = bw.norm_bwd(ops, r.yc, dx, None, 1, 0, None, None, ACT_GELU)[0]
+        w_c = self.w(f'{p}.conv.weight')
+        spec_c = self.spec(p + '.conv', None)
+        dw, db = bw.conv_wgrad(ops, dyc, r.x_conv, spec_c.df, spec_c.dt, fstride=enc.stride)
+        self._put(f'{p}.conv.weight', dw.permute(1, 2, 0))
+        self._put(f'{p}.conv.bias', db)
+        need_dx = enc.freq_attn or enc.is_first or i > 0
+        if not need_dx:
+            return None
+        K, s = enc.kernel_size, enc.stride
+        dxc = ops.conv(self.spec(p + '.conv_dgrad', lambda: bw.dgrad_conv_fstride(w_c, s, dev)), dyc, None, B, Fo, (Fo - 1) * s + K, T,
+                       dst_f_off=enc.pad, dst_F=Fq)
+        if enc.freq_attn:
+            dxc = self._ftb_bwd(p + '.freq_attn_block', enc.freq_attn_block, r.ftb, dxc, B, Fq, T)
+        if enc.is_first:
+            dw, db = bw.conv_wgrad(ops, dxc, r.x_in, [0], [0])
+            self._put(f'{p}.pre_conv.weight', dw.permute(1, 2, 0))
+            self._put(f'{p}.pre_conv.bias', db)
+            return None
+        return dxc
+
+    def _ftb_bwd(self, q, ftb, r, dout, B, Fq, T):
+        ops, dev = self.ops, dout.device
+        Cc, rch, rp = ftb.in_channel, ftb.r_channel, r.rp
+        x = r.x
+        # conv2 -> BN -> ReLU
+        res = bw.norm_bwd(ops, r.y3, dout, r.st3, Cc, 2, r.g3, r.b3, ACT_RELU, eps=ftb.conv2[1].eps)
+        self._put(f'{q}.conv2.1.weight', res[1])
+        self._put(f'{q}.conv2.1.bias', res[2])
+        dy3 = res[0]
+        w2 = self.w(f'{q}.conv2.0.weight')                                              # [C, 2C, 1, 1]: [att | inputs]
+        dwa, db = bw.conv_wgrad(ops, dy3, r.fc, [0], [0])
+        dwb, _ = bw.conv_wgrad(ops, dy3, x, [0], [0], bias=False)
+        gw = self.g[f'{q}.conv2.0.weight']
+        gw[:, :Cc, 0, 0].copy_(dwa[0])
+        gw[:, Cc:, 0, 0].copy_(dwb[0])
+        self._put(f'{q}.conv2.0.bias', db)
+        dfc = ops.conv(self.spec(q + '.c2_dgrad_a', lambda: bw.dgrad_conv2d(w2[:, :Cc], 0, 0, dev)), dy3, None, B, Fq, Fq, T)
+        dxa = ops.conv(self.spec(q + '.c2_dgrad_b', lambda: bw.dgrad_conv2d(w2[:, Cc:], 0, 0, dev)), dy3, None, B, Fq, Fq, T)
+        # freq_fc and the gate product
+        gfc = self.g[f'{q}.freq_fc.weight']
+        gfc.copy_(TO.freqfc_wgrad(ops, dfc, x, r.gate))
+        okey = ('ones', B, T, Cc, str(dev))
+        if okey not in self._tables:
+            self._tables[okey] = torch.ones(B, T, Cc, dtype=torch.float16, device=dev)
+        v = ops.freqfc(dfc, self.spec(q + '.fc', None)[1], self._tables[okey])
+        dxb, dgate = TO.ftb_gate_bwd(ops, v, x, r.gate, add=dxa)
+        # conv1d -> BN -> ReLU (the gate)
+        res = bw.norm_bwd(ops, r.y2, dgate.view(B, 1, T, Cc), r.st2, Cc, 2, r.g2, r.b2, ACT_RELU, eps=ftb.conv1d[1].eps)
+        self._put(f'{q}.conv1d.1.weight', res[1])
+        self._put(f'{q}.conv1d.1.bias', res[2])
+        dy2 = res[0]
+        spec1d = self.spec(q + '.c1d', None)
+        k9 = len(spec1d.dt)
+        img = r.c1.view(B, 1, T, Fq * rp)
+        dw, db = bw.conv_wgrad(ops, dy2, img, spec1d.df, spec1d.dt)                     # [k9, C, F*rp], ours channel f*rp + c
+        dw = dw.view(k9, Cc, Fq, rp)[..., :rch].permute(1, 3, 2, 0)                     # -> [C, r, F, k]: reference channel c*F + f
+        self._put(f'{q}.conv1d.0.weight', dw)
+        self._put(f'{q}.conv1d.0.bias', db)
+
+        def b_dg1d():
+            w = self.w(f'{q}.conv1d.0.weight')
+            wv = w.view(Cc, rch, Fq, k9).permute(0, 2, 1, 3)                            # [C, F, r, k]
+            wp = torch.zeros(Cc, Fq, rp, k9, device=dev)
+            wp[:, :, :rch] = wv
+            return bw.dgrad_conv1d(wp.reshape(Cc, Fq * rp, k9), 1, k9 // 2, dev)
+        dc1 = ops.conv(self.spec(q + '.c1d_dgrad', b_dg1d), dy2, None, B, 1, 1, T)      # [B,1,T,F*rp]
+        # conv1 -> BN -> ReLU (dy arrives in the [B,T,F*rp] image layout)
+        dimg = dc1.view(B, T, Fq, rp).permute(0, 2, 1, 3)                               # [B,F,T,rp] strided view
+        res = bw.norm_bwd(ops, r.y1, dimg, r.st1, rp, 2, r.g1, r.b1, ACT_RELU, eps=ftb.conv1[1].eps)
+        self._put(f'{q}.conv1.1.weight', res[1][:rch])
+        self._put(f'{q}.conv1.1.bias', res[2][:rch])
+        dy1 = res[0]
+        dw, db = bw.conv_wgrad(ops, dy1, x, [0], [0])
+        self._put(f'{q}.conv1.0.weight', dw[0, :rch])
+        self._put(f'{q}.conv1.0.bias', db[:rch])
+
+        def b_dg1():
+            w = self.w(f'{q}.conv1.0.weight')
+            wp = torch.zeros(rp, Cc, 1, 1, device=dev)
+            wp[:rch] = w
+            return bw.dgrad_conv2d(wp, 0, 0, dev)
+        return ops.conv(self.spec(q + '.c1_dgrad', b_dg1), dy1, None, B, Fq, Fq, T, res=dxb)
+
+    def _dconv_layer_bwd(self, q, dc, d_, r, dy, B, Fo, T):
+        ops, dev = self.ops, dy.device
+        Cc, hid, hp = dc.channels, dc.hidden, r.hp
+        k = dc.kernel
+        dy = dy.contiguous()
+        res = bw.norm_bwd(ops, r.h2, dy, r.st2, 1, 1, self.w(f'{q}.conv2.1.weight'), self.w(f'{q}.conv2.1.bias'), ACT_GLU,
+                          layer_scale=self.w(f'{q}.conv2.3.scale'))
+        dh2 = res[0]
+        self._put(f'{q}.conv2.1.weight', res[1])
+        self._put(f'{q}.conv2.1.bias', res[2])
+        self._put(f'{q}.conv2.3.scale', res[3])
+        dw2, db2 = bw.conv_wgrad(ops, dh2, r.a, [0], [0])
+        self._put(f'{q}.conv2.0.weight', dw2.permute(1, 2, 0)[:, :hid])
+        self._put(f'{q}.conv2.0.bias', db2)
+        w2p = self.spec(q + '.c2', None)[1]
+        da = ops.conv(self.spec(q + '.c2_dgrad', lambda: bw.dgrad_conv1d(w2p, 1, 0, dev)), dh2, None, B, Fo, Fo, T)
+        if r.attn is not None:
+            da = self._attn_bwd(q + '.time_attn', hid, r.attn, da, B, Fo, T)
+        if r.lstm is not None:
+            da = self._blstm_bwd(q + '.lstm', hid, r.lstm, da, B, Fo, T)
+        res = bw.norm_bwd(ops, r.h1, da, r.st1, 1, 1, r.g1, r.be1, r.act, stat_count=T * hid, snake_a=r.snake_a)
+        dh1 = res[0]
+        self._put(f'{q}.conv1.1.weight', res[1][:hid])
+        self._put(f'{q}.conv1.1.bias', res[2][:hid])
+        if r.act == ACT_SNAKE:
+            self._put(f'{q}.act.a', res[4])
+        spec1, w1p = self.spec(q + '.c1', None)
+        dw1, db1 = bw.conv_wgrad(ops, dh1, r.x, spec1.df, spec1.dt)
+        self._put(f'{q}.conv1.0.weight', dw1.permute(1, 2, 0)[:hid])
+        self._put(f'{q}.conv1.0.bias', db1[:hid])
+        return ops.conv(self.spec(q + '.c1_dgrad', lambda: bw.dgrad_conv1d(w1p, r.dil, r.dil * (k // 2), dev)), dh1, None, B, Fo, Fo, T, res=dy)
+
+    def _attn_bwd(self, q, Cc, r, dy, B, Fo, T):
+        ops, dev = self.ops, dy.device
+        qk, pj, wq, wp = self.spec(q + '.specs', None)
+        R = B * Fo
+        dw, db = bw.conv_wgrad(ops, dy, r.att.view(B, Fo, T, Cc), [0], [0])
+        self._put(f'{q}.proj.weight', dw[0])
+        self._put(f'{q}.proj.bias', db)
+        datt = ops.conv(self.spec(q + '.proj_dgrad', lambda: bw.dgrad_conv1d(wp[:, :, None], 1, 0, dev)), dy, None, B, Fo, Fo, T)
+        dqkvd = TO.localstate_bwd(ops, r.qkvd.view(R, T, -1), r.att, datt.view(R, T, Cc), R, T, Cc, r.heads, r.ndecay)
+        dqk = dqkvd.view(B, Fo, T, -1)
+        dw, db = bw.conv_wgrad(ops, dqk, r.a, [0], [0])
+        o = 0
+        for nme, n in (('query', Cc), ('key', Cc), ('content', Cc), ('query_decay', r.heads * r.ndecay)):
+            self._put(f'{q}.{nme}.weight', dw[0, o:o + n])
+            self._put(f'{q}.{nme}.bias', db[o:o + n])
+            o += n
+        return ops.conv(self.spec(q + '.qkvd_dgrad', lambda: bw.dgrad_conv1d(wq[:, :, None], 1, 0, dev)), dqk, None, B, Fo, Fo, T, res=dy)
+
+    def _blstm_bwd(self, q, H, r, dy, B, Fo, T):
+        ops, dev = self.ops, dy.device
+        layers, whh_t, lin, sdl = self._lstm_specs(q, H, dev)
+        R = B * Fo
+        dw, db = bw.conv_wgrad(ops, dy, r.out1s.view(B, Fo, T, 2 * H), [0], [0])
+        self._put(f'{q}.linear.weight', dw[0])
+        self._put(f'{q}.linear.bias', db)
+        wl = self.w(f'{q}.linear.weight')
+        dout = ops.conv(self.spec(q + '.lin_dgrad', lambda: bw.dgrad_conv1d(wl[:, :, None], 1, 0, dev)), dy, None, B, Fo, Fo, T).view(R, T, 2 * H)
+        xs = [r.fr0, r.outs[0]]
+        for l in (1, 0):
+            stitched = r.framed and l == 1
+            da = TO.lstm_bwd(ops, dout, whh_t[l], r.saves[l][0], r.saves[l][1], H, r.nseq, r.W, out_mode=1 if stitched else 0,
+                             nframes=r.nf, S=r.S, T=T)
+            xin = xs[l].reshape(r.nseq, r.W, -1)
+            g = lstm_param_grads(ops, da, xin, r.outs[l], sdl, l, H, r.nseq, r.W, xin.shape[-1], dev)
+            for kname, v in g.items():
+                if kname != 'dx':
+                    self._put(f'{q}.lstm.{kname}', v)
+            dout = g['dx']
+        dfr = dout                                               # [nseq, W, H]
+        da_in = TO.frames_op(ops, dfr.contiguous(), 1, R, T, H, r.nf, r.W, r.S) if r.framed else dfr
+        return TO.add_f16(ops, dy.contiguous(), da_in.reshape(dy.shape).contiguous())
+
+
+class AeroFunction(torch.autograd.Function):
+    """autograd through Aero.forward (solver.py:296-305 forward, :602-605 backward): inputs are the waveform and every parameter;
+    the gradient of the waveform output is taken back through the HIP backward pass above."""
+
+    @staticmethod
+    def forward(ctx, engine, names, mix, *params):
+        with torch.no_grad():
+            y, spec_out, lr_spec, c = engine.forward(mix)
+        ctx.engine, ctx.c, ctx.names = engine, c, names
+        ctx.shapes = [p.shape for p in params]
+        ctx.mark_non_differentiable(spec_out, lr_spec)
+        return y, spec_out, lr_spec
+
+    @staticmethod
+    def backward(ctx, dy, _dspec, _dlr):
+        eng = ctx.engine
+        dev = dy.device
+        offs, n = [], 0
+        for s in ctx.shapes:
+            offs.append(n)
+            n += (s.numel() + 3) // 4 * 4
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        views = [flat[o:o + s.numel()].view(s) for o, s in zip(offs, ctx.shapes)]
+        grads = dict(zip(ctx.names, views))
+        with torch.no_grad():
+            scale = eng.backward(ctx.c, dy.contiguous(), grads)
+            TO.scale_f32(eng.ops, flat, scale[1:])
+        ctx.c = None
+        return (None, None, None) + tuple(views)

@@ -204,6 +204,10 @@ typedef struct {
      * zero padded (KPI from aero_lstm_geometry_in), bias fp32 [2][4H] = b_ih + b_hh in the same row order. */
     const void* x; const void* wih; const float* bias;
     int32_t in_ch, x_pitch;
+    /* training-mode forward (both NULL otherwise): per (block of 16 sequences ib = s/16, direction, step tau) the gate
+     * activations i,f,g,o as fp16 [H][16][4] at save_gates + (((ib*2 + dir)*W + tau)*H*64) and the cell state c_tau as fp32
+     * [H][16] at save_c + (((ib*2 + dir)*W + tau)*H*16): what aero_lstm_bwd reads.  Runs the step-wise kernel. */
+    void* save_gates; float* save_c;
 } aero_lstm_desc;
 int aero_lstm_fwd(const aero_lstm_desc* d, void* stream);
 /* padded W_hh geometry the kernel instantiation for hidden size H expects: MP rows, KP columns */
@@ -352,6 +356,71 @@ int aero_norm_bwd_apply(const aero_norm_bwd_desc* d, void* stream);
  * aero_amd/backward.py: istft_bwd(). */
 int aero_istft_bwd_prep(const float* dy, const float* inv_env, float* s, int32_t nsig, int32_t L, int32_t Ls, int32_t off, int32_t env_off, void* stream);
 int aero_istft_bwd_pack(const float* spec, float* dz, int32_t nsig, int32_t nbins, int32_t Tsrc, int32_t T, int32_t t_off, void* stream);
+
+/* ---- the rest of one training step of the generator (solver.py:602-605; k_train.h) ------------------------------------- */
+
+/* BPTT of one bidirectional nn.LSTM layer (modules.py:28,46) from the activations aero_lstm_fwd saved (save_gates / save_c).
+ * dout fp16: gradient of the layer output h, [nseq*W][2H] (out_mode 0) or, out_mode 1, the STITCHED rows [R*T][2H] read through
+ * the stitch map of modules.py:52-61 (zero outside a frame's kept range).  whh_t fp16 [2][HP][K4P]: W_hh transposed, row = hidden
+ * unit j, column 4*j' + gate = W_hh[gate*H + j'][j]; HP = H rounded up to 16, K4P = aero_lstm_bwd_k4p(H), zero padded.
+ * da fp16 [nseq*W][2][4H] (column 4*j + gate): the gradient of the gate PRE-activations -- every parameter / input gradient of the
+ * layer is a GEMM of it (aero_conv_wgrad with x_t / h_{t-1}, aero_conv_fwd with W_ih^T): aero_amd/train.py. */
+typedef struct {
+    const void* dout; const void* whh_t; const void* save_gates; const float* save_c; void* da;
+    int32_t H, nseq, W, out_mode, nframes, S, T;
+} aero_lstm_bwd_desc;
+int aero_lstm_bwd(const aero_lstm_bwd_desc* d, void* stream);
+int aero_lstm_bwd_k4p(int32_t H);
+
+/* LocalState backward (modules.py:94-127): qkvd as aero_localstate_fwd read it, out = its output O [R][T][C], dout = dL/dO;
+ * dqkvd [R][T][ld] receives dQ | dK | dV | d(decay pre-activations); qstats fp32 [R][heads][T][4] is scratch
+ * (log-sum-exp, O.dO, decay slope per query). */
+typedef struct {
+    const void* qkvd; int64_t ld; const void* out; const void* dout; void* dqkvd; float* qstats;
+    int32_t R, T, C, heads, ndecay;
+} aero_attn_bwd_desc;
+int aero_localstate_bwd(const aero_attn_bwd_desc* d, void* stream);
+
+/* FTB (modules.py:304-325) pieces without a convolution form.  aero_freqfc_wgrad: dw[f][f'] += sum_{b,t,c} dfc[b,f,t,c] *
+ * gate[b,t,c] * x[b,f',t,c] (freq_fc weight, modules.py:296,320; slabs fp32 [nslab][F][F] scratch, partial sums added in slice
+ * order).  aero_ftb_gate_bwd: with v = W_fc^T dfc (aero_freqfc_fwd on the transposed weight, gate of ones):
+ * dx = add + v * gate (add may be NULL), dgate[b,t,c] = sum_f v * x (the product of modules.py:316).  All fp16 [B,F,T,C]
+ * contiguous, gate / dgate [B,T,C]; T*C a multiple of 8. */
+int aero_freqfc_wgrad(const void* dfc, const void* x, const void* gate, float* dw, float* slabs, int32_t nslab, int32_t B, int32_t F,
+                      int32_t T, int32_t C, void* stream);
+int aero_ftb_gate_bwd(const void* v, const void* x, const void* gate, const void* add, void* dx, void* dgate, int32_t B, int32_t F,
+                      int32_t T, int32_t C, void* stream);
+
+/* out[f][c] += scale * sum_{b,t} x[b,f,t,c]  (x fp16 [B,F,T,C] contiguous, out fp32): the frequency-embedding gradient (aero.py:475-480) */
+int aero_sum_bt(const void* x, float* out, int32_t B, int32_t F, int32_t T, int32_t C, float scale, void* stream);
+
+/* BLSTM framing / stitching as copies (models/utils.py:22-35, modules.py:36-62): mode 0 unfold rows [R][T][C] -> frames
+ * [R*nframes][W][C] (zero beyond T), 1 its adjoint (overlap-add), 2 stitch frames -> rows, 3 its adjoint.  W = 2*S. */
+int aero_frames_op(const void* src, void* dst, int32_t mode, int32_t R, int32_t T, int32_t C, int32_t nframes, int32_t W, int32_t S,
+                   void* stream);
+
+/* Spectral loss of ONE resolution (stft_loss.py:11-27,30-64,84-117) on complex64 STFTs zx (prediction) / zy (target) [n] from
+ * aero_stft_fwd; power = |z|^2 * pscale (pscale = n_fft: torch.stft's scale).  sums (3 doubles): sum (ymag-xmag)^2, sum ymag^2,
+ * sum |log ymag - log xmag|; part: scratch of 3*npart doubles.  aero_stft_loss_bwd: g = d(w_sc*sqrt(s0/s1)*gout[0] +
+ * w_mag*s2/n*gout[1])/d zx (gout: 2 device floats or NULL = 1). */
+int aero_stft_loss_sums(const float* zx, const float* zy, int64_t n, float pscale, double* part, int32_t npart, double* sums, void* stream);
+int aero_stft_loss_bwd(const float* zx, const float* zy, int64_t n, float pscale, const double* sums, float w_sc, float w_mag,
+                       const float* gout, float* g, void* stream);
+
+/* Adjoint of aero_stft_fwd (centred, reflect padded, normalised; n_bins = n_fft/2 or n_fft/2+1): aero_irfft_frames turns the
+ * spectrogram gradient g complex64 [nsig][nb][T] into windowed time frames fp32 [nsig][T][n_fft], aero_stft_adj_fold overlap-adds
+ * them at t*hop and folds the reflect padding back: dx fp32 [nsig][L] (accumulate != 0: added to dx). */
+int aero_irfft_frames(const float* g, int32_t nsig, int32_t nb, int32_t T, int32_t n_fft, const float* window, float* frames, void* stream);
+int aero_stft_adj_fold(const float* frames, float* dx, int32_t nsig, int32_t T, int32_t n_fft, int32_t hop, int32_t L, int32_t accumulate,
+                       void* stream);
+
+/* Element-wise plumbing of the gradient path: dst = a + b (fp16 [n]);  the fp32 -> fp16 boundary with the dynamic loss scale
+ * (dst = fp16(x * item_scale[item] * S), S = 2^floor(log2(target / max|x * item_scale|)), scale_out = {S, 1/S}; amax: one
+ * zeroed uint32 of scratch) -- the adjoint of the de-normalisation x*std + mean of aero.py:497-498;  x *= scale[0] (fp32). */
+int aero_add_f16(const void* a, const void* b, void* dst, int64_t n, void* stream);
+int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const float* item_scale, void* amax, float target, void* dst,
+                    float* scale_out, void* stream);
+int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -415,3 +415,23 @@ def aero_forward(sd, cfg, mix, return_spec=False, return_lr_spec=False, fast=Fal
     if return_spec:
         return (y, zc, z) if return_lr_spec else (y, zc)
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-resolution STFT loss (src/models/stft_loss.py), restated with return_complex=True: the reference's
+# `torch.stft(x, fft_size, hop_size, win_length, window)` (stft_loss.py:22) raises on torch >= 2.
+def stft_magnitude(x, fft_size, hop_size, win_length):
+    """stft_loss.py:11-27: sqrt(clamp(re^2 + im^2, 1e-7)) of the centred, reflect-padded, un-normalised STFT -> [B, frames, bins]"""
+    z = torch.stft(x, fft_size, hop_size, win_length, torch.hann_window(win_length, dtype=x.dtype), return_complex=True)
+    return torch.sqrt(torch.clamp(z.real ** 2 + z.imag ** 2, min=1e-7)).transpose(2, 1)
+
+
+def mrstft_loss(x, y, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win_lengths=(600, 1200, 240), factor_sc=0.1, factor_mag=0.1):
+    """stft_loss.py:84-138: (factor_sc * mean spectral convergence, factor_mag * mean log-magnitude L1); x prediction, y target [B, T]"""
+    sc = mag = 0.0
+    for n, h, w in zip(fft_sizes, hop_sizes, win_lengths):
+        xm, ym = stft_magnitude(x, n, h, w), stft_magnitude(y, n, h, w)
+        sc = sc + torch.norm(ym - xm, p='fro') / torch.norm(ym, p='fro')          # stft_loss.py:47
+        mag = mag + torch.nn.functional.l1_loss(torch.log(ym), torch.log(xm))    # stft_loss.py:64
+    k = len(fft_sizes)
+    return factor_sc * sc / k, factor_mag * mag / k

@@ -151,6 +151,13 @@ static inline T __shfl(T v, int src) { return emu::shfl_idx(v, src); }
 
 static inline float atomicAdd(float* a, float v) { return emu::atomic_add_cas(a, v); }
 static inline double atomicAdd(double* a, double v) { return emu::atomic_add_cas(a, v); }
+static inline unsigned int atomicMax(unsigned int* a, unsigned int v) {
+    unsigned int old = __atomic_load_n(a, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(a, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+static inline unsigned int __float_as_uint(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
 
 
 typedef float emu_f4 __attribute__((ext_vector_type(4)));

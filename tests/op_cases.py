@@ -881,3 +881,264 @@ def case_istft_bwd(lib, dev, nfft, hop, T, crop=5, B=2, seed=160):
     dz = bw.istft_bwd(ops, gy.reshape(B, Lout).contiguous().to(dev), nfft, hop, w.to(dev), (1 / env).float().to(dev), T)
     got = torch.view_as_complex(dz.cpu().contiguous())
     assert rel_l2(torch.view_as_real(got), torch.view_as_real(z.grad)) < 5 * TOL32, rel_l2(torch.view_as_real(got), torch.view_as_real(z.grad))
+
+
+# ------------------------------------------------------------------------------------------------
+# the rest of the training step (csrc/k_train.h) against torch.autograd on fp16-rounded operands
+from aero_amd import train_ops as TO  # noqa: E402
+
+
+def case_freqfc_wgrad(lib, dev, Fq, Cc, T, B=2, seed=200):
+    ops = Ops(lib)
+    w = q16(_rand((Fq, Fq), seed, 1.0 / math.sqrt(Fq))).requires_grad_()
+    x = q16(_rand((B, Cc, Fq, T), seed + 1))
+    gate = q16(_rand((B, Cc, T), seed + 2).abs())
+    dy = q16(_rand((B, Cc, Fq, T), seed + 3))
+    att = gate[:, :, None, :] * x
+    ((att.transpose(2, 3) @ w.t()).transpose(2, 3) * dy).sum().backward()
+    dw = TO.freqfc_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), gate.permute(0, 2, 1).contiguous().half().to(dev))
+    assert rel_l2(dw.cpu(), w.grad) < TOL16
+
+
+def case_ftb_gate_bwd(lib, dev, Fq, Cc, T, B=2, seed=210):
+    ops = Ops(lib)
+    v, x, add = (q16(_rand((B, Fq, T, Cc), seed + i)) for i in range(3))
+    gate = q16(_rand((B, T, Cc), seed + 4).abs())
+    dx, dg = TO.ftb_gate_bwd(ops, v.half().to(dev), x.half().to(dev), gate.half().to(dev), add.half().to(dev))
+    assert rel_l2(dx.cpu().float(), add + v * gate[:, None]) < TOL16
+    assert rel_l2(dg.cpu().float(), (v * x).sum(1)) < TOL16
+    dx2, _ = TO.ftb_gate_bwd(ops, v.half().to(dev), x.half().to(dev), gate.half().to(dev))
+    assert rel_l2(dx2.cpu().float(), v * gate[:, None]) < TOL16
+
+
+def case_sum_bt(lib, dev, Fq, Cc, T, B=3, seed=220):
+    ops = Ops(lib)
+    x = q16(_rand((B, Fq, T, Cc), seed))
+    out = torch.ones(Fq, Cc, dtype=torch.float32, device=dev)
+    TO.sum_bt(ops, x.half().to(dev), out, 0.5)
+    assert rel_l2(out.cpu(), 1.0 + 0.5 * x.sum((0, 2))) < 1e-5
+
+
+def case_frames_op(lib, dev, R, T, Cc, seed=230):
+    """unfold / stitch against the oracle's index helpers (models/utils.py:22-35, modules.py:49-61) and their adjoints by <Ax, y> = <x, A^T y>"""
+    ops = Ops(lib)
+    W, S = 200, 100
+    nf = math.ceil(T / S)
+    x = q16(_rand((R, T, Cc), seed))
+    fr = TO.frames_op(ops, x.half().to(dev), 0, R, T, Cc, nf, W, S).cpu().float()
+    ref = torch.zeros(R, nf, W, Cc)
+    for k in range(nf):
+        n = min(W, T - k * S)
+        ref[:, k, :n] = x[:, k * S:k * S + n]
+    assert torch.equal(fr.view(R, nf, W, Cc), ref)
+    y = q16(_rand((R * nf, W, Cc), seed + 1))
+    st = TO.frames_op(ops, y.half().to(dev), 2, R, T, Cc, nf, W, S).cpu().float()
+    smap = O.stitch_map(T, W, S, nf)                      # (frame, tau) per output step
+    yv = y.view(R, nf, W, Cc)
+    ref = torch.stack([yv[:, k, tau] for (k, tau) in smap], 1)
+    assert torch.equal(st, ref)
+    # adjoints (outputs are fp16-rounded sums of at most two terms)
+    g = q16(_rand((R, T, Cc), seed + 2))
+    ut = TO.frames_op(ops, y.half().to(dev), 1, R, T, Cc, nf, W, S).cpu().float()
+    assert abs(float((ut.double() * g.double()).sum() - (y.double() * fr_of(g, R, T, Cc, nf, W, S).double()).sum())) < 2e-3 * float(ut.abs().sum())
+    stt = TO.frames_op(ops, g.half().to(dev), 3, R, T, Cc, nf, W, S).cpu().float().view(R, nf, W, Cc)
+    ref = torch.zeros(R, nf, W, Cc)
+    for t, (k, tau) in enumerate(smap):
+        ref[:, k, tau] = g[:, t]
+    assert torch.equal(stt, ref)
+
+
+def fr_of(x, R, T, Cc, nf, W, S):
+    out = torch.zeros(R * nf, W, Cc)
+    o = out.view(R, nf, W, Cc)
+    for k in range(nf):
+        n = min(W, T - k * S)
+        o[:, k, :n] = x[:, k * S:k * S + n]
+    return out
+
+
+def case_lstm_bwd(lib, dev, H, nseq, W, in_ch=None, seed=240, framed_T=None):
+    """one bidirectional nn.LSTM layer: training-mode forward (gates / cell states saved) + aero_lstm_bwd + the GEMMs of the host
+    side, against torch.autograd of nn.LSTM on fp16-rounded weights and inputs.  framed_T: dout arrives stitched (out_mode 1)."""
+    from aero_amd import backward as bw
+    ops = Ops(lib)
+    in_ch = H if in_ch is None else in_ch
+    torch.manual_seed(seed)
+    ref = torch.nn.LSTM(in_ch, H, num_layers=1, bidirectional=True)
+    with torch.no_grad():
+        for p_ in ref.parameters():
+            p_.copy_(q16(p_))
+    x = q16(_rand((nseq, W, in_ch), seed + 1)).requires_grad_()
+    y = ref(x.permute(1, 0, 2))[0].permute(1, 0, 2)                      # [nseq, W, 2H]
+    sd = {'l.' + k: v.detach() for k, v in ref.state_dict().items()}
+    spec, xb, whh, fused = pack.pack_lstm_layer(lib, sd, 'l', 0, H, dev)
+    out = torch.empty(nseq, W, 2 * H, dtype=torch.float16, device=dev)
+    save = TO.lstm_save_buffers(nseq, W, H, dev)
+    xd = x.detach().half().to(dev)
+    if fused is not None:
+        ops.lstm(None, None, whh, H, nseq, W, 0, 0, 1, 1, W, out, x=xd, fused=fused, save=save)
+    else:
+        xp = ops.conv(spec, xd.view(1, 1, nseq * W, in_ch), None, 1, 1, 1, nseq * W)
+        ops.lstm(xp, xb, whh, H, nseq, W, 0, 0, 1, 1, W, out, save=save)
+    assert rel_l2(out.cpu().float(), y.detach()) < TOL16
+    whh_t = TO.pack_whh_t(lib, [sd['l.weight_hh_l0'], sd['l.weight_hh_l0_reverse']], H, dev)
+    if framed_T is None:
+        dy = q16(_rand((nseq, W, 2 * H), seed + 2, 0.5))
+        y.backward(dy)
+        da = TO.lstm_bwd(ops, dy.half().to(dev), whh_t, save[0], save[1], H, nseq, W)
+    else:
+        T, S = framed_T, W // 2
+        nf = math.ceil(T / S)
+        R = nseq // nf
+        dys = q16(_rand((R, T, 2 * H), seed + 2, 0.5))
+        smap = O.stitch_map(T, W, S, nf)
+        dyf = torch.zeros(R, nf, W, 2 * H)
+        for t, (k, tau) in enumerate(smap):
+            dyf[:, k, tau] = dys[:, t]
+        y.backward(dyf.view(nseq, W, 2 * H))
+        da = TO.lstm_bwd(ops, dys.half().to(dev), whh_t, save[0], save[1], H, nseq, W, out_mode=1, nframes=nf, S=S, T=T)
+    g = lstm_layer_grads(ops, da, xd, out, sd, 'l', 0, H, nseq, W, in_ch, dev)
+    tol = 3 * TOL16
+    for k, v in g.items():
+        if k == 'dx':
+            assert rel_l2(v.cpu().float(), x.grad) < tol, k
+        else:
+            assert rel_l2(v.cpu(), dict(ref.named_parameters())[k].grad) < tol, (k, rel_l2(v.cpu(), dict(ref.named_parameters())[k].grad))
+
+
+def lstm_layer_grads(ops, da, x, out, sd, pre, layer, H, nseq, W, in_ch, dev):
+    from aero_amd.train import lstm_param_grads
+    return lstm_param_grads(ops, da, x, out, {k[len(pre) + 1:]: v for k, v in sd.items()}, layer, H, nseq, W, in_ch, dev)
+
+
+def case_localstate_bwd(lib, dev, Cc, heads, R, T, seed=250):
+    ops = Ops(lib)
+    nd = 4
+    ld = 3 * Cc + heads * nd
+    qkvd = q16(_rand((R, T, ld), seed, 0.8))
+    qkvd[..., 3 * Cc:] = q16(qkvd[..., 3 * Cc:] * 2 - 1.0)
+    qkvd = qkvd.requires_grad_()
+    dh = Cc // heads
+    q = qkvd[..., :Cc].view(R, T, heads, dh)
+    k = qkvd[..., Cc:2 * Cc].view(R, T, heads, dh)
+    v = qkvd[..., 2 * Cc:3 * Cc].view(R, T, heads, dh)
+    dq = qkvd[..., 3 * Cc:].view(R, T, heads, nd)
+    idx = torch.arange(T, dtype=torch.float32)
+    delta = idx[:, None] - idx[None, :]
+    dots = torch.einsum('rthc,rshc->rhts', k, q) / dh ** 0.5
+    decays = torch.arange(1, nd + 1, dtype=torch.float32)
+    kern = -decays.view(-1, 1, 1) * delta.abs() / nd ** 0.5
+    dots = dots + torch.einsum('fts,rshf->rhts', kern, torch.sigmoid(dq) / 2)
+    dots = dots.masked_fill(torch.eye(T, dtype=torch.bool), -100)
+    w = torch.softmax(dots, dim=2)
+    out = torch.einsum('rhts,rthc->rshc', w, v).reshape(R, T, Cc)
+    dout = q16(_rand((R, T, Cc), seed + 1))
+    out.backward(dout)
+    o16 = out.detach().half().to(dev)
+    att = ops.localstate(qkvd.detach().half().to(dev), R, T, Cc, heads, nd)
+    assert rel_l2(att.cpu().float(), out.detach()) < 3e-3
+    g = TO.localstate_bwd(ops, qkvd.detach().half().to(dev), o16, dout.half().to(dev), R, T, Cc, heads, nd)
+    ref = qkvd.grad
+    for nm, sl in (('dq', slice(0, Cc)), ('dk', slice(Cc, 2 * Cc)), ('dv', slice(2 * Cc, 3 * Cc)), ('ddecay', slice(3 * Cc, ld))):
+        assert rel_l2(g.cpu().float()[..., sl], ref[..., sl]) < TOL16, (nm, rel_l2(g.cpu().float()[..., sl], ref[..., sl]))
+
+
+def _mag_ref(x, n, h, w):
+    z = torch.stft(x, n, h, w, torch.hann_window(w), return_complex=True)
+    return torch.sqrt(torch.clamp(z.real ** 2 + z.imag ** 2, min=1e-7)).transpose(2, 1)
+
+
+def case_stft_loss(lib, dev, n_fft, hop, win, L, B=2, seed=260):
+    """one resolution of the multi-resolution STFT loss (stft_loss.py:84-117): values and the gradient w.r.t. the predicted signal
+    (aero_stft_fwd -> aero_stft_loss_sums / _bwd -> aero_irfft_frames + aero_stft_adj_fold) against torch.autograd through torch.stft"""
+    ops = Ops(lib)
+    x = _rand((B, L), seed).requires_grad_()
+    y = _rand((B, L), seed + 1)
+    xm, ym = _mag_ref(x, n_fft, hop, win), _mag_ref(y, n_fft, hop, win)
+    sc = torch.norm(ym - xm, p='fro') / torch.norm(ym, p='fro')
+    mg = torch.nn.functional.l1_loss(torch.log(ym), torch.log(xm))
+    (0.3 * sc + 0.7 * mg).backward()
+    wpad = _hann_padded(win, n_fft, dev)
+    T = 1 + L // hop
+    zx = ops.stft(x.detach().to(dev), L, L, n_fft, hop, wpad, n_fft // 2 + 1)
+    zy = ops.stft(y.to(dev), L, L, n_fft, hop, wpad, n_fft // 2 + 1)
+    assert zx.shape[2] == T
+    sums = TO.stft_loss_sums(ops, zx, zy, float(n_fft))
+    s = sums.cpu()
+    n = zx.numel() // 2
+    assert abs(float((s[0] / s[1]).sqrt()) - float(sc)) < 2e-5 * float(sc)
+    assert abs(float(s[2] / n) - float(mg)) < 2e-5 * float(mg)
+    gout = torch.tensor([0.3, 0.7], dtype=torch.float32, device=dev)
+    g = TO.stft_loss_bwd(ops, zx, zy, float(n_fft), sums, 1.0, 1.0, gout)
+    dx = TO.stft_adjoint(ops, g, n_fft, hop, wpad, L)
+    # fp32 throughout; the L1 term's sign(log xmag - log ymag) is discontinuous, so a handful of near-ties may flip: 1e-3
+    assert rel_l2(dx.cpu(), x.grad) < 1e-3, rel_l2(dx.cpu(), x.grad)
+    dx2 = TO.stft_adjoint(ops, g, n_fft, hop, wpad, L, dx=dx.clone())
+    assert rel_l2(dx2.cpu(), 2 * x.grad) < 1e-3
+
+
+def case_scale_cast(lib, dev, B=3, n=1000, seed=270):
+    ops = Ops(lib)
+    x = _rand((B, n), seed, 1e-5)
+    sc = torch.tensor([0.5, 2.0, 1.0][:B])
+    y, scale = TO.scale_cast(ops, x.to(dev), sc.to(dev), 1024.0)
+    am = float((x * sc[:, None]).abs().max())
+    S = 2.0 ** math.floor(math.log2(1024.0 / am))
+    assert float(scale[0]) == S and float(scale[1]) == 1.0 / S
+    assert rel_l2(y.cpu().float(), x * sc[:, None] * S) < 1e-3
+    buf = torch.full((777,), 3.0, device=dev)
+    TO.scale_f32(ops, buf, scale[1:])
+    assert torch.allclose(buf.cpu(), torch.full((777,), 3.0 / S))
+    a, b_ = q16(_rand((1001,), seed + 1)), q16(_rand((1001,), seed + 2))
+    pad = torch.zeros(7)
+    s = TO.add_f16(ops, torch.cat([a, pad]).half().to(dev), torch.cat([b_, pad]).half().to(dev))
+    assert torch.equal(s.cpu()[:1001], (a + b_).half())
+
+
+class _Holder(torch.nn.Module):
+    """a one-attribute module tree so that TrainEngine sees state-dict names like '<attr>.conv1.0.weight'"""
+
+    def __init__(self, **mods):
+        super().__init__()
+        for k, v in mods.items():
+            setattr(self, k, v)
+    nfft = 512
+
+
+def _train_engine(lib, holder, dev):
+    from aero_amd.train import TrainEngine
+    eng = TrainEngine(holder, lib=lib)
+    eng._sync_weights(torch.device(dev))
+    eng.g = {k: torch.zeros_like(v, dtype=torch.float32, device=dev) for k, v in holder.named_parameters()}
+    return eng
+
+
+def case_ftb_autograd(lib, dev, Cc, Fq, T, B=2, seed=300):
+    """the whole FTB in training mode (modules.py:304-325), forward and backward on the HIP kernels (aero_amd/train.py) against
+    torch.autograd through the oracle's restatement on fp16-rounded weights / input"""
+    from aero_amd.modules import FTB
+    torch.manual_seed(seed)
+    ftb = FTB(input_dim=Fq, in_channel=Cc).train()
+    with torch.no_grad():
+        for n_, p_ in ftb.named_parameters():
+            if p_.dim() == 1 and 'weight' in n_:
+                p_.add_(0.3 * torch.randn_like(p_))             # BatchNorm gammas off 1
+            p_.copy_(q16(p_))
+    hold = _Holder(fab=ftb).to(dev)
+    x = q16(_rand((B, Cc, Fq, T), seed + 1))
+    dy = q16(_rand((B, Cc, Fq, T), seed + 2))
+    sd = {k: v.detach().clone().cpu().requires_grad_(v.is_floating_point()) for k, v in hold.state_dict().items()}
+    xr = x.clone().requires_grad_()
+    O.ftb(sd, 'fab', xr, train=True, new_stats={}).backward(dy)
+    eng = _train_engine(lib, hold, dev)
+    y, r = eng._ftb_fwd('fab', hold.fab, cl(x).to(dev), B, Fq, T)
+    assert rel_l2(uncl(y.cpu()), O.ftb({k: v.detach() for k, v in sd.items()}, 'fab', x, train=True)) < TOL16
+    dx = eng._ftb_bwd('fab', hold.fab, r, cl(dy).to(dev), B, Fq, T)
+    errs = {'dx': rel_l2(uncl(dx.cpu()), xr.grad)}
+    for k, p_ in hold.named_parameters():
+        gref = sd[k].grad
+        if float(gref.norm()) > 1e-6 * float(dy.norm()):          # (conv biases in front of a batch-statistics BatchNorm have zero gradient)
+            errs[k] = rel_l2(eng.g[k].cpu(), gref)
+    bad = {k: v for k, v in errs.items() if v > 3 * TOL16}
+    assert not bad, bad
+    return errs

@@ -279,3 +279,42 @@ def test_batchnorm_bwd(emu, kw):
 @pytest.mark.parametrize('kw', [dict(nfft=512, hop=64, T=24), dict(nfft=64, hop=16, T=13, crop=0)])
 def test_istft_bwd(emu, kw):
     oc.case_istft_bwd(emu, DEV, **kw)
+
+
+# ---- the rest of the training step (csrc/k_train.h) ------------------------------------------------------------
+@pytest.mark.parametrize('a', [(16, 8, 21), (70, 16, 13)])
+def test_freqfc_wgrad(emu, a):
+    oc.case_freqfc_wgrad(emu, DEV, *a)
+
+
+def test_ftb_gate_bwd_sum_bt_scale_cast(emu):
+    oc.case_ftb_gate_bwd(emu, DEV, 5, 8, 21)
+    oc.case_sum_bt(emu, DEV, 4, 16, 37)
+    oc.case_sum_bt(emu, DEV, 3, 48, 20)
+    oc.case_scale_cast(emu, DEV)
+
+
+@pytest.mark.parametrize('a', [(2, 251, 8), (1, 430, 4)])
+def test_frames_op(emu, a):
+    oc.case_frames_op(emu, DEV, *a)
+
+
+@pytest.mark.parametrize('geom', [(512, 50, 240, 1777), (1024, 120, 600, 3000), (2048, 240, 1200, 5000)])
+def test_stft_loss_value_and_gradient(emu, geom):
+    oc.case_stft_loss(emu, DEV, *geom)
+
+
+@pytest.mark.parametrize('a', [(16, 4, 2, 77), (48, 4, 1, 150)])
+def test_localstate_bwd(emu, a):
+    oc.case_localstate_bwd(emu, DEV, *a)
+
+
+@pytest.mark.parametrize('kw', [dict(H=8, nseq=5, W=12), dict(H=16, nseq=20, W=9, in_ch=32), dict(H=48, nseq=3, W=7),
+                                dict(H=8, nseq=6, W=200, framed_T=251)])
+def test_lstm_bwd(emu, kw):
+    oc.case_lstm_bwd(emu, DEV, **kw)
+
+
+@pytest.mark.parametrize('a', [(16, 8, 40), (32, 16, 33)])
+def test_ftb_autograd(emu, a):
+    oc.case_ftb_autograd(emu, DEV, *a)

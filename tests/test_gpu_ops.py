@@ -255,3 +255,41 @@ def test_batchnorm_bwd(lib, kw):
 @pytest.mark.parametrize('kw', [dict(nfft=512, hop=64, T=501, B=8), dict(nfft=64, hop=16, T=13, crop=0)])
 def test_istft_bwd(lib, kw):
     oc.case_istft_bwd(lib, DEV, **kw)
+
+
+# ---- the rest of the training step (csrc/k_train.h) at the flagship / config-5 shapes ---------------------------
+@pytest.mark.parametrize('a', [(256, 48, 501), (64, 96, 120), (8, 384, 501)])
+def test_freqfc_wgrad(lib, a):
+    oc.case_freqfc_wgrad(lib, DEV, *a)
+
+
+def test_ftb_gate_bwd_sum_bt_scale_cast(lib):
+    oc.case_ftb_gate_bwd(lib, DEV, 64, 96, 501)
+    oc.case_sum_bt(lib, DEV, 64, 48, 501)
+    oc.case_scale_cast(lib, DEV, n=100000)
+
+
+@pytest.mark.parametrize('a', [(16, 1724, 48), (8, 501, 96), (3, 251, 8)])
+def test_frames_op(lib, a):
+    oc.case_frames_op(lib, DEV, *a)
+
+
+@pytest.mark.parametrize('geom', [(512, 50, 240, 32000), (1024, 120, 600, 32000), (2048, 240, 1200, 32000), (2048, 240, 1200, 441000)])
+def test_stft_loss_value_and_gradient(lib, geom):
+    oc.case_stft_loss(lib, DEV, *geom)
+
+
+@pytest.mark.parametrize('a', [(48, 4, 4, 501), (96, 4, 2, 501), (48, 4, 2, 1724), (16, 4, 2, 77)])
+def test_localstate_bwd(lib, a):
+    oc.case_localstate_bwd(lib, DEV, *a)
+
+
+@pytest.mark.parametrize('kw', [dict(H=48, nseq=96, W=200), dict(H=96, nseq=48, W=200, in_ch=192), dict(H=48, nseq=36, W=200, framed_T=1724),
+                                dict(H=96, nseq=20, W=200, framed_T=501), dict(H=16, nseq=20, W=9, in_ch=32)])
+def test_lstm_bwd(lib, kw):
+    oc.case_lstm_bwd(lib, DEV, **kw)
+
+
+@pytest.mark.parametrize('a', [(48, 64, 501), (96, 16, 501), (384, 4, 300)])
+def test_ftb_autograd(lib, a):
+    oc.case_ftb_autograd(lib, DEV, *a)

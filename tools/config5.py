@@ -1,0 +1,49 @@
+"""BASELINE config 5 on one GPU: aero_11-44_512_256 (11.025 -> 44.1 kHz, n_fft 512, hop 256), 10-s segments, train mode:
+forward -> multi-resolution STFT loss -> backward -> FlatAdam.step.  usage: config5.py [B] [steps]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from aero_amd import Aero, losses  # noqa: E402
+from aero_amd.config import load_config  # noqa: E402
+from aero_amd.optim import FlatAdam  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    args = load_config(os.path.join(ROOT, 'conf'), ['experiment=aero_11-44_512_256'])
+    torch.manual_seed(2036)
+    model = Aero(**dict(args.experiment.aero)).cuda().train()
+    opt = FlatAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.999), model=model)
+    crit = losses.MultiResolutionSTFTLoss()
+    g = torch.Generator().manual_seed(0)
+    lr = torch.randn(B, 1, 110250, generator=g).cuda()
+    hr = (0.1 * torch.randn(B, 1, 441000, generator=g)).cuda()
+    for s in range(steps):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        y = model(lr)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        sc, mg = crit(y.squeeze(1), hr.squeeze(1))
+        loss = sc + mg
+        opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        t2 = time.time()
+        opt.step()
+        torch.cuda.synchronize()
+        t3 = time.time()
+        gn = float(opt.flat_g.norm())
+        print(f'step {s}: loss {float(loss):.5f} (sc {float(sc):.5f} mag {float(mg):.5f})  |grad| {gn:.4e}  forward {1e3 * (t1 - t0):.1f} ms  '
+              f'loss+backward {1e3 * (t2 - t1):.1f} ms  adam {1e3 * (t3 - t2):.2f} ms  y {tuple(y.shape)}  mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB')
+        assert torch.isfinite(loss) and gn == gn and gn > 0
+
+
+if __name__ == '__main__':
+    main()
