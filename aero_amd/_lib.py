@@ -82,7 +82,7 @@ class LstmBwdDesc(C.Structure):
 
 class AttnBwdDesc(C.Structure):
     _fields_ = [('qkvd', vp), ('ld', i64), ('out', vp), ('dout', vp), ('dqkvd', vp), ('qstats', fp),
-                ('R', i32), ('T', i32), ('C', i32), ('heads', i32), ('ndecay', i32)]
+                ('R', i32), ('T', i32), ('C', i32), ('heads', i32), ('ndecay', i32), ('decay_scale', C.c_float)]
 
 
 class AttnDesc(C.Structure):
@@ -165,7 +165,7 @@ _PROTOS = {
     'aero_stft_loss_bwd': (i32, [fp, fp, i64, C.c_float, dp, C.c_float, C.c_float, fp, fp, vp]),
     'aero_irfft_frames': (i32, [fp, i32, i32, i32, i32, fp, fp, vp]),
     'aero_stft_adj_fold': (i32, [fp, fp, i32, i32, i32, i32, i32, i32, vp]),
-    'aero_add_f16': (i32, [vp, vp, vp, i64, vp]),
+    'aero_add_f16': (i32, [vp, vp, vp, i64, C.c_float, vp]),
     'aero_scale_cast': (i32, [fp, i32, i64, fp, vp, C.c_float, vp, fp, vp]),
     'aero_scale_f32': (i32, [fp, i64, fp, vp]),
 }

@@ -308,9 +308,9 @@ int aero_stft_adj_fold(const float* frames, float* dx, int32_t nsig, int32_t T, 
     return aero_finish(rc, err);
 }
 
-int aero_add_f16(const void* a, const void* b, void* dst, int64_t n, void* stream) {
+int aero_add_f16(const void* a, const void* b, void* dst, int64_t n, float scale_b, void* stream) {
     const char* err = "";
-    int rc = aero_axpy_f16_launch(a, b, dst, n, (hipStream_t)stream, &err);
+    int rc = aero_axpy_f16_launch(a, b, dst, n, scale_b, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 

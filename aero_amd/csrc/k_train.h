@@ -497,7 +497,8 @@ __global__ __launch_bounds__(128) void aero_attn_bwd_q_kernel(AeroAttnBwdK p) {
     for (int i = 0; i < DP; ++i)
         if (i < dh) orow[h * dh + i] = (h16)(dQ[i] * qscale);
     const float dn = 0.5f * aero_rsqrt((float)(d.ndecay > 0 ? d.ndecay : 1));
-    for (int f = 0; f < d.ndecay; ++f) orow[3 * Cc + h * d.ndecay + f] = (h16)(dD * (float)(f + 1) * dn * sg[f] * (1.f - sg[f]));
+    const float dsc = d.decay_scale > 0.f ? d.decay_scale : 1.f;      // (these are orders of magnitude below dQ / dK / dV: own power-of-two scale)
+    for (int f = 0; f < d.ndecay; ++f) orow[3 * Cc + h * d.ndecay + f] = (h16)(dD * dsc * (float)(f + 1) * dn * sg[f] * (1.f - sg[f]));
     float* st = d.qstats + (((int64_t)r * d.heads + h) * T + s) * 4;
     st[0] = m + logf(l);
     st[1] = delta;
@@ -761,18 +762,22 @@ static int aero_stft_adj_fold_launch(const float* frames, float* dx, int nsig, i
 
 // ------------------------------------------------------------------------------------------------------------------
 // Element-wise plumbing of the gradient path.
-__global__ __launch_bounds__(256) void aero_axpy_f16_kernel(const h16* a, const h16* b, h16* dst, int64_t n) {
+__global__ __launch_bounds__(256) void aero_axpy_f16_kernel(const h16* a, const h16* b, h16* dst, int64_t n, float sb) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i + 8 <= n) {
-        *(h16x8*)(dst + i) = *(const h16x8*)(a + i) + *(const h16x8*)(b + i);
+        const h16x8 va = *(const h16x8*)(a + i), vb = *(const h16x8*)(b + i);
+        h16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (h16)((float)va[e] + sb * (float)vb[e]);
+        *(h16x8*)(dst + i) = r;
     } else {
-        for (int64_t e = i; e < n; ++e) dst[e] = a[e] + b[e];
+        for (int64_t e = i; e < n; ++e) dst[e] = (h16)((float)a[e] + sb * (float)b[e]);
     }
 }
 
-static int aero_axpy_f16_launch(const void* a, const void* b, void* dst, int64_t n, hipStream_t stream, const char** err) {
+static int aero_axpy_f16_launch(const void* a, const void* b, void* dst, int64_t n, float sb, hipStream_t stream, const char** err) {
     if (!a || !b || !dst || n < 1 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)dst) & 15)) { *err = "add_f16: bad arguments"; return AERO_ERR_ARG; }
-    AERO_LAUNCH(aero_axpy_f16_kernel, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), stream, (const h16*)a, (const h16*)b, (h16*)dst, n);
+    AERO_LAUNCH(aero_axpy_f16_kernel, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), stream, (const h16*)a, (const h16*)b, (h16*)dst, n, sb);
     return AERO_OK;
 }
 

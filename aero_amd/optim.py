@@ -43,6 +43,7 @@ class FlatAdam:
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._offs, self._sizes = offs, sizes
         with torch.no_grad():
             for p, o, sz in zip(self.params, offs, sizes):
                 self.flat_p[o:o + sz].copy_(p.detach().reshape(-1))
@@ -53,11 +54,34 @@ class FlatAdam:
     def zero_grad(self, set_to_none=False):
         """(gradients stay views of the flat buffer: set_to_none is accepted for API compatibility and ignored)"""
         self.flat_g.zero_()
+        self._reattach()
+
+    def _reattach(self):
+        """The kernel reads ONLY the flat buffers.  `module.zero_grad()` (set_to_none=True is torch's default), `model.to()` or
+        `load_state_dict(assign=True)` replace `p.grad` / `p.data` by fresh tensors that are no longer views of them: copy such
+        strays in and re-home the parameter, so that a step always follows the gradients autograd produced.  A gradient that is
+        None counts as zero (torch.optim.Adam would skip that parameter; here its moments still decay)."""
+        esz = self.flat_p.element_size()
+        with torch.no_grad():
+            for p, o, sz in zip(self.params, self._offs, self._sizes):
+                if p.data_ptr() != self.flat_p.data_ptr() + o * esz:
+                    if p.device != self.flat_p.device or p.dtype != torch.float32 or p.numel() != sz:
+                        raise RuntimeError('FlatAdam: a parameter changed device, dtype or size after the optimizer was built')
+                    self.flat_p[o:o + sz].copy_(p.detach().reshape(-1))
+                    p.data = self.flat_p[o:o + sz].view_as(p)
+                g = p.grad
+                if g is None:
+                    self.flat_g[o:o + sz].zero_()
+                    p.grad = self.flat_g[o:o + sz].view_as(p)
+                elif g.data_ptr() != self.flat_g.data_ptr() + o * esz:
+                    self.flat_g[o:o + sz].copy_(g.detach().reshape(-1).to(self.flat_g.dtype))
+                    p.grad = self.flat_g[o:o + sz].view_as(p)
 
     def step(self, grad_scale=1.0):
         lib = self.lib or _lib.load()
         if not self.flat_p.is_cuda and self.lib is None:
             raise RuntimeError('FlatAdam.step: parameters must live on the MI355X (no CPU path)')
+        self._reattach()
         self.step_count += 1
         stream = torch.cuda.current_stream(self.flat_p.device).cuda_stream if self.flat_p.is_cuda else 0
         lib.call('aero_adam_step', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
@@ -66,12 +90,49 @@ class FlatAdam:
         if self.model is not None and hasattr(self.model, 'repack'):
             self.model.repack()
 
+    # ---- checkpoints: the schema of torch.optim.Adam.state_dict() (the reference stores it under the checkpoint's optimizer entry,
+    # src/solver.py:111-118 / model_serializer.py), so checkpoints move both ways between the two optimizers
     def state_dict(self):
-        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr, 'betas': self.betas,
-                'eps': self.eps}
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o, sz) in enumerate(zip(self.params, self._offs, self._sizes)):
+                state[i] = {'step': torch.tensor(float(self.step_count)),
+                            'exp_avg': self.exp_avg[o:o + sz].view_as(p).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[o:o + sz].view_as(p).clone()}
+        group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
+                 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'decoupled_weight_decay': False,
+                 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd['step'])
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-        self.lr, self.betas, self.eps = float(sd['lr']), tuple(sd['betas']), float(sd['eps'])
+        if 'param_groups' not in sd:                             # the flat layout this class wrote before round 3
+            if sd['exp_avg'].numel() != self.n or sd['exp_avg_sq'].numel() != self.n:
+                raise ValueError('FlatAdam.load_state_dict: flat moment buffers of the wrong size')
+            self.step_count = int(sd['step'])
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+            self.lr, self.betas, self.eps = float(sd['lr']), tuple(sd['betas']), float(sd['eps'])
+            return
+        groups = sd['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.params):
+            raise ValueError('FlatAdam.load_state_dict: expected one parameter group with %d parameters' % len(self.params))
+        g = groups[0]
+        if g.get('amsgrad') or g.get('weight_decay'):
+            raise ValueError('FlatAdam.load_state_dict: amsgrad / weight decay are not supported')
+        self.lr, self.betas, self.eps = float(g['lr']), (float(g['betas'][0]), float(g['betas'][1])), float(g['eps'])
+        state = sd['state']
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, (p, o, sz) in enumerate(zip(self.params, self._offs, self._sizes)):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            if tuple(st['exp_avg'].shape) != tuple(p.shape) or tuple(st['exp_avg_sq'].shape) != tuple(p.shape):
+                raise ValueError(f'FlatAdam.load_state_dict: moment shape mismatch for parameter {i}')
+            self.exp_avg[o:o + sz].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + sz].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('FlatAdam.load_state_dict: parameters with different step counts (one fused step count is kept)')
+        self.step_count = steps.pop() if steps else 0

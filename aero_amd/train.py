@@ -332,6 +332,14 @@ class TrainEngine:
         r.h2 = ops.conv(self.spec(q + '.c2', b_c2)[0], a, None, B, Fo, Fo, T)
         y, r.st2 = self._norm(r.h2, 1, 1, self.w(f'{q}.conv2.1.weight'), self.w(f'{q}.conv2.1.bias'), ACT_GLU,
                               layer_scale=self.w(f'{q}.conv2.3.scale'), res=x)
+
+        def b_boost():
+            # LayerScale (init 1e-3, modules.py:130-141) shrinks every gradient inside the residual branch by its magnitude: a power of
+            # two of that size is put back where the gradient enters the branch and taken out where it leaves (one host read per
+            # parameter version), so the branch's fp16 gradients sit in the same range as the main path's
+            mean = float(self.w(f'{q}.conv2.3.scale').abs().mean())
+            return float(2.0 ** min(12, max(0, round(-math.log2(max(mean, 2.0 ** -12))))))
+        r.boost = self.spec(q + '.boost', b_boost)
         return y, r
 
     def _lstm_specs(self, q, H, dev):
@@ -471,8 +479,16 @@ class TrainEngine:
             dx = self._enc_bwd(i, m.encoder[i], ctx.enc[i], dout, B, T)
         return scale
 
-    def _put(self, name, t):
-        self.g[name].copy_(t.reshape(self.g[name].shape))
+    _unboost = 1.0
+
+    def _put(self, name, t, unboost=True):
+        dst = self.g[name]
+        dst.copy_(t.reshape(dst.shape))
+        if unboost and self._unboost != 1.0:                     # a gradient from inside a boosted DConv branch (see _dconv_layer_fwd)
+            key = ('unboost', self._unboost, str(dst.device))
+            if key not in self._tables:
+                self._tables[key] = torch.full((1,), self._unboost, dtype=torch.float32, device=dst.device)
+            TO.scale_f32(self.ops, dst, self._tables[key])
 
     # ------------------------------------------------------------------ decoder layer
     def _dec_bwd(self, j, dec, r, dout, B, T):
@@ -655,32 +671,38 @@ class TrainEngine:
         Cc, hid, hp = dc.channels, dc.hidden, r.hp
         k = dc.kernel
         dy = dy.contiguous()
-        res = bw.norm_bwd(ops, r.h2, dy, r.st2, 1, 1, self.w(f'{q}.conv2.1.weight'), self.w(f'{q}.conv2.1.bias'), ACT_GLU,
-                          layer_scale=self.w(f'{q}.conv2.3.scale'))
-        dh2 = res[0]
-        self._put(f'{q}.conv2.1.weight', res[1])
-        self._put(f'{q}.conv2.1.bias', res[2])
-        self._put(f'{q}.conv2.3.scale', res[3])
-        dw2, db2 = bw.conv_wgrad(ops, dh2, r.a, [0], [0])
-        self._put(f'{q}.conv2.0.weight', dw2.permute(1, 2, 0)[:, :hid])
-        self._put(f'{q}.conv2.0.bias', db2)
-        w2p = self.spec(q + '.c2', None)[1]
-        da = ops.conv(self.spec(q + '.c2_dgrad', lambda: bw.dgrad_conv1d(w2p, 1, 0, dev)), dh2, None, B, Fo, Fo, T)
-        if r.attn is not None:
-            da = self._attn_bwd(q + '.time_attn', hid, r.attn, da, B, Fo, T)
-        if r.lstm is not None:
-            da = self._blstm_bwd(q + '.lstm', hid, r.lstm, da, B, Fo, T)
-        res = bw.norm_bwd(ops, r.h1, da, r.st1, 1, 1, r.g1, r.be1, r.act, stat_count=T * hid, snake_a=r.snake_a)
-        dh1 = res[0]
-        self._put(f'{q}.conv1.1.weight', res[1][:hid])
-        self._put(f'{q}.conv1.1.bias', res[2][:hid])
-        if r.act == ACT_SNAKE:
-            self._put(f'{q}.act.a', res[4])
-        spec1, w1p = self.spec(q + '.c1', None)
-        dw1, db1 = bw.conv_wgrad(ops, dh1, r.x, spec1.df, spec1.dt)
-        self._put(f'{q}.conv1.0.weight', dw1.permute(1, 2, 0)[:hid])
-        self._put(f'{q}.conv1.0.bias', db1[:hid])
-        return ops.conv(self.spec(q + '.c1_dgrad', lambda: bw.dgrad_conv1d(w1p, r.dil, r.dil * (k // 2), dev)), dh1, None, B, Fo, Fo, T, res=dy)
+        bst = r.boost
+        self._unboost = 1.0 / bst                               # applied by _put to every parameter gradient inside the branch
+        try:
+            res = bw.norm_bwd(ops, r.h2, dy, r.st2, 1, 1, self.w(f'{q}.conv2.1.weight'), self.w(f'{q}.conv2.1.bias'), ACT_GLU,
+                              layer_scale=self.w(f'{q}.conv2.3.scale') * bst)
+            dh2 = res[0]                                        # = boost * dL/dh2
+            self._put(f'{q}.conv2.1.weight', res[1])
+            self._put(f'{q}.conv2.1.bias', res[2])
+            self._put(f'{q}.conv2.3.scale', res[3], unboost=False)      # sum dy * GLU(.): does not pass through the scale
+            dw2, db2 = bw.conv_wgrad(ops, dh2, r.a, [0], [0])
+            self._put(f'{q}.conv2.0.weight', dw2.permute(1, 2, 0)[:, :hid])
+            self._put(f'{q}.conv2.0.bias', db2)
+            w2p = self.spec(q + '.c2', None)[1]
+            da = ops.conv(self.spec(q + '.c2_dgrad', lambda: bw.dgrad_conv1d(w2p, 1, 0, dev)), dh2, None, B, Fo, Fo, T)
+            if r.attn is not None:
+                da = self._attn_bwd(q + '.time_attn', hid, r.attn, da, B, Fo, T)
+            if r.lstm is not None:
+                da = self._blstm_bwd(q + '.lstm', hid, r.lstm, da, B, Fo, T)
+            res = bw.norm_bwd(ops, r.h1, da, r.st1, 1, 1, r.g1, r.be1, r.act, stat_count=T * hid, snake_a=r.snake_a)
+            dh1 = res[0]
+            self._put(f'{q}.conv1.1.weight', res[1][:hid])
+            self._put(f'{q}.conv1.1.bias', res[2][:hid])
+            if r.act == ACT_SNAKE:
+                self._put(f'{q}.act.a', res[4])
+            spec1, w1p = self.spec(q + '.c1', None)
+            dw1, db1 = bw.conv_wgrad(ops, dh1, r.x, spec1.df, spec1.dt)
+            self._put(f'{q}.conv1.0.weight', dw1.permute(1, 2, 0)[:hid])
+            self._put(f'{q}.conv1.0.bias', db1[:hid])
+            dxb = ops.conv(self.spec(q + '.c1_dgrad', lambda: bw.dgrad_conv1d(w1p, r.dil, r.dil * (k // 2), dev)), dh1, None, B, Fo, Fo, T)
+        finally:
+            self._unboost = 1.0
+        return TO.add_f16(ops, dy, dxb, scale_b=1.0 / bst)      # skip path + the branch, un-boosted in fp32
 
     def _attn_bwd(self, q, Cc, r, dy, B, Fo, T):
         ops, dev = self.ops, dy.device
@@ -690,15 +712,24 @@ class TrainEngine:
         self._put(f'{q}.proj.weight', dw[0])
         self._put(f'{q}.proj.bias', db)
         datt = ops.conv(self.spec(q + '.proj_dgrad', lambda: bw.dgrad_conv1d(wp[:, :, None], 1, 0, dev)), dy, None, B, Fo, Fo, T)
-        dqkvd = TO.localstate_bwd(ops, r.qkvd.view(R, T, -1), r.att, datt.view(R, T, Cc), R, T, Cc, r.heads, r.ndecay)
+        dsc = 4096.0                                             # own power-of-two scale of the decay columns (~1e-6 below dQ / dK / dV)
+        dqkvd = TO.localstate_bwd(ops, r.qkvd.view(R, T, -1), r.att, datt.view(R, T, Cc), R, T, Cc, r.heads, r.ndecay, decay_scale=dsc)
         dqk = dqkvd.view(B, Fo, T, -1)
         dw, db = bw.conv_wgrad(ops, dqk, r.a, [0], [0])
+        nd = r.heads * r.ndecay
+        dw[0, 3 * Cc:3 * Cc + nd] *= 1.0 / dsc                    # (parameter-sized fp32 rows: exact power of two)
+        db[3 * Cc:3 * Cc + nd] *= 1.0 / dsc
         o = 0
-        for nme, n in (('query', Cc), ('key', Cc), ('content', Cc), ('query_decay', r.heads * r.ndecay)):
+        for nme, n in (('query', Cc), ('key', Cc), ('content', Cc), ('query_decay', nd)):
             self._put(f'{q}.{nme}.weight', dw[0, o:o + n])
             self._put(f'{q}.{nme}.bias', db[o:o + n])
             o += n
-        return ops.conv(self.spec(q + '.qkvd_dgrad', lambda: bw.dgrad_conv1d(wq[:, :, None], 1, 0, dev)), dqk, None, B, Fo, Fo, T, res=dy)
+
+        def b_dg():
+            w = wq.clone()
+            w[3 * Cc:3 * Cc + nd] *= 1.0 / dsc
+            return bw.dgrad_conv1d(w[:, :, None], 1, 0, dev)
+        return ops.conv(self.spec(q + '.qkvd_dgrad', b_dg), dqk, None, B, Fo, Fo, T, res=dy)
 
     def _blstm_bwd(self, q, H, r, dy, B, Fo, T):
         ops, dev = self.ops, dy.device

@@ -81,7 +81,7 @@ def lstm_bwd(ops, dout, whh_t, save_gates, save_c, H, nseq, W, out_mode=0, nfram
     return da
 
 
-def localstate_bwd(ops, qkvd, out, dout, R, T, Cc, heads, ndecay):
+def localstate_bwd(ops, qkvd, out, dout, R, T, Cc, heads, ndecay, decay_scale=1.0):
     """-> dqkvd fp16 [R, T, ld] (dQ | dK | dV | d decay pre-activations); modules.py:94-127"""
     assert qkvd.is_contiguous() and out.is_contiguous() and dout.is_contiguous()
     ld = qkvd.shape[-1]
@@ -89,7 +89,7 @@ def localstate_bwd(ops, qkvd, out, dout, R, T, Cc, heads, ndecay):
     qstats = torch.empty(R, heads, T, 4, dtype=torch.float32, device=qkvd.device)
     d = _lib.AttnBwdDesc()
     d.qkvd, d.ld, d.out, d.dout, d.dqkvd, d.qstats = _ptr(qkvd), ld, _ptr(out), _ptr(dout), _ptr(dq), _ptr(qstats)
-    d.R, d.T, d.C, d.heads, d.ndecay = R, T, Cc, heads, ndecay
+    d.R, d.T, d.C, d.heads, d.ndecay, d.decay_scale = R, T, Cc, heads, ndecay, decay_scale
     ops.lib.call('aero_localstate_bwd', C.byref(d), ops.stream(qkvd))
     return dq
 
@@ -124,10 +124,11 @@ def stft_adjoint(ops, g, n_fft, hop, window, L, dx=None):
     return dx
 
 
-def add_f16(ops, a, b, out=None):
+def add_f16(ops, a, b, out=None, scale_b=1.0):
+    """a + scale_b * b (fp16 tensors, fp32 arithmetic)"""
     assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == b.dtype == torch.float16
     out = torch.empty_like(a) if out is None else out
-    ops.lib.call('aero_add_f16', _ptr(a), _ptr(b), _ptr(out), a.numel(), ops.stream(a))
+    ops.lib.call('aero_add_f16', _ptr(a), _ptr(b), _ptr(out), a.numel(), C.c_float(scale_b), ops.stream(a))
     return out
 
 

@@ -378,6 +378,7 @@ int aero_lstm_bwd_k4p(int32_t H);
 typedef struct {
     const void* qkvd; int64_t ld; const void* out; const void* dout; void* dqkvd; float* qstats;
     int32_t R, T, C, heads, ndecay;
+    float decay_scale;      /* the decay columns of dqkvd are written multiplied by this (0 = 1): they sit ~1e-6 below the others */
 } aero_attn_bwd_desc;
 int aero_localstate_bwd(const aero_attn_bwd_desc* d, void* stream);
 
@@ -414,10 +415,10 @@ int aero_irfft_frames(const float* g, int32_t nsig, int32_t nb, int32_t T, int32
 int aero_stft_adj_fold(const float* frames, float* dx, int32_t nsig, int32_t T, int32_t n_fft, int32_t hop, int32_t L, int32_t accumulate,
                        void* stream);
 
-/* Element-wise plumbing of the gradient path: dst = a + b (fp16 [n]);  the fp32 -> fp16 boundary with the dynamic loss scale
+/* Element-wise plumbing of the gradient path: dst = a + scale_b * b (fp16 [n], fp32 arithmetic);  the fp32 -> fp16 boundary with the dynamic loss scale
  * (dst = fp16(x * item_scale[item] * S), S = 2^floor(log2(target / max|x * item_scale|)), scale_out = {S, 1/S}; amax: one
  * zeroed uint32 of scratch) -- the adjoint of the de-normalisation x*std + mean of aero.py:497-498;  x *= scale[0] (fp32). */
-int aero_add_f16(const void* a, const void* b, void* dst, int64_t n, void* stream);
+int aero_add_f16(const void* a, const void* b, void* dst, int64_t n, float scale_b, void* stream);
 int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const float* item_scale, void* amax, float target, void* dst,
                     float* scale_out, void* stream);
 int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream);

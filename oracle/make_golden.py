@@ -26,6 +26,7 @@ FULL_CFG = dict(in_channels=1, out_channels=1, channels=48, growth=2, nfft=512, 
 TINY_CFG = dict(channels=4, nfft=128, hop_length=16, lr_sr=4000, hr_sr=16000, enc_freq_attn=0)
 SMALL_CFG = dict(channels=16, nfft=256, hop_length=32, lr_sr=4000, hr_sr=16000, enc_freq_attn=0)
 WIDE_CFG = dict(FULL_CFG, nfft=1024, hop_length=256, lr_sr=12000, hr_sr=48000)   # BASELINE config 4 geometry
+MUSIC_CFG = dict(FULL_CFG, nfft=512, hop_length=256, lr_sr=11025, hr_sr=44100)    # BASELINE config 5 geometry (conf/experiment/aero_11-44_512_256.yaml)
 
 
 def seeded(shape, seed):
@@ -248,6 +249,52 @@ def main():
         xa, sk = seeded((2, 8, 8, 19), 66), seeded((2, 8, 8, 19), 67)
         put('hdec', m, dict(y=m(xa, sk, None)), x=xa, skip=sk)
     np.savez_compressed(os.path.join(OUT, 'modules.npz'), **mods)
+
+    # ---- BASELINE config 5 geometry: 11.025 -> 44.1 kHz, n_fft 512, hop 256, 10-s segments (T = 1724: 18 LSTM frames, the
+    # streaming attention form, hop_in 64); B = 2 clips, eval and train mode, outputs sub-sampled (VERDICT r2 missing #3) ----------
+    torch.manual_seed(51)
+    music = Aero(**MUSIC_CFG).eval()
+    randomize_running_stats(music, 52)
+    meta.update(music_cfg=MUSIC_CFG, music_seed=51, music_bn_seed=52, music_input_seed=5)
+    meta['music_checksums'] = checksums(music.state_dict())
+    xm = seeded((2, 1, 110250), 5)
+    with torch.no_grad():
+        y, s = music(xm, return_spec=True)
+        music.train()
+        yt, stt = music(xm, return_spec=True)
+    np.savez_compressed(os.path.join(OUT, 'music_io.npz'), y=y.numpy()[..., ::16], spec=s.numpy().astype(np.complex64)[:, :, ::4, ::7],
+                        y_train=yt.numpy()[..., ::16], spec_train=stt.numpy().astype(np.complex64)[:, :, ::4, ::7])
+
+    # ---- one training step of the reference (solver.py:296-305,560-584,602-605): train-mode forward -> multi-resolution STFT loss
+    # -> backward, on the small model.  stft_loss.py:22 calls torch.stft without return_complex (raises on torch >= 2): the call is
+    # made with return_complex=True and handed back in the old real layout -- nothing else of the reference's loss is touched. ----
+    import src.models.stft_loss as ref_loss
+    real_stft = torch.stft
+
+    def stft_compat(x, n_fft, hop_length=None, win_length=None, window=None, **kw):
+        return torch.view_as_real(real_stft(x, n_fft, hop_length, win_length, window, return_complex=True, **kw))
+    torch.manual_seed(21)
+    tsm = Aero(**SMALL_CFG)
+    randomize_running_stats(tsm, 22)
+    tsm.train()
+    xg, hg = seeded((2, 1, 800), 7), seeded((2, 1, 3200), 8) * 0.1
+    crit = ref_loss.MultiResolutionSTFTLoss(factor_sc=0.1, factor_mag=0.1)                  # main_config.yaml: stft_sc_factor / stft_mag_factor
+    pr = tsm(xg)
+    pr.retain_grad()
+    torch.stft = stft_compat
+    try:
+        sc, mag = crit(pr.squeeze(1), hg.squeeze(1))
+    finally:
+        torch.stft = real_stft
+    (sc + mag).backward()
+    gnorm = {k: float(p.grad.double().norm()) for k, p in tsm.named_parameters()}
+    keep = ('decoder.3.conv_tr.weight', 'decoder.0.rewrite.bias', 'encoder.3.conv.weight', 'encoder.2.dconv.layers.0.lstm.lstm.weight_hh_l0',
+            'encoder.2.dconv.layers.1.time_attn.content.weight', 'encoder.1.freq_attn_block.freq_fc.weight', 'encoder.0.pre_conv.weight',
+            'freq_emb.embedding.weight')
+    np.savez_compressed(os.path.join(OUT, 'train_small_grads.npz'), y=pr.detach().numpy(), dy=pr.grad.numpy(), loss=np.array([float(sc.detach()), float(mag.detach())]),
+                        **{'g.' + k: dict(tsm.named_parameters())[k].grad.numpy() for k in keep})
+    meta['train_small_grad_norms'] = gnorm
+    meta['train_small_inputs'] = {'x_seed': 7, 'hr_seed': 8, 'hr_scale': 0.1, 'L': 800}
 
     with open(os.path.join(OUT, 'meta.json'), 'w') as f:
         json.dump(meta, f, indent=1)

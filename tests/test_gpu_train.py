@@ -1,0 +1,87 @@
+"""GPU (-m gpu): the training step of the generator on the MI355X (BASELINE config 5): forward under autograd ->
+multi-resolution STFT loss -> HIP backward -> fused Adam.  tests/train_cases.py states what is compared and why."""
+import json
+import os
+
+import pytest
+import torch
+
+import train_cases as tc
+from conftest import GOLDEN, build_model, load_npz, rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def meta():
+    return json.load(open(os.path.join(GOLDEN, 'meta.json')))
+
+
+def test_training_step_small_model_vs_reference_golden():
+    rows = tc.case_training_step_small('cuda')
+    assert len(rows) > 250
+
+
+@pytest.mark.parametrize('which', ['full', 'stress_full'])
+def test_full_model_backward_vs_oracle(meta, which):
+    """flagship model (fresh and 'trained-like': LayerScale O(1), live attention decay), B = 2 x 2 s: the oracle's dL/dy of the
+    MR-STFT loss pushed back through the HIP graph"""
+    m = build_model(meta, which).train()
+    cfg = meta['full_cfg']
+    x, hr = seeded((2, 1, 8000), 7), seeded((2, 1, 32000), 8) * 0.1
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    y32, dy, g32, _ = tc.oracle_grads(m, cfg, x, hr=hr)
+    _, _, gq, _ = tc.oracle_grads(m, cfg, x, dy=dy, rounded=True)
+    m.cuda()
+    y = m(x.cuda())
+    assert rel_l2(y.detach().cpu(), y32) < 4e-3
+    y.backward(dy.cuda())
+    tc.check_param_grads(m, g32, gq, which)
+
+
+def test_music_config_forward_golden(meta):
+    """BASELINE config 5 geometry (11.025 -> 44.1 kHz, n_fft 512, hop 256, 10-s segments: T = 1724, 18 LSTM frames, the streaming
+    attention form inside the model), eval and train mode, against the reference's outputs"""
+    io = load_npz('music_io.npz')
+    torch.manual_seed(meta['music_seed'])
+    from aero_amd import Aero
+    from conftest import randomize_running_stats
+    m = Aero(**meta['music_cfg']).eval()
+    randomize_running_stats(m, meta['music_bn_seed'])
+    m.cuda()
+    x = seeded((2, 1, 110250), meta['music_input_seed']).cuda()
+    with torch.no_grad():
+        y, s = m(x, return_spec=True)
+        assert y.shape == (2, 1, 441000) and s.shape == (2, 1, 256, 1724)
+        assert rel_l2(s.cpu()[:, :, ::4, ::7], io['spec']) < 1e-3
+        assert rel_l2(y.cpu()[..., ::16], io['y']) < 5e-3
+        m.train()
+        yt, st = m(x, return_spec=True)
+        assert rel_l2(st.cpu()[:, :, ::4, ::7], io['spec_train']) < 1e-3
+        assert rel_l2(yt.cpu()[..., ::16], io['y_train']) < 5e-3
+
+
+def test_config5_training_steps(meta):
+    """BASELINE config 5 per GPU: B = 2 x 10 s at 11.025 -> 44.1 kHz, train mode: forward -> loss -> backward -> FlatAdam.step,
+    three steps; the loss of this fixed batch goes down and every parameter receives a finite gradient"""
+    from aero_amd import Aero, losses
+    from aero_amd.optim import FlatAdam
+    torch.manual_seed(2036)
+    m = Aero(**meta['music_cfg']).cuda().train()
+    opt = FlatAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.999), model=m)
+    crit = losses.MultiResolutionSTFTLoss(factor_sc=0.5, factor_mag=0.5)          # main_config.yaml:64-65
+    lr = seeded((2, 1, 110250), 1).cuda()
+    hr = (0.1 * seeded((2, 1, 441000), 2)).cuda()
+    hist = []
+    for _ in range(3):
+        y = m(lr)
+        sc, mg = crit(y.squeeze(1), hr.squeeze(1))
+        loss = sc + mg
+        opt.zero_grad()
+        loss.backward()
+        assert torch.isfinite(opt.flat_g).all() and float(opt.flat_g.abs().max()) > 0
+        for n, p in m.named_parameters():
+            assert p.grad is not None and p.grad.data_ptr() >= opt.flat_g.data_ptr(), n
+        opt.step()
+        hist.append(float(loss.detach()))
+    assert hist[2] < hist[0], hist

@@ -72,3 +72,53 @@ def test_cpu_parameters_without_the_emulator_fail_loudly():
 @pytest.mark.gpu
 def test_flat_adam_matches_torch_on_the_mi355x():
     _run(None, 'cuda', steps=8)
+
+
+def test_stray_gradients_and_torch_checkpoints():
+    """(i) after `module.zero_grad()` (set_to_none) autograd allocates fresh .grad tensors that are not views of the flat
+    buffer -- step() must still follow them; (ii) the checkpoint schema is torch.optim.Adam's, both ways."""
+    from emu.build_emu import build
+    lib = _lib.load(build())
+    g = torch.Generator().manual_seed(3)
+    shapes = [(6, 5), (7,), (3, 2, 2)]
+    ref = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    opt_ref = torch.optim.Adam(ref, lr=1e-2)
+    opt = FlatAdam(mine, lr=1e-2, lib=lib)
+    for it in range(3):
+        for p, q in zip(ref, mine):
+            gr = torch.randn(*p.shape, generator=g)
+            p.grad = gr.clone()
+            if it == 1:
+                q.grad = None                           # what zero_grad(set_to_none=True) leaves behind ...
+            q.grad = gr.clone() if it else q.grad.copy_(gr)   # ... and what autograd then allocates: a stray tensor
+        if it == 2:
+            mine[0].data = mine[0].data.clone()         # a re-homed parameter (model.to(), load_state_dict(assign=True))
+        opt_ref.step()
+        opt.step()
+        for p, q in zip(ref, mine):
+            assert torch.allclose(q.detach(), p.detach(), rtol=2e-6, atol=1e-9)
+            assert q.grad.untyped_storage().data_ptr() == opt.flat_g.untyped_storage().data_ptr()
+    # torch -> flat
+    opt2 = FlatAdam([torch.nn.Parameter(p.detach().clone()) for p in ref], lr=5.0, lib=lib)
+    opt2.load_state_dict(opt_ref.state_dict())
+    assert opt2.step_count == 3 and opt2.lr == 1e-2
+    assert torch.allclose(opt2.exp_avg, opt.exp_avg, rtol=1e-5, atol=1e-7)
+    # flat -> torch
+    fresh = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    opt3 = torch.optim.Adam(fresh, lr=1.0)
+    opt3.load_state_dict(opt.state_dict())
+    for p, q, r in zip(ref, mine, fresh):
+        gr = torch.randn(*p.shape, generator=g)
+        p.grad, r.grad = gr.clone(), gr.clone()
+        q.grad.copy_(gr)
+    opt_ref.step()
+    opt3.step()
+    opt.step()
+    for p, q, r in zip(ref, mine, fresh):
+        assert torch.allclose(r.detach(), p.detach(), rtol=2e-6, atol=1e-7), (r.detach() - p.detach()).abs().max()
+        assert torch.allclose(q.detach(), p.detach(), rtol=2e-6, atol=1e-7), (q.detach() - p.detach()).abs().max()
+    with pytest.raises(ValueError):
+        bad = opt_ref.state_dict()
+        bad['state'][0]['exp_avg'] = torch.zeros(2)
+        opt2.load_state_dict(bad)

@@ -1,0 +1,123 @@
+"""Whole-model training-step cases shared by the emulator (CPU) and MI355X tests: `Aero.forward` under autograd (aero_amd/train.py)
+-> multi-resolution STFT loss (aero_amd/losses.py) -> HIP backward, checked against torch.autograd through the CPU oracle and the
+reference-generated golden of oracle/make_golden.py (tests/golden/train_small_grads.npz).
+
+What "parity" can mean for a gradient.  The product stores activations in fp16 (forward parity 1e-3).  The gradient is NOT a
+continuous function of those activations: the FTB's three ReLUs behind BatchNorms on batch statistics (modules.py:285-302) flip
+their masks for every pre-activation within the forward tolerance of zero, and a flipped fraction p changes the gradient by
+~sqrt(p).  So the fp32 oracle is not a 1e-2 yardstick for parameters up-stream of an FTB -- ANY implementation with fp16 storage is
+off by several 1e-2 there.  The tests therefore hold three things:
+  (1) same-forward op-level checks of every backward kernel and block (tests/op_cases.py: <= 6e-3);
+  (2) whole model, the reference's / oracle's dL/dy pushed back through the HIP graph: decoder and deepest-encoder main path
+      (no ReLU on the way) <= 1.5e-2 of the fp32 oracle; every other parameter no further from the fp32 oracle than 4x the distance
+      of the SAME oracle run with fp16-rounded activation storage (oracle.fp16_storage: exact fp32 gradients of a forward that
+      differs by the product's storage precision), with a floor of 3e-2;
+  (3) the loss gradient dL/dy at the SAME y: <= 1e-3 of torch.autograd (d log|X| / dx is ill-conditioned at near-zero bins, so it
+      must not be compared across different forwards).
+"""
+import re
+
+import torch
+
+from conftest import build_model, load_npz, rel_l2, seeded
+from oracle import aero_oracle as O
+
+SMOOTH = re.compile(r'^(decoder\.\d+\.|encoder\.3\.(conv|norm1|rewrite|norm2)\.)')
+# a conv bias in front of a BatchNorm on batch statistics, and the key bias of a softmax over keys, have NO gradient
+ZERO = re.compile(r'(freq_attn_block\.(conv1|conv1d|conv2)\.0\.bias|time_attn\.key\.bias)$')
+
+
+def oracle_grads(m, cfg, x, dy=None, hr=None, rounded=False):
+    """parameter gradients by torch.autograd through the oracle (train mode): of <y, dy>, or of the MR-STFT loss against hr"""
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    if rounded:
+        with O.fp16_storage():
+            y = O.aero_forward(sd, cfg, x, train=True, new_stats={})
+    else:
+        y = O.aero_forward(sd, cfg, x, train=True, new_stats={})
+    y.retain_grad()
+    if dy is None:
+        sc, mg = O.mrstft_loss(y.squeeze(1), hr.squeeze(1))
+        (sc + mg).backward()
+        loss = (float(sc.detach()), float(mg.detach()))
+    else:
+        y.backward(dy)
+        loss = None
+    return y.detach(), y.grad.detach(), {k: v.grad for k, v in sd.items() if v.grad is not None}, loss
+
+
+def check_param_grads(m, g32, gq, label=''):
+    """policy (2) of the module docstring; returns the per-parameter table"""
+    rows, bad = [], []
+    gmax = max(float(g.norm()) for g in g32.values())
+    for n, p in m.named_parameters():
+        ref = g32[n]
+        nrm = float(ref.norm())
+        got = p.grad.detach().cpu()
+        if ZERO.search(n):                                      # mathematically zero: the fp32 oracle itself returns rounding noise
+            sib = float(g32[n[:-4] + 'weight'].norm())
+            assert float(got.norm()) < 5e-3 * max(sib, 1e-30) + 1e-6 * gmax, (n, float(got.norm()), sib)
+            continue
+        e = rel_l2(got, ref)
+        eq = rel_l2(gq[n], ref)
+        lim = 1.5e-2 if SMOOTH.match(n) else max(3e-2, 4.0 * eq)
+        if n.endswith('act.a'):                                 # Snake's alpha: a sum of x sin(2ax) - sin^2(ax)/a terms of both signs over
+            lim = max(lim, 0.1)                                 # (b, t, c) -- cancellation leaves ~1e-7 of the largest gradient
+        if ref.numel() <= 8:                                    # (the FTB's 5-channel BatchNorm: a handful of numbers, each a sum over ReLU masks)
+            lim = max(lim, 0.2)
+        rows.append((n, e, eq, lim, nrm))
+        if not e < lim:
+            bad.append((n, f'{e:.2e}', f'limit {lim:.2e}', f'|g| {nrm:.1e}'))
+    assert not bad, (label, len(bad), bad[:12])
+    return rows
+
+
+def case_training_step_small(dev, lib=None, L=800):
+    """small model, the inputs of the reference golden: forward, loss value, dL/dy at the same y, and the VJP policy above"""
+    import json
+    import os
+    from conftest import GOLDEN
+    from aero_amd import losses
+    meta = json.load(open(os.path.join(GOLDEN, 'meta.json')))
+    gold = load_npz('train_small_grads.npz')
+    inp = meta['train_small_inputs']
+    assert L == inp['L']
+    m = build_model(meta, 'small').train()
+    # (build_model puts the model in eval() and randomises the running statistics exactly as make_golden.py did)
+    x, hr = seeded((2, 1, L), inp['x_seed']), seeded((2, 1, 4 * L), inp['hr_seed']) * inp['hr_scale']
+    dy_ref = torch.from_numpy(gold['dy'])
+    y32, _, g32, _ = oracle_grads(m, meta['small_cfg'], x, dy=dy_ref)
+    assert rel_l2(y32, gold['y']) < 1e-5                                             # oracle == reference (forward, train mode)
+    for k in [k for k in gold if k.startswith('g.')]:
+        assert rel_l2(g32[k[2:]], gold[k]) < 2e-4, k                                 # oracle autograd == reference autograd
+    _, _, gq, _ = oracle_grads(m, meta['small_cfg'], x, dy=dy_ref, rounded=True)
+    if lib is not None:                                                              # emulator: explicit test double
+        from aero_amd.engine import HipEngine
+        object.__setattr__(m, '_engine', HipEngine(m, lib=lib))
+        losses.use_library(lib)
+    try:
+        m.to(dev)
+        y = m(x.to(dev))
+        assert y.requires_grad and rel_l2(y.detach().cpu(), gold['y']) < 3e-3
+        crit = losses.MultiResolutionSTFTLoss()
+        sc, mg = crit(y.squeeze(1), hr.to(dev).squeeze(1))
+        assert abs(float(sc.detach()) - gold['loss'][0]) < 2e-3 * gold['loss'][0] and abs(float(mg.detach()) - gold['loss'][1]) < 2e-3 * gold['loss'][1]
+        # (3) the loss gradient at the SAME y
+        yy = y.detach().clone().requires_grad_()
+        s2, m2 = crit(yy.squeeze(1), hr.to(dev).squeeze(1))
+        (s2 + m2).backward()
+        yc = y.detach().cpu().clone().requires_grad_()
+        so, mo = O.mrstft_loss(yc.squeeze(1), hr.squeeze(1))
+        (so + mo).backward()
+        assert rel_l2(yy.grad.cpu(), yc.grad) < 1e-3
+        # (2) the reference's dL/dy through the HIP backward
+        y.backward(dy_ref.to(dev))
+        rows = check_param_grads(m, g32, gq, 'small')
+        norms = meta['train_small_grad_norms']
+        for n, p in m.named_parameters():
+            if norms[n] > 1e-3 * max(norms.values()):
+                assert abs(float(p.grad.norm()) - norms[n]) < 0.1 * norms[n], (n, float(p.grad.norm()), norms[n])
+        return rows
+    finally:
+        if lib is not None:
+            losses.use_library(None)
