@@ -38,7 +38,7 @@ def lstm_param_grads(ops, da, x, out, sd, layer, H, nseq, W, in_ch, dev):
     H4 = 4 * H
     perm = pack.lstm_gate_perm(H).to(dev)                       # kernel row 4j+g <- nn.LSTM row g*H+j
     g = {}
-    dw, db = bw.conv_wgrad(ops, da.view(1, 1, npos, 2 * H4), x.reshape(1, 1, npos, in_ch), [0], [0])      # [1, 8H, in_ch], [8H]
+    dw, db = bw.conv_wgrad(ops, da.view(nseq, 1, W, 2 * H4), x.reshape(nseq, 1, W, in_ch), [0], [0])      # [1, 8H, in_ch], [8H] (a row per sequence: the kernel cuts rows into parallel chunks)
     w_t = []
     for dr, sfx in enumerate(('', '_reverse')):
         gi = torch.empty(H4, in_ch, dtype=torch.float32, device=dev)

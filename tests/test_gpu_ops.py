@@ -285,7 +285,7 @@ def test_localstate_bwd(lib, a):
 
 
 @pytest.mark.parametrize('kw', [dict(H=48, nseq=96, W=200), dict(H=96, nseq=48, W=200, in_ch=192), dict(H=48, nseq=36, W=200, framed_T=1724),
-                                dict(H=96, nseq=20, W=200, framed_T=501), dict(H=16, nseq=20, W=9, in_ch=32)])
+                                dict(H=96, nseq=24, W=200, framed_T=501), dict(H=16, nseq=20, W=9, in_ch=32)])
 def test_lstm_bwd(lib, kw):
     oc.case_lstm_bwd(lib, DEV, **kw)
 
