@@ -90,6 +90,12 @@ class AttnDesc(C.Structure):
                 ('R', i32), ('T', i32), ('C', i32), ('heads', i32), ('ndecay', i32)]
 
 
+class GconvDesc(C.Structure):
+    _fields_ = [('x', vp), ('w', vp), ('bias', fp), ('y', vp),
+                ('B', i32), ('Tin', i32), ('Cin', i32), ('Cout', i32), ('groups', i32), ('K', i32), ('stride', i32), ('pad', i32),
+                ('reflect', i32), ('slope', C.c_float)]
+
+
 class FreqFcDesc(C.Structure):
     _fields_ = [('x', vp), ('w', vp), ('gate', vp), ('dst', vp),
                 ('B', i32), ('F', i32), ('T', i32), ('C', i32)]
@@ -168,6 +174,10 @@ _PROTOS = {
     'aero_add_f16': (i32, [vp, vp, vp, i64, C.c_float, vp]),
     'aero_scale_cast': (i32, [fp, i32, i64, fp, vp, C.c_float, vp, fp, vp]),
     'aero_scale_f32': (i32, [fp, i64, fp, vp]),
+    'aero_gconv1d_fwd': (i32, [C.POINTER(GconvDesc), vp]),
+    'aero_leaky_relu': (i32, [vp, i64, C.c_float, vp]),
+    'aero_avgpool1d': (i32, [vp, vp, i32, i32, vp]),
+    'aero_loss_sum': (i32, [vp, vp, i64, C.c_float, i32, dp, i32, dp, vp]),
 }
 
 EXPORTS = tuple(_PROTOS)

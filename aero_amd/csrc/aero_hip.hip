@@ -17,6 +17,7 @@
 #include "k_optim.h"
 #include "k_bwd.h"
 #include "k_train.h"
+#include "k_disc.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -324,6 +325,30 @@ int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const fl
 int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream) {
     const char* err = "";
     int rc = aero_scale_f32_launch(x, n, scale, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_gconv1d_fwd(const aero_gconv_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_gconv1d_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_leaky_relu(void* x, int64_t n, float slope, void* stream) {
+    const char* err = "";
+    int rc = aero_leaky_relu_launch(x, n, slope, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_avgpool1d(const void* x, void* y, int32_t B, int32_t T, void* stream) {
+    const char* err = "";
+    int rc = aero_avgpool1d_launch(x, y, B, T, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_loss_sum(const void* a, const void* b, int64_t n, float sign, int32_t mode, double* part, int32_t npart, double* out, void* stream) {
+    const char* err = "";
+    int rc = aero_loss_sum_launch(a, b, n, sign, mode, part, npart, out, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 

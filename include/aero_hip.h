@@ -423,6 +423,25 @@ int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const fl
                     float* scale_out, void* stream);
 int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream);
 
+/* ---- MelGAN multi-scale discriminator (src/models/discriminators.py:14-78; k_disc.h) ---------------------- */
+
+/* grouped, strided nn.Conv1d over time (discriminators.py:17-19,29-38,42-47) on channels-last rows: x fp16 [B][Tin][Cin],
+ * w fp16 [Cout][K][Cin/groups] (weight norm w = g v / |v| already applied, modules.py:10-11), bias fp32 [Cout] or NULL,
+ * y fp16 [B][Tout][Cout], Tout = (Tin + 2 pad - K) / stride + 1; reflect != 0: ReflectionPad1d(pad) instead of zero padding
+ * (discriminators.py:17); y = LeakyReLU_slope(conv + bias) (slope 1 = none). */
+typedef struct {
+    const void* x; const void* w; const float* bias; void* y;
+    int32_t B, Tin, Cin, Cout, groups, K, stride, pad, reflect;
+    float slope;
+} aero_gconv_desc;
+int aero_gconv1d_fwd(const aero_gconv_desc* d, void* stream);
+int aero_leaky_relu(void* x, int64_t n, float slope, void* stream);                      /* fp16 [n], in place */
+/* nn.AvgPool1d(4, stride=2, padding=1, count_include_pad=False) (discriminators.py:70): x fp16 [B][T] -> y fp16 [B][(T-2)/2+1] */
+int aero_avgpool1d(const void* x, void* y, int32_t B, int32_t T, void* stream);
+/* reductions of the hinge / feature-matching losses (solver.py:489-512): out[0] += sum relu(1 + sign * a[i]) (mode 0) or
+ * sum |a[i] - b[i]| (mode 1); a, b fp16 [n]; part: scratch of npart doubles; block partials added in order (deterministic). */
+int aero_loss_sum(const void* a, const void* b, int64_t n, float sign, int32_t mode, double* part, int32_t npart, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

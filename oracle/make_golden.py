@@ -296,6 +296,34 @@ def main():
     meta['train_small_grad_norms'] = gnorm
     meta['train_small_inputs'] = {'x_seed': 7, 'hr_seed': 8, 'hr_scale': 0.1, 'L': 800}
 
+    # ---- MelGAN multi-scale discriminator (discriminators.py:14-78): the reference's critic at the config of
+    # conf/experiment/aero_4-16*.yaml:66-70 on a seeded waveform pair; feature maps sub-sampled, weights by seed + checksums.
+    # `src.utils` imports cv2 (absent here, unused by the critic): an empty stand-in MODULE OBJECT lets the import proceed. ----------
+    import types
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    from src.models.discriminators import Discriminator
+    torch.manual_seed(71)
+    disc = Discriminator(num_D=3, ndf=16, n_layers=4, downsampling_factor=4).eval()
+    meta['disc_seed'], meta['disc_cfg'] = 71, dict(num_D=3, ndf=16, n_layers=4, downsampling_factor=4)
+    meta['disc_checksums'] = checksums(disc.state_dict())
+    xd, xr = seeded((2, 1, 8192), 72) * 0.3, seeded((2, 1, 8192), 73) * 0.3
+    dg = {}
+    with torch.no_grad():
+        outs_f, outs_r = disc(xd), disc(xr)
+        for si, sc_ in enumerate(outs_f):
+            for j, fm in enumerate(sc_):
+                dg[f'fake.{si}.{j}'] = fm.numpy()[:, ::max(1, fm.shape[1] // 16), ::max(1, fm.shape[2] // 64)]
+        for si, sc_ in enumerate(outs_r):
+            dg[f'real.{si}.6'] = sc_[-1].numpy()
+        # the losses of solver.py:489-520 (features_loss_lambda 100, aero_4-16.yaml:58)
+        import torch.nn.functional as Fn
+        d_loss = sum(Fn.relu(1 + s_[-1]).mean() for s_ in outs_f) + sum(Fn.relu(1 - s_[-1]).mean() for s_ in outs_r)
+        g_adv = sum(Fn.relu(1 - s_[-1]).mean() for s_ in outs_f)
+        wts = (4.0 / 5) * (1.0 / 3)
+        g_feat = sum(wts * Fn.l1_loss(outs_f[i_][j], outs_r[i_][j]) for i_ in range(3) for j in range(6))
+        dg['losses'] = np.array([float(d_loss), float(g_adv), float(100.0 * g_feat)])
+    np.savez_compressed(os.path.join(OUT, 'disc_io.npz'), **dg)
+
     with open(os.path.join(OUT, 'meta.json'), 'w') as f:
         json.dump(meta, f, indent=1)
     print('golden vectors written to', os.path.abspath(OUT))

@@ -19,6 +19,8 @@ from oracle import aero_oracle as O
 
 TOL16 = 2e-3
 TOL32 = 2e-6
+BLSTM_TOL = 1e-3      # whole BLSTM block / LocalState block (output incl. the skip path) against the oracle: the north-star bar itself
+ATTN_TOL = 1e-3
 
 
 def _g(seed):
@@ -321,7 +323,9 @@ def case_blstm(lib, dev, H, R, T, seed=60, fuse=True):
     L['lstm_lin'] = pack.make_conv_spec(w[None, :, None, :], sd['b.linear.bias'], 2 * H, 0, [0], [0], dev)
     h = x.permute(0, 2, 1).contiguous().half().view(1, R, T, H).to(dev)
     y = eng._blstm(_DC, L, h, 1, R, T)
-    assert rel_l2(y.cpu().float()[0].permute(0, 2, 1), ref) < 4e-3
+    err = rel_l2(y.cpu().float()[0].permute(0, 2, 1), ref)
+    assert err < BLSTM_TOL, err
+    return err
 
 
 def case_localstate(lib, dev, Cc, heads, R, T, seed=70):
@@ -342,7 +346,9 @@ def case_localstate(lib, dev, Cc, heads, R, T, seed=70):
     qkvd = ops.conv(qk, h, None, 1, R, R, T)
     att = ops.localstate(qkvd, R, T, Cc, heads, nd)
     y = ops.conv(pj, att.view(1, R, T, Cc), None, 1, R, R, T, res=h)
-    assert rel_l2(y.cpu().float()[0].permute(0, 2, 1), ref) < 3e-3
+    err = rel_l2(y.cpu().float()[0].permute(0, 2, 1), ref)
+    assert err < ATTN_TOL, err
+    return err
 
 
 def case_freqfc(lib, dev, Fq, Cc, T, B=2, seed=80):
@@ -1145,4 +1151,130 @@ def case_ftb_autograd(lib, dev, Cc, Fq, T, B=2, seed=300):
     tol = 2e-2 if Cc * Fq * T > 100000 else 3 * TOL16
     bad = {k: v for k, v in errs.items() if v > tol}
     assert not bad, bad
+    return errs
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own module vectors (tests/golden/modules.npz, oracle/make_golden.py: BLSTM / LocalState / FTB / Snake / DConv /
+# HEncLayer / HDecLayer of the REFERENCE on seeded inputs) fed to the HIP kernels -- VERDICT r2 missing #5
+def _mod_golden(tag):
+    from conftest import load_npz
+    g = load_npz('modules.npz')
+    w = {k[len(tag) + 3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(tag + '.w.')}
+    i = {k[len(tag) + 4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(tag + '.in.')}
+    o = {k[len(tag) + 5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(tag + '.out.')}
+    return w, i, o
+
+
+def _engine_for(lib, holder, dev):
+    from aero_amd.engine import HipEngine
+    eng = HipEngine(holder.to(dev), lib=lib)
+    eng._train = False
+    eng._prepare(torch.device(dev))
+    return eng
+
+
+def case_module_golden(lib, dev, tag):
+    """returns the measured rel-L2 errors {case: error} against the REFERENCE's outputs (fp32 weights and inputs as committed)"""
+    from aero_amd import modules as M
+    from aero_amd.engine import HipEngine
+    ops = Ops(lib)
+    w, i, o = _mod_golden(tag)
+    errs = {}
+    if tag == 'blstm':
+        H = 8
+
+        class _DC:
+            hidden = H
+        sd = {'b.' + k: v for k, v in w.items()}
+        eng = HipEngine.__new__(HipEngine)
+        eng.lib, eng.ops, eng.fuse_lstm_proj = lib, ops, True
+        L = {'lstm': [pack.pack_lstm_layer(lib, sd, 'b.lstm', l, H, dev) for l in range(2)]}
+        wl = sd['b.linear.weight']
+        L['lstm_lin'] = pack.make_conv_spec(wl[None, :, None, :], sd['b.linear.bias'], 2 * H, 0, [0], [0], dev)
+        for case in ('framed', 'unframed'):
+            x = i[case]
+            R, _, T = x.shape
+            h = x.permute(0, 2, 1).contiguous().half().view(1, R, T, H).to(dev)
+            y = eng._blstm(_DC, L, h, 1, R, T)
+            errs[case] = rel_l2(y.cpu().float()[0].permute(0, 2, 1), o[case])
+    elif tag == 'localstate':
+        Cc, heads, nd = 16, 4, 4
+        wq = torch.cat([w[f'{n}.weight'][:, :, 0] for n in ('query', 'key', 'content', 'query_decay')], 0)
+        bq = torch.cat([w[f'{n}.bias'] for n in ('query', 'key', 'content', 'query_decay')], 0)
+        qk = pack.make_conv_spec(wq[None, :, None, :], bq, Cc, 0, [0], [0], dev)
+        pj = pack.make_conv_spec(w['proj.weight'][:, :, 0][None, :, None, :], w['proj.bias'], Cc, 0, [0], [0], dev)
+        x = i['x']
+        R, _, T = x.shape
+        h = x.permute(0, 2, 1).contiguous().half().view(1, R, T, Cc).to(dev)
+        qkvd = ops.conv(qk, h, None, 1, R, R, T)
+        att = ops.localstate(qkvd, R, T, Cc, heads, nd)
+        y = ops.conv(pj, att.view(1, R, T, Cc), None, 1, R, R, T, res=h)
+        errs['y'] = rel_l2(y.cpu().float()[0].permute(0, 2, 1), o['y'])
+    elif tag == 'snake':
+        x = i['x']                                                       # [B, hid, T, F]: a per frequency bin (modules.py:232-236)
+        xc = x.permute(0, 3, 2, 1).contiguous().half().to(dev)           # [B, F, T, hid]
+        y = ops.norm_act(xc, 1, True, None, None, _lib.ACT_SNAKE, snake_a=w['a'].reshape(-1).float().to(dev), normalize=False)
+        errs['y'] = rel_l2(y.cpu().float().permute(0, 3, 2, 1), o['y'])
+    elif tag == 'ftb':
+        ftb = M.FTB(input_dim=16, in_channel=8)
+        ftb.load_state_dict(w)
+        x = i['x']
+        B, Cc, Fq, T = x.shape
+        # train mode (batch statistics).  The committed state is the one AFTER the reference's train-mode call: the output does not
+        # depend on the running statistics, only the update does -- checked by the oracle test (test_ftb_module_golden_eval_and_train)
+        hold = _Holder(fab=ftb).to(dev)
+        eng = _train_engine(lib, hold, dev)
+        y, _ = eng._ftb_fwd('fab', hold.fab.train(), cl(x).to(dev), B, Fq, T)
+        errs['train'] = rel_l2(uncl(y.cpu()), o['train'])
+        # eval mode: BatchNorm on the running statistics BEFORE that call = what the oracle reproduces; here the folded-conv path of
+        # the inference engine on the committed state against the oracle on the same state
+        enc = M.HEncLayer(8, 8, kernel_size=8, stride=4, norm_groups=4, dconv=False, freq_attn=True, freq_dim=16, norm=False, rewrite=False)
+        enc.freq_attn_block.load_state_dict(w)
+        holder = _Holder(encoder=torch.nn.ModuleList([enc]), decoder=torch.nn.ModuleList([]))
+        holder.freq_emb = None
+        e2 = _engine_for(lib, holder, dev)
+        ye = e2._encode_head_unfused(e2.P['encoder.0'], cl(x).to(dev), B, Fq, T)
+        ref = O.ftb({'m.' + k: v for k, v in w.items()}, 'm', x)
+        errs['eval'] = rel_l2(uncl(ye.cpu()), ref)
+    elif tag == 'dconv':
+        dc = M.DConv(16, compress=4, depth=2, init=0.5, norm=True, time_attn=True, heads=4, ndecay=4, lstm=True, act_func='snake', freq_dim=4,
+                     reshape=True)
+        dc.load_state_dict(w)
+        x = i['x']
+        B, Cc, Fq, T = x.shape
+        eng = HipEngine.__new__(HipEngine)
+        eng.lib, eng.ops = lib, ops
+        eng.fuse_lstm_proj, eng.fuse_dconv_tail, eng.gram_stats, eng.fuse_stats, eng.fuse_dconv_row = True, True, True, 'auto', True
+        eng._tables = {}
+        layers = eng._pack_dconv({'m.' + k: v.float() for k, v in w.items()}, 'm', dc, dev)
+        ops.begin_step(torch.device(dev))
+        y = eng._dconv(dc, layers, cl(x).to(dev), B, Fq, T)
+        errs['y'] = rel_l2(uncl(y.cpu()), o['y'])
+    elif tag == 'henc':
+        enc = M.HEncLayer(4, 8, kernel_size=8, stride=4, norm_groups=4, freq=True, dconv=False, is_first=False, freq_attn=False, freq_dim=32,
+                          norm=True, context=0, pad=True, rewrite=True)
+        enc.load_state_dict(w)
+        holder = _Holder(encoder=torch.nn.ModuleList([enc]), decoder=torch.nn.ModuleList([]))
+        holder.freq_emb = None
+        eng = _engine_for(lib, holder, dev)
+        x = i['x']
+        B, _, Fq, T = x.shape
+        eng.ops.begin_step(torch.device(dev))
+        y, Fo = eng._encode(0, enc, eng.P['encoder.0'], cl(x).to(dev), B, Fq, T)
+        errs['y'] = rel_l2(uncl(y.cpu()), o['y'])
+    elif tag == 'hdec':
+        dec = M.HDecLayer(16, 4, last=False, kernel_size=8, stride=4, norm_groups=4, freq=True, dconv=False, norm=True, context=1, pad=True,
+                          context_freq=True, rewrite=True)
+        dec.load_state_dict(w)
+        holder = _Holder(encoder=torch.nn.ModuleList([]), decoder=torch.nn.ModuleList([dec]))
+        holder.freq_emb = None
+        eng = _engine_for(lib, holder, dev)
+        x, sk = i['x'], i['skip']
+        B, _, Fq, T = x.shape
+        eng.ops.begin_step(torch.device(dev))
+        y = eng._decode(0, dec, eng.P['decoder.0'], cl(x).to(dev), cl(sk).to(dev), B, Fq, T, None, None)
+        errs['y'] = rel_l2(uncl(y.cpu()), o['y'])
+    else:
+        raise KeyError(tag)
     return errs

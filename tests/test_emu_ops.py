@@ -318,3 +318,10 @@ def test_lstm_bwd(emu, kw):
 @pytest.mark.parametrize('a', [(16, 8, 40), (32, 16, 33)])
 def test_ftb_autograd(emu, a):
     oc.case_ftb_autograd(emu, DEV, *a)
+
+
+@pytest.mark.parametrize('tag', ['blstm', 'localstate', 'snake', 'ftb', 'dconv', 'henc', 'hdec'])
+def test_reference_module_vectors(emu, tag):
+    """the REFERENCE's own module outputs (tests/golden/modules.npz) reproduced by the kernels: <= 1e-3, the north-star bar"""
+    errs = oc.case_module_golden(emu, DEV, tag)
+    assert errs and max(errs.values()) < 1e-3, errs

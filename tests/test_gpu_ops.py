@@ -293,3 +293,11 @@ def test_lstm_bwd(lib, kw):
 @pytest.mark.parametrize('a', [(48, 64, 501), (96, 16, 501), (384, 4, 300)])
 def test_ftb_autograd(lib, a):
     oc.case_ftb_autograd(lib, DEV, *a)
+
+
+@pytest.mark.parametrize('tag', ['blstm', 'localstate', 'snake', 'ftb', 'dconv', 'henc', 'hdec'])
+def test_reference_module_vectors(lib, tag):
+    """the REFERENCE's own module outputs (tests/golden/modules.npz: BLSTM framed / unframed, LocalState, FTB eval + train, Snake,
+    DConv with BLSTM + LocalState, HEncLayer, HDecLayer) reproduced by the HIP kernels: <= 1e-3 (VERDICT r2 missing #5)"""
+    errs = oc.case_module_golden(lib, DEV, tag)
+    assert errs and max(errs.values()) < 1e-3, errs
