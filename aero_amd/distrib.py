@@ -107,13 +107,13 @@ def count_ranks(device=None):
 
 
 def sum_gradients(flat_grad):
-    """One collective for the whole generator: all-reduce (SUM) of FlatAdam's flat gradient buffer over RCCL / xGMI (what
-    DistributedDataParallel does bucket by bucket, distrib.py:66).  Returns the factor the optimizer applies to turn the sum into
-    the mean (FlatAdam.step(grad_scale=...)): the division rides along in the fused step instead of a separate pass."""
+    """One collective for a whole flat gradient buffer (FlatAdam.flat_g) for callers that do not wrap the model: all-reduce (SUM)
+    over RCCL / xGMI; returns the factor that turns the sum into the mean (FlatAdam.step(grad_scale=...))."""
     if world_size == 1 or not is_initialized():
         return 1.0
-    t = flat_grad if flat_grad.is_cuda or _dist().get_backend() != 'nccl' else flat_grad.cuda()
-    _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
+    if not flat_grad.is_cuda and _dist().get_backend() == 'nccl':
+        raise RuntimeError('sum_gradients: a CPU buffer cannot be reduced over the nccl (RCCL) backend -- keep the gradients on the device')
+    _dist().all_reduce(flat_grad, op=_dist().ReduceOp.SUM)
     return 1.0 / world_size
 
 
@@ -149,16 +149,82 @@ def gather_batch(y_local, n_total):
     return out
 
 
+class GradSync:
+    """Gradient all-reduce of a wrapped generator (what DistributedDataParallel's reducer does, distrib.py:66-69): the HIP backward
+    (aero_amd/train.py) hands over contiguous fp32 segments of its flat gradient buffer as soon as a stage's gradients are final --
+    the decoder first, then the encoders from the deepest up -- and each goes out as ONE asynchronous all-reduce on RCCL's stream
+    while the rest of the backward runs; the mean's 1 / world-size rides in the un-scaling pass that precedes the reduce."""
+
+    def __init__(self):
+        self._work = []
+        self.launched = 0
+
+    def unscale(self, scale):
+        """{S, 1/S} of this rank's backward -> the device factor 1 / (S * world_size)"""
+        return scale[1:] * (1.0 / world_size)
+
+    def reduce_async(self, seg):
+        if world_size == 1 or not is_initialized():
+            return
+        self._work.append(_dist().all_reduce(seg, op=_dist().ReduceOp.SUM, async_op=True))
+        self.launched += 1
+
+    def wait(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+
+class DataParallel(torch.nn.Module):
+    """What `wrap` returns for world_size > 1: the role of DistributedDataParallel around the generator (distrib.py:66-69) without its
+    autograd hooks -- `forward` broadcasts the BatchNorm running buffers from rank 0 in training mode (DDP's broadcast_buffers) and runs
+    the module; gradients are averaged over ranks by the module's `GradSync` inside the HIP backward.  `.module` as in DDP."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+        object.__setattr__(module, '_grad_sync', GradSync())
+        params = [p.detach() for p in module.parameters()]
+        if is_initialized() and params:                          # DDP's constructor: every rank starts from rank 0's weights
+            flat = torch.cat([p.reshape(-1) for p in params])
+            _dist().broadcast(flat, 0)
+            o = 0
+            for p in params:
+                p.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            if hasattr(module, 'repack'):
+                module.repack()
+
+    def _broadcast_buffers(self):
+        bufs = [b for b in self.module.buffers() if b.is_floating_point()]
+        if not bufs or not is_initialized():
+            return
+        flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+        _dist().broadcast(flat, 0)
+        o = 0
+        with torch.no_grad():
+            for b in bufs:
+                b.copy_(flat[o:o + b.numel()].view_as(b).to(b.dtype))
+                o += b.numel()
+
+    def forward(self, *args, **kwargs):
+        if self.module.training and torch.is_grad_enabled():
+            self._broadcast_buffers()
+        return self.module(*args, **kwargs)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__('module'), name)
+
+
 def wrap(model):
-    """Inference needs no wrapper (weights are replicated, clips are independent).  Training-time
-    gradient all-reduce over RCCL is listed as follow-up work in DESIGN.md."""
+    """distrib.py:59-69.  Inference needs no wrapper (weights are replicated, clips are independent); for training the generator is
+    wrapped in `DataParallel` (gradient all-reduce in flat segments overlapped with the HIP backward, BatchNorm buffers from rank 0)."""
     if world_size == 1:
         return model
-    from torch.nn.parallel.distributed import DistributedDataParallel
-    if next(model.parameters()).is_cuda:
-        return DistributedDataParallel(model, device_ids=[torch.cuda.current_device()],
-                                       output_device=torch.cuda.current_device())
-    return DistributedDataParallel(model)
+    return DataParallel(model)
 
 
 def loader(dataset, *args, shuffle=False, klass=None, **kwargs):

@@ -454,7 +454,7 @@ class TrainEngine:
         return out, r
 
     # ================================================================== backward
-    def backward(self, ctx, dy, grads):
+    def backward(self, ctx, dy, grads, stage_done=None):
         """dy fp32 [B,1,Lout]: gradient of the waveform.  `grads`: {state-dict name: fp32 view of the flat gradient buffer} -- every
         parameter gradient is WRITTEN there, still multiplied by the loss scale; returns the device tensor {S, 1/S}."""
         m, ops = self.model, self.ops
@@ -471,12 +471,16 @@ class TrainEngine:
             dx, dskip = self._dec_bwd(j, m.decoder[j], ctx.dec[j], dx, B, T)
             dskips.append(dskip)                                 # decoder j used the output of encoder len-1-j
         dskips.reverse()                                         # dskips[j] <-> encoder len-1-j
+        if stage_done is not None:
+            stage_done('decoder.', scale)                        # every decoder gradient is final: its all-reduce can start now
         dx = None
         n = len(m.encoder)
         for i in reversed(range(n)):
             dsk = dskips[n - 1 - i]
             dout = dsk if dx is None else TO.add_f16(ops, dsk, dx)
             dx = self._enc_bwd(i, m.encoder[i], ctx.enc[i], dout, B, T)
+            if stage_done is not None:
+                stage_done(f'encoder.{i}.', scale)
         return scale
 
     _unboost = 1.0
@@ -780,8 +784,35 @@ class AeroFunction(torch.autograd.Function):
         flat = torch.zeros(n, dtype=torch.float32, device=dev)
         views = [flat[o:o + s.numel()].view(s) for o, s in zip(offs, ctx.shapes)]
         grads = dict(zip(ctx.names, views))
+        sync = getattr(eng.model, '_grad_sync', None)            # distrib.wrap(): gradient all-reduce over RCCL, overlapped with the backward
+        done_upto = [len(ctx.names)]                             # parameters [done_upto, end) are final (the backward walks the list from its end)
+
+        def finish_segment(lo, hi, scale):
+            if hi <= lo:
+                return
+            a, b = offs[lo], (offs[hi] if hi < len(offs) else n)
+            seg = flat[a:b]
+            TO.scale_f32(eng.ops, seg, sync.unscale(scale) if sync is not None else scale[1:])
+            if sync is not None:
+                sync.reduce_async(seg)
+
+        def stage_done(prefix, scale):
+            # named_parameters order is encoder.0 .. encoder.N-1, decoder.*, freq_emb: a finished stage closes the tail of the list down
+            # to its first parameter (freq_emb belongs to encoder 0's stage)
+            first = next(i for i, nme in enumerate(ctx.names) if nme.startswith(prefix))
+            if prefix == 'decoder.':
+                last = max(i for i, nme in enumerate(ctx.names) if nme.startswith(prefix)) + 1
+                finish_segment(first, last, scale)               # (freq_emb, behind the decoder in the list, is not final yet)
+                done_upto[0] = first
+                ctx_tail[0] = last
+            else:
+                finish_segment(first, done_upto[0], scale)
+                done_upto[0] = first
+        ctx_tail = [len(ctx.names)]
         with torch.no_grad():
-            scale = eng.backward(ctx.c, dy.contiguous(), grads)
-            TO.scale_f32(eng.ops, flat, scale[1:])
+            scale = eng.backward(ctx.c, dy.contiguous(), grads, stage_done=stage_done)
+            finish_segment(ctx_tail[0], len(ctx.names), scale)   # freq_emb (written by encoder 0's stage)
+            if sync is not None:
+                sync.wait()
         ctx.c = None
         return (None, None, None) + tuple(views)

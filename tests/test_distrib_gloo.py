@@ -107,3 +107,96 @@ def test_two_rank_gradient_allreduce_and_fused_step():
         t.grad.fill_(1.5)
     o.step()
     assert torch.equal(ref[0].detach(), torch.from_numpy(got[0][3]))
+
+
+# ---- training: the role of DistributedDataParallel (distrib.py:59-69) around the HIP backward ----------------------------------------
+def _train_worker(rank, world, port, q):
+    try:
+        _train_worker_body(rank, world, port, q)
+    except BaseException as e:                                  # a dead rank must not leave the other one (and the test) hanging
+        import traceback
+        q.put((rank, 'error', traceback.format_exc()))
+        raise
+
+
+def _train_worker_body(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank),
+                      AERO_EMU_THREADS='2')
+    torch.set_num_threads(1)
+    import json
+    from aero_amd import Aero, _lib, distrib
+    from aero_amd.engine import HipEngine
+    from aero_amd.optim import FlatAdam
+    from emu.build_emu import build
+    lib = _lib.load(build())
+    cfg = dict(channels=16, nfft=128, hop_length=16, lr_sr=4000, hr_sr=16000, enc_freq_attn=1)      # FTB (BatchNorm buffers) on encoders 1-3
+    if world > 1:
+        distrib.init_from_env(backend='gloo')
+    torch.manual_seed(100 + rank)                               # different initial weights per rank: wrap() must broadcast rank 0's
+    m = Aero(**cfg).train()
+    object.__setattr__(m, '_engine', HipEngine(m, lib=lib))
+    model = distrib.wrap(m)
+    opt = FlatAdam(m.parameters(), lr=1e-3, lib=lib, model=m)
+    x = torch.randn(2, 1, 256, generator=torch.Generator().manual_seed(5))
+    w = torch.randn(2, 1, 1024, generator=torch.Generator().manual_seed(6))
+    mine, wm = distrib.shard_batch(x), distrib.shard_batch(w)
+
+    def loss_of(net):
+        return (net(mine) * wm).sum(dim=(1, 2)).mean()
+    # this rank's own gradient (no reduction), on the weights wrap() distributed
+    sync = m._grad_sync
+    object.__setattr__(m, '_grad_sync', None)
+    opt.zero_grad()
+    loss_of(m).backward()
+    g_local = opt.flat_g.clone()
+    object.__setattr__(m, '_grad_sync', sync)
+    grads = None
+    for step in range(2):
+        opt.zero_grad()
+        loss_of(model).backward()
+        if step == 0:
+            grads = opt.flat_g.clone()
+        opt.step()
+    model._broadcast_buffers()                                 # what the next training forward does first (each rank's last update used its own batch)
+    bufs = torch.cat([b.reshape(-1).float() for b in m.buffers()])
+    q.put((rank, opt.flat_p.numpy().copy(), grads.numpy(), bufs.numpy(), sync.launched, g_local.numpy()))      # by value (no shared fds)
+    distrib.barrier()
+    distrib.close()
+
+
+def test_two_rank_training_matches_one_process():
+    """2 ranks over gloo, each with one clip of a 2-clip batch: wrap() starts both from rank 0's weights, the HIP backward averages the
+    gradients in flat segments while it runs, BatchNorm buffers follow rank 0 -- after two fused-Adam steps both ranks hold bit-identical
+    parameters, and the reduced gradient is the mean of the ranks' own gradients (for a loss that is a mean over clips and a model
+    whose clips do not interact -- every layer but the FTB's per-rank BatchNorm, which the reference does not synchronise either,
+    SURVEY 8e -- that mean is the one-process gradient of the whole batch)."""
+    from emu.build_emu import build
+    build()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r = q.get(timeout=600)
+            assert not (isinstance(r[1], str) and r[1] == 'error'), r[2]
+            res[r[0]] = r
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    (_, p0, g0, b0, n0, l0), (_, p1, g1, b1, n1, l1) = [tuple(torch.from_numpy(v) if hasattr(v, 'dtype') else v for v in res[r]) for r in (0, 1)]
+    assert torch.equal(p0, p1) and torch.equal(g0, g1)          # same averaged gradients, same weights, bit for bit
+    assert torch.equal(b0, b1)                                  # BatchNorm running buffers follow rank 0 (distrib.py:66 broadcast_buffers)
+    assert n0 == n1 and n0 >= 3                                 # the all-reduce went out in several segments, not one blocking call
+    assert float(g0.abs().max()) > 0 and torch.isfinite(p0).all()
+    # the reduced gradient IS the mean of the two ranks' own gradients (the power-of-two loss scales make 1/(S W) exact)
+    assert not torch.equal(l0, l1)
+    mean = 0.5 * (l0 + l1)
+    assert torch.allclose(g0, mean, rtol=1e-4, atol=1e-6 * float(mean.abs().max())), float((g0 - mean).abs().max())   # (two separate backward passes: atomics order)
