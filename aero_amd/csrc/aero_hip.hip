@@ -352,4 +352,11 @@ int aero_loss_sum(const void* a, const void* b, int64_t n, float sign, int32_t m
     return aero_finish(rc, err);
 }
 
+int aero_rescale_f16(const void* a, const float* sa, const void* b, const float* sb, int64_t n, void* amax, float target, void* out,
+                     float* scale_out, void* stream) {
+    const char* err = "";
+    int rc = aero_rescale_f16_launch(a, sa, b, sb, n, (unsigned int*)amax, target, out, scale_out, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 }  // extern "C"

@@ -838,3 +838,50 @@ static int aero_scale_f32_launch(float* x, int64_t n, const float* scale, hipStr
     AERO_LAUNCH(aero_scale_f32_kernel, dim3((unsigned)nb), dim3(256), stream, x, n, scale);
     return AERO_OK;
 }
+
+// Re-normalisation of an fp16 gradient between stages of the backward: v = a / Sa + b / Sb (b optional), S = 2^floor(log2(target / max|v|)),
+// out = fp16(v * S), scale_out = {S, 1/S}.  sa / sb: the {S, 1/S} pairs the operands carry (device memory; NULL = 1).  Powers of two: exact
+// unless a value leaves the fp16 range, which is what this pass prevents (gradients may grow or shrink by orders of magnitude from
+// one encoder level to the next).
+__global__ __launch_bounds__(256) void aero_rescale_amax_kernel(const h16* a, const float* sa, const h16* b, const float* sb, int64_t n, unsigned int* amax) {
+    __shared__ float red[4];
+    const float ia = sa ? sa[1] : 1.f, ib = sb ? sb[1] : 1.f;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = (float)a[i] * ia + (b ? (float)b[i] * ib : 0.f);
+        m = fmaxf(m, fabsf(v));
+    }
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    if (aero_lane() == 0) red[aero_wave()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m == m && m < 3.0e38f) atomicMax(amax, __float_as_uint(m));
+        else atomicMax(amax, 0x7f7fffffu);
+    }
+}
+
+__global__ __launch_bounds__(256) void aero_rescale_apply_kernel(const h16* a, const float* sa, const h16* b, const float* sb, int64_t n, const unsigned int* amax,
+                                                                 float target, h16* out, float* scale_out) {
+    const float ia = sa ? sa[1] : 1.f, ib = sb ? sb[1] : 1.f;
+    const float am = __uint_as_float(amax[0]);
+    float S = 1.f;
+    if (am > 0.f) S = exp2f(floorf(log2f(target / am)));
+    if (!(S > 1e-30f)) S = 1e-30f;
+    if (S > 1e30f) S = 1e30f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scale_out[0] = S; scale_out[1] = 1.f / S; }
+    const float fa = ia * S, fb = ib * S;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = (h16)((float)a[i] * fa + (b ? (float)b[i] * fb : 0.f));
+}
+
+static int aero_rescale_f16_launch(const void* a, const float* sa, const void* b, const float* sb, int64_t n, unsigned int* amax, float target, void* out,
+                                   float* scale_out, hipStream_t stream, const char** err) {
+    if (!a || !amax || !out || !scale_out || n < 1 || !(target > 0.f)) { *err = "rescale_f16: bad arguments"; return AERO_ERR_ARG; }
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    AERO_LAUNCH(aero_rescale_amax_kernel, dim3((unsigned)nb), dim3(256), stream, (const h16*)a, sa, (const h16*)b, sb, n, amax);
+    AERO_LAUNCH(aero_rescale_apply_kernel, dim3((unsigned)nb), dim3(256), stream, (const h16*)a, sa, (const h16*)b, sb, n, (const unsigned int*)amax, target,
+                (h16*)out, scale_out);
+    return AERO_OK;
+}

@@ -23,7 +23,8 @@ from . import _lib, backward as bw, pack, train_ops as TO
 from ._lib import ACT_GELU, ACT_GLU, ACT_NONE, ACT_RELU, ACT_SNAKE
 from .engine import Ops, _hann_padded
 
-GRAD_TARGET = 4096.0        # the activation gradient enters fp16 with its largest magnitude in [2048, 4096]
+GRAD_TARGET = 64.0          # a stage's input gradient has its largest magnitude in [32, 64]: three orders of magnitude of headroom
+                            # to the fp16 maximum for growth inside the stage, six down to the smallest normal number
 
 
 def _r8(n):
@@ -456,7 +457,8 @@ class TrainEngine:
     # ================================================================== backward
     def backward(self, ctx, dy, grads, stage_done=None):
         """dy fp32 [B,1,Lout]: gradient of the waveform.  `grads`: {state-dict name: fp32 view of the flat gradient buffer} -- every
-        parameter gradient is WRITTEN there, still multiplied by the loss scale; returns the device tensor {S, 1/S}."""
+        parameter gradient is WRITTEN there, still multiplied by its stage's scale; stage_done(prefix, scale) is called when the
+        gradients of the parameters `prefix*` are final, with that stage's device pair {S, 1/S}."""
         m, ops = self.model, self.ops
         dev = dy.device
         B, T, F0 = ctx.B, ctx.T, ctx.F0
@@ -464,24 +466,33 @@ class TrainEngine:
         dz = bw.istft_bwd(ops, dy.reshape(B, ctx.Lout).contiguous().float(), m.nfft, ctx.hop_o, self._window(ctx.win_o, dev),
                           self._inv_env(ctx.win_o, ctx.hop_o, T, dev), T)                               # fp32 [B,F0,T,2]
         # adjoint of x * std + mean (aero.py:497-498) and the fp32 -> fp16 boundary with the loss scale
-        d16, scale = TO.scale_cast(ops, dz, ctx.std, GRAD_TARGET)
+        d16, sc = TO.scale_cast(ops, dz, ctx.std, GRAD_TARGET)
+        # Every gradient tensor that crosses a stage boundary carries its own power-of-two scale {S, 1/S} (device memory): the
+        # magnitudes change by orders of magnitude from level to level (LayerScale, GroupNorm, the 0.1-rescaled init), in either
+        # direction, so each stage's input is re-normalised to GRAD_TARGET from its own maximum (aero_rescale_f16) and the stage's
+        # parameter gradients are un-scaled with that stage's factor (stage_done).
         dx = d16
         dskips = []
         for j in reversed(range(len(m.decoder))):
-            dx, dskip = self._dec_bwd(j, m.decoder[j], ctx.dec[j], dx, B, T)
-            dskips.append(dskip)                                 # decoder j used the output of encoder len-1-j
+            dxp, dskip = self._dec_bwd(j, m.decoder[j], ctx.dec[j], dx, B, T)
+            dskips.append((dskip, sc))                           # decoder j used the output of encoder len-1-j
+            if stage_done is not None:
+                stage_done(f'decoder.{j}.', sc)
+            if dxp is not None:
+                dx, sc = TO.rescale_f16(ops, dxp, sc, target=GRAD_TARGET)
         dskips.reverse()                                         # dskips[j] <-> encoder len-1-j
-        if stage_done is not None:
-            stage_done('decoder.', scale)                        # every decoder gradient is final: its all-reduce can start now
         dx = None
         n = len(m.encoder)
         for i in reversed(range(n)):
-            dsk = dskips[n - 1 - i]
-            dout = dsk if dx is None else TO.add_f16(ops, dsk, dx)
+            dsk, ssk = dskips[n - 1 - i]
+            if dx is None:
+                dout, sc = TO.rescale_f16(ops, dsk, ssk, target=GRAD_TARGET)
+            else:
+                dout, sc = TO.rescale_f16(ops, dsk, ssk, dx.contiguous(), sc, target=GRAD_TARGET)
             dx = self._enc_bwd(i, m.encoder[i], ctx.enc[i], dout, B, T)
             if stage_done is not None:
-                stage_done(f'encoder.{i}.', scale)
-        return scale
+                stage_done(f'encoder.{i}.', sc)
+        return None
 
     _unboost = 1.0
 
@@ -785,33 +796,32 @@ class AeroFunction(torch.autograd.Function):
         views = [flat[o:o + s.numel()].view(s) for o, s in zip(offs, ctx.shapes)]
         grads = dict(zip(ctx.names, views))
         sync = getattr(eng.model, '_grad_sync', None)            # distrib.wrap(): gradient all-reduce over RCCL, overlapped with the backward
-        done_upto = [len(ctx.names)]                             # parameters [done_upto, end) are final (the backward walks the list from its end)
+        names = ctx.names
 
-        def finish_segment(lo, hi, scale):
-            if hi <= lo:
-                return
-            a, b = offs[lo], (offs[hi] if hi < len(offs) else n)
-            seg = flat[a:b]
-            TO.scale_f32(eng.ops, seg, sync.unscale(scale) if sync is not None else scale[1:])
-            if sync is not None:
-                sync.reduce_async(seg)
+        def span(prefix):
+            idx = [i for i, nme in enumerate(names) if nme.startswith(prefix)]
+            lo, hi = idx[0], idx[-1] + 1
+            assert idx == list(range(lo, hi))                    # a module's parameters are contiguous in named_parameters order
+            return offs[lo], (offs[hi] if hi < len(offs) else n)
 
         def stage_done(prefix, scale):
-            # named_parameters order is encoder.0 .. encoder.N-1, decoder.*, freq_emb: a finished stage closes the tail of the list down
-            # to its first parameter (freq_emb belongs to encoder 0's stage)
-            first = next(i for i, nme in enumerate(ctx.names) if nme.startswith(prefix))
-            if prefix == 'decoder.':
-                last = max(i for i, nme in enumerate(ctx.names) if nme.startswith(prefix)) + 1
-                finish_segment(first, last, scale)               # (freq_emb, behind the decoder in the list, is not final yet)
-                done_upto[0] = first
-                ctx_tail[0] = last
-            else:
-                finish_segment(first, done_upto[0], scale)
-                done_upto[0] = first
-        ctx_tail = [len(ctx.names)]
+            prefixes = [prefix] + (['freq_emb.'] if prefix == 'encoder.0.' and any(nme.startswith('freq_emb.') for nme in names) else [])
+            for pf in prefixes:
+                a, b = span(pf)
+                TO.scale_f32(eng.ops, flat[a:b], sync.unscale(scale) if sync is not None else scale[1:])
+            if sync is None:
+                return
+            # all-reduce in a few flat segments as stages complete: the whole decoder once its last layer is done (it overlaps with the
+            # encoders' backward, the bulk of the time), then each encoder level
+            if prefix == 'decoder.0.':
+                a, b = span('decoder.')
+                sync.reduce_async(flat[a:b])
+            elif prefix.startswith('encoder.'):
+                for pf in prefixes:
+                    a, b = span(pf)
+                    sync.reduce_async(flat[a:b])
         with torch.no_grad():
-            scale = eng.backward(ctx.c, dy.contiguous(), grads, stage_done=stage_done)
-            finish_segment(ctx_tail[0], len(ctx.names), scale)   # freq_emb (written by encoder 0's stage)
+            eng.backward(ctx.c, dy.contiguous(), grads, stage_done=stage_done)
             if sync is not None:
                 sync.wait()
         ctx.c = None

@@ -148,3 +148,14 @@ def scale_f32(ops, x, scale):
     assert x.is_contiguous() and x.dtype == torch.float32
     ops.lib.call('aero_scale_f32', _ptr(x), x.numel(), _ptr(scale), ops.stream(x))
     return x
+
+
+def rescale_f16(ops, a, sa, b=None, sb=None, target=4096.0):
+    """(a / Sa + b / Sb) * S as fp16 with S = 2^floor(log2(target / amax)); returns (tensor, scale fp32 [2] = {S, 1/S}).
+    sa / sb: the {S, 1/S} device pairs the operands carry (None = 1)."""
+    assert a.is_contiguous() and (b is None or (b.is_contiguous() and b.shape == a.shape))
+    out = torch.empty_like(a)
+    amax = torch.zeros(1, dtype=torch.int32, device=a.device)
+    scale = torch.empty(2, dtype=torch.float32, device=a.device)
+    ops.lib.call('aero_rescale_f16', _ptr(a), _ptr(sa), _ptr(b), _ptr(sb), a.numel(), _ptr(amax), C.c_float(target), _ptr(out), _ptr(scale), ops.stream(a))
+    return out, scale

@@ -422,6 +422,11 @@ int aero_add_f16(const void* a, const void* b, void* dst, int64_t n, float scale
 int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const float* item_scale, void* amax, float target, void* dst,
                     float* scale_out, void* stream);
 int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream);
+/* re-normalisation between stages of the backward: v = a / Sa + b / Sb (b may be NULL), S = 2^floor(log2(target / max|v|)),
+ * out = fp16(v * S), scale_out = {S, 1/S}; sa / sb: the {S, 1/S} pairs of the operands (device floats, NULL = 1); amax: one zeroed
+ * uint32 of scratch.  out may alias a. */
+int aero_rescale_f16(const void* a, const float* sa, const void* b, const float* sb, int64_t n, void* amax, float target, void* out,
+                     float* scale_out, void* stream);
 
 /* ---- MelGAN multi-scale discriminator (src/models/discriminators.py:14-78; k_disc.h) ---------------------- */
 

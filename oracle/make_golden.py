@@ -277,7 +277,7 @@ def main():
     tsm = Aero(**SMALL_CFG)
     randomize_running_stats(tsm, 22)
     tsm.train()
-    xg, hg = seeded((2, 1, 800), 7), seeded((2, 1, 3200), 8) * 0.1
+    xg, hg = seeded((2, 1, 400), 7), seeded((2, 1, 1600), 8) * 0.1
     crit = ref_loss.MultiResolutionSTFTLoss(factor_sc=0.1, factor_mag=0.1)                  # main_config.yaml: stft_sc_factor / stft_mag_factor
     pr = tsm(xg)
     pr.retain_grad()
@@ -294,7 +294,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'train_small_grads.npz'), y=pr.detach().numpy(), dy=pr.grad.numpy(), loss=np.array([float(sc.detach()), float(mag.detach())]),
                         **{'g.' + k: dict(tsm.named_parameters())[k].grad.numpy() for k in keep})
     meta['train_small_grad_norms'] = gnorm
-    meta['train_small_inputs'] = {'x_seed': 7, 'hr_seed': 8, 'hr_scale': 0.1, 'L': 800}
+    meta['train_small_inputs'] = {'x_seed': 7, 'hr_seed': 8, 'hr_scale': 0.1, 'L': 400}
 
     # ---- MelGAN multi-scale discriminator (discriminators.py:14-78): the reference's critic at the config of
     # conf/experiment/aero_4-16*.yaml:66-70 on a seeded waveform pair; feature maps sub-sampled, weights by seed + checksums.

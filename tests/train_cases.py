@@ -74,7 +74,7 @@ def check_param_grads(m, g32, gq, label=''):
     return rows
 
 
-def case_training_step_small(dev, lib=None, L=800):
+def case_training_step_small(dev, lib=None, L=400):
     """small model, the inputs of the reference golden: forward, loss value, dL/dy at the same y, and the VJP policy above"""
     import json
     import os
