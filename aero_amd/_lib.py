@@ -96,6 +96,12 @@ class GconvDesc(C.Structure):
                 ('reflect', i32), ('slope', C.c_float)]
 
 
+class GconvBwdDesc(C.Structure):
+    _fields_ = [('x', vp), ('w', vp), ('y', vp), ('dy', vp), ('dx', vp), ('dw', fp), ('db', fp),
+                ('B', i32), ('Tin', i32), ('Cin', i32), ('Cout', i32), ('groups', i32), ('K', i32), ('stride', i32), ('pad', i32),
+                ('reflect', i32), ('slope', C.c_float)]
+
+
 class FreqFcDesc(C.Structure):
     _fields_ = [('x', vp), ('w', vp), ('gate', vp), ('dst', vp),
                 ('B', i32), ('F', i32), ('T', i32), ('C', i32)]
@@ -179,6 +185,9 @@ _PROTOS = {
     'aero_leaky_relu': (i32, [vp, i64, C.c_float, vp]),
     'aero_avgpool1d': (i32, [vp, vp, i32, i32, vp]),
     'aero_loss_sum': (i32, [vp, vp, i64, C.c_float, i32, dp, i32, dp, vp]),
+    'aero_gconv1d_bwd': (i32, [C.POINTER(GconvBwdDesc), vp]),
+    'aero_loss_grad': (i32, [vp, vp, i64, C.c_float, C.c_float, i32, vp, vp]),
+    'aero_avgpool1d_bwd': (i32, [vp, vp, i32, i32, vp]),
 }
 
 EXPORTS = tuple(_PROTOS)

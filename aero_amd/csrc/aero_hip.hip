@@ -359,4 +359,22 @@ int aero_rescale_f16(const void* a, const float* sa, const void* b, const float*
     return aero_finish(rc, err);
 }
 
+int aero_gconv1d_bwd(const aero_gconv_bwd_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_gconv1d_bwd_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_loss_grad(const void* a, const void* b, int64_t n, float sign, float coef, int32_t mode, void* g, void* stream) {
+    const char* err = "";
+    int rc = aero_loss_grad_launch(a, b, n, sign, coef, mode, g, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_avgpool1d_bwd(const void* dy, void* dx, int32_t B, int32_t T, void* stream) {
+    const char* err = "";
+    int rc = aero_avgpool1d_bwd_launch(dy, dx, B, T, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 }  // extern "C"

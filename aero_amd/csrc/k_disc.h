@@ -177,3 +177,217 @@ static int aero_loss_sum_launch(const void* a, const void* b, int64_t n, float s
     AERO_LAUNCH(aero_loss_sum_finish_kernel, dim3(1), dim3(64), stream, (const double*)part, (int)nb, out);
     return AERO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the critic (solver.py:602-611 through discriminators.py:14-78).  dy arrives as the gradient of the layer's
+// POST-activation output y; LeakyReLU is sign preserving, so its derivative is read off y: dyp = dy * (y > 0 ? 1 : slope).
+//
+//   aero_gconv1d_dgrad   dx[b][t][g*cig + c] = sum_{o in group, k : (t' + pad - k) % stride == 0} dyp[b][(t' + pad - k)/stride][o] w[o][k][c]
+//                        summed over the padded positions t' that alias t (ReflectionPad1d: up to three)
+//   aero_gconv1d_wgrad   dw[o][k][c] += sum_{b, to} dyp[b][to][o] x[b][to*stride - pad + k][g*cig + c],   db[o] += sum dyp
+//   aero_loss_grad       the hinge / L1 loss gradients as fp16 with a power-of-two scale
+//   aero_avgpool1d_bwd   adjoint of aero_avgpool1d
+struct AeroGconvBwdK {
+    const h16* x; const h16* w; const h16* y; const h16* dy; h16* dx; float* dw; float* db;
+    int B, Tin, Tout, Cin, Cout, groups, K, stride, pad, reflect;
+    float slope;
+    int cig, cog, tiles_per_block, ntile;
+};
+
+__global__ __launch_bounds__(256) void aero_gconv1d_dgrad_kernel(AeroGconvBwdK p) {
+    // block: 256 input steps of one (batch item, group); thread = one step, loops over the group's input channels in chunks
+    float* ws = (float*)AERO_DYN_SMEM;                           // [cog][K][cc]
+    const int g = blockIdx.y, b = blockIdx.z;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const h16* dyb = p.dy + (int64_t)b * p.Tout * p.Cout + g * p.cog;
+    const h16* yb = p.y + (int64_t)b * p.Tout * p.Cout + g * p.cog;
+    for (int c0 = 0; c0 < p.cig; c0 += AERO_GCONV_CIC) {
+        const int cc = (p.cig - c0) < AERO_GCONV_CIC ? (p.cig - c0) : AERO_GCONV_CIC;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < p.cog * p.K * cc; idx += 256) {
+            const int c = idx % cc, k = (idx / cc) % p.K, o = idx / (cc * p.K);
+            ws[(o * p.K + k) * AERO_GCONV_CIC + c] = (float)p.w[((int64_t)(g * p.cog + o) * p.K + k) * p.cig + c0 + c];
+        }
+        __syncthreads();
+        if (t >= p.Tin) continue;
+        float acc[AERO_GCONV_CIC];
+#pragma unroll
+        for (int c = 0; c < AERO_GCONV_CIC; ++c) acc[c] = 0.f;
+        // padded positions that read x[t]: t + pad, and with reflection the mirror images
+        int pp[3];
+        int npp = 0;
+        pp[npp++] = t + p.pad;
+        if (p.reflect) {
+            if (t >= 1 && t <= p.pad) pp[npp++] = p.pad - t;
+            if (t <= p.Tin - 2 && t >= p.Tin - 1 - p.pad) pp[npp++] = p.pad + 2 * (p.Tin - 1) - t;
+        }
+        for (int q = 0; q < npp; ++q) {
+            for (int k = 0; k < p.K; ++k) {
+                const int num = pp[q] - k;
+                if (num < 0 || num % p.stride) continue;
+                const int to = num / p.stride;
+                if (to >= p.Tout) continue;
+                for (int o = 0; o < p.cog; ++o) {
+                    const float yv = (float)yb[(int64_t)to * p.Cout + o];
+                    const float d = (float)dyb[(int64_t)to * p.Cout + o] * (yv > 0.f ? 1.f : p.slope);
+                    const float* wr = ws + (o * p.K + k) * AERO_GCONV_CIC;
+                    for (int c = 0; c < cc; ++c) acc[c] += d * wr[c];
+                }
+            }
+        }
+        h16* dxo = p.dx + ((int64_t)b * p.Tin + t) * p.Cin + g * p.cig + c0;
+        for (int c = 0; c < cc; ++c) dxo[c] = (h16)acc[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void aero_gconv1d_wgrad_kernel(AeroGconvBwdK p) {
+    // block: (range of 64-step output tiles, group, batch item); a thread owns outputs (o, k, c) = idx, idx + 256, ... of the group chunk
+    float* xs = (float*)AERO_DYN_SMEM;                           // [span][cc]
+    const int span = (AERO_GCONV_TO - 1) * p.stride + p.K;
+    float* ds = xs + span * AERO_GCONV_CIC;                      // [TO][cog]
+    const int g = blockIdx.y, b = blockIdx.z;
+    const int tile0 = blockIdx.x * p.tiles_per_block;
+    int tile1 = tile0 + p.tiles_per_block;
+    if (tile1 > p.ntile) tile1 = p.ntile;
+    const h16* xb = p.x + (int64_t)b * p.Tin * p.Cin + g * p.cig;
+    const h16* dyb = p.dy + (int64_t)b * p.Tout * p.Cout + g * p.cog;
+    const h16* yb = p.y + (int64_t)b * p.Tout * p.Cout + g * p.cog;
+    constexpr int MAXO = 12;                                     // cog * K * cc <= 12 * 256 outputs per pass
+    for (int c0 = 0; c0 < p.cig; c0 += AERO_GCONV_CIC) {
+        const int cc = (p.cig - c0) < AERO_GCONV_CIC ? (p.cig - c0) : AERO_GCONV_CIC;
+        const int nout = p.cog * p.K * cc;
+        for (int o0 = 0; o0 < nout; o0 += MAXO * 256) {
+            float acc[MAXO];
+#pragma unroll
+            for (int j = 0; j < MAXO; ++j) acc[j] = 0.f;
+            float dbacc = 0.f;
+            for (int tile = tile0; tile < tile1; ++tile) {
+                const int t0 = tile * AERO_GCONV_TO;
+                __syncthreads();
+                for (int idx = threadIdx.x; idx < span * cc; idx += 256) {
+                    const int s = idx / cc, c = idx - s * cc;
+                    int t = t0 * p.stride - p.pad + s;
+                    if (p.reflect) {
+                        if (t < 0) t = -t;
+                        if (t >= p.Tin) t = 2 * (p.Tin - 1) - t;
+                    }
+                    xs[s * AERO_GCONV_CIC + c] = (t >= 0 && t < p.Tin) ? (float)xb[(int64_t)t * p.Cin + c0 + c] : 0.f;
+                }
+                for (int idx = threadIdx.x; idx < AERO_GCONV_TO * p.cog; idx += 256) {
+                    const int s = idx / p.cog, o = idx - s * p.cog;
+                    float d = 0.f;
+                    if (t0 + s < p.Tout) {
+                        const float yv = (float)yb[(int64_t)(t0 + s) * p.Cout + o];
+                        d = (float)dyb[(int64_t)(t0 + s) * p.Cout + o] * (yv > 0.f ? 1.f : p.slope);
+                    }
+                    ds[s * p.cog + o] = d;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < MAXO; ++j) {
+                    const int idx = o0 + threadIdx.x + j * 256;
+                    if (idx < nout) {
+                        const int c = idx % cc, k = (idx / cc) % p.K, o = idx / (cc * p.K);
+                        float s = 0.f;
+                        for (int q = 0; q < AERO_GCONV_TO; ++q) s += ds[q * p.cog + o] * xs[(q * p.stride + k) * AERO_GCONV_CIC + c];
+                        acc[j] += s;
+                    }
+                }
+                if (c0 == 0 && o0 == 0 && p.db && (int)threadIdx.x < p.cog) {
+                    float s = 0.f;
+                    for (int q = 0; q < AERO_GCONV_TO; ++q) s += ds[q * p.cog + threadIdx.x];
+                    dbacc += s;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MAXO; ++j) {
+                const int idx = o0 + threadIdx.x + j * 256;
+                if (idx < nout) {
+                    const int c = idx % cc, k = (idx / cc) % p.K, o = idx / (cc * p.K);
+                    atomicAdd(p.dw + ((int64_t)(g * p.cog + o) * p.K + k) * p.cig + c0 + c, acc[j]);
+                }
+            }
+            if (c0 == 0 && o0 == 0 && p.db && (int)threadIdx.x < p.cog) atomicAdd(p.db + g * p.cog + threadIdx.x, dbacc);
+        }
+    }
+}
+
+static int aero_gconv1d_bwd_launch(const aero_gconv_bwd_desc* d, hipStream_t stream, const char** err) {
+    if (!d || !d->w || !d->y || !d->dy || (!d->dx && !d->dw)) { *err = "gconv1d_bwd: null pointer"; return AERO_ERR_ARG; }
+    if (d->dw && !d->x) { *err = "gconv1d_bwd: the weight gradient needs x"; return AERO_ERR_ARG; }
+    if (d->B < 1 || d->Tin < 1 || d->Cin < 1 || d->Cout < 1 || d->groups < 1 || d->Cin % d->groups || d->Cout % d->groups || d->K < 1 || d->stride < 1 ||
+        d->pad < 0 || d->B > 65535 || d->groups > 65535) { *err = "gconv1d_bwd: bad geometry"; return AERO_ERR_ARG; }
+    AeroGconvBwdK p;
+    p.x = (const h16*)d->x; p.w = (const h16*)d->w; p.y = (const h16*)d->y; p.dy = (const h16*)d->dy; p.dx = (h16*)d->dx; p.dw = d->dw; p.db = d->db;
+    p.B = d->B; p.Tin = d->Tin; p.Cin = d->Cin; p.Cout = d->Cout; p.groups = d->groups; p.K = d->K; p.stride = d->stride; p.pad = d->pad;
+    p.reflect = d->reflect; p.slope = d->slope;
+    p.Tout = (d->Tin + 2 * d->pad - d->K) / d->stride + 1;
+    p.cig = d->Cin / d->groups;
+    p.cog = d->Cout / d->groups;
+    if (p.cog > 64) { *err = "gconv1d_bwd: more than 64 output channels per group"; return AERO_ERR_UNSUPPORTED; }
+    p.ntile = (p.Tout + AERO_GCONV_TO - 1) / AERO_GCONV_TO;
+    p.tiles_per_block = 1;
+    if (d->dx) {
+        const size_t lds = (size_t)p.cog * p.K * AERO_GCONV_CIC * sizeof(float);
+        if (lds > 150 * 1024) { *err = "gconv1d_bwd: weights exceed the LDS"; return AERO_ERR_UNSUPPORTED; }
+        AERO_LAUNCH_DYN(aero_gconv1d_dgrad_kernel, dim3((unsigned)((p.Tin + 255) / 256), (unsigned)d->groups, (unsigned)d->B), dim3(256), lds, stream, p);
+    }
+    if (d->dw) {
+        const int span = (AERO_GCONV_TO - 1) * p.stride + p.K;
+        const size_t lds = ((size_t)span * AERO_GCONV_CIC + (size_t)AERO_GCONV_TO * p.cog) * sizeof(float);
+        if (lds > 150 * 1024) { *err = "gconv1d_bwd: tile exceeds the LDS"; return AERO_ERR_UNSUPPORTED; }
+        // ~512 blocks: each walks a range of output tiles with its partial sums in registers, then one atomic pass
+        long want = 512 / ((long)d->groups * d->B);
+        if (want < 1) want = 1;
+        int nbx = (int)(want < p.ntile ? want : p.ntile);
+        p.tiles_per_block = (p.ntile + nbx - 1) / nbx;
+        nbx = (p.ntile + p.tiles_per_block - 1) / p.tiles_per_block;
+        AERO_LAUNCH_DYN(aero_gconv1d_wgrad_kernel, dim3((unsigned)nbx, (unsigned)d->groups, (unsigned)d->B), dim3(256), lds, stream, p);
+    }
+    return AERO_OK;
+}
+
+// loss gradients (solver.py:489-512), written as fp16 multiplied by `scale` (a power of two chosen by the caller):
+//   mode 0 (hinge)  g[i] = coef * sign * [1 + sign * a[i] > 0]                  d/da of coef * relu(1 + sign * a)
+//   mode 1 (L1)     g[i] = coef * sgn(a[i] - b[i])                              d/da of coef * |a - b|
+//   mode 2          g[i] = dy[i] * (y[i] > 0 ? 1 : slope)   (a = dy, b = y, coef = slope): LeakyReLU backward for the dense layer
+__global__ __launch_bounds__(256) void aero_loss_grad_kernel(const h16* a, const h16* b, int64_t n, float sign, float coef, int mode, h16* g) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v;
+        if (mode == 0) v = (1.f + sign * (float)a[i] > 0.f) ? coef * sign : 0.f;
+        else if (mode == 1) { const float d = (float)a[i] - (float)b[i]; v = d > 0.f ? coef : (d < 0.f ? -coef : 0.f); }
+        else v = (float)a[i] * ((float)b[i] > 0.f ? 1.f : coef);
+        g[i] = (h16)v;
+    }
+}
+
+static int aero_loss_grad_launch(const void* a, const void* b, int64_t n, float sign, float coef, int mode, void* g, hipStream_t stream, const char** err) {
+    if (!a || !g || n < 1 || mode < 0 || mode > 2 || (mode >= 1 && !b)) { *err = "loss_grad: bad arguments"; return AERO_ERR_ARG; }
+    int64_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    AERO_LAUNCH(aero_loss_grad_kernel, dim3((unsigned)nb), dim3(256), stream, (const h16*)a, (const h16*)b, n, sign, coef, mode, (h16*)g);
+    return AERO_OK;
+}
+
+__global__ __launch_bounds__(256) void aero_avgpool1d_bwd_kernel(const h16* dy, h16* dx, int T, int To) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    // windows t with 2t - 1 <= i <= 2t + 2  <=>  (i - 2) / 2 <= t <= (i + 1) / 2
+    float s = 0.f;
+    for (int t = (i - 2 + 1) / 2 < 0 ? 0 : (i - 1) / 2; t <= (i + 1) / 2; ++t) {
+        if (t < 0 || t >= To || 2 * t - 1 > i || 2 * t + 2 < i) continue;
+        int lo = 2 * t - 1, hi = 2 * t + 2;
+        if (lo < 0) lo = 0;
+        if (hi > T - 1) hi = T - 1;
+        s += (float)dy[(int64_t)b * To + t] / (float)(hi - lo + 1);
+    }
+    dx[(int64_t)b * T + i] = (h16)s;
+}
+
+static int aero_avgpool1d_bwd_launch(const void* dy, void* dx, int B, int T, hipStream_t stream, const char** err) {
+    if (!dy || !dx || B < 1 || T < 2 || B > 65535) { *err = "avgpool1d_bwd: bad arguments"; return AERO_ERR_ARG; }
+    const int To = (T + 2 - 4) / 2 + 1;
+    AERO_LAUNCH(aero_avgpool1d_bwd_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)B), dim3(256), stream, (const h16*)dy, (h16*)dx, T, To);
+    return AERO_OK;
+}

@@ -79,6 +79,10 @@ class Discriminator(nn.Module):
         self.apply(weights_init)
         self._ops, self._packed, self._key = None, None, None
 
+    def repack(self):
+        """the weights were edited behind autograd's version counters (FlatAdam's fused step): re-pack on the next forward"""
+        self._key = None
+
     def use_library(self, lib):
         """tests: an explicitly loaded library (the CPU-emulated test double)"""
         self._ops = Ops(lib)
@@ -110,8 +114,8 @@ class Discriminator(nn.Module):
         self._packed, self._key = packed, key
         return packed
 
-    def forward(self, x):
-        """x [B, 1, T] float waveform on the device -> list over scales of [fmap_0 .. fmap_5, logits], each [B, C, T']"""
+    def _run(self, x):
+        """-> per scale: (waveform fp16 [B, T_s], [(layer entry, input h [B,T,Cin], output y [B,T',Cout]) ...])"""
         ops = self._get_ops()
         if not x.is_cuda and not ops.lib.is_emulator:
             raise RuntimeError('aero_amd.discriminators runs on the MI355X: move the signals to "cuda"')
@@ -121,11 +125,11 @@ class Discriminator(nn.Module):
         packed = self._pack(dev)
         B = x.shape[0]
         cur = x.detach().reshape(B, -1).to(torch.float16).contiguous()                   # the fp16 boundary of the critic's input
-        results = []
+        scales = []
         for si, layers in enumerate(packed):
             T = cur.shape[1]
             h, Tc = cur.view(B, T, 1), T
-            feats = []
+            recs = []
             for ent in layers:
                 if 'spec' in ent:
                     y = ops.conv(ent['spec'], h.view(B, 1, Tc, ent['Cin']), None, B, 1, 1, Tc).view(B, Tc, ent['Cout'])
@@ -140,15 +144,186 @@ class Discriminator(nn.Module):
                         ent['stride'], ent['pad'], ent['reflect']
                     d.slope = ent['slope']
                     ops.lib.call('aero_gconv1d_fwd', C.byref(d), ops.stream(y))
-                feats.append(y.permute(0, 2, 1))                                        # [B, C, T'] view, as nn.Conv1d returns
+                recs.append((ent, h, y))
                 h, Tc = y, To
-            results.append(feats)
+            scales.append((cur, recs))
             if si + 1 < len(packed):
                 To = (T + 2 - 4) // 2 + 1
                 nxt = torch.empty(B, To, dtype=torch.float16, device=dev)
                 ops.lib.call('aero_avgpool1d', _ptr(cur), _ptr(nxt), B, T, ops.stream(cur))
                 cur = nxt
-        return results
+        return scales
+
+    def forward(self, x):
+        """x [B, 1, T] float waveform on the device -> list over scales of [fmap_0 .. fmap_5, logits], each [B, C, T'] (values; the
+        differentiable entry points are `discriminator_loss` and `generator_losses`)"""
+        return [[y.permute(0, 2, 1) for (_, _, y) in recs] for (_, recs) in self._run(x)]
+
+    # ------------------------------------------------------------------ losses with their HIP backward (solver.py:475-520)
+    def discriminator_loss(self, fake, real):
+        """solver.py:489-496: sum over scales of relu(1 + D(fake)).mean() + relu(1 - D(real)).mean(); differentiable w.r.t. the
+        critic's parameters (the generator output is detached, solver.py:479)"""
+        names, params = zip(*self.named_parameters())
+        return _CriticLoss.apply(self, names, fake.detach(), real.detach(), *params)
+
+    def generator_losses(self, fake, real, n_layers=4, features_loss_lambda=100.0):
+        """solver.py:498-520: (adversarial = sum relu(1 - D(fake)).mean(), lambda * feature matching); differentiable w.r.t. `fake`"""
+        return _GeneratorLoss.apply(self, fake, real.detach(), n_layers, features_loss_lambda)
+
+    def _backward(self, runs, dtop, dfeat, want_params, want_input):
+        """runs: _run() record; dtop[s]: (gradient of scale s's logits fp16 [B,T',1], {S,1/S}); dfeat[s][j]: the same for feature map j
+        or None.  Returns ({parameter name: fp32 gradient of weight_g / weight_v / bias}, d waveform fp32 [B,T] or None)."""
+        from . import backward as bw, train_ops as TO
+        ops = self._get_ops()
+        grads = {}
+        dwave = None                                             # (tensor fp16 [B, T_s], scale) flowing from the coarser scales
+        for si in reversed(range(len(runs))):
+            cur, recs = runs[si]
+            B = cur.shape[0]
+            disc = self.model[f'disc_{si}']
+            keys = list(disc.model.keys())
+            g, sc = dtop[si]
+            dx = None
+            for j in reversed(range(len(recs))):
+                ent, h, y = recs[j]
+                if j < len(recs) - 1:
+                    f = dfeat[si][j] if dfeat is not None else None
+                    if f is not None:
+                        g, sc = TO.rescale_f16(ops, dx, sc, f[0], f[1])
+                    else:
+                        g, sc = TO.rescale_f16(ops, dx, sc)
+                Tin, To = h.shape[1], y.shape[1]
+                conv = disc.convs()[j]
+                prefix = f'model.disc_{si}.model.{keys[j]}.' + ('1.' if keys[j] == 'layer_0' else ('0.' if isinstance(disc.model[keys[j]], nn.Sequential) else ''))
+                need_dx = want_input or j > 0
+                if 'spec' in ent:
+                    dyp = torch.empty_like(g)
+                    ops.lib.call('aero_loss_grad', _ptr(g), _ptr(y), g.numel(), C.c_float(0.0), C.c_float(ent['slope']), 2, _ptr(dyp), ops.stream(g))
+                    w = self._wn(conv)
+                    if want_params:
+                        spec = ent['spec']
+                        dw, db = bw.conv_wgrad(ops, dyp.view(B, 1, To, ent['Cout']), h.view(B, 1, Tin, ent['Cin']), spec.df, spec.dt)
+                        dwt = dw.permute(1, 2, 0).contiguous()                     # [Cout, Cin, K]
+                    dx = ops.conv(bw.dgrad_conv1d(w, 1, ent['pad'], g.device), dyp.view(B, 1, To, ent['Cout']), None, B, 1, 1, To).view(B, Tin, ent['Cin']) \
+                        if need_dx else None
+                else:
+                    d = _lib.GconvBwdDesc()
+                    dx = torch.empty(B, Tin, ent['Cin'], dtype=torch.float16, device=g.device) if need_dx else None
+                    if want_params:
+                        dwk = torch.zeros(ent['Cout'], ent['K'], ent['Cin'] // ent['groups'], dtype=torch.float32, device=g.device)
+                        db = torch.zeros(ent['Cout'], dtype=torch.float32, device=g.device)
+                    d.x, d.w, d.y, d.dy, d.dx = _ptr(h), _ptr(ent['w']), _ptr(y), _ptr(g), _ptr(dx)
+                    d.dw, d.db = (_ptr(dwk), _ptr(db)) if want_params else (None, None)
+                    d.B, d.Tin, d.Cin, d.Cout, d.groups, d.K, d.stride, d.pad, d.reflect = B, Tin, ent['Cin'], ent['Cout'], ent['groups'], ent['K'], \
+                        ent['stride'], ent['pad'], ent['reflect']
+                    d.slope = ent['slope']
+                    ops.lib.call('aero_gconv1d_bwd', C.byref(d), ops.stream(g))
+                    if want_params:
+                        dwt = dwk.permute(0, 2, 1).contiguous()                     # [Cout, Cin/groups, K]
+                if want_params:
+                    TO.scale_f32(ops, dwt, sc[1:])
+                    TO.scale_f32(ops, db, sc[1:])
+                    # weight norm (w = g v / |v| per output channel): parameter-sized bookkeeping of torch.nn.utils.weight_norm
+                    v, gg = conv.weight_v.detach().float(), conv.weight_g.detach().float()
+                    nv = v.flatten(1).norm(dim=1).view(-1, 1, 1)
+                    dot = (dwt * v).flatten(1).sum(1).view(-1, 1, 1)
+                    grads[prefix + 'weight_g'] = dot / nv
+                    grads[prefix + 'weight_v'] = gg / nv * (dwt - v * dot / (nv * nv))
+                    grads[prefix + 'bias'] = db
+            if want_input:
+                dxw = dx.view(B, -1)                             # gradient of this scale's waveform
+                if dwave is not None:                            # + the coarser scales through the AvgPool1d between them
+                    up = torch.empty(B, cur.shape[1], dtype=torch.float16, device=g.device)
+                    ops.lib.call('aero_avgpool1d_bwd', _ptr(dwave[0]), _ptr(up), B, cur.shape[1], ops.stream(up))
+                    dwave = TO.rescale_f16(ops, dxw.contiguous(), sc, up, dwave[1])
+                else:
+                    dwave = (dxw.contiguous(), sc)
+        out = None
+        if want_input:
+            out = dwave[0].float()
+            TO.scale_f32(ops, out, dwave[1][1:])
+        return grads, out
+
+    @staticmethod
+    def _wn(conv):
+        v, gg = conv.weight_v.detach().float(), conv.weight_g.detach().float()
+        return v * (gg / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+
+
+def _scaled_grad(ops, a, b, n_mean, sign, coef, mode):
+    """gradient of coef * mean(...) as fp16 with a host-chosen power-of-two scale: returns (tensor, {S, 1/S} on the device)"""
+    import math
+    c = coef / n_mean
+    S = 2.0 ** round(math.log2(32.0 / max(abs(c), 1e-30)))
+    g = torch.empty(a.shape, dtype=torch.float16, device=a.device)
+    ops.lib.call('aero_loss_grad', _ptr(a), _ptr(b), a.numel(), C.c_float(sign), C.c_float(c * S), mode, _ptr(g), ops.stream(a))
+    return g, torch.tensor([S, 1.0 / S], dtype=torch.float32, device=a.device)
+
+
+class _CriticLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disc, names, fake, real, *params):
+        ops = disc._get_ops()
+        rf, rr = disc._run(fake), disc._run(real)
+        acc = torch.zeros(2, dtype=torch.float64, device=fake.device)
+        loss = torch.zeros((), dtype=torch.float64, device=fake.device)
+        for (_, a), (_, b) in zip(rf, rr):
+            acc.zero_()
+            _loss_sum(ops, a[-1][2], None, 1.0, 0, acc[0:1])
+            _loss_sum(ops, b[-1][2], None, -1.0, 0, acc[1:2])
+            loss = loss + acc[0] / a[-1][2].numel() + acc[1] / b[-1][2].numel()
+        ctx.disc, ctx.names, ctx.runs = disc, names, (rf, rr)
+        return loss.float()
+
+    @staticmethod
+    def backward(ctx, gl):
+        disc, ops = ctx.disc, ctx.disc._get_ops()
+        rf, rr = ctx.runs
+        total = {}
+        for runs, sign in ((rf, 1.0), (rr, -1.0)):
+            dtop = [_scaled_grad(ops, recs[-1][2], None, recs[-1][2].numel(), sign, 1.0, 0) for (_, recs) in runs]
+            grads, _ = disc._backward(runs, dtop, None, True, False)
+            for k, v in grads.items():
+                total[k] = v if k not in total else total[k] + v
+        ctx.runs = None
+        g = gl.float()
+        return (None, None, None, None) + tuple(total[n] * g for n in ctx.names)
+
+
+class _GeneratorLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disc, fake, real, n_layers, lam):
+        ops = disc._get_ops()
+        rf, rr = disc._run(fake), disc._run(real)
+        num_D = len(rf)
+        w_feat = (4.0 / (n_layers + 1)) * (1.0 / num_D)
+        acc = torch.zeros(1, dtype=torch.float64, device=fake.device)
+        adv = torch.zeros((), dtype=torch.float64, device=fake.device)
+        feat = torch.zeros((), dtype=torch.float64, device=fake.device)
+        for (_, a), (_, b) in zip(rf, rr):
+            acc.zero_()
+            _loss_sum(ops, a[-1][2], None, -1.0, 0, acc)
+            adv = adv + acc[0] / a[-1][2].numel()
+            for j in range(len(a) - 1):
+                acc.zero_()
+                _loss_sum(ops, a[j][2], b[j][2], 0.0, 1, acc)
+                feat = feat + w_feat * acc[0] / a[j][2].numel()
+        ctx.disc, ctx.runs, ctx.cfg, ctx.shape = disc, (rf, rr), (w_feat, lam), fake.shape
+        return adv.float(), (lam * feat).float()
+
+    @staticmethod
+    def backward(ctx, gadv, gfeat):
+        from . import train_ops as TO
+        disc, ops = ctx.disc, ctx.disc._get_ops()
+        rf, rr = ctx.runs
+        w_feat, lam = ctx.cfg
+        ga, gf = float(gadv), float(gfeat)                       # (upstream scalars: 1 in solver.py:314-316)
+        dtop = [_scaled_grad(ops, recs[-1][2], None, recs[-1][2].numel(), -1.0, ga, 0) for (_, recs) in rf]
+        dfeat = [[_scaled_grad(ops, ra[j][2], rb[j][2], ra[j][2].numel(), 0.0, gf * lam * w_feat, 1) for j in range(len(ra) - 1)]
+                 for (_, ra), (_, rb) in zip(rf, rr)]
+        _, dx = disc._backward(rf, dtop, dfeat, False, True)
+        ctx.runs = None
+        return None, dx.view(ctx.shape), None, None, None
 
 
 def _loss_sum(ops, a, b, sign, mode, out):

@@ -447,6 +447,21 @@ int aero_avgpool1d(const void* x, void* y, int32_t B, int32_t T, void* stream);
  * sum |a[i] - b[i]| (mode 1); a, b fp16 [n]; part: scratch of npart doubles; block partials added in order (deterministic). */
 int aero_loss_sum(const void* a, const void* b, int64_t n, float sign, int32_t mode, double* part, int32_t npart, double* out, void* stream);
 
+/* Backward of aero_gconv1d_fwd (solver.py:602-611).  y: the layer's post-activation output, dy: its gradient (fp16 [B][Tout][Cout]); the
+ * LeakyReLU derivative is read off y.  dx (fp16 [B][Tin][Cin], may be NULL) is WRITTEN -- with reflect != 0 the contributions of the
+ * mirrored positions are folded back; dw fp32 [Cout][K][Cin/groups] and db fp32 [Cout] (may be NULL) are ACCUMULATED with atomics
+ * (x required for dw). */
+typedef struct {
+    const void* x; const void* w; const void* y; const void* dy; void* dx; float* dw; float* db;
+    int32_t B, Tin, Cin, Cout, groups, K, stride, pad, reflect;
+    float slope;
+} aero_gconv_bwd_desc;
+int aero_gconv1d_bwd(const aero_gconv_bwd_desc* d, void* stream);
+/* gradients of the loss terms as fp16: mode 0 g = coef * sign * [1 + sign a > 0] (hinge, solver.py:489-496,508), mode 1
+ * g = coef * sgn(a - b) (L1, solver.py:505), mode 2 g = a * (b > 0 ? 1 : coef) (LeakyReLU backward: a = dy, b = y, coef = slope) */
+int aero_loss_grad(const void* a, const void* b, int64_t n, float sign, float coef, int32_t mode, void* g, void* stream);
+int aero_avgpool1d_bwd(const void* dy, void* dx, int32_t B, int32_t T, void* stream);      /* adjoint of aero_avgpool1d */
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,3 +43,61 @@ def case_discriminator(dev, lib=None):
     errs['g_adv'] = abs(float(ga) - lo[1]) / lo[1]
     errs['g_feat'] = abs(float(gf) - lo[2]) / lo[2]
     return errs
+
+
+def _torch_critic(d, x):
+    """the same weight-normed nn modules run by torch (fp32): discriminators.py:50-56,72-78"""
+    results = []
+    for key, disc in d.model.items():
+        h = x
+        feats = []
+        for _, layer in disc.model.items():
+            h = layer(h)
+            feats.append(h)
+        results.append(feats)
+        x = d.downsample(x)
+    return results
+
+
+def case_critic_backward(dev, lib=None, T=2048):
+    """discriminator_loss (gradients of every weight_g / weight_v / bias) and generator_losses (gradient of the fake waveform) on the
+    HIP kernels against torch.autograd through the same modules"""
+    import torch.nn.functional as Fn
+    from aero_amd.discriminators import Discriminator
+    torch.manual_seed(5)
+    d = Discriminator(num_D=3, ndf=4, n_layers=4, downsampling_factor=4)
+    with torch.no_grad():
+        for p in d.parameters():
+            p.copy_(p.half().float())
+    xf, xr = (seeded((2, 1, T), 1) * 0.3).half().float(), (seeded((2, 1, T), 2) * 0.3).half().float()
+    # torch reference
+    ref = {}
+    of, orr = _torch_critic(d, xf), _torch_critic(d, xr)
+    dl = sum(Fn.relu(1 + s[-1]).mean() for s in of) + sum(Fn.relu(1 - s[-1]).mean() for s in orr)
+    dl.backward()
+    ref['d'] = {n: p.grad.clone() for n, p in d.named_parameters()}
+    d.zero_grad()
+    xg = xf.clone().requires_grad_()
+    of, orr = _torch_critic(d, xg), _torch_critic(d, xr)
+    adv = sum(Fn.relu(1 - s[-1]).mean() for s in of)
+    wts = (4.0 / 5) * (1.0 / 3)
+    feat = 100.0 * sum(wts * Fn.l1_loss(of[i][j], orr[i][j].detach()) for i in range(3) for j in range(6))
+    (adv + feat).backward()
+    ref['dx'] = xg.grad.clone()
+    d.zero_grad()
+    if lib is not None:
+        d.use_library(lib)
+    d.to(dev)
+    errs = {}
+    loss = d.discriminator_loss(xf.to(dev), xr.to(dev))
+    errs['d_loss'] = abs(float(loss) - float(dl)) / float(dl)
+    loss.backward()
+    for n, p in d.named_parameters():
+        errs['d.' + n] = rel_l2(p.grad.cpu(), ref['d'][n])
+    xh = xf.to(dev).clone().requires_grad_()
+    a2, f2 = d.generator_losses(xh, xr.to(dev))
+    errs['adv'] = abs(float(a2) - float(adv)) / float(adv)
+    errs['feat'] = abs(float(f2) - float(feat)) / float(feat)
+    (a2 + f2).backward()
+    errs['dx'] = rel_l2(xh.grad.cpu(), ref['dx'])
+    return errs

@@ -16,11 +16,17 @@ from aero_amd.optim import FlatAdam  # noqa: E402
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    gan = '--gan' in sys.argv                                   # + the msd_melgan critic: adversarial / feature losses and the critic's own step
     args = load_config(os.path.join(ROOT, 'conf'), ['experiment=aero_11-44_512_256'])
     torch.manual_seed(2036)
     model = Aero(**dict(args.experiment.aero)).cuda().train()
     opt = FlatAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.999), model=model)
-    crit = losses.MultiResolutionSTFTLoss()
+    crit = losses.MultiResolutionSTFTLoss(factor_sc=0.5, factor_mag=0.5)                  # main_config.yaml:64-65
+    disc = opt_d = None
+    if gan:
+        from aero_amd.discriminators import Discriminator
+        disc = Discriminator(num_D=3, ndf=16, n_layers=4, downsampling_factor=4).cuda()
+        opt_d = FlatAdam(disc.parameters(), lr=3e-4, betas=(0.9, 0.999), model=disc)
     g = torch.Generator().manual_seed(0)
     lr = torch.randn(B, 1, 110250, generator=g).cuda()
     hr = (0.1 * torch.randn(B, 1, 441000, generator=g)).cuda()
@@ -32,6 +38,11 @@ def main():
         t1 = time.time()
         sc, mg = crit(y.squeeze(1), hr.squeeze(1))
         loss = sc + mg
+        extra = ''
+        if gan:
+            adv, feat = disc.generator_losses(y, hr, n_layers=4, features_loss_lambda=100.0)      # solver.py:498-520
+            loss = loss + adv + feat
+            extra = f' adv {float(adv.detach()):.4f} feat {float(feat.detach()):.4f}'
         opt.zero_grad()
         loss.backward()
         torch.cuda.synchronize()
@@ -39,8 +50,17 @@ def main():
         opt.step()
         torch.cuda.synchronize()
         t3 = time.time()
+        td = 0.0
+        if gan:                                                  # solver.py:607-611: the critic's own step on the detached prediction
+            d_loss = disc.discriminator_loss(y.detach(), hr)
+            opt_d.zero_grad()
+            d_loss.backward()
+            opt_d.step()
+            torch.cuda.synchronize()
+            td = time.time() - t3
+            extra += f' d_loss {float(d_loss.detach()):.4f}  critic step {1e3 * td:.1f} ms'
         gn = float(opt.flat_g.norm())
-        print(f'step {s}: loss {float(loss):.5f} (sc {float(sc):.5f} mag {float(mg):.5f})  |grad| {gn:.4e}  forward {1e3 * (t1 - t0):.1f} ms  '
+        print(f'step {s}: loss {float(loss.detach()):.5f} (sc {float(sc.detach()):.5f} mag {float(mg.detach()):.5f}{extra})  |grad| {gn:.4e}  forward {1e3 * (t1 - t0):.1f} ms  '
               f'loss+backward {1e3 * (t2 - t1):.1f} ms  adam {1e3 * (t3 - t2):.2f} ms  y {tuple(y.shape)}  mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB')
         assert torch.isfinite(loss) and gn == gn and gn > 0
 
