@@ -248,7 +248,16 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
     __shared__ AERO_LDS_ALIGN h16 Vt[DT * 16 * VS];
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int g = lane >> 4, col = lane & 15;
-    const int h = blockIdx.y, row = blockIdx.z;
+    // (row, head) of this block.  Blocks are handed to the 8 XCDs round-robin by linear id, and the heads of one row read the SAME
+    // qkvd lines (80 useful bytes out of every 320-byte row each): with the natural order they land on different XCDs and every
+    // private L2 fetches those lines again (PMC r02: 476 MB fetched for 107 MB).  Remap so that the heads of a row share an XCD.
+    int h = blockIdx.y, row = blockIdx.z;
+    if ((d.R & 7) == 0) {
+        const int lin = (int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z;
+        const int xcd = lin & 7, j = lin >> 3;
+        h = j % d.heads;
+        row = (j / d.heads) * 8 + xcd;
+    }
     const int C = d.C, T = d.T;
     const int dh = C / d.heads;
     const int pos = (dh + 3) & ~3;                               // first of the four bias k-slots

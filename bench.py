@@ -31,6 +31,20 @@ PEAK_MFMA_F16_TFLOPS = 2500.0      # dense fp16 MFMA peak, MI355X_MICROARCH.md "
 PEAK_HBM_GBS = 8000.0              # HBM3E spec peak, same table
 
 
+INFERENCE_KERNEL_SOURCES = ('aero_common.h', 'k_attn.h', 'k_conv.h', 'k_conv_ring.h', 'k_dconv.h', 'k_enc0.h', 'k_ftb.h', 'k_gram.h', 'k_lstm.h',
+                            'k_norm.h', 'k_stft.h')
+
+
+def kernels_sha():
+    """fingerprint of the kernel sources the forward pass runs: profiles/pmc_traffic.json carries the one of its PMC visit
+    (tools/pmc_traffic.py), and `roofline.traffic` is reported only while the two agree"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in INFERENCE_KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, 'aero_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def _usable_cores():
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     try:                                                    # cgroup v2 CPU quota, if any
@@ -89,6 +103,67 @@ def cpu_baseline(seconds_per_clip, lr_sr, timeout_s=240):
         return {'value': None, 'kind': 'port', 'sample': f'cpu baseline worker exceeded {timeout_s} s and was stopped'}
 
 
+def extra_configs(dev, steps, warmup):
+    """The other single-GPU configurations of BASELINE.json, same JSON shape, so that they have driver-visible numbers:
+    config 4 (12->48 kHz, nfft 1024, hop 256, batch 32, inference) and config 5's per-GPU share (11.025->44.1 kHz, nfft 512, hop 256,
+    10-s segments, 2 clips per GPU of the batch of 16: ONE TRAINING STEP = forward + multi-resolution STFT loss + backward + Adam)."""
+    from aero_amd import Aero, losses
+    from aero_amd.optim import FlatAdam
+    out = []
+    try:
+        torch.manual_seed(31)
+        m = Aero(**dict(FULL_CFG, nfft=1024, hop_length=256, lr_sr=12000, hr_sr=48000)).eval().to(dev)
+        x = torch.randn(32, 1, 24000, generator=torch.Generator().manual_seed(41)).to(dev)
+        with torch.no_grad():
+            for _ in range(warmup):
+                m(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = m(x)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        out.append({'metric': 'real-time-factor (audio-sec/wall-sec), Aero.forward, 12->48kHz nfft=1024 hop=256 batch=32', 'value': round(32 * 2.0 * steps / dt, 2),
+                    'unit': 'audio-sec/wall-sec', 'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 3), 'dtype': 'f16',
+                    'data': 'synthetic', 'config': {'workload': 'BASELINE config 4: batch=32 synthetic 2s clips, 12->48 kHz, nfft=1024 hop=256, inference',
+                                                    'frames': 376, 'output_samples': int(y.shape[-1])}})
+        del m, x, y
+    except Exception as e:                                       # an extra line must never cost the headline number
+        out.append({'config': 'BASELINE config 4', 'error': repr(e)})
+    try:
+        torch.manual_seed(2036)
+        m = Aero(**dict(FULL_CFG, nfft=512, hop_length=256, lr_sr=11025, hr_sr=44100)).to(dev).train()
+        opt = FlatAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.999), model=m)
+        crit = losses.MultiResolutionSTFTLoss(factor_sc=0.5, factor_mag=0.5)
+        g = torch.Generator().manual_seed(0)
+        lr_, hr_ = torch.randn(2, 1, 110250, generator=g).to(dev), (0.1 * torch.randn(2, 1, 441000, generator=g)).to(dev)
+
+        def step():
+            y = m(lr_)
+            sc, mg = crit(y.squeeze(1), hr_.squeeze(1))
+            opt.zero_grad()
+            (sc + mg).backward()
+            opt.step()
+            return sc + mg
+        k5 = max(2, min(steps, 5))
+        for _ in range(max(1, min(warmup, 2))):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k5):
+            last = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out.append({'metric': 'training steps per second per GPU (forward + MR-STFT loss + backward + Adam), 11.025->44.1kHz nfft=512 hop=256, 2 x 10-s clips',
+                    'value': round(k5 / dt, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': k5, 'ms_per_step': round(dt / k5 * 1e3, 2), 'dtype': 'f16',
+                    'data': 'synthetic', 'audio_sec_per_wall_sec': round(2 * 10.0 * k5 / dt, 1), 'loss': round(float(last.detach()), 5),
+                    'config': {'workload': "BASELINE config 5, one GPU's share (2 of the 16 clips): aero_11-44_512_256, train mode, generator step with "
+                                           'losses: [stft]; the msd_melgan critic (tools/config5.py --gan) is not part of this line', 'frames': 1724}})
+    except Exception as e:
+        out.append({'config': 'BASELINE config 5 (training step)', 'error': repr(e)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -98,6 +173,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP-event pass')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the BASELINE config 4 / config 5 lines under extra_configs')
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         print(json.dumps(cpu_baseline_worker(2.0, FULL_CFG['lr_sr'])))
@@ -174,25 +250,32 @@ def main():
         dom = max(kernels, key=lambda n: kernels[n]['ms'])
         k = kernels[dom]
         avg_ms = k['ms'] / k['launches']
-        traffic = None
+        traffic, traffic_note = None, 'no PMC visit on record (profiles/pmc_traffic.json)'
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
             try:
-                ent = json.load(open(pmc)).get(dom.replace('void ', '').split('(')[0])
-                traffic = ent['bytes'] if ent else None       # HBM-side bytes per launch (rocprofv3 --pmc, see tools/pmc_traffic.py)
-            except Exception:
-                traffic = None
+                table = json.load(open(pmc))
+                stamp = table.get('_meta', {})
+                if stamp.get('kernels_sha') != kernels_sha():
+                    traffic_note = (f"PMC visit {stamp.get('kernels_sha', '(unstamped)')} predates the current kernel sources {kernels_sha()}: "
+                                    'omitted rather than reported stale (re-run tools/gpu/r3_evidence.sh)')
+                else:
+                    ent = table.get(dom.replace('void ', '').split('(')[0])
+                    traffic = ent['bytes'] if ent else None   # HBM-side bytes per launch (rocprofv3 --pmc, see tools/pmc_traffic.py)
+                    traffic_note = f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, kernel sources {stamp['kernels_sha']}, {stamp.get('date', '')}"
+            except Exception as e:
+                traffic, traffic_note = None, f'pmc_traffic.json unreadable: {e}'
         if k['flops'] > 0:
             ach = k['flops'] / k['launches'] / (avg_ms * 1e-3) / 1e12
             roof = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_MFMA_F16_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_MFMA_F16_TFLOPS, 4), 'traffic': traffic,
                     'avg_launch_ms': round(avg_ms, 4), 'launches_per_step': k['launches'] // max(1, min(args.steps, 5)),
-                    'flops_per_launch': k['flops'] / k['launches'],
+                    'flops_per_launch': k['flops'] / k['launches'], 'traffic_source': traffic_note,
                     'note': 'executed FLOPs (2*MAC; structurally-zero first-decoder input skipped) / HIP-event time'}
         else:
             ach = k['bytes'] / k['launches'] / (avg_ms * 1e-3) / 1e9
             roof = {'kernel': dom, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': traffic, 'avg_launch_ms': round(avg_ms, 4)}
+                    'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_note, 'avg_launch_ms': round(avg_ms, 4)}
 
         # the conv stack as a whole (Conv2d + ConvTranspose2d of the encoder / decoder layers -- strided convs,
         # rewrite convs, transposed convs; executed FLOPs over the summed HIP-event time of exactly those launches)
@@ -216,6 +299,9 @@ def main():
     if rank != 0:
         distrib.close()
         return
+    extra = None
+    if world == 1 and not args.no_extra_configs:
+        extra = extra_configs(dev, args.steps, args.warmup)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(secs, FULL_CFG['lr_sr'])
@@ -229,7 +315,7 @@ def main():
                                f'(nfft=512 hop=64), random-init weights seed 2036, inference, inputs resident in HBM',
                    'global_batch': world * B, 'clip_samples': L, 'frames': 501, 'parallelism': f'clips sharded over {world} GPU(s), no data-path collective',
                    'precision': 'fp16 operands/storage, fp32 accumulate; STFT/iSTFT/statistics fp32'},
-        'roofline': roof, 'roofline_conv_stack': roof_stack, 'roofline_stft': roof_stft, 'cpu_baseline': cpu,
+        'roofline': roof, 'roofline_conv_stack': roof_stack, 'roofline_stft': roof_stft, 'cpu_baseline': cpu, 'extra_configs': extra,
         'kernels_ms_per_step': {n: round(v['ms'] / max(1, min(args.steps, 5)), 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
         # per kernel over the same launches: [executed TFLOP/s, algorithmic GB/s] (HIP-event time; 0 = not applicable)
         'kernels_achieved': {n: [round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) if v['ms'] > 0 else 0.0,

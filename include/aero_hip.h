@@ -14,6 +14,16 @@
  *     (strides in ELEMENTS); spectrograms are complex64 interleaved [.., F, T] like torch;
  *   - return 0 on success, negative on error; message via aero_last_error() (thread local);
  *     no C++ exception crosses the ABI; all functions are re-entrant.
+ *   - process-wide state: none that a call mutates after its first use.  The library reads these environment variables ONCE, at the
+ *     first launch of the kernel family concerned (A/B and profiling switches; the defaults are what is tested and benchmarked, and
+ *     a value must be set before the first call -- later changes are ignored):
+ *       AERO_CONV_RING, AERO_CONV_GLDS, AERO_CONV_MODE, AERO_CONV_BM256, AERO_CONV_SKINNY, AERO_CONV_STREAM, AERO_CONV_TINY_OFF,
+ *       AERO_CONVTR_CARRY, AERO_CARRY_QC, AERO_CONV_DEBUG, AERO_RING_ABL        (convolution family: kernel selection / ablations)
+ *       AERO_LSTM_RING, AERO_LSTM_WIDE                                          (recurrent kernel form)
+ *       AERO_ATTN_FOLD                                                          (LocalState: folded vs streaming kernel)
+ *       AERO_NORM_CHUNK_KB                                                      (GroupNorm work-item size)
+ *       AERO_WGRAD_256, AERO_WGRAD_ABL                                          (weight-gradient tile / ablations)
+ *     The Python host side has its own AERO_* switches (aero_amd/engine.py); they never reach the library.
  */
 #ifndef AERO_HIP_H
 #define AERO_HIP_H

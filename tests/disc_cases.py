@@ -45,7 +45,7 @@ def case_discriminator(dev, lib=None):
     return errs
 
 
-def _torch_critic(d, x):
+def _torch_critic(d, x, rounded=False):
     """the same weight-normed nn modules run by torch (fp32): discriminators.py:50-56,72-78"""
     results = []
     for key, disc in d.model.items():
@@ -53,15 +53,20 @@ def _torch_critic(d, x):
         feats = []
         for _, layer in disc.model.items():
             h = layer(h)
+            if rounded:                 # the product's storage: fp16 feature maps (straight-through for the gradient)
+                h = h + (h.half().float() - h).detach()
             feats.append(h)
         results.append(feats)
         x = d.downsample(x)
+        if rounded:
+            x = x + (x.half().float() - x).detach()
     return results
 
 
 def case_critic_backward(dev, lib=None, T=2048):
     """discriminator_loss (gradients of every weight_g / weight_v / bias) and generator_losses (gradient of the fake waveform) on the
-    HIP kernels against torch.autograd through the same modules"""
+    HIP kernels against torch.autograd through the same modules with the feature maps rounded to fp16 where the product stores them
+    (a LeakyReLU mask is a discontinuous function of its pre-activation: see tests/train_cases.py)"""
     import torch.nn.functional as Fn
     from aero_amd.discriminators import Discriminator
     torch.manual_seed(5)
@@ -72,13 +77,21 @@ def case_critic_backward(dev, lib=None, T=2048):
     xf, xr = (seeded((2, 1, T), 1) * 0.3).half().float(), (seeded((2, 1, T), 2) * 0.3).half().float()
     # torch reference
     ref = {}
-    of, orr = _torch_critic(d, xf), _torch_critic(d, xr)
-    dl = sum(Fn.relu(1 + s[-1]).mean() for s in of) + sum(Fn.relu(1 - s[-1]).mean() for s in orr)
-    dl.backward()
-    ref['d'] = {n: p.grad.clone() for n, p in d.named_parameters()}
+    of, orr = _torch_critic(d, xf, True), _torch_critic(d, xr, True)
+    # the two hinge terms pull the critic's parameters in opposite directions with similar strength (fake ~ real at initialisation), so
+    # their sum is a small difference of large numbers: errors are measured against the size of the TERMS, |g_fake| + |g_real|
+    lf, lr_ = sum(Fn.relu(1 + s[-1]).mean() for s in of), sum(Fn.relu(1 - s[-1]).mean() for s in orr)
+    dl = lf + lr_
+    lf.backward()
+    gf = {n: p.grad.clone() for n, p in d.named_parameters()}
+    d.zero_grad()
+    lr_.backward()
+    gr = {n: p.grad.clone() for n, p in d.named_parameters()}
+    ref['d'] = {n: gf[n] + gr[n] for n in gf}
+    ref['dn'] = {n: float(gf[n].norm() + gr[n].norm()) for n in gf}
     d.zero_grad()
     xg = xf.clone().requires_grad_()
-    of, orr = _torch_critic(d, xg), _torch_critic(d, xr)
+    of, orr = _torch_critic(d, xg, True), _torch_critic(d, xr, True)
     adv = sum(Fn.relu(1 - s[-1]).mean() for s in of)
     wts = (4.0 / 5) * (1.0 / 3)
     feat = 100.0 * sum(wts * Fn.l1_loss(of[i][j], orr[i][j].detach()) for i in range(3) for j in range(6))
@@ -93,7 +106,7 @@ def case_critic_backward(dev, lib=None, T=2048):
     errs['d_loss'] = abs(float(loss) - float(dl)) / float(dl)
     loss.backward()
     for n, p in d.named_parameters():
-        errs['d.' + n] = rel_l2(p.grad.cpu(), ref['d'][n])
+        errs['d.' + n] = float((p.grad.cpu().double() - ref['d'][n].double()).norm()) / max(ref['dn'][n], 1e-30)
     xh = xf.to(dev).clone().requires_grad_()
     a2, f2 = d.generator_losses(xh, xr.to(dev))
     errs['adv'] = abs(float(a2) - float(adv)) / float(adv)

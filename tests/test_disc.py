@@ -23,20 +23,13 @@ def test_discriminator_on_the_mi355x():
 
 
 def _check_bwd(errs):
-    """fp16 feature maps: a LeakyReLU mask flips where a pre-activation within fp16 rounding of zero changes sign (slopes 1 vs 0.2), so
-    the comparison with fp32 autograd is at the 1e-2 level (tests/train_cases.py has the argument); the last layer's weight_g is ONE
-    number, a dot product of its weight gradient with v that nearly cancels"""
+    """loss values <= 1e-4 / 1e-3; the gradient of the fake waveform (the generator's adversarial + feature-matching signal) <= 1e-2;
+    every critic parameter gradient <= 3e-2 of |g_fake| + |g_real| (disc_cases.py: the two hinge terms nearly cancel; measured <= 1.6e-2,
+    the grouped-conv kernels themselves are exact to fp32 rounding: test_grouped_conv_op)"""
     assert errs['d_loss'] < 1e-4 and errs['adv'] < 1e-4 and errs['feat'] < 1e-3, errs
-    assert errs['dx'] < 2e-2, errs['dx']
-    for k, v in errs.items():
-        if not k.startswith('d.'):
-            continue
-        if k.endswith('layer_6.weight_g'):
-            assert v < 1.5, (k, v)
-        elif k.endswith('layer_6.bias'):
-            assert v < 1e-3, (k, v)
-        else:
-            assert v < 0.1, (k, v)
+    assert errs['dx'] < 1e-2, errs['dx']
+    bad = {k: v for k, v in errs.items() if k.startswith('d.') and not v < 3e-2}
+    assert not bad, bad
 
 
 def test_critic_backward_on_the_emulator():
@@ -48,3 +41,59 @@ def test_critic_backward_on_the_emulator():
 @pytest.mark.gpu
 def test_critic_backward_on_the_mi355x():
     _check_bwd(dc.case_critic_backward('cuda', T=8192))
+
+
+def _gconv_case(lib, dev, B, Cin, Cout, groups, K, stride, pad, T, reflect=0, slope=0.2, seed=0):
+    """aero_gconv1d_fwd / aero_gconv1d_bwd against torch.nn.functional.conv1d + autograd on fp16-rounded operands"""
+    import ctypes as C
+    import torch
+    import torch.nn.functional as F
+    from aero_amd import _lib
+    from aero_amd.engine import _ptr
+    from conftest import rel_l2
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, T, generator=g).half().float().requires_grad_()
+    w = (torch.randn(Cout, Cin // groups, K, generator=g) * 0.1).half().float().requires_grad_()
+    b = torch.randn(Cout, generator=g).requires_grad_()
+    xp = F.pad(x, (pad, pad), mode='reflect') if reflect else x
+    y = F.leaky_relu(F.conv1d(xp, w, b, stride=stride, padding=0 if reflect else pad, groups=groups), slope)
+    dy = torch.randn(y.shape, generator=g).half().float()
+    y.backward(dy)
+    xc = x.detach().permute(0, 2, 1).contiguous().half().to(dev)
+    wc = w.detach().permute(0, 2, 1).contiguous().half().to(dev)
+    bias = b.detach().to(dev)
+    To = y.shape[2]
+    yk = torch.empty(B, To, Cout, dtype=torch.float16, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream if dev != 'cpu' else 0
+    d = _lib.GconvDesc()
+    d.x, d.w, d.bias, d.y = _ptr(xc), _ptr(wc), _ptr(bias), _ptr(yk)
+    d.B, d.Tin, d.Cin, d.Cout, d.groups, d.K, d.stride, d.pad, d.reflect, d.slope = B, T, Cin, Cout, groups, K, stride, pad, reflect, slope
+    lib.call('aero_gconv1d_fwd', C.byref(d), stream)
+    assert rel_l2(yk.float().cpu().permute(0, 2, 1), y.detach()) < 5e-4
+    dyc = dy.permute(0, 2, 1).contiguous().half().to(dev)
+    dx = torch.empty(B, T, Cin, dtype=torch.float16, device=dev)
+    dw, db = torch.zeros(Cout, K, Cin // groups, device=dev), torch.zeros(Cout, device=dev)
+    bd = _lib.GconvBwdDesc()
+    bd.x, bd.w, bd.y, bd.dy, bd.dx, bd.dw, bd.db = _ptr(xc), _ptr(wc), _ptr(yk), _ptr(dyc), _ptr(dx), _ptr(dw), _ptr(db)
+    bd.B, bd.Tin, bd.Cin, bd.Cout, bd.groups, bd.K, bd.stride, bd.pad, bd.reflect, bd.slope = B, T, Cin, Cout, groups, K, stride, pad, reflect, slope
+    lib.call('aero_gconv1d_bwd', C.byref(bd), stream)
+    assert rel_l2(dx.float().cpu().permute(0, 2, 1), x.grad) < 5e-4
+    assert rel_l2(dw.cpu().permute(0, 2, 1), w.grad) < 1e-5 and rel_l2(db.cpu(), b.grad) < 1e-5
+
+
+GCONV = [(2, 16, 64, 4, 41, 4, 20, 300), (2, 256, 256, 64, 41, 4, 20, 16), (2, 1, 16, 1, 15, 1, 7, 200, 1), (2, 128, 1, 1, 3, 1, 1, 9, 0, 1.0),
+         (2, 4, 16, 1, 41, 4, 20, 2048)]
+
+
+@pytest.mark.parametrize('a', GCONV)
+def test_grouped_conv_op(a):
+    from aero_amd import _lib
+    from emu.build_emu import build
+    _gconv_case(_lib.load(build()), 'cpu', *a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('a', GCONV + [(2, 64, 256, 16, 41, 4, 20, 27562), (1, 1024, 1024, 256, 41, 4, 20, 6890)])
+def test_grouped_conv_op_on_the_mi355x(a):
+    from aero_amd import _lib
+    _gconv_case(_lib.load(), 'cuda', *a)

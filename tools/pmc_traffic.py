@@ -26,6 +26,12 @@ def main():
         name = k.replace('void ', '').split('(')[0]
         out[name] = {'fetch_bytes': 2.0 * fetch.get(k, 0.0) * 1024.0, 'write_bytes': write.get(k, 0.0) * 1024.0,
                      'bytes': (2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0}
+    import datetime
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernels_sha
+    out['_meta'] = {'kernels_sha': kernels_sha(), 'date': datetime.date.today().isoformat(),
+                    'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950), KiB -> bytes, average per launch'}
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(f'{len(out)} kernels -> {sys.argv[3]}')
 
