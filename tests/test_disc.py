@@ -85,7 +85,7 @@ GCONV = [(2, 16, 64, 4, 41, 4, 20, 300), (2, 256, 256, 64, 41, 4, 20, 16), (2, 1
          (2, 4, 16, 1, 41, 4, 20, 2048)]
 
 
-@pytest.mark.parametrize('a', GCONV)
+@pytest.mark.parametrize('a', GCONV[:4])
 def test_grouped_conv_op(a):
     from aero_amd import _lib
     from emu.build_emu import build
