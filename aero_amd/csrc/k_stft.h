@@ -454,11 +454,12 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
     const int kg = lane >> 4, col = lane & 15;
     const int wr = wave >> 1, wc = wave & 1;                     // wave tile: rows wr*32 .. +32, frames wc*64 .. +64
     const int sig = blockIdx.y, quarter = blockIdx.z;
-    const int t0 = blockIdx.x * 128;
     const int n_fft = p.n_fft, hop = p.hop, n_bins = n_fft >> 1;
     const float* xs = p.x + (int64_t)sig * p.L;
     // the block's table slice, all four chunks at once (one L2 latency instead of four): 4 x 2 x 128 rows x 4 slots = 4096
-    // 16-byte units, 8 per thread; the image is already in tile order, so the copy is linear
+    // 16-byte units, 8 per thread; the image is already in tile order, so the copy is linear.  The block then WALKS the 128-frame
+    // tiles of its signal (blockIdx.x, + gridDim.x, ...) with the slice resident: the 64-KiB fill and its latency are paid once
+    // per block instead of once per 128 x 128 output tile (it equalled the output traffic: 64 MB through L2 for 66 MB written).
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int W = wave + 8 * u;                              // 64-unit piece: (chunk, part) = W >> 3, rows (W & 7) * 16 .. +16
@@ -466,8 +467,13 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
         const h16* src = p.table + ((size_t)(part * 4 + kc) * n_fft + quarter * 128) * 32 + ((W & 7) * 64 + lane) * 8;
         aero_glds16(src, &As[kc][part][0] + (W & 7) * 512);
     }
-    // the span of the (hop-padded, reflect-padded) signal the block's 128 frames read: split into hi + lo fp16.  All loads first.
     const int span = 127 * hop + AERO_DFT_K;
+    const int ntile = (p.T + 127) >> 7;
+    float s = 0.f, ss = 0.f;
+    float* out = p.spec + (int64_t)sig * n_bins * p.T * 2;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int t0 = tile * 128;
+    // the span of the (hop-padded, reflect-padded) signal the tile's 128 frames read: split into hi + lo fp16.  All loads first.
     {
         constexpr int NV = (AERO_DFT_SPAN + 511) / 512;
         float v[NV];
@@ -479,6 +485,7 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
             if (xi >= p.Lp) xi = 2 * (p.Lp - 1) - xi;
             v[u] = (j < span && xi >= 0 && xi < p.L) ? xs[xi] : 0.f;
         }
+        if (tile != (int)blockIdx.x) __syncthreads();            // the previous tile's fragment reads of xh / xl are done
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int j = tid + u * 512;
@@ -518,8 +525,6 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
         }
     }
     // rows m = quarter*128 + wr*32 + i*16 + kg*4 + r = 2f + {re, im}: registers (0,1) and (2,3) are two complex bins
-    float s = 0.f, ss = 0.f;
-    float* out = p.spec + (int64_t)sig * n_bins * p.T * 2;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int t = t0 + wc * 64 + n * 16 + col;
@@ -533,6 +538,7 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
             s += (v[0] + v[1]) + (v[2] + v[3]);
             ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
+    }
     }
     if (p.stats) {
         const double ds = aero_wave_sum((double)s), dss = aero_wave_sum((double)ss);
@@ -573,7 +579,15 @@ static int aero_stft_dft_launch(const float* x, int nsig, int L, int Lp, int n_f
     p.x = x; p.table = (const h16*)table; p.spec = spec; p.stats = stats;
     p.nsig = nsig; p.L = L; p.Lp = Lp; p.n_fft = n_fft; p.hop = hop; p.win_off = win_off; p.T = T;
     p.sig_per_item = sig_per_item > 0 ? sig_per_item : 1;
-    dim3 grid((unsigned)((T + 127) / 128), (unsigned)nsig, (unsigned)(n_fft / 128)), block(512);
+    // blocks walk the time tiles of their (signal, table quarter) with the table slice resident; enough blocks to fill the chip
+    // twice over (two 74-KiB blocks fit a CU), never more than one per tile
+    const int ntile = (T + 127) / 128;
+    static int tpb_env = -1;
+    if (tpb_env < 0) { const char* e = getenv("AERO_STFT_DFT_BLOCKS"); tpb_env = e ? atoi(e) : 0; }
+    int gx = tpb_env > 0 ? tpb_env : (int)((512 + (long)nsig * (n_fft / 128) - 1) / ((long)nsig * (n_fft / 128)));
+    if (gx < 1) gx = 1;
+    if (gx > ntile) gx = ntile;
+    dim3 grid((unsigned)gx, (unsigned)nsig, (unsigned)(n_fft / 128)), block(512);
     AERO_LAUNCH(aero_stft_dft_kernel, grid, block, stream, p);
     return AERO_OK;
 }

@@ -314,19 +314,13 @@ __global__ __launch_bounds__(512) void aero_lstm_bwd_kernel(AeroLstmBwdK p) {
     // cooperative store of a step's da rows from LDS: 16 sequences x 4H values
     const int vec = (H4 % 8 == 0) ? 8 : 4;                     // H4 is a multiple of 4
     const int per = H4 / vec;
-    __syncthreads();
-    int cur = 0;
-    for (int step = 0; step < W; ++step) {
-        // forward order of dir 0 is tau = 0..W-1 (dir 1: W-1..0); the backward pass walks it in reverse
+    // the saved activations and dout of a step do not depend on the recurrence: they are fetched ONE STEP AHEAD into registers, so
+    // the step's dependent chain is LDS read -> MFMA -> cell algebra -> LDS write -> barrier with no global-memory latency in it
+    // (first version: loads after the MFMA, 4.5 us per step; the launch has only nseq/16 x 2 blocks, so latency is all there is)
+    struct Pre { h16x4 g4[4]; float ct[4], cp[4]; h16 dy[4]; };
+    auto fetch = [&](int step, Pre& pr) {
         const int tau = dir ? step : W - 1 - step;
-        const int tau_prev = dir ? tau + 1 : tau - 1;          // the forward step BEFORE tau (source of c_prev); outside [0, W): none
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < KT4; ++kt) {
-            const h16x8 bf = *(const h16x8*)&dabuf[cur][col * LD + kt * 32 + q * 8];
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt], bf, acc, 0, 0, 0);
-        }
-        h16x4 dav[4];
+        const int tau_prev = dir ? tau + 1 : tau - 1;
         bool kept = seq_ok;
         int64_t opos = o_base + tau;
         if (d.out_mode == 1) {
@@ -337,18 +331,44 @@ __global__ __launch_bounds__(512) void aero_lstm_bwd_kernel(AeroLstmBwdK p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = j0 + r;
+            pr.g4[r] = (h16x4){0, 0, 0, 0};
+            pr.ct[r] = pr.cp[r] = 0.f;
+            pr.dy[r] = (h16)0;
+            if (j < H && seq_ok) {
+                pr.g4[r] = *(const h16x4*)(gs + (int64_t)tau * H * 64 + ((int64_t)j * 16 + col) * 4);
+                pr.ct[r] = cs[(int64_t)tau * H * 16 + j * 16 + col];
+                if (tau_prev >= 0 && tau_prev < W) pr.cp[r] = cs[(int64_t)tau_prev * H * 16 + j * 16 + col];
+                if (kept) pr.dy[r] = dout[opos * H2 + dir * H + j];
+            }
+        }
+    };
+    Pre nxt;
+    fetch(0, nxt);
+    __syncthreads();
+    int cur = 0;
+    for (int step = 0; step < W; ++step) {
+        // forward order of dir 0 is tau = 0..W-1 (dir 1: W-1..0); the backward pass walks it in reverse
+        const int tau = dir ? step : W - 1 - step;
+        const Pre pre = nxt;
+        if (step + 1 < W) fetch(step + 1, nxt);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT4; ++kt) {
+            const h16x8 bf = *(const h16x8*)&dabuf[cur][col * LD + kt * 32 + q * 8];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt], bf, acc, 0, 0, 0);
+        }
+        h16x4 dav[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + r;
             dav[r] = (h16x4){0, 0, 0, 0};
             if (j < H && seq_ok) {
-                float dh = acc[r];
-                if (kept) dh += (float)dout[opos * H2 + dir * H + j];
-                const h16x4 g4 = *(const h16x4*)(gs + (int64_t)tau * H * 64 + ((int64_t)j * 16 + col) * 4);
-                const float ct = cs[(int64_t)tau * H * 16 + j * 16 + col];
-                const float cp = (tau_prev >= 0 && tau_prev < W) ? cs[(int64_t)tau_prev * H * 16 + j * 16 + col] : 0.f;
-                const float ig = (float)g4[0], fg = (float)g4[1], gg = (float)g4[2], og = (float)g4[3];
-                const float th = aero_tanh(ct);
+                const float dh = acc[r] + (float)pre.dy[r];
+                const float ig = (float)pre.g4[r][0], fg = (float)pre.g4[r][1], gg = (float)pre.g4[r][2], og = (float)pre.g4[r][3];
+                const float th = aero_tanh(pre.ct[r]);
                 const float d_o = dh * th;
                 const float dct = dc[r] + dh * og * (1.f - th * th);
-                const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cp;
+                const float d_i = dct * gg, d_g = dct * ig, d_f = dct * pre.cp[r];
                 dc[r] = dct * fg;
                 dav[r] = (h16x4){(h16)(d_i * ig * (1.f - ig)), (h16)(d_f * fg * (1.f - fg)), (h16)(d_g * (1.f - gg * gg)), (h16)(d_o * og * (1.f - og))};
             }
@@ -415,6 +435,11 @@ struct AeroAttnBwdK {
     int dh;                                                    // channels per head
 };
 
+// The key (pass A) / query (pass B) range of one owner is split over AERO_ATTN_KS lanes that are combined with wave shuffles: at the
+// per-GPU batch of BASELINE config 5 a thread per query is only ~7 waves per CU of 3448 dependent iterations each.
+#define AERO_ATTN_KS 4
+#define AERO_ATTN_OWN (128 / AERO_ATTN_KS)                       /* owners (queries / keys) per 128-thread block */
+
 template <int DP>
 __global__ __launch_bounds__(128) void aero_attn_bwd_q_kernel(AeroAttnBwdK p) {
     __shared__ AERO_LDS_ALIGN float Ks[64][DP];
@@ -422,7 +447,8 @@ __global__ __launch_bounds__(128) void aero_attn_bwd_q_kernel(AeroAttnBwdK p) {
     const aero_attn_bwd_desc& d = p.d;
     const int dh = p.dh, T = d.T, Cc = d.C;
     const int h = blockIdx.y, r = blockIdx.z;
-    const int s = blockIdx.x * 128 + threadIdx.x;
+    const int part = threadIdx.x % AERO_ATTN_KS;
+    const int s = blockIdx.x * AERO_ATTN_OWN + threadIdx.x / AERO_ATTN_KS;
     const bool live = s < T;
     const h16* base = (const h16*)d.qkvd + (int64_t)r * T * d.ld;
     const float qscale = aero_rsqrt((float)dh);
@@ -450,6 +476,15 @@ __global__ __launch_bounds__(128) void aero_attn_bwd_q_kernel(AeroAttnBwdK p) {
     }
     float m = -1e30f, l = 0.f, dD = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
+        if (pass) {                                              // combine the parts' softmax statistics
+#pragma unroll
+            for (int k = 1; k < AERO_ATTN_KS; k <<= 1) {
+                const float mo = __shfl_xor(m, k), lo = __shfl_xor(l, k);
+                const float mn = fmaxf(m, mo);
+                l = l * aero_fast_exp(m - mn) + lo * aero_fast_exp(mo - mn);
+                m = mn;
+            }
+        }
         const float inv_l = pass ? 1.f / l : 0.f;
         for (int t0 = 0; t0 < T; t0 += 64) {
             __syncthreads();
@@ -467,7 +502,7 @@ __global__ __launch_bounds__(128) void aero_attn_bwd_q_kernel(AeroAttnBwdK p) {
             __syncthreads();
             if (!live) continue;
             const int tn = T - t0 < 64 ? T - t0 : 64;
-            for (int tt = 0; tt < tn; ++tt) {
+            for (int tt = part; tt < tn; tt += AERO_ATTN_KS) {
                 const int t = t0 + tt;
                 float sv = 0.f;
 #pragma unroll
@@ -491,7 +526,13 @@ __global__ __launch_bounds__(128) void aero_attn_bwd_q_kernel(AeroAttnBwdK p) {
             }
         }
     }
-    if (!live) return;
+#pragma unroll
+    for (int k = 1; k < AERO_ATTN_KS; k <<= 1) {
+        dD += __shfl_xor(dD, k);
+#pragma unroll
+        for (int i = 0; i < DP; ++i) dQ[i] += __shfl_xor(dQ[i], k);
+    }
+    if (!live || part) return;
     h16* orow = (h16*)d.dqkvd + ((int64_t)r * T + s) * d.ld;
 #pragma unroll
     for (int i = 0; i < DP; ++i)
@@ -513,7 +554,8 @@ __global__ __launch_bounds__(128) void aero_attn_bwd_kv_kernel(AeroAttnBwdK p) {
     const aero_attn_bwd_desc& d = p.d;
     const int dh = p.dh, T = d.T, Cc = d.C;
     const int h = blockIdx.y, r = blockIdx.z;
-    const int t = blockIdx.x * 128 + threadIdx.x;
+    const int part = threadIdx.x % AERO_ATTN_KS;
+    const int t = blockIdx.x * AERO_ATTN_OWN + threadIdx.x / AERO_ATTN_KS;
     const bool live = t < T;
     const h16* base = (const h16*)d.qkvd + (int64_t)r * T * d.ld;
     const float qscale = aero_rsqrt((float)dh);
@@ -546,7 +588,7 @@ __global__ __launch_bounds__(128) void aero_attn_bwd_kv_kernel(AeroAttnBwdK p) {
         __syncthreads();
         if (!live) continue;
         const int sn = T - s0 < 64 ? T - s0 : 64;
-        for (int ss = 0; ss < sn; ++ss) {
+        for (int ss = part; ss < sn; ss += AERO_ATTN_KS) {
             const int s = s0 + ss;
             float sv = 0.f, dP = 0.f;
 #pragma unroll
@@ -558,7 +600,12 @@ __global__ __launch_bounds__(128) void aero_attn_bwd_kv_kernel(AeroAttnBwdK p) {
             for (int i = 0; i < DP; ++i) { dV[i] += P * Os[ss][i]; dK[i] += dS * Qs[ss][i]; }
         }
     }
-    if (!live) return;
+#pragma unroll
+    for (int k = 1; k < AERO_ATTN_KS; k <<= 1) {
+#pragma unroll
+        for (int i = 0; i < DP; ++i) { dK[i] += __shfl_xor(dK[i], k); dV[i] += __shfl_xor(dV[i], k); }
+    }
+    if (!live || part) return;
     h16* orow = (h16*)d.dqkvd + ((int64_t)r * T + t) * d.ld;
 #pragma unroll
     for (int i = 0; i < DP; ++i)
@@ -575,7 +622,7 @@ static int aero_attn_bwd_launch(const aero_attn_bwd_desc* d, hipStream_t stream,
     p.d = *d;
     p.dh = d->C / d->heads;
     if (p.dh > 32) { *err = "localstate_bwd: more than 32 channels per head"; return AERO_ERR_UNSUPPORTED; }
-    dim3 grid((unsigned)((d->T + 127) / 128), (unsigned)d->heads, (unsigned)d->R), block(128);
+    dim3 grid((unsigned)((d->T + AERO_ATTN_OWN - 1) / AERO_ATTN_OWN), (unsigned)d->heads, (unsigned)d->R), block(128);
 #define AERO_ATTN_BWD_GO(DP_)                                                         \
     do {                                                                              \
         AERO_LAUNCH(aero_attn_bwd_q_kernel<DP_>, grid, block, stream, p);             \

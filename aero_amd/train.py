@@ -495,15 +495,27 @@ class TrainEngine:
         return None
 
     _unboost = 1.0
+    _range_of = None             # AeroFunction: prefix -> contiguous fp32 view of the flat gradient buffer covering those parameters
+
+    def _factor(self, f, dev):
+        key = ('factor', f, str(dev))
+        if key not in self._tables:
+            self._tables[key] = torch.full((1,), f, dtype=torch.float32, device=dev)
+        return self._tables[key]
 
     def _put(self, name, t, unboost=True):
+        """write one parameter gradient.  Inside a boosted DConv branch (_dconv_layer_fwd) the gradients carry the branch's boost: with the
+        flat buffer at hand the whole layer's range is un-boosted in ONE pass at the end of the layer (_dconv_layer_bwd) -- a gradient
+        that must not be (LayerScale's own) is pre-multiplied here so that the range pass restores it exactly (powers of two)"""
         dst = self.g[name]
         dst.copy_(t.reshape(dst.shape))
-        if unboost and self._unboost != 1.0:                     # a gradient from inside a boosted DConv branch (see _dconv_layer_fwd)
-            key = ('unboost', self._unboost, str(dst.device))
-            if key not in self._tables:
-                self._tables[key] = torch.full((1,), self._unboost, dtype=torch.float32, device=dst.device)
-            TO.scale_f32(self.ops, dst, self._tables[key])
+        if self._unboost == 1.0:
+            return
+        if self._range_of is not None:
+            if not unboost:
+                TO.scale_f32(self.ops, dst, self._factor(1.0 / self._unboost, dst.device))
+        elif unboost:
+            TO.scale_f32(self.ops, dst, self._factor(self._unboost, dst.device))
 
     # ------------------------------------------------------------------ decoder layer
     def _dec_bwd(self, j, dec, r, dout, B, T):
@@ -715,6 +727,8 @@ class TrainEngine:
             self._put(f'{q}.conv1.0.weight', dw1.permute(1, 2, 0)[:hid])
             self._put(f'{q}.conv1.0.bias', db1[:hid])
             dxb = ops.conv(self.spec(q + '.c1_dgrad', lambda: bw.dgrad_conv1d(w1p, r.dil, r.dil * (k // 2), dev)), dh1, None, B, Fo, Fo, T)
+            if self._range_of is not None and bst != 1.0:
+                TO.scale_f32(ops, self._range_of(q + '.'), self._factor(1.0 / bst, dev))
         finally:
             self._unboost = 1.0
         return TO.add_f16(ops, dy, dxb, scale_b=1.0 / bst)      # skip path + the branch, un-boosted in fp32
@@ -820,8 +834,15 @@ class AeroFunction(torch.autograd.Function):
                 for pf in prefixes:
                     a, b = span(pf)
                     sync.reduce_async(flat[a:b])
+        def range_of(prefix):
+            a, b = span(prefix)
+            return flat[a:b]
         with torch.no_grad():
-            eng.backward(ctx.c, dy.contiguous(), grads, stage_done=stage_done)
+            eng._range_of = range_of
+            try:
+                eng.backward(ctx.c, dy.contiguous(), grads, stage_done=stage_done)
+            finally:
+                eng._range_of = None
             if sync is not None:
                 sync.wait()
         ctx.c = None

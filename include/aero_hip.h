@@ -22,6 +22,7 @@
  *       AERO_LSTM_RING, AERO_LSTM_WIDE                                          (recurrent kernel form)
  *       AERO_ATTN_FOLD                                                          (LocalState: folded vs streaming kernel)
  *       AERO_NORM_CHUNK_KB                                                      (GroupNorm work-item size)
+ *       AERO_STFT_DFT_BLOCKS                                                    (GEMM-form STFT: blocks per (signal, table quarter))
  *       AERO_WGRAD_256, AERO_WGRAD_ABL                                          (weight-gradient tile / ablations)
  *     The Python host side has its own AERO_* switches (aero_amd/engine.py); they never reach the library.
  */

@@ -78,7 +78,8 @@ def _gconv_case(lib, dev, B, Cin, Cout, groups, K, stride, pad, T, reflect=0, sl
     bd.B, bd.Tin, bd.Cin, bd.Cout, bd.groups, bd.K, bd.stride, bd.pad, bd.reflect, bd.slope = B, T, Cin, Cout, groups, K, stride, pad, reflect, slope
     lib.call('aero_gconv1d_bwd', C.byref(bd), stream)
     assert rel_l2(dx.float().cpu().permute(0, 2, 1), x.grad) < 5e-4
-    assert rel_l2(dw.cpu().permute(0, 2, 1), w.grad) < 1e-5 and rel_l2(db.cpu(), b.grad) < 1e-5
+    # (fp32 atomics over up to ~5e4 positions per output: the sum order is not fixed)
+    assert rel_l2(dw.cpu().permute(0, 2, 1), w.grad) < 2e-4 and rel_l2(db.cpu(), b.grad) < 2e-4
 
 
 GCONV = [(2, 16, 64, 4, 41, 4, 20, 300), (2, 256, 256, 64, 41, 4, 20, 16), (2, 1, 16, 1, 15, 1, 7, 200, 1), (2, 128, 1, 1, 3, 1, 1, 9, 0, 1.0),

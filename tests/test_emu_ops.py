@@ -325,3 +325,17 @@ def test_reference_module_vectors(emu, tag):
     """the REFERENCE's own module outputs (tests/golden/modules.npz) reproduced by the kernels: <= 1e-3, the north-star bar"""
     errs = oc.case_module_golden(emu, DEV, tag)
     assert errs and max(errs.values()) < 1e-3, errs
+
+
+def test_stft_dft_blocks_walk_several_time_tiles():
+    """AERO_STFT_DFT_BLOCKS=1: ONE block per (signal, table quarter) walks all 128-frame tiles with its table slice resident -- the
+    form a full batch takes on the device (few signals get one block per tile: that path is what the other DFT cases run)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import op_cases as oc\nfrom aero_amd import _lib\nfrom emu.build_emu import build\n"
+            "oc.case_stft(_lib.load(build()), 'cpu', 512, 16, 128, 5000, B=2, dft=True)\nprint('ok')\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_STFT_DFT_BLOCKS': '1'}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
