@@ -146,6 +146,7 @@ _PROTOS = {
     'aero_conv_fwd': (i32, [C.POINTER(ConvDesc), vp]),
     'aero_split_finish': (i32, [fp, i32, fp, i32, vp, i64, i32, vp]),
     'aero_adam_step': (i32, [fp, fp, fp, fp, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float, vp]),
+    'aero_adam_step_dev': (i32, [fp, fp, fp, fp, i64, C.c_float, C.c_float, C.c_float, C.c_float, fp, C.c_float, vp]),
     'aero_conv_wgrad': (i32, [C.POINTER(WgradDesc), vp]),
     'aero_norm_bwd_reduce': (i32, [C.POINTER(NormBwdDesc), vp]),
     'aero_norm_bwd_apply': (i32, [C.POINTER(NormBwdDesc), vp]),

@@ -83,9 +83,12 @@ def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None, dw_acc=None
     d.B, d.Fin, d.Fout, d.T, d.M, d.C, d.ntaps, d.fstride = B, Fin, Fout, T, M, Cc, len(df), fstride
     for i, (a, b_) in enumerate(zip(df, dt)):
         d.df[i], d.dt[i] = a, b_
-    if nslab is None:                           # as many row chunks as the kernel would like (4096 blocks / tiles), within 1 GiB
+    if nslab is None:
+        # row chunks: enough blocks to fill the chip (4096 / tiles), but no chunk shorter than ~2048 positions (64 steps of the
+        # kernel) -- each chunk costs a [taps, M, C] fp32 slab written and read back: on the LSTM / attention 1x1 shapes of
+        # config 5 (57 600 positions, 384 x 96) 256 chunks meant 38 MB of slab traffic for a 4-GFLOP product (0.28 ms -> see DESIGN 4.8)
         tiles = ((M + 127) // 128) * ((Cc + 127) // 128) * len(df)
-        nslab = max(1, min(-(-4096 // tiles), 256, B * Fout, (1 << 30) // (len(df) * M * Cc * 4)))
+        nslab = max(1, min(-(-4096 // tiles), 256, B * Fout, (B * Fout * T) // 2048, (1 << 30) // (len(df) * M * Cc * 4)))
     if nslab:                                   # per-chunk partial slabs added in fixed order (deterministic); nslab = 0: fp32 atomics
         slabs = torch.empty(nslab, len(df), M, Cc, dtype=torch.float32, device=dy.device)
         d.slabs, d.nslab = _ptr(slabs), nslab

@@ -186,6 +186,14 @@ int aero_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
     return aero_finish(rc, err);
 }
 
+int aero_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, const float* bc,
+                       float grad_scale, void* stream) {
+    const char* err = "";
+    if (!bc) return aero_fail(AERO_ERR_ARG, "adam_step_dev: null bias-correction pointer");
+    int rc = aero_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, 1, grad_scale, (hipStream_t)stream, &err, bc);
+    return aero_finish(rc, err);
+}
+
 int aero_split_finish(const float* acc, int32_t nsplit, const float* bias, int32_t act, void* dst, int64_t npos, int32_t M, void* stream) {
     const char* err = "";
     int rc = aero_split_finish_launch(acc, nsplit, bias, act, dst, npos, M, (hipStream_t)stream, &err);

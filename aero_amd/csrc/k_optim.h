@@ -8,7 +8,8 @@
 #include "aero_common.h"
 
 __global__ __launch_bounds__(256) void aero_adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
-                                                         float b2, float eps, float bc1, float bc2_sqrt, float grad_scale) {
+                                                         float b2, float eps, float bc1, float bc2_sqrt, float grad_scale, const float* bc_dev) {
+    if (bc_dev) { bc1 = bc_dev[0]; bc2_sqrt = bc_dev[1]; }                  // bias corrections from device memory (a replayed HIP graph: see aero_adam_step_dev)
     const float step_size = lr / bc1;
     const int64_t nv = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
@@ -37,14 +38,15 @@ __global__ __launch_bounds__(256) void aero_adam_kernel(float* p, const float* g
     }
 }
 
-static int aero_adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int32_t step,
-                            float grad_scale, hipStream_t stream, const char** err) {
+ static int aero_adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int32_t step,
+                            float grad_scale, hipStream_t stream, const char** err, const float* bc_dev = nullptr) {
     if (!p || !g || !m || !v || n < 1) { *err = "adam: null pointer / empty buffer"; return AERO_ERR_ARG; }
+    if (bc_dev) step = 1;
     if (step < 1 || !(b1 >= 0.f && b1 < 1.f) || !(b2 >= 0.f && b2 < 1.f) || !(eps >= 0.f)) { *err = "adam: bad hyper-parameters"; return AERO_ERR_ARG; }
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) { *err = "adam: buffers must be 16-byte aligned"; return AERO_ERR_ARG; }
     const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
     const int64_t want = ((n >> 2) + 255) / 256;
     const unsigned nb = (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
-    AERO_LAUNCH(aero_adam_kernel, dim3(nb), dim3(256), stream, p, g, m, v, n, lr, b1, b2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    AERO_LAUNCH(aero_adam_kernel, dim3(nb), dim3(256), stream, p, g, m, v, n, lr, b1, b2, eps, (float)bc1, (float)sqrt(bc2), grad_scale, bc_dev);
     return AERO_OK;
 }

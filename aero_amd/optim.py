@@ -82,13 +82,40 @@ class FlatAdam:
         if not self.flat_p.is_cuda and self.lib is None:
             raise RuntimeError('FlatAdam.step: parameters must live on the MI355X (no CPU path)')
         self._reattach()
-        self.step_count += 1
         stream = torch.cuda.current_stream(self.flat_p.device).cuda_stream if self.flat_p.is_cuda else 0
+        if self.flat_p.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture (aero_amd.train.CapturedStep): the step count must advance at every REPLAY, so the bias
+            # corrections come from device memory, uploaded by before_replay()
+            if self._bc is None:
+                raise RuntimeError('FlatAdam: call prepare_capture() before capturing a step in a HIP graph')
+            lib.call('aero_adam_step_dev', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                     self.n, C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), self._bc.data_ptr(),
+                     C.c_float(grad_scale), stream)
+            if self.model is not None and hasattr(self.model, 'repack'):
+                self.model.repack()
+            return
+        self.step_count += 1
         lib.call('aero_adam_step', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                  self.n, C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), self.step_count,
                  C.c_float(grad_scale), stream)
         if self.model is not None and hasattr(self.model, 'repack'):
             self.model.repack()
+
+    # ---- HIP-graph replay (aero_amd.train.CapturedStep)
+    _bc = None
+
+    def prepare_capture(self):
+        """allocate the device-side bias-correction pair the captured step reads"""
+        if self._bc is None:
+            self._bc = torch.ones(2, dtype=torch.float32, device=self.flat_p.device)
+            self._bc_host = torch.ones(2, dtype=torch.float32).pin_memory() if self.flat_p.is_cuda else torch.ones(2)
+
+    def before_replay(self):
+        """advance the step count and upload {1 - beta1^t, sqrt(1 - beta2^t)} for the replay that follows"""
+        self.step_count += 1
+        self._bc_host[0] = 1.0 - self.betas[0] ** self.step_count
+        self._bc_host[1] = (1.0 - self.betas[1] ** self.step_count) ** 0.5
+        self._bc.copy_(self._bc_host, non_blocking=True)
 
     # ---- checkpoints: the schema of torch.optim.Adam.state_dict() (the reference stores it under the checkpoint's optimizer entry,
     # src/solver.py:111-118 / model_serializer.py), so checkpoints move both ways between the two optimizers

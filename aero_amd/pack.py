@@ -156,15 +156,22 @@ def gram_tables(w, bias, device):
     return G.to(device).contiguous(), g1.to(device).contiguous()
 
 
-def lstm_gate_perm(H):
-    """row index 4*j+gate of the kernel <- row gate*H + j of nn.LSTM (i,f,g,o blocks)."""
-    j = torch.arange(H)
-    return torch.stack([g * H + j for g in range(4)], 1).reshape(-1)
+_PERM = {}
+
+
+def lstm_gate_perm(H, device='cpu'):
+    """row index 4*j+gate of the kernel <- row gate*H + j of nn.LSTM (i,f,g,o blocks); cached per device (no host-to-device copy
+    per call: the training step re-packs after every optimizer step, possibly inside a HIP-graph capture)."""
+    key = (H, str(device))
+    if key not in _PERM:
+        j = torch.arange(H)
+        _PERM[key] = torch.stack([g * H + j for g in range(4)], 1).reshape(-1).to(device)
+    return _PERM[key]
 
 
 def pack_lstm_layer(lib, sd, prefix, layer, H, device):
     """-> (ConvSpec for the input projection of both directions, xbias fp16 [8H], whh fp16 [2,MP,KP])."""
-    perm = lstm_gate_perm(H).to(sd[f'{prefix}.weight_ih_l{layer}'].device)
+    perm = lstm_gate_perm(H, sd[f'{prefix}.weight_ih_l{layer}'].device)
     w_ih, b, w_hh = [], [], []
     for sfx in ('', '_reverse'):
         w_ih.append(sd[f'{prefix}.weight_ih_l{layer}{sfx}'].float()[perm])

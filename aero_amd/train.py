@@ -37,7 +37,7 @@ def lstm_param_grads(ops, da, x, out, sd, layer, H, nseq, W, in_ch, dev):
     sd: the nn.LSTM state dict (`weight_ih_l{layer}[_reverse]`, ...).  Returns {parameter name: fp32 gradient, 'dx': fp16 [nseq, W, in_ch]}."""
     npos = nseq * W
     H4 = 4 * H
-    perm = pack.lstm_gate_perm(H).to(dev)                       # kernel row 4j+g <- nn.LSTM row g*H+j
+    perm = pack.lstm_gate_perm(H, dev)                       # kernel row 4j+g <- nn.LSTM row g*H+j
     g = {}
     dw, db = bw.conv_wgrad(ops, da.view(nseq, 1, W, 2 * H4), x.reshape(nseq, 1, W, in_ch), [0], [0])      # [1, 8H, in_ch], [8H] (a row per sequence: the kernel cuts rows into parallel chunks)
     w_t = []
@@ -77,6 +77,7 @@ class TrainEngine:
         self._cache, self._key = {}, None
         self._tables = {}
         self._epoch = 0
+        self._boosts, self._nfwd = {}, 0
 
     # ------------------------------------------------------------------ weights (packed on the device, per parameter version)
     def invalidate(self):
@@ -150,6 +151,7 @@ class TrainEngine:
             raise RuntimeError('aero_amd trains on the MI355X only: move the model and the input to "cuda"')
         dev = mix.device
         self._sync_weights(dev)
+        self._nfwd += 1
         B, _, L = mix.shape
         mix = mix.contiguous()
         ops.begin_step(dev)
@@ -334,13 +336,19 @@ class TrainEngine:
         y, r.st2 = self._norm(r.h2, 1, 1, self.w(f'{q}.conv2.1.weight'), self.w(f'{q}.conv2.1.bias'), ACT_GLU,
                               layer_scale=self.w(f'{q}.conv2.3.scale'), res=x)
 
-        def b_boost():
-            # LayerScale (init 1e-3, modules.py:130-141) shrinks every gradient inside the residual branch by its magnitude: a power of
-            # two of that size is put back where the gradient enters the branch and taken out where it leaves (one host read per
-            # parameter version), so the branch's fp16 gradients sit in the same range as the main path's
+        # LayerScale (init 1e-3, modules.py:130-141) shrinks every gradient inside the residual branch by its magnitude: a power of
+        # two of that size is put back where the gradient enters the branch and taken out where it leaves, so the branch's fp16
+        # gradients sit in the same range as the main path's.  The factor only positions the fp16 window (any power of two is
+        # exact), so it is read from the device once and refreshed every 64 forwards -- never while a HIP graph is being captured.
+        ent = self._boosts.get(q)
+        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
+        if ent is None or (not capturing and self._nfwd - ent[1] >= 64):
+            if capturing:
+                raise RuntimeError('aero_amd: run at least one eager training step before capturing it in a HIP graph')
             mean = float(self.w(f'{q}.conv2.3.scale').abs().mean())
-            return float(2.0 ** min(12, max(0, round(-math.log2(max(mean, 2.0 ** -12))))))
-        r.boost = self.spec(q + '.boost', b_boost)
+            ent = (float(2.0 ** min(12, max(0, round(-math.log2(max(mean, 2.0 ** -12)))))), self._nfwd)
+            self._boosts[q] = ent
+        r.boost = ent[0]
         return y, r
 
     def _lstm_specs(self, q, H, dev):
@@ -847,3 +855,40 @@ class AeroFunction(torch.autograd.Function):
                 sync.wait()
         ctx.c = None
         return (None, None, None) + tuple(views)
+
+
+class CapturedStep:
+    """One whole training step -- forward, criterion, backward, fused Adam -- captured ONCE as a HIP graph and replayed.
+
+    At BASELINE config 5's per-GPU batch (2 x 10 s) the step is ~500 kernel launches of the library plus a few thousand small
+    device-side layout operations (weights re-packed on the device after every optimizer step): a third of the wall time is host work.
+    A replay has none.  `step_fn(*inputs)` must run the step on the given STATIC input tensors and return the loss tensor(s); it is
+    run eagerly `warmup` times first (lazy tables, the DConv boosts, allocator warm-up), then captured.
+
+        cap = CapturedStep(lambda lr, hr: train_step(lr, hr), lr0, hr0)      # captures on lr0 / hr0's shapes
+        loss = cap(lr, hr)                                                    # copies into the static inputs, replays
+    """
+
+    def __init__(self, step_fn, *example_inputs, warmup=2, optimizers=()):
+        self.optimizers = list(optimizers)                       # FlatAdam instances stepped inside step_fn
+        for o in self.optimizers:
+            o.prepare_capture()
+        self.static_in = [t.clone() for t in example_inputs]
+        side = torch.cuda.Stream(device=example_inputs[0].device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                            # (capture must not run on the legacy default stream)
+            for _ in range(warmup):
+                step_fn(*self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = step_fn(*self.static_in)
+
+    def __call__(self, *inputs):
+        for s, t in zip(self.static_in, inputs):
+            s.copy_(t)
+        for o in self.optimizers:
+            o.before_replay()
+        self.graph.replay()
+        return self.static_out

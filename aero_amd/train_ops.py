@@ -64,7 +64,7 @@ def pack_whh_t(lib, w_hh_dirs, H, device):
     if K4P <= 0:
         raise _lib.AeroHipError(f'aero_lstm_bwd: hidden size {H} unsupported')
     HP = (H + 15) // 16 * 16
-    perm = pack.lstm_gate_perm(H).to(w_hh_dirs[0].device)
+    perm = pack.lstm_gate_perm(H, w_hh_dirs[0].device)
     img = torch.zeros(2, HP, K4P, dtype=torch.float32, device=w_hh_dirs[0].device)
     for dr in range(2):
         img[dr, :H, :4 * H] = w_hh_dirs[dr].detach().float()[perm].t()

@@ -144,7 +144,7 @@ def extra_configs(dev, steps, warmup):
             opt.zero_grad()
             (sc + mg).backward()
             opt.step()
-            return sc + mg
+            return (sc + mg).detach()
         k5 = max(2, min(steps, 5))
         for _ in range(max(1, min(warmup, 2))):
             step()
@@ -154,14 +154,43 @@ def extra_configs(dev, steps, warmup):
             last = step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # the same step replayed as ONE HIP graph (aero_amd.train.CapturedStep): no host work between the ~500 library launches
+        graph_ms = None
+        try:
+            from aero_amd.train import CapturedStep
+            cap = CapturedStep(lambda a, b: step(), lr_, hr_, warmup=1, optimizers=[opt])
+            cap(lr_, hr_)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k5):
+                cap(lr_, hr_)
+            torch.cuda.synchronize()
+            graph_ms = round((time.perf_counter() - t0) / k5 * 1e3, 2)
+        except Exception as e:
+            graph_ms = 'capture failed: ' + repr(e)[:200]
         out.append({'metric': 'training steps per second per GPU (forward + MR-STFT loss + backward + Adam), 11.025->44.1kHz nfft=512 hop=256, 2 x 10-s clips',
-                    'value': round(k5 / dt, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': k5, 'ms_per_step': round(dt / k5 * 1e3, 2), 'dtype': 'f16',
+                    'value': round(k5 / dt, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': k5, 'ms_per_step': round(dt / k5 * 1e3, 2), 'ms_per_step_hip_graph': graph_ms, 'dtype': 'f16',
                     'data': 'synthetic', 'audio_sec_per_wall_sec': round(2 * 10.0 * k5 / dt, 1), 'loss': round(float(last.detach()), 5),
                     'config': {'workload': "BASELINE config 5, one GPU's share (2 of the 16 clips): aero_11-44_512_256, train mode, generator step with "
                                            'losses: [stft]; the msd_melgan critic (tools/config5.py --gan) is not part of this line', 'frames': 1724}})
     except Exception as e:
         out.append({'config': 'BASELINE config 5 (training step)', 'error': repr(e)})
     return out
+
+
+def extra_configs_subprocess(steps, warmup, timeout_s=300):
+    """run extra_configs() in a child process: whatever happens there (a failed HIP-graph capture can take the process down) cannot
+    cost the headline line"""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--extra-configs-worker', '--steps', str(steps), '--warmup', str(warmup)],
+                             capture_output=True, text=True, timeout=timeout_s)
+        for line in out.stdout.splitlines():
+            if line.startswith('['):
+                return json.loads(line)
+        return [{'error': 'extra-configs worker produced no result', 'stderr_tail': out.stderr[-400:]}]
+    except subprocess.TimeoutExpired:
+        return [{'error': f'extra-configs worker exceeded {timeout_s} s and was stopped'}]
 
 
 def main():
@@ -172,11 +201,16 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU (BASELINE config 2: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--extra-configs-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP-event pass')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the BASELINE config 4 / config 5 lines under extra_configs')
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         print(json.dumps(cpu_baseline_worker(2.0, FULL_CFG['lr_sr'])))
+        return
+    if args.extra_configs_worker:
+        torch.cuda.set_device(0)
+        print(json.dumps(extra_configs(torch.device('cuda', 0), args.steps, args.warmup)))
         return
 
     from aero_amd import distrib, launcher
@@ -301,7 +335,7 @@ def main():
         return
     extra = None
     if world == 1 and not args.no_extra_configs:
-        extra = extra_configs(dev, args.steps, args.warmup)
+        extra = extra_configs_subprocess(args.steps, args.warmup)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(secs, FULL_CFG['lr_sr'])

@@ -312,6 +312,10 @@ int aero_dconv_row_fits(int T, int C, int hidden, int max_dilation);
  * all-reduce, or 1).  Same arithmetic and operation order as torch's Adam without amsgrad / weight decay. */
 int aero_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    int32_t step, float grad_scale, void* stream);
+/* the same step with the bias corrections bc = {1 - beta1^t, sqrt(1 - beta2^t)} read from DEVICE memory: a training step captured as
+ * a HIP graph is replayed with the step count advancing (the host uploads the pair before each replay; aero_amd.optim.FlatAdam) */
+int aero_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       const float* bc, float grad_scale, void* stream);
 
 /* ---- backward (loss.backward() of src/solver.py:602-605 through the modules of aero.py / modules.py).
  * Data gradients of the convolutions are aero_conv_fwd calls with re-packed weights (aero_amd/backward.py). */

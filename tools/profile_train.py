@@ -1,0 +1,84 @@
+"""Where one training step of BASELINE config 5 spends its time: HIP-event timing of every C-ABI call of one forward + backward
+(`lib.call` is wrapped), grouped by entry point and, for the weight gradients, by shape.  usage: profile_train.py [B]"""
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from aero_amd import Aero, _lib, losses  # noqa: E402
+from aero_amd import backward as bw  # noqa: E402
+from aero_amd.config import load_config  # noqa: E402
+from aero_amd.optim import FlatAdam  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    args = load_config(os.path.join(ROOT, 'conf'), ['experiment=aero_11-44_512_256'])
+    torch.manual_seed(2036)
+    model = Aero(**dict(args.experiment.aero)).cuda().train()
+    opt = FlatAdam(model.parameters(), lr=3e-4, model=model)
+    crit = losses.MultiResolutionSTFTLoss(factor_sc=0.5, factor_mag=0.5)
+    g = torch.Generator().manual_seed(0)
+    lr = torch.randn(B, 1, 110250, generator=g).cuda()
+    hr = (0.1 * torch.randn(B, 1, 441000, generator=g)).cuda()
+
+    def step():
+        y = model(lr)
+        sc, mg = crit(y.squeeze(1), hr.squeeze(1))
+        opt.zero_grad()
+        (sc + mg).backward()
+        opt.step()
+    for _ in range(2):
+        step()
+    lib = _lib.load()
+    rec = []
+    orig_call = lib.call
+    note = ['']
+
+    def timed(name, *a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_call(name, *a)
+        e1.record()
+        rec.append((name, note[0], e0, e1))
+    lib.call = timed
+    orig_wgrad = bw.conv_wgrad
+
+    def wgrad(ops, dy, x, df, dt, *a, **k):
+        note[0] = f'dy{tuple(dy.shape)} x{tuple(x.shape)} taps{len(df)}'
+        try:
+            return orig_wgrad(ops, dy, x, df, dt, *a, **k)
+        finally:
+            note[0] = ''
+    bw.conv_wgrad = wgrad
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True)
+    t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    step()
+    t1.record()
+    torch.cuda.synchronize()
+    lib.call = orig_call
+    by = collections.defaultdict(lambda: [0, 0.0])
+    wg = collections.defaultdict(lambda: [0, 0.0])
+    for name, nt, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        by[name][0] += 1
+        by[name][1] += ms
+        if name == 'aero_conv_wgrad':
+            wg[nt][0] += 1
+            wg[nt][1] += ms
+    tot = sum(v[1] for v in by.values())
+    print(f'B={B}: one step {t0.elapsed_time(t1):.1f} ms wall (with per-call events), {len(rec)} C-ABI calls, {tot:.1f} ms inside them')
+    for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:22]:
+        print(f'{v[1]:8.2f} ms {v[0]:5d} calls  {k}')
+    print('-- aero_conv_wgrad by shape')
+    for k, v in sorted(wg.items(), key=lambda kv: -kv[1][1])[:16]:
+        print(f'{v[1]:8.3f} ms {v[0]:3d} calls  {k}')
+
+
+if __name__ == '__main__':
+    main()
