@@ -523,7 +523,9 @@ static int aero_conv_ring_pick_bm(int M, int Ktot) {
     const int mode = aero_conv_ring_mode();
     if (!mode || M <= 0 || Ktot % 32) return 0;
     if (M % 256 == 0 && Ktot >= 1024) return 256;
-    if (mode >= 2 && M % 192 == 0 && Ktot >= 768) return 192;
+    static int no192 = -1;                                       // AERO_RING_TILE192=0: 128 / 64-row x 512-step tiles instead of the 192 x 256 one (A/B)
+    if (no192 < 0) { const char* e = getenv("AERO_RING_TILE192"); no192 = (e && e[0] == '0') ? 1 : 0; }
+    if (mode >= 2 && !no192 && M % 192 == 0 && Ktot >= 768) return 192;
     if (mode >= 2 && M % 128 == 0 && Ktot >= 768) return 128;
     if (mode >= 2 && M % 64 == 0 && Ktot >= 768) return 64;
     return 0;

@@ -306,7 +306,7 @@ def main():
     disc = Discriminator(num_D=3, ndf=16, n_layers=4, downsampling_factor=4).eval()
     meta['disc_seed'], meta['disc_cfg'] = 71, dict(num_D=3, ndf=16, n_layers=4, downsampling_factor=4)
     meta['disc_checksums'] = checksums(disc.state_dict())
-    xd, xr = seeded((2, 1, 8192), 72) * 0.3, seeded((2, 1, 8192), 73) * 0.3
+    xd, xr = seeded((2, 1, 4096), 72) * 0.3, seeded((2, 1, 4096), 73) * 0.3
     dg = {}
     with torch.no_grad():
         outs_f, outs_r = disc(xd), disc(xr)

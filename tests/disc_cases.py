@@ -22,7 +22,7 @@ def case_discriminator(dev, lib=None):
     if lib is not None:
         d.use_library(lib)
     d.to(dev)
-    xf, xr = (seeded((2, 1, 8192), 72) * 0.3).to(dev), (seeded((2, 1, 8192), 73) * 0.3).to(dev)
+    xf, xr = (seeded((2, 1, 4096), 72) * 0.3).to(dev), (seeded((2, 1, 4096), 73) * 0.3).to(dev)
     with torch.no_grad():
         of, orr = d(xf), d(xr)
     errs = {}
@@ -63,7 +63,7 @@ def _torch_critic(d, x, rounded=False):
     return results
 
 
-def case_critic_backward(dev, lib=None, T=2048):
+def case_critic_backward(dev, lib=None, T=1024):
     """discriminator_loss (gradients of every weight_g / weight_v / bias) and generator_losses (gradient of the fake waveform) on the
     HIP kernels against torch.autograd through the same modules with the feature maps rounded to fp16 where the product stores them
     (a LeakyReLU mask is a discontinuous function of its pre-activation: see tests/train_cases.py)"""

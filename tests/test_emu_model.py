@@ -120,8 +120,10 @@ def test_train_mode_forward_golden(emu, meta):
 
 
 def test_train_mode_with_autograd_is_refused(emu, meta):
-    """There are no HIP backward kernels: a training-mode call that autograd would have to differentiate must fail
-    loudly instead of returning a tensor without a graph."""
+    """The training engine needs 8-channel vectors (hidden sizes that are multiples of 8: every reference config and the small test
+    model have them, tests/test_emu_train.py); the TINY model (4 channels, LSTM width 4) does not: a training-mode call that autograd
+    would have to differentiate must fail loudly instead of returning a tensor without a graph.  With frozen parameters the same call
+    is the inference engine in train mode."""
     m = _with_engine(build_model(meta, 'tiny'), emu).train()
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 1, 400))
