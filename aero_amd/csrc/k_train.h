@@ -612,6 +612,248 @@ __global__ __launch_bounds__(128) void aero_attn_bwd_kv_kernel(AeroAttnBwdK p) {
         if (i < dh) { orow[Cc + h * dh + i] = (h16)dK[i]; orow[2 * Cc + h * dh + i] = (h16)dV[i]; }
 }
 
+// ---- MFMA form of the two passes (d.R*heads*T^2 pairs: 34 ms of a 131-ms step at B = 16 in the VALU form above) --------------
+// v_mfma_f32_16x16x16_f16 throughout, ND = ceil(dh / 16) dimension tiles.  The score tile comes out of the MFMA with lane
+// (g = lane >> 4, col = lane & 15) holding rows 4g..4g+3 of column col -- which IS the A-operand layout (i = col, k = 4g + e) of the
+// transposed tile, so P and dS feed the second MFMA straight from registers (packed to fp16), as the forward kernel does.
+//   pass A (a wave = 16 queries, walks key tiles): S^T = K Q^T, dP^T = V dO^T  ->  dS  ->  dQ += dS^T K  (A = dS, B = K^T from LDS)
+//   pass B (a wave = 16 keys, walks query tiles):  S = Q K^T, dP = dO V^T      ->  P, dS  ->  dV += P^T dO, dK += dS^T Q
+typedef h16 h16x4_t __attribute__((ext_vector_type(4)));
+#define AERO_ATTN_TK 64                                          /* rows of the other side staged per LDS tile */
+
+template <int ND>
+__global__ __launch_bounds__(256) void aero_attn_bwd_q_mfma_kernel(AeroAttnBwdK p) {
+    constexpr int DP = 16 * ND, LT = AERO_ATTN_TK + 4;
+    __shared__ AERO_LDS_ALIGN h16 Kr[AERO_ATTN_TK * DP];        // [key][dim]
+    __shared__ AERO_LDS_ALIGN h16 Vr[AERO_ATTN_TK * DP];
+    __shared__ AERO_LDS_ALIGN h16 Kt[DP * LT];                   // [dim][key]
+    const aero_attn_bwd_desc& d = p.d;
+    const int dh = p.dh, T = d.T, Cc = d.C;
+    const int h = blockIdx.y, r = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const int s = blockIdx.x * 64 + wave * 16 + col;             // this lane's query (MFMA column)
+    const bool live = s < T;
+    const h16* base = (const h16*)d.qkvd + (int64_t)r * T * d.ld;
+    const float qscale = aero_rsqrt((float)dh);
+    // B operands, constant per wave: Q^T and dO^T, lane = (dims 4g..4g+3 of tile n, query col)
+    h16x4_t qb[ND], ob[ND];
+    float delta = 0.f, D = 0.f;
+    float sg[8];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+        qb[n] = (h16x4_t){0, 0, 0, 0};
+        ob[n] = (h16x4_t){0, 0, 0, 0};
+    }
+    if (live) {
+        const h16* row = base + (int64_t)s * d.ld + h * dh;
+        const h16* orow = (const h16*)d.out + ((int64_t)r * T + s) * Cc + h * dh;
+        const h16* drow = (const h16*)d.dout + ((int64_t)r * T + s) * Cc + h * dh;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = n * 16 + g * 4 + e;
+                if (i < dh) { qb[n][e] = row[i]; ob[n][e] = drow[i]; }
+            }
+        for (int i = 0; i < dh; ++i) delta += (float)orow[i] * (float)drow[i];
+        const h16* rowd = base + (int64_t)s * d.ld + 3 * Cc + h * d.ndecay;
+        const float dn = 0.5f * aero_rsqrt((float)(d.ndecay > 0 ? d.ndecay : 1));
+        for (int f = 0; f < d.ndecay; ++f) {
+            sg[f] = aero_sigmoid((float)rowd[f]);
+            D += (float)(f + 1) * sg[f] * dn;
+        }
+    }
+    float m = -1e30f, l = 0.f, dD = 0.f, L = 0.f;
+    f32x4 dq[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) dq[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) {
+#pragma unroll
+            for (int k = 16; k <= 32; k <<= 1) {                 // the four lane groups of a column hold different keys: combine
+                const float mo = __shfl_xor(m, k), lo = __shfl_xor(l, k);
+                const float mn = fmaxf(m, mo);
+                l = l * aero_fast_exp(m - mn) + lo * aero_fast_exp(mo - mn);
+                m = mn;
+            }
+            L = m + logf(l);
+        }
+        for (int t0 = 0; t0 < T; t0 += AERO_ATTN_TK) {
+            __syncthreads();
+            for (int idx = tid; idx < AERO_ATTN_TK * DP; idx += 256) {
+                const int tt = idx / DP, i = idx - tt * DP;
+                h16 kv = (h16)0, vv = (h16)0;
+                if (t0 + tt < T && i < dh) {
+                    const h16* rowk = base + (int64_t)(t0 + tt) * d.ld + h * dh + i;
+                    kv = rowk[Cc];
+                    vv = rowk[2 * Cc];
+                }
+                Kr[tt * DP + i] = kv;
+                Vr[tt * DP + i] = vv;
+                Kt[i * LT + tt] = kv;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kt = 0; kt < AERO_ATTN_TK / 16; ++kt) {
+                if (t0 + kt * 16 >= T) break;
+                f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < ND; ++n) {
+                    const h16x4_t ka = *(const h16x4_t*)&Kr[(kt * 16 + col) * DP + n * 16 + g * 4];
+                    sc = __builtin_amdgcn_mfma_f32_16x16x16f16(ka, qb[n], sc, 0, 0, 0);
+                    if (pass) {
+                        const h16x4_t va = *(const h16x4_t*)&Vr[(kt * 16 + col) * DP + n * 16 + g * 4];
+                        dp = __builtin_amdgcn_mfma_f32_16x16x16f16(va, ob[n], dp, 0, 0, 0);
+                    }
+                }
+                h16x4_t dsv = (h16x4_t){0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = t0 + kt * 16 + g * 4 + e;
+                    const float dist = fabsf((float)(t - s));
+                    float sv = (t == s) ? -100.f : sc[e] * qscale - dist * D;
+                    if (t >= T) sv = -1e30f;
+                    if (!pass) {
+                        const float mn = fmaxf(m, sv);
+                        l = l * aero_fast_exp(m - mn) + aero_fast_exp(sv - mn);
+                        m = mn;
+                    } else if (t != s && t < T) {
+                        const float P = aero_fast_exp(sv - L);
+                        const float dS = P * (dp[e] - delta);
+                        dsv[e] = (h16)dS;
+                        dD -= dist * dS;
+                    }
+                }
+                if (pass) {
+#pragma unroll
+                    for (int n = 0; n < ND; ++n) {
+                        const h16x4_t kb = *(const h16x4_t*)&Kt[(n * 16 + col) * LT + kt * 16 + g * 4];
+                        dq[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(dsv, kb, dq[n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    dD += __shfl_xor(dD, 16);
+    dD += __shfl_xor(dD, 32);
+    // dq[n][e]: query 4g + e of the wave, dimension n*16 + col
+    h16* outb = (h16*)d.dqkvd + (int64_t)r * T * d.ld;
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int sq = blockIdx.x * 64 + wave * 16 + g * 4 + e, i = n * 16 + col;
+            if (sq < T && i < dh) outb[(int64_t)sq * d.ld + h * dh + i] = (h16)(dq[n][e] * qscale);
+        }
+    if (!live || g) return;
+    h16* orow = outb + (int64_t)s * d.ld;
+    const float dn = 0.5f * aero_rsqrt((float)(d.ndecay > 0 ? d.ndecay : 1));
+    const float dsc = d.decay_scale > 0.f ? d.decay_scale : 1.f;
+    for (int f = 0; f < d.ndecay; ++f) orow[3 * Cc + h * d.ndecay + f] = (h16)(dD * dsc * (float)(f + 1) * dn * sg[f] * (1.f - sg[f]));
+    float* st = d.qstats + (((int64_t)r * d.heads + h) * T + s) * 4;
+    st[0] = L;
+    st[1] = delta;
+    st[2] = D;
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void aero_attn_bwd_kv_mfma_kernel(AeroAttnBwdK p) {
+    constexpr int DP = 16 * ND, LT = AERO_ATTN_TK + 4;
+    __shared__ AERO_LDS_ALIGN h16 Qr[AERO_ATTN_TK * DP];        // [query][dim], pre-scaled by 1/sqrt(dh)
+    __shared__ AERO_LDS_ALIGN h16 Or[AERO_ATTN_TK * DP];        // dO [query][dim]
+    __shared__ AERO_LDS_ALIGN h16 Qt[DP * LT];                   // [dim][query]
+    __shared__ AERO_LDS_ALIGN h16 Ot[DP * LT];
+    __shared__ AERO_LDS_ALIGN float St[AERO_ATTN_TK][4];
+    const aero_attn_bwd_desc& d = p.d;
+    const int dh = p.dh, T = d.T, Cc = d.C;
+    const int h = blockIdx.y, r = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const int t = blockIdx.x * 64 + wave * 16 + col;             // this lane's key (MFMA column)
+    const h16* base = (const h16*)d.qkvd + (int64_t)r * T * d.ld;
+    const float qscale = aero_rsqrt((float)dh);
+    h16x4_t kb[ND], vb[ND];                                      // B operands: K^T, V^T (dims 4g..4g+3 of tile n, key col)
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+        kb[n] = (h16x4_t){0, 0, 0, 0};
+        vb[n] = (h16x4_t){0, 0, 0, 0};
+    }
+    if (t < T) {
+        const h16* row = base + (int64_t)t * d.ld + h * dh;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = n * 16 + g * 4 + e;
+                if (i < dh) { kb[n][e] = row[Cc + i]; vb[n][e] = row[2 * Cc + i]; }
+            }
+    }
+    f32x4 dk[ND], dv[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) { dk[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const float* qst = d.qstats + ((int64_t)r * d.heads + h) * T * 4;
+    for (int s0 = 0; s0 < T; s0 += AERO_ATTN_TK) {
+        __syncthreads();
+        for (int idx = tid; idx < AERO_ATTN_TK * DP; idx += 256) {
+            const int ss = idx / DP, i = idx - ss * DP;
+            h16 qv = (h16)0, ov = (h16)0;
+            if (s0 + ss < T && i < dh) {
+                qv = (h16)((float)base[(int64_t)(s0 + ss) * d.ld + h * dh + i] * qscale);
+                ov = ((const h16*)d.dout)[((int64_t)r * T + s0 + ss) * Cc + h * dh + i];
+            }
+            Qr[ss * DP + i] = qv;
+            Or[ss * DP + i] = ov;
+            Qt[i * LT + ss] = qv;
+            Ot[i * LT + ss] = ov;
+        }
+        for (int idx = tid; idx < AERO_ATTN_TK * 4; idx += 256) {
+            const int ss = idx >> 2, e = idx & 3;
+            St[ss][e] = (s0 + ss < T) ? qst[(int64_t)(s0 + ss) * 4 + e] : (e == 0 ? 1e30f : 0.f);      // L = +inf: P = 0 beyond T
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qt = 0; qt < AERO_ATTN_TK / 16; ++qt) {
+            if (s0 + qt * 16 >= T) break;
+            f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < ND; ++n) {
+                const h16x4_t qa = *(const h16x4_t*)&Qr[(qt * 16 + col) * DP + n * 16 + g * 4];
+                const h16x4_t oa = *(const h16x4_t*)&Or[(qt * 16 + col) * DP + n * 16 + g * 4];
+                sc = __builtin_amdgcn_mfma_f32_16x16x16f16(qa, kb[n], sc, 0, 0, 0);       // rows: queries 4g + e, column: key col
+                dp = __builtin_amdgcn_mfma_f32_16x16x16f16(oa, vb[n], dp, 0, 0, 0);
+            }
+            h16x4_t pv = (h16x4_t){0, 0, 0, 0}, dsv = (h16x4_t){0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ss = qt * 16 + g * 4 + e, sq = s0 + ss;
+                const float sv = (t == sq) ? -100.f : sc[e] - fabsf((float)(t - sq)) * St[ss][2];
+                const float P = aero_fast_exp(sv - St[ss][0]);
+                pv[e] = (h16)P;
+                dsv[e] = (h16)((t == sq) ? 0.f : P * (dp[e] - St[ss][1]));
+            }
+#pragma unroll
+            for (int n = 0; n < ND; ++n) {
+                const h16x4_t ob = *(const h16x4_t*)&Ot[(n * 16 + col) * LT + qt * 16 + g * 4];
+                const h16x4_t qb = *(const h16x4_t*)&Qt[(n * 16 + col) * LT + qt * 16 + g * 4];
+                dv[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(pv, ob, dv[n], 0, 0, 0);    // rows: keys 4g + e of the wave, column: dim
+                dk[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(dsv, qb, dk[n], 0, 0, 0);
+            }
+        }
+    }
+    h16* outb = (h16*)d.dqkvd + (int64_t)r * T * d.ld;
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int tk = blockIdx.x * 64 + wave * 16 + g * 4 + e, i = n * 16 + col;
+            if (tk < T && i < dh) {
+                outb[(int64_t)tk * d.ld + Cc + h * dh + i] = (h16)dk[n][e];
+                outb[(int64_t)tk * d.ld + 2 * Cc + h * dh + i] = (h16)dv[n][e];
+            }
+        }
+}
+
 static int aero_attn_bwd_launch(const aero_attn_bwd_desc* d, hipStream_t stream, const char** err) {
     if (!d || !d->qkvd || !d->out || !d->dout || !d->dqkvd || !d->qstats) { *err = "localstate_bwd: null pointer"; return AERO_ERR_ARG; }
     if (d->R < 1 || d->T < 1 || d->heads < 1 || d->C % d->heads || d->ndecay < 0 || d->ndecay > 8 || d->ld < 3 * d->C + d->heads * d->ndecay) {
@@ -622,6 +864,19 @@ static int aero_attn_bwd_launch(const aero_attn_bwd_desc* d, hipStream_t stream,
     p.d = *d;
     p.dh = d->C / d->heads;
     if (p.dh > 32) { *err = "localstate_bwd: more than 32 channels per head"; return AERO_ERR_UNSUPPORTED; }
+    static int valu = -1;                                        // AERO_ATTN_BWD_VALU=1: the fp32 VALU form (A/B, and dh > 32 never reaches here)
+    if (valu < 0) { const char* e = getenv("AERO_ATTN_BWD_VALU"); valu = (e && e[0] == '1') ? 1 : 0; }
+    if (!valu) {
+        dim3 mgrid((unsigned)((d->T + 63) / 64), (unsigned)d->heads, (unsigned)d->R), mblock(256);
+        if (p.dh <= 16) {
+            AERO_LAUNCH(aero_attn_bwd_q_mfma_kernel<1>, mgrid, mblock, stream, p);
+            AERO_LAUNCH(aero_attn_bwd_kv_mfma_kernel<1>, mgrid, mblock, stream, p);
+        } else {
+            AERO_LAUNCH(aero_attn_bwd_q_mfma_kernel<2>, mgrid, mblock, stream, p);
+            AERO_LAUNCH(aero_attn_bwd_kv_mfma_kernel<2>, mgrid, mblock, stream, p);
+        }
+        return AERO_OK;
+    }
     dim3 grid((unsigned)((d->T + AERO_ATTN_OWN - 1) / AERO_ATTN_OWN), (unsigned)d->heads, (unsigned)d->R), block(128);
 #define AERO_ATTN_BWD_GO(DP_)                                                         \
     do {                                                                              \

@@ -24,6 +24,7 @@
  *       AERO_NORM_CHUNK_KB                                                      (GroupNorm work-item size)
  *       AERO_STFT_DFT_BLOCKS                                                    (GEMM-form STFT: blocks per (signal, table quarter))
  *       AERO_WGRAD_256, AERO_WGRAD_ABL                                          (weight-gradient tile / ablations)
+ *       AERO_ATTN_BWD_VALU, AERO_RING_TILE192                                   (LocalState backward form; ring-tile A/B)
  *     The Python host side has its own AERO_* switches (aero_amd/engine.py); they never reach the library.
  */
 #ifndef AERO_HIP_H

@@ -304,7 +304,7 @@ def test_stft_loss_value_and_gradient(emu, geom):
     oc.case_stft_loss(emu, DEV, *geom)
 
 
-@pytest.mark.parametrize('a', [(16, 4, 2, 77), (48, 4, 1, 150)])
+@pytest.mark.parametrize('a', [(16, 4, 2, 77), (48, 4, 1, 150), (96, 4, 1, 70)])
 def test_localstate_bwd(emu, a):
     oc.case_localstate_bwd(emu, DEV, *a)
 
@@ -338,4 +338,17 @@ def test_stft_dft_blocks_walk_several_time_tiles():
             "oc.case_stft(_lib.load(build()), 'cpu', 512, 16, 128, 5000, B=2, dft=True)\nprint('ok')\n"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_STFT_DFT_BLOCKS': '1'}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
+
+
+def test_localstate_bwd_valu_form():
+    """AERO_ATTN_BWD_VALU=1: the fp32 VALU form of the LocalState backward (the default is the MFMA form)"""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import op_cases as oc\nfrom aero_amd import _lib\nfrom emu.build_emu import build\n"
+            "oc.case_localstate_bwd(_lib.load(build()), 'cpu', 48, 4, 1, 150)\nprint('ok')\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_ATTN_BWD_VALU': '1'}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
