@@ -405,7 +405,10 @@ class HipEngine:
         self._key = None
         self._params, self._epoch = None, 0
         self._tables = _ShapeCache()
-        self.streams = int(os.environ.get('AERO_STREAMS', '1'))   # sub-batches in flight on separate HIP streams
+        # sub-batches in flight on separate HIP streams: 0 = auto (two from 32 clips up: the latency-bound recurrent launches of one half
+        # overlap with the MFMA / bandwidth-bound launches of the other: B = 64: 11.05 -> 10.72 ms, B = 128: 21.1 -> 20.2; neutral at 16,
+        # +1..6 % at <= 8 clips, where it stays off)
+        self.streams = int(os.environ.get('AERO_STREAMS', '0'))
         self.use_graph = os.environ.get('AERO_GRAPH', '0') != '0'  # replay the forward as a captured HIP graph (per input shape)
         # GroupNorm fused into conv epilogues (stat_mode 1-3 of aero_conv_fwd, lean epilogue paths).  Measured on MI355X:
         #  * DConv tail as a recompute pair (statistics pass without stores + normalise/GLU/LayerScale/skip pass): the
@@ -671,7 +674,8 @@ class HipEngine:
         the others.  Results are identical to the single-stream order (per-clip arithmetic does not change)."""
         if train:
             return self._forward_one(mix, want_spec, want_lr_spec, train=True)
-        ns = min(self.streams, mix.shape[0]) if mix.is_cuda else 1
+        want = self.streams if self.streams > 0 else (2 if mix.shape[0] >= 32 else 1)
+        ns = min(want, mix.shape[0]) if mix.is_cuda else 1
         if self.use_graph and mix.is_cuda and self.ops.prof is None and not self.lib.is_emulator:
             return self._forward_graph(mix, want_spec, want_lr_spec)
         if ns <= 1 or self.ops.prof is not None:

@@ -214,3 +214,19 @@ def test_train_mode_forward_golden(meta):
     reference's train-mode output."""
     from test_emu_model import _train_golden
     _train_golden(build_model(meta, 'tiny').cuda(), load_npz('train_tiny_io.npz'))
+
+
+def test_two_stream_forward_equals_one_stream(meta):
+    """From 32 clips up the forward runs as two half-batches on two HIP streams (engine.py: AERO_STREAMS auto): same per-clip results as
+    the single-stream order (clips are independent units; agreement to the fp64-atomics rounding of the GroupNorm sums)."""
+    m = build_model(meta, 'full').cuda()
+    eng = m._get_engine()
+    x = torch.randn(32, 1, 8000, generator=torch.Generator().manual_seed(5))
+    try:
+        eng.streams = 1
+        y1, s1, _ = _fwd(m, x)
+        eng.streams = 0
+        y2, s2, _ = _fwd(m, x)
+    finally:
+        eng.streams = 0
+    assert rel_l2(s2, s1) < 1e-5 and rel_l2(y2, y1) < 1e-5
