@@ -77,7 +77,8 @@ def _gconv_case(lib, dev, B, Cin, Cout, groups, K, stride, pad, T, reflect=0, sl
     bd.x, bd.w, bd.y, bd.dy, bd.dx, bd.dw, bd.db = _ptr(xc), _ptr(wc), _ptr(yk), _ptr(dyc), _ptr(dx), _ptr(dw), _ptr(db)
     bd.B, bd.Tin, bd.Cin, bd.Cout, bd.groups, bd.K, bd.stride, bd.pad, bd.reflect, bd.slope = B, T, Cin, Cout, groups, K, stride, pad, reflect, slope
     lib.call('aero_gconv1d_bwd', C.byref(bd), stream)
-    assert rel_l2(dx.float().cpu().permute(0, 2, 1), x.grad) < 5e-4
+    # (the LeakyReLU derivative is read off the fp16 output: an element whose fp32 pre-activation rounds across zero flips slope 0.2 <-> 1)
+    assert rel_l2(dx.float().cpu().permute(0, 2, 1), x.grad) < 2e-3
     # (fp32 atomics over up to ~5e4 positions per output: the sum order is not fixed)
     assert rel_l2(dw.cpu().permute(0, 2, 1), w.grad) < 2e-4 and rel_l2(db.cpu(), b.grad) < 2e-4
 
