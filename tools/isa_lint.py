@@ -1,0 +1,116 @@
+"""ISA lint of the gfx950 code object inside aero_amd/libaero_hip.so: a cheap guard for the hazard class that
+produced the two hardware-only wrong results of round 1 -- kernels that synchronise with RAW `s_barrier`s and stage
+operands with direct global->LDS copies, where (i) hipcc may schedule a register-only MFMA into the window between the LDS wait and
+the barrier that closes a phase, and (ii) a ring slot may be refilled by a `global_load_lds` that is not separated by a barrier from the
+last LDS reads of the previous phase.
+
+Per kernel it reports: barriers, direct-to-LDS copies, MFMAs, and
+  W1  MFMAs that sit between an `s_waitcnt ... lgkmcnt(0)` and the `s_barrier` that follows it with no LDS read in between
+      (the compiler moved matrix work into the wait -> barrier window);
+  W2  direct-to-LDS copies issued after LDS reads with NO `s_barrier` between the last `ds_read` and the copy (same basic block).
+Neither is an error by itself (W1 is harmless when the MFMA's operands were read before the wait; W2 when the slot is not the one being
+read): the report is for review whenever a kernel with rings of LDS slots changes, and `--strict K1,K2` fails if a named kernel's counts grow
+over the committed baseline (profiles/isa_lint_baseline.json).   usage: isa_lint.py [--write-baseline] [--strict]"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = '/opt/rocm/lib/llvm/bin'
+
+
+def disassemble(lib):
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, 'fat.bin'), os.path.join(td, 'gfx950.co')
+        subprocess.run([f'{LLVM}/llvm-objcopy', '-O', 'binary', '--only-section=.hip_fatbin', lib, fat], check=True)
+        subprocess.run([f'{LLVM}/clang-offload-bundler', '--type=o', f'--input={fat}', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
+                        f'--output={co}', '--unbundle'], check=True)
+        return subprocess.run([f'{LLVM}/llvm-objdump', '-d', co], check=True, capture_output=True, text=True).stdout
+
+
+def lint(text):
+    out = {}
+    name, ins = None, []
+
+    def flush():
+        if name is None or not ins:
+            return
+        nbar = sum(i.startswith('s_barrier') for i in ins)
+        nglds = sum(('global_load_lds' in i) or (i.startswith('buffer_load') and ' lds' in i) for i in ins)
+        nmfma = sum(i.startswith('v_mfma') for i in ins)
+        w1 = w2 = 0
+        in_window, mf_in_window = False, 0
+        reads_since_barrier = 0
+        for i in ins:
+            if i.startswith('s_waitcnt') and 'lgkmcnt(0)' in i:
+                in_window, mf_in_window = True, 0
+            elif i.startswith('ds_read') or i.startswith('ds_load'):
+                in_window = False
+                reads_since_barrier += 1
+            elif i.startswith('v_mfma') and in_window:
+                mf_in_window += 1
+            elif i.startswith('s_barrier'):
+                if in_window:
+                    w1 += mf_in_window
+                in_window = False
+                reads_since_barrier = 0
+            elif ('global_load_lds' in i) or (i.startswith('buffer_load') and ' lds' in i):
+                if reads_since_barrier:
+                    w2 += 1
+            elif i.startswith(('s_cbranch', 's_branch', 's_endpgm')):
+                in_window = False
+        if nbar and (nglds or nmfma):
+            out[name] = {'barriers': nbar, 'lds_copies': nglds, 'mfma': nmfma, 'W1_mfma_in_wait_barrier_window': w1,
+                         'W2_lds_copy_after_reads_without_barrier': w2}
+    for line in text.splitlines():
+        m = re.match(r'^[0-9a-f]+ <(.+)>:$', line)
+        if m:
+            flush()
+            name, ins = m.group(1), []
+            continue
+        s = line.strip()
+        if s and not s.startswith(('//', 'Disassembly', 'gfx')) and name is not None:
+            ins.append(s.split('//')[0].strip())
+    flush()
+    return out
+
+
+def demangle(names):
+    try:
+        p = subprocess.run([f'{LLVM}/llvm-cxxfilt'], input='\n'.join(names), capture_output=True, text=True, check=True)
+        return dict(zip(names, p.stdout.splitlines()))
+    except Exception:
+        return {n: n for n in names}
+
+
+def main():
+    lib = os.path.join(ROOT, 'aero_amd', 'libaero_hip.so')
+    rep = lint(disassemble(lib))
+    dm = demangle(list(rep))
+    rep = {dm[k].split('(')[0].replace('void ', ''): v for k, v in rep.items()}
+    base_path = os.path.join(ROOT, 'profiles', 'isa_lint_baseline.json')
+    if '--write-baseline' in sys.argv:
+        json.dump(rep, open(base_path, 'w'), indent=1, sort_keys=True)
+    bad = []
+    if os.path.exists(base_path):
+        base = json.load(open(base_path))
+        for k, v in rep.items():
+            b = base.get(k)
+            if b and (v['W1_mfma_in_wait_barrier_window'] > b['W1_mfma_in_wait_barrier_window'] or
+                      v['W2_lds_copy_after_reads_without_barrier'] > b['W2_lds_copy_after_reads_without_barrier']):
+                bad.append((k, b, v))
+    print(f'{len(rep)} kernels with barriers + (MFMA | direct-to-LDS copies)')
+    print(f'{"kernel":70s} {"bar":>4s} {"glds":>5s} {"mfma":>5s} {"W1":>4s} {"W2":>4s}')
+    for k, v in sorted(rep.items(), key=lambda kv: -(kv[1]['W1_mfma_in_wait_barrier_window'] + kv[1]['W2_lds_copy_after_reads_without_barrier'])):
+        print(f'{k[:70]:70s} {v["barriers"]:4d} {v["lds_copies"]:5d} {v["mfma"]:5d} {v["W1_mfma_in_wait_barrier_window"]:4d} {v["W2_lds_copy_after_reads_without_barrier"]:4d}')
+    if bad:
+        print('GREW over the baseline:', [b[0] for b in bad])
+        if '--strict' in sys.argv:
+            sys.exit(1)
+
+
+if __name__ == '__main__':
+    main()
