@@ -148,6 +148,7 @@ _PROTOS = {
     'aero_adam_step': (i32, [fp, fp, fp, fp, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float, vp]),
     'aero_adam_step_dev': (i32, [fp, fp, fp, fp, i64, C.c_float, C.c_float, C.c_float, C.c_float, fp, C.c_float, vp]),
     'aero_conv_wgrad': (i32, [C.POINTER(WgradDesc), vp]),
+    'aero_conv_wgrad_chunks': (i32, [i32, i32, i32, i32, i32]),
     'aero_norm_bwd_reduce': (i32, [C.POINTER(NormBwdDesc), vp]),
     'aero_norm_bwd_apply': (i32, [C.POINTER(NormBwdDesc), vp]),
     'aero_istft_bwd_prep': (i32, [fp, fp, fp, i32, i32, i32, i32, i32, vp]),

@@ -72,6 +72,15 @@ def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None, dw_acc=None
             dw_acc += dw
             return dw_acc, db
         return dw.contiguous(), db
+    if len(df) == 1 and df[0] == 0 and dt[0] == 0 and fstride == 1 and Fin == Fout and dy.is_contiguous() and x.is_contiguous():
+        # a pointwise product has no row structure: one long row (no ragged last 64-step segment per row -- the LSTM / attention
+        # layers come as [sequences, 1, 200, .]: 200 = 3 * 64 + 8), as far as the kernel's 32-bit in-row offsets reach
+        for lead in (1, B):
+            n = B * Fout * T // lead
+            if (n + 64) * max(M, Cc) + 512 < 2 ** 31:
+                dy, x = dy.view(lead, 1, n, M), x.view(lead, 1, n, Cc)
+                B, Fout, Fin, T = lead, 1, 1, n
+                break
     d = _lib.WgradDesc()
     d.dy, d.x = _ptr(dy), _ptr(x)
     d.dy_b, d.dy_f, d.dy_t = _strides4(dy)
@@ -84,13 +93,12 @@ def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None, dw_acc=None
     for i, (a, b_) in enumerate(zip(df, dt)):
         d.df[i], d.dt[i] = a, b_
     if nslab is None:
-        # row chunks: enough blocks to fill the chip (4096 / tiles), but no chunk shorter than ~2048 positions (64 steps of the
-        # kernel) -- each chunk costs a [taps, M, C] fp32 slab written and read back: on the LSTM / attention 1x1 shapes of
-        # config 5 (57 600 positions, 384 x 96) 256 chunks meant 38 MB of slab traffic for a 4-GFLOP product (0.28 ms -> see DESIGN 4.8)
-        tiles = ((M + 127) // 128) * ((Cc + 127) // 128) * len(df)
-        nslab = max(1, min(-(-4096 // tiles), 256, B * Fout, (B * Fout * T) // 2048, (1 << 30) // (len(df) * M * Cc * 4)))
+        # position chunks: the launcher's own plan (enough blocks to fill the chip; a chunk's partial tile -- written, then read back
+        # by the finish kernel -- under a quarter of the operand bytes the chunk reads), within a 1-GiB workspace
+        nslab = ops.lib.cdll.aero_conv_wgrad_chunks(M, Cc, len(df), B * Fout, T)
+        nslab = max(1, min(nslab, (1 << 28) // (len(df) * M * Cc + M)))
     if nslab:                                   # per-chunk partial slabs added in fixed order (deterministic); nslab = 0: fp32 atomics
-        slabs = torch.empty(nslab, len(df), M, Cc, dtype=torch.float32, device=dy.device)
+        slabs = torch.empty(nslab, len(df) * M * Cc + (M if bias else 0), dtype=torch.float32, device=dy.device)
         d.slabs, d.nslab = _ptr(slabs), nslab
     ops.lib.call('aero_conv_wgrad', C.byref(d), ops.stream(dy))
     return dw, db

@@ -220,6 +220,14 @@ int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream) {
     return aero_finish(rc, err);
 }
 
+int aero_conv_wgrad_chunks(int32_t M, int32_t C, int32_t ntaps, int32_t nrows, int32_t T) {
+    if (M < 1 || C < 1 || ntaps < 1 || nrows < 1 || T < 1) return 1;
+    bool big;
+    int nchunk, SC;
+    aero_wgrad_plan(M, C, ntaps, nrows, T, &big, &nchunk, &SC);
+    return nchunk;
+}
+
 int aero_norm_bwd_reduce(const aero_norm_bwd_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_norm_bwd_launch(d, 0, (hipStream_t)stream, &err);

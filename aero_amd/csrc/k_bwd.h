@@ -24,7 +24,7 @@
 // torch's own weight gradients do).
 struct AeroWgradK {
     aero_wgrad_desc d;
-    int nmt, nct, RC, nchunk, noswz;
+    int nmt, nct, SC, nchunk, noswz; int64_t w_n, sl_stride;                 // SC = 64-position steps per chunk; w_n = ntaps * M * C
 };
 
 static __device__ __forceinline__ void aero_transpose8x8(const h16x8* r, h16x8* c) {
@@ -68,9 +68,9 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
     const int opnd = tid >> 7, o = tid & 15, g8 = (tid >> 4) & 7;
     const int dtj = d.dt[tap], dfj = d.df[tap];
     const int nrows = d.B * d.Fout;
-    const int r_lo = chunk * p.RC;
-    const int r_hi = r_lo + p.RC < nrows ? r_lo + p.RC : nrows;
     const int nT = (d.T + 63) >> 6;
+    const int it_lo = chunk * p.SC;                           // chunks are runs of the linear step index (row, 64-step segment): a tensor
+    const int it_hi = it_lo + p.SC < nrows * nT ? it_lo + p.SC : nrows * nT;   // of few long rows still fills the chip
     const h16* zpv = aero_zero_page;
     const int ch = (opnd ? c0 : m0) + 8 * o;                  // first of this thread's 8 channels
     const bool ch_ok = ch < (opnd ? d.C : d.M);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
     const int st_e = (int)(opu ? d.x_t : d.dy_t);
     const int coff = ch + 8 * g8 * st_e;                      // (the eight positions of a lane add block-uniform multiples of the step stride)
     auto load = [&](int it) {
-        const int row = r_lo + it / nT, t0 = (it % nT) * 64;
+        const int row = (it_lo + it) / nT, t0 = (it_lo + it - row * nT) * 64;
         const int b = row / d.Fout, fo = row - b * d.Fout;
         const int fi = fo * d.fstride + dfj;
         const bool row_ok = fi >= 0 && fi < d.Fin;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
             r[i] = *(const h16x8*)(ok ? base + (int64_t)tt * st : zpv);
         }
     };
-    const int nit = (r_hi - r_lo) * nT;
+    const int nit = it_hi - it_lo;
     if (nit > 0) load(0);
     for (int it = 0; it < nit; ++it) {
         h16x8 c[8];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
     if (d.slabs) {
         // this chunk's partial tile -> its own slab with plain 16-byte stores (a lane's eight j' are eight consecutive c);
         // aero_wgrad_finish_kernel adds the slabs in chunk order: deterministic, and no scattered 4-byte atomics
-        float* sl = d.slabs + ((int64_t)chunk * d.ntaps + tap) * d.M * d.C;
+        float* sl = d.slabs + (int64_t)chunk * p.sl_stride + (int64_t)tap * d.M * d.C;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -172,10 +172,21 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
                 if (m < d.M && cc < d.C && !(p.noswz & 2)) atomicAdd(dw + (int64_t)m * d.C + cc, acc[a][j][i]);
             }
     }
-    if (do_bias && ch_ok) {
+    if (d.db != nullptr && ct == 0 && tap == 0) {            // (block-uniform) the eight position octets of a channel: summed in fixed order
+        __syncthreads();
+        float* bs = (float*)&FR2[0][0][0][0][0];               // [8][128]
+        if (opnd == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (ch + j < d.M) atomicAdd(d.db + ch + j, bsum[j]);
+            for (int j = 0; j < 8; ++j) bs[g8 * 128 + 8 * o + j] = bsum[j];
+        }
+        __syncthreads();
+        if (tid < 128 && m0 + tid < d.M) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) sacc += bs[g * 128 + tid];
+            if (d.slabs) d.slabs[(int64_t)chunk * p.sl_stride + p.w_n + m0 + tid] = sacc;
+            else atomicAdd(d.db + m0 + tid, sacc);
+        }
     }
 }
 
@@ -198,9 +209,9 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
     const int half = o32 >> 4, o = o32 & 15;
     const int dtj = d.dt[tap], dfj = d.df[tap];
     const int nrows = d.B * d.Fout;
-    const int r_lo = chunk * p.RC;
-    const int r_hi = r_lo + p.RC < nrows ? r_lo + p.RC : nrows;
     const int nT = (d.T + 63) >> 6;
+    const int it_lo = chunk * p.SC;                           // chunks are runs of the linear step index (row, 64-step segment): a tensor
+    const int it_hi = it_lo + p.SC < nrows * nT ? it_lo + p.SC : nrows * nT;   // of few long rows still fills the chip
     const h16* zpv = aero_zero_page;
     const int ch = (opnd ? c0 : m0) + 128 * half + 8 * o;
     const bool ch_ok = ch < (opnd ? d.C : d.M);
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
     const int st_e = (int)(opu ? d.x_t : d.dy_t);
     const int coff = ch + 8 * g8 * st_e;                      // (the eight positions of a lane add block-uniform multiples of the step stride)
     auto load = [&](int it) {
-        const int row = r_lo + it / nT, t0 = (it % nT) * 64;
+        const int row = (it_lo + it) / nT, t0 = (it_lo + it - row * nT) * 64;
         const int b = row / d.Fout, fo = row - b * d.Fout;
         const int fi = fo * d.fstride + dfj;
         const bool row_ok = fi >= 0 && fi < d.Fin;
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
     h16* wr = FR + ((((opnd * 2 + half) * 2 + (g8 >> 2)) * 8) * 64 + (o + 16 * (g8 & 3))) * 8;
     const h16* ra = FR + (((0 * 2 + mh) * 2) * 8 * 64 + lane) * 8;
     const h16* rb = FR + (((1 * 2 + chh) * 2) * 8 * 64 + lane) * 8;
-    const int nit = (r_hi - r_lo) * nT;
+    const int nit = it_hi - it_lo;
     if (nit > 0) load(0);
     for (int it = 0; it < nit; ++it) {
         h16x8 c[8];
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
         }
     }
     if (d.slabs) {
-        float* sl = d.slabs + ((int64_t)chunk * d.ntaps + tap) * d.M * d.C;
+        float* sl = d.slabs + (int64_t)chunk * p.sl_stride + (int64_t)tap * d.M * d.C;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -305,20 +316,79 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
                 if (m < d.M && cc < d.C && !(p.noswz & 2)) atomicAdd(dw + (int64_t)m * d.C + cc, acc[a][j][i]);
             }
     }
-    if (do_bias && ch_ok) {
+    if (d.db != nullptr && ct == 0 && tap == 0) {
+        __syncthreads();
+        float* bs = (float*)FR;                                // [8][256]
+        if (opnd == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (ch + j < d.M) atomicAdd(d.db + ch + j, bsum[j]);
+            for (int j = 0; j < 8; ++j) bs[g8 * 256 + 8 * o32 + j] = bsum[j];
+        }
+        __syncthreads();
+        if (tid < 256 && m0 + tid < d.M) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) sacc += bs[g * 256 + tid];
+            if (d.slabs) d.slabs[(int64_t)chunk * p.sl_stride + p.w_n + m0 + tid] = sacc;
+            else atomicAdd(d.db + m0 + tid, sacc);
+        }
     }
 }
 
-// dw[e] += slab_0[e] + slab_1[e] + ... in chunk order (n = ntaps * M * C, a multiple of 4)
-__global__ __launch_bounds__(256) void aero_wgrad_finish_kernel(const float* slabs, int nslab, float* dw, int64_t n) {
-    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (int64_t)gridDim.x * 1024) {
-        f32x4 v = *(const f32x4*)(dw + e);
-        for (int sidx = 0; sidx < nslab; ++sidx) v += *(const f32x4*)(slabs + (int64_t)sidx * n + e);
-        *(f32x4*)(dw + e) = v;
+// dw[e] += slab_0[e] + slab_1[e] + ... (e < w_n) and db[e - w_n] += ... (the bias partials behind each chunk's tile), in a FIXED
+// order: thread (q, s) adds slabs s, s + 8, ... of element quad q (independent loads, four in flight), the eight lane sums are then
+// added in lane order.  (One thread walking all slabs of its quad was a chain of nslab dependent L2 / HBM round trips.)
+__global__ __launch_bounds__(256) void aero_wgrad_finish_kernel(const float* slabs, int nslab, int64_t stride, float* dw, int64_t w_n, float* db, int64_t n) {
+    __shared__ f32x4 part[8][32];
+    const int q = threadIdx.x & 31, s = threadIdx.x >> 5;
+    const int64_t e = ((int64_t)blockIdx.x * 32 + q) * 4;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (e < n) {
+        const float* src = slabs + e;
+        int k = s;
+        for (; k + 24 < nslab; k += 32) {
+            const f32x4 a0 = *(const f32x4*)(src + (int64_t)k * stride);
+            const f32x4 a1 = *(const f32x4*)(src + (int64_t)(k + 8) * stride);
+            const f32x4 a2 = *(const f32x4*)(src + (int64_t)(k + 16) * stride);
+            const f32x4 a3 = *(const f32x4*)(src + (int64_t)(k + 24) * stride);
+            v += a0; v += a1; v += a2; v += a3;
+        }
+        for (; k < nslab; k += 8) v += *(const f32x4*)(src + (int64_t)k * stride);
     }
+    part[s][q] = v;
+    __syncthreads();
+    if (s == 0 && e < n) {
+        f32x4 t = part[0][q];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += part[i][q];
+        float* dst = e < w_n ? dw + e : db + (e - w_n);
+        *(f32x4*)dst += t;
+    }
+}
+
+// Tile size and number of position chunks of a weight-gradient launch (also exported: the caller sizes `slabs` with it).
+// Chunks are runs of 64-position steps.  Enough blocks to fill the chip several times over (a block's steps are a chain of
+// load -> transpose -> exchange -> MFMA round trips, ~1.7 us each: parallelism is what hides them), but a chunk's partial tile
+// (written, then read back by the finish kernel) stays under ~1/4 of the operand bytes the chunk reads.
+static void aero_wgrad_plan(int M, int C, int ntaps, int nrows, int T, bool* big_out, int* nchunk_out, int* SC_out) {
+    const char* e256 = getenv("AERO_WGRAD_256");             // (read per call: tests/op_cases.py forces the 256 tile on small shapes)
+    const int mode = e256 ? atoi(e256) : 1;
+    // AERO_WGRAD_256: 0 never, 2 whenever both sides are >= 192 channels (tests), default: only the widest layers -- measured
+    // D0 (1536 x 768) 427 -> 510 TF/s, D1 (768 x 384) 380 -> 366: with one 8-wave block per CU the smaller problem has too few tiles
+    const bool big = mode && M >= 192 && C >= 192 && (mode == 2 || (long)M * C >= 768L * 1024);
+    const int TS = big ? 256 : 128;
+    const long tiles = (long)((M + TS - 1) / TS) * ((C + TS - 1) / TS) * ntaps;
+    const long nsteps = (long)nrows * ((T + 63) / 64);
+    const long Mc = M < TS ? M : TS, Cc = C < TS ? C : TS;
+    long min_steps = (Mc * Cc + 4 * (Mc + Cc) - 1) / (4 * (Mc + Cc));
+    if (min_steps < 4) min_steps = 4;
+    long nchunk = ((big ? 1024 : 2048) + tiles - 1) / tiles;
+    if (nchunk > nsteps / min_steps) nchunk = nsteps / min_steps;
+    if (nchunk > 512) nchunk = 512;
+    if (nchunk < 1) nchunk = 1;
+    const long SC = (nsteps + nchunk - 1) / nchunk;
+    *big_out = big;
+    *SC_out = (int)SC;
+    *nchunk_out = (int)((nsteps + SC - 1) / SC);
 }
 
 static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, const char** err) {
@@ -326,40 +396,43 @@ static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, 
     if (d->ntaps < 1 || d->ntaps > 9 || d->B < 1 || d->Fin < 1 || d->Fout < 1 || d->T < 1 || d->M < 1 || d->C < 1 || d->fstride < 1) {
         *err = "wgrad: bad geometry"; return AERO_ERR_ARG;
     }
-    if (d->slabs && (d->nslab < 1 || ((uintptr_t)d->slabs & 15) || ((uintptr_t)d->dw & 15))) { *err = "wgrad: slabs / dw must be 16-byte aligned, nslab >= 1"; return AERO_ERR_ARG; }
+    if (d->slabs && (d->nslab < 1 || ((uintptr_t)d->slabs & 15) || ((uintptr_t)d->dw & 15) || ((uintptr_t)d->db & 15))) {
+        *err = "wgrad: slabs / dw / db must be 16-byte aligned, nslab >= 1"; return AERO_ERR_ARG;
+    }
     if ((d->M % 8) || (d->C % 8) || (d->dy_b % 8) || (d->dy_f % 8) || (d->dy_t % 8) || (d->x_b % 8) || (d->x_f % 8) || (d->x_t % 8) ||
         ((uintptr_t)d->dy & 15) || ((uintptr_t)d->x & 15)) {
         *err = "wgrad: channel counts and strides must be multiples of 8 (16-byte aligned channel vectors)"; return AERO_ERR_UNSUPPORTED;
     }
     if ((int64_t)(d->T + 64) * d->dy_t + d->M + 256 > 0x7fffffffLL || (int64_t)(d->T + 64) * d->x_t + d->C + 256 > 0x7fffffffLL) { *err = "wgrad: rows too long for 32-bit in-row offsets"; return AERO_ERR_UNSUPPORTED; }
+    if ((int64_t)d->B * d->Fout * ((d->T + 63) / 64) > 0x3fffffffLL) { *err = "wgrad: too many positions"; return AERO_ERR_UNSUPPORTED; }
     AeroWgradK p;
     p.d = *d;
-    { const char* e = getenv("AERO_WGRAD_ABL"); p.noswz = e ? atoi(e) : 0; }       // ablation bits (timing experiments): 1 no XCD swizzle, 2 no atomics, 4 no loads after the first step
-    // AERO_WGRAD_256: 0 never, 2 whenever both sides are >= 192 channels (tests), default: only the widest layers -- measured
-    // D0 (1536 x 768) 427 -> 510 TF/s, D1 (768 x 384) 380 -> 366: with one 8-wave block per CU the smaller problem has too few tiles
-    const char* e256 = getenv("AERO_WGRAD_256");
-    const int mode = e256 ? atoi(e256) : 1;
-    const bool big = mode && d->M >= 192 && d->C >= 192 && (mode == 2 || (long)d->M * d->C >= 768L * 1024);
+    static const int abl = [] { const char* e = getenv("AERO_WGRAD_ABL"); return e ? atoi(e) : 0; }();
+    p.noswz = abl;                                            // ablation bits (timing experiments): 1 no XCD swizzle, 2 no atomics, 4 no loads after the first step
+    bool big;
+    int nchunk, SC;
+    const int nrows = d->B * d->Fout;
+    aero_wgrad_plan(d->M, d->C, d->ntaps, nrows, d->T, &big, &nchunk, &SC);
+    if (d->slabs && nchunk > d->nslab) {                      // a smaller workspace than planned: longer chunks
+        const long nsteps = (long)nrows * ((d->T + 63) / 64);
+        SC = (int)((nsteps + d->nslab - 1) / d->nslab);
+        nchunk = (int)((nsteps + SC - 1) / SC);
+    }
     const int TS = big ? 256 : 128;
     p.nmt = (d->M + TS - 1) / TS;
     p.nct = (d->C + TS - 1) / TS;
-    const long tiles = (long)p.nmt * p.nct * d->ntaps;
-    const int nrows = d->B * d->Fout;
-    long nchunk = ((big ? 1024 : 4096) + tiles - 1) / tiles;  // enough blocks to fill the chip a few times over
-    if (nchunk > nrows) nchunk = nrows;
-    if (d->slabs && nchunk > d->nslab) nchunk = d->nslab;
-    if (nchunk < 1) nchunk = 1;
-    p.RC = (int)((nrows + nchunk - 1) / nchunk);
-    p.nchunk = (nrows + p.RC - 1) / p.RC;
-    const long nb = tiles * p.nchunk;
+    p.SC = SC;
+    p.nchunk = nchunk;
+    p.w_n = (int64_t)d->ntaps * d->M * d->C;
+    p.sl_stride = p.w_n + (d->db ? d->M : 0);
+    const long nb = (long)p.nmt * p.nct * d->ntaps * p.nchunk;
     if (nb > 0x7fffffffL) { *err = "wgrad: grid too large"; return AERO_ERR_ARG; }
     if (big) AERO_LAUNCH_DYN(aero_conv_wgrad256_kernel, dim3((unsigned)nb), dim3(512), (size_t)128 * 1024, stream, p);
     else AERO_LAUNCH(aero_conv_wgrad_kernel, dim3((unsigned)nb), dim3(256), stream, p);
     if (d->slabs) {
-        const int64_t n = (int64_t)d->ntaps * d->M * d->C;
-        int64_t fb = (n / 4 + 255) / 256;
-        if (fb > 2048) fb = 2048;
-        AERO_LAUNCH(aero_wgrad_finish_kernel, dim3((unsigned)fb), dim3(256), stream, (const float*)d->slabs, p.nchunk, d->dw, n);
+        const int64_t n = p.sl_stride;
+        const int64_t fb = (n / 4 + 31) / 32;
+        AERO_LAUNCH(aero_wgrad_finish_kernel, dim3((unsigned)fb), dim3(256), stream, (const float*)d->slabs, p.nchunk, p.sl_stride, d->dw, p.w_n, d->db, n);
     }
     return AERO_OK;
 }

@@ -23,7 +23,8 @@
  *       AERO_ATTN_FOLD                                                          (LocalState: folded vs streaming kernel)
  *       AERO_NORM_CHUNK_KB                                                      (GroupNorm work-item size)
  *       AERO_STFT_DFT_BLOCKS                                                    (GEMM-form STFT: blocks per (signal, table quarter))
- *       AERO_WGRAD_256, AERO_WGRAD_ABL                                          (weight-gradient tile / ablations)
+ *       AERO_WGRAD_ABL                                                          (weight-gradient ablations; AERO_WGRAD_256 -- the tile
+ *                                                                                choice -- is the one switch read at every call)
  *       AERO_ATTN_BWD_VALU, AERO_RING_TILE192                                   (LocalState backward form; ring-tile A/B)
  *     The Python host side has its own AERO_* switches (aero_amd/engine.py); they never reach the library.
  */
@@ -326,10 +327,12 @@ int aero_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, 
  *   dw[j][m][c] += sum_{b, fo, t} dy[b, fo, t, m] * x[b, fo*fstride + df[j], t + dt[j], c]      (x = 0 outside its rows / steps)
  *   db[m]       += sum_{b, fo, t} dy[b, fo, t, m]                                                (db may be NULL)
  * dy fp16 [B, Fout, T, M], x fp16 [B, Fin, T, C] (element strides; M, C and strides multiples of 8); dw fp32 [ntaps][M][C] and
- * db fp32 [M] are ACCUMULATED (the caller zeroes them).  The positions are cut into row chunks for parallelism: with
- * slabs == NULL the chunks add their partial tiles to dw with fp32 atomics (sum order not fixed); with a workspace
- * slabs fp32 [nslab][ntaps][M][C] each chunk (at most nslab of them) stores its partial with plain vector stores and a second
- * kernel adds them to dw in chunk order -- deterministic, and faster (no scattered 4-byte atomics). */
+ * db fp32 [M] are ACCUMULATED (the caller zeroes them).  The positions (b, fo, t) are cut into chunks -- runs of 64-step segments in
+ * (b, fo, t) order -- for parallelism: with slabs == NULL the chunks add their partial tiles (and bias sums) with fp32 atomics (sum
+ * order not fixed); with a workspace slabs fp32 [nslab][ntaps*M*C + (db ? M : 0)] each chunk (at most nslab of them) stores its
+ * partial tile, followed by its bias partial, with plain stores and a second kernel adds them to dw / db in a fixed order --
+ * deterministic, and faster (no scattered 4-byte atomics).  aero_conv_wgrad_chunks: the number of chunks the launch would like for
+ * this geometry (nrows = B * Fout): the nslab to allocate; fewer is legal (longer chunks). */
 typedef struct {
     const void* dy; int64_t dy_b, dy_f, dy_t;
     const void* x; int64_t x_b, x_f, x_t;
@@ -339,6 +342,7 @@ typedef struct {
     float* slabs; int32_t nslab;
 } aero_wgrad_desc;
 int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream);
+int aero_conv_wgrad_chunks(int32_t M, int32_t C, int32_t ntaps, int32_t nrows, int32_t T);
 
 /* nn.GroupNorm + GELU / GLU(+LayerScale) backward (aero.py:56,127,133,148,198,214; modules.py:189,232-236).  x is the saved INPUT
  * of the norm (fp16 [B,F,T,C]), stats / stat_count the forward statistics (aero_norm_stats / the conv epilogues), dy the gradient

@@ -541,10 +541,10 @@ def case_wgrad_conv2d(lib, dev, Cin, Cout, kF, kT, Fr, T, B=2, seed=82):
         if Cin >= 192 and Cout >= 192:
             assert 'wgrad256' in ops.lib.cdll.aero_last_kernel_name().decode()
         dw, db = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt)                 # per-chunk slabs, added in order
-        dw2, _ = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt)
+        dw2, db2 = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt)
     finally:
         del os.environ['AERO_WGRAD_256']
-    assert torch.equal(dw, dw2)                                  # the slab form is deterministic
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)         # the slab form is deterministic (bias partials included)
     assert rel_l2(dwa.cpu(), dw.cpu()) < 1e-5
     got = dw.cpu().view(kF, kT, Cout, Cin).permute(2, 3, 0, 1)
     assert rel_l2(got, gw) < TOL16, rel_l2(got, gw)

@@ -76,8 +76,19 @@ def main():
     for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:22]:
         print(f'{v[1]:8.2f} ms {v[0]:5d} calls  {k}')
     print('-- aero_conv_wgrad by shape')
-    for k, v in sorted(wg.items(), key=lambda kv: -kv[1][1])[:16]:
-        print(f'{v[1]:8.3f} ms {v[0]:3d} calls  {k}')
+    import re
+    ideal_tot = 0.0
+    for k, v in sorted(wg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('WGRAD_ROWS', '16'))]:
+        # memory floor of one call: both operands read once at 4 TB/s (what a streaming kernel reaches here), dw written once
+        dims = [int(t) for t in re.findall(r'\d+', k)]
+        dyn = dims[0] * dims[1] * dims[2] * dims[3]
+        xn = dims[4] * dims[5] * dims[6] * dims[7]
+        byt = 2 * (dyn + xn) + 4 * dims[8] * dims[3] * dims[7]
+        fl = 2.0 * dyn * dims[7] * dims[8]
+        floor = max(byt / 4e12, fl / 1.2e15) * 1e3
+        ideal_tot += floor * v[0]
+        print(f'{v[1]:8.3f} ms {v[0]:3d} calls  {k}   per call {v[1] / v[0] * 1e3:7.1f} us, floor {floor * 1e3:6.1f} us')
+    print(f'   (sum of floors of the rows shown: {ideal_tot:.2f} ms)')
 
 
 if __name__ == '__main__':
