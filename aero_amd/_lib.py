@@ -48,7 +48,8 @@ class WgradDesc(C.Structure):
                 ('x', vp), ('x_b', i64), ('x_f', i64), ('x_t', i64),
                 ('dw', fp), ('db', fp),
                 ('B', i32), ('Fin', i32), ('Fout', i32), ('T', i32), ('M', i32), ('C', i32), ('ntaps', i32), ('fstride', i32),
-                ('df', i32 * 9), ('dt', i32 * 9), ('slabs', fp), ('nslab', i32)]
+                ('df', i32 * 9), ('dt', i32 * 9), ('slabs', fp), ('nslab', i32),
+                ('store', i32), ('dw_layout', i32), ('dw_rowlen', i32), ('dw_coff', i32)]
 
 
 class NormBwdDesc(C.Structure):

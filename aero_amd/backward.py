@@ -55,14 +55,23 @@ import ctypes as C  # noqa: E402
 from .engine import _ptr, _strides4  # noqa: E402
 
 
-def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None, dw_acc=None):
+def wgrad_direct_ok(dy, x):
+    """can conv_wgrad write straight into a caller's destination for these operands?  (8-aligned channel counts: no padded copies)"""
+    return dy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0
+
+
+def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None, dw_acc=None, dw_out=None, db_out=None, layout=0, rowlen=0, coff=0):
     """dy fp16 [B,Fout,T,M], x fp16 [B,Fin,T,C] (channels-last) -> (dw fp32 [ntaps, M, C], db fp32 [M] or None):
     dw[j][m][c] = sum dy[b,fo,t,m] * x[b, fo*fstride + df[j], t + dt[j], c]  (aero_conv_wgrad).  dw_acc: an earlier result to accumulate
-    into (the kernel adds to dw), e.g. the second source of a two-source conv."""
+    into (the kernel adds to dw), e.g. the second source of a two-source conv.
+    dw_out / db_out: fp32 destinations the result is ADDED to in place (views of the flat gradient buffer; nothing is allocated, filled
+    or copied) -- dw_out with layout 0 as [ntaps, M, C], with layout 1 in the layout of the nn.Conv weight itself,
+    [M, rowlen, taps] at column offset coff (include/aero_hip.h, aero_wgrad_desc).  Needs 8-aligned M and C (`wgrad_direct_ok`)."""
     B, Fout, T, M = dy.shape
     Bx, Fin, Tx, Cc = x.shape
     assert B == Bx and T == Tx and len(df) == len(dt)
     if M % 8 or Cc % 8:
+        assert dw_out is None and db_out is None
         # narrow sides (the last decoder's 2 output channels, the FTB's 5): zero-padded copies to the kernel's 8-channel vectors
         # (data movement only), the padding rows / columns of the result dropped
         pad = lambda t: torch.nn.functional.pad(t, (0, -t.shape[-1] % 8))       # noqa: E731
@@ -85,18 +94,33 @@ def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None, dw_acc=None
     d.dy, d.x = _ptr(dy), _ptr(x)
     d.dy_b, d.dy_f, d.dy_t = _strides4(dy)
     d.x_b, d.x_f, d.x_t = _strides4(x)
-    dw = torch.zeros(len(df), M, Cc, dtype=torch.float32, device=dy.device) if dw_acc is None else dw_acc
-    assert dw.shape == (len(df), M, Cc) and dw.is_contiguous()
-    db = torch.zeros(M, dtype=torch.float32, device=dy.device) if bias else None
-    d.dw, d.db = _ptr(dw), _ptr(db)
+    plan = nslab if nslab is not None else ops.lib.cdll.aero_conv_wgrad_chunks(M, Cc, len(df), B * Fout, T)
+    store = dw_acc is None and dw_out is None and db_out is None and plan > 0   # fresh outputs, slab form: written, not added to
+    if dw_out is not None:
+        assert dw_acc is None and dw_out.dtype == torch.float32 and dw_out.is_contiguous() and plan > 0
+        assert dw_out.numel() == len(df) * M * (rowlen or Cc) and coff + Cc <= (rowlen or Cc)
+        dw = dw_out
+        d.dw_layout, d.dw_rowlen, d.dw_coff = layout, rowlen, coff
+    elif dw_acc is not None:
+        dw = dw_acc
+        assert dw.shape == (len(df), M, Cc) and dw.is_contiguous()
+    else:
+        dw = (torch.empty if store else torch.zeros)(len(df), M, Cc, dtype=torch.float32, device=dy.device)
+    if not bias:
+        db = None
+    elif db_out is not None:
+        assert db_out.dtype == torch.float32 and db_out.is_contiguous() and db_out.numel() == M and not store
+        db = db_out
+    else:
+        db = (torch.empty if store else torch.zeros)(M, dtype=torch.float32, device=dy.device)
+    d.dw, d.db, d.store = _ptr(dw), _ptr(db), int(store)
     d.B, d.Fin, d.Fout, d.T, d.M, d.C, d.ntaps, d.fstride = B, Fin, Fout, T, M, Cc, len(df), fstride
     for i, (a, b_) in enumerate(zip(df, dt)):
         d.df[i], d.dt[i] = a, b_
     if nslab is None:
         # position chunks: the launcher's own plan (enough blocks to fill the chip; a chunk's partial tile -- written, then read back
         # by the finish kernel -- under a quarter of the operand bytes the chunk reads), within a 1-GiB workspace
-        nslab = ops.lib.cdll.aero_conv_wgrad_chunks(M, Cc, len(df), B * Fout, T)
-        nslab = max(1, min(nslab, (1 << 28) // (len(df) * M * Cc + M)))
+        nslab = max(1, min(plan, (1 << 28) // (len(df) * M * Cc + M)))
     if nslab:                                   # per-chunk partial slabs added in fixed order (deterministic); nslab = 0: fp32 atomics
         slabs = torch.empty(nslab, len(df) * M * Cc + (M if bias else 0), dtype=torch.float32, device=dy.device)
         d.slabs, d.nslab = _ptr(slabs), nslab
@@ -104,11 +128,13 @@ def conv_wgrad(ops, dy, x, df, dt, fstride=1, bias=True, nslab=None, dw_acc=None
     return dw, db
 
 
-def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, eps=1e-5, stat_count=None, snake_a=None):
+def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, eps=1e-5, stat_count=None, snake_a=None, out=None):
     """Backward of aero_norm_apply (GroupNorm + GELU / GLU(+LayerScale) / identity).  x: the norm's input fp16 [B,F,T,C]; stats: the
     forward statistics (fp64 sum / sum of squares per (item, group)); dy: gradient of the output.  Returns
     (dx fp16 [B,F,T,C], dgamma, dbeta fp32 [C], dlayer_scale fp32 [C/2] or None) -- and, for Snake (act 4, snake_a fp32 [F]), the
-    gradient of snake_a as a fifth item.  stats None = identity norm (the layers before norm_starts)."""
+    gradient of snake_a as a fifth item.  stats None = identity norm (the layers before norm_starts).
+    out: optional dict of fp32 destinations {'dgamma', 'dbeta', 'dls', 'dsn'} the kernel ADDS into (views of the flat gradient buffer);
+    what is not given comes out of ONE zero-filled scratch allocation (with the fp64 group sums)."""
     B, F, T, Cc = x.shape
     d = _lib.NormBwdDesc()
     d.x, d.dy = _ptr(x), _ptr(dy)
@@ -121,12 +147,28 @@ def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, 
     d.stats = _ptr(stats)
     d.stat_count = float((1 if per_row == 1 else (B * F if per_row == 2 else F)) * T * (Cc // G)) if stat_count is None else float(stat_count)
     d.gamma, d.beta, d.layer_scale, d.act = _ptr(gamma), _ptr(beta), _ptr(layer_scale), act
-    sums = None if (stats is None or per_row == 2) else torch.zeros_like(stats)
-    dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device) if gamma is not None else None
-    dbeta = torch.zeros(Cc, dtype=torch.float32, device=x.device) if beta is not None else None
-    dsn = torch.zeros(F, dtype=torch.float32, device=x.device) if snake_a is not None else None
+    out = out or {}
+    want = {'sums': (0 if (stats is None or per_row == 2) else stats.numel() * 2), 'dgamma': (Cc if gamma is not None else 0),
+            'dbeta': (Cc if beta is not None else 0), 'dsn': (F if snake_a is not None else 0),
+            'dls': (Cc // 2 if (layer_scale is not None and act == _lib.ACT_GLU) else 0)}        # fp32 words (the sums are fp64 pairs)
+    offs, n = {}, 0
+    for k, sz in want.items():
+        if sz and out.get(k) is None:
+            offs[k] = n
+            n += (sz + 3) // 4 * 4
+    scratch = torch.zeros(n, dtype=torch.float32, device=x.device) if n else None
+    res = {}
+    for k, sz in want.items():
+        if not sz:
+            res[k] = None
+        elif k in offs:
+            res[k] = scratch[offs[k]:offs[k] + sz]
+        else:
+            res[k] = out[k]
+            assert res[k].dtype == torch.float32 and res[k].is_contiguous() and res[k].numel() == sz
+    sums = None if res['sums'] is None else res['sums'].view(torch.float64).view(stats.shape)
+    dgamma, dbeta, dsn, dls = res['dgamma'], res['dbeta'], res['dsn'], res['dls']
     d.snake_a, d.dsnake_a = _ptr(snake_a), _ptr(dsn)
-    dls = torch.zeros(Cc // 2, dtype=torch.float32, device=x.device) if (layer_scale is not None and act == _lib.ACT_GLU) else None
     d.sums, d.dgamma, d.dbeta, d.dlayer_scale = _ptr(sums), _ptr(dgamma), _ptr(dbeta), _ptr(dls)
     ops.lib.call('aero_norm_bwd_reduce', C.byref(d), ops.stream(x))
     ops.lib.call('aero_norm_bwd_apply', C.byref(d), ops.stream(x))

@@ -337,31 +337,49 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
 // dw[e] += slab_0[e] + slab_1[e] + ... (e < w_n) and db[e - w_n] += ... (the bias partials behind each chunk's tile), in a FIXED
 // order: thread (q, s) adds slabs s, s + 8, ... of element quad q (independent loads, four in flight), the eight lane sums are then
 // added in lane order.  (One thread walking all slabs of its quad was a chain of nslab dependent L2 / HBM round trips.)
-__global__ __launch_bounds__(256) void aero_wgrad_finish_kernel(const float* slabs, int nslab, int64_t stride, float* dw, int64_t w_n, float* db, int64_t n) {
+struct AeroWgradFinishK {
+    const float* slabs; float* dw; float* db;
+    int64_t stride, w_n, n;
+    int nslab, store, layout, ntaps, MC, C, rowlen, coff;
+};
+__global__ __launch_bounds__(256) void aero_wgrad_finish_kernel(AeroWgradFinishK p) {
     __shared__ f32x4 part[8][32];
     const int q = threadIdx.x & 31, s = threadIdx.x >> 5;
     const int64_t e = ((int64_t)blockIdx.x * 32 + q) * 4;
     f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (e < n) {
-        const float* src = slabs + e;
+    if (e < p.n) {
+        const float* src = p.slabs + e;
         int k = s;
-        for (; k + 24 < nslab; k += 32) {
-            const f32x4 a0 = *(const f32x4*)(src + (int64_t)k * stride);
-            const f32x4 a1 = *(const f32x4*)(src + (int64_t)(k + 8) * stride);
-            const f32x4 a2 = *(const f32x4*)(src + (int64_t)(k + 16) * stride);
-            const f32x4 a3 = *(const f32x4*)(src + (int64_t)(k + 24) * stride);
+        for (; k + 24 < p.nslab; k += 32) {
+            const f32x4 a0 = *(const f32x4*)(src + (int64_t)k * p.stride);
+            const f32x4 a1 = *(const f32x4*)(src + (int64_t)(k + 8) * p.stride);
+            const f32x4 a2 = *(const f32x4*)(src + (int64_t)(k + 16) * p.stride);
+            const f32x4 a3 = *(const f32x4*)(src + (int64_t)(k + 24) * p.stride);
             v += a0; v += a1; v += a2; v += a3;
         }
-        for (; k < nslab; k += 8) v += *(const f32x4*)(src + (int64_t)k * stride);
+        for (; k < p.nslab; k += 8) v += *(const f32x4*)(src + (int64_t)k * p.stride);
     }
     part[s][q] = v;
     __syncthreads();
-    if (s == 0 && e < n) {
+    if (s == 0 && e < p.n) {
         f32x4 t = part[0][q];
 #pragma unroll
         for (int i = 1; i < 8; ++i) t += part[i][q];
-        float* dst = e < w_n ? dw + e : db + (e - w_n);
-        *(f32x4*)dst += t;
+        if (e >= p.w_n || p.layout == 0) {
+            float* dst = e < p.w_n ? p.dw + e : p.db + (e - p.w_n);
+            if (p.store) *(f32x4*)dst = t;
+            else *(f32x4*)dst += t;
+        } else {                                               // the weight's own layout: [m][c][tap] (C is a multiple of 8: a quad stays in one row)
+            const int tap = (int)(e / p.MC);
+            const int r = (int)(e - (int64_t)tap * p.MC);
+            const int m = r / p.C, c = r - m * p.C;
+            float* dst = p.dw + ((int64_t)m * p.rowlen + p.coff + c) * p.ntaps + tap;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (p.store) dst[(int64_t)i * p.ntaps] = t[i];
+                else dst[(int64_t)i * p.ntaps] += t[i];
+            }
+        }
     }
 }
 
@@ -405,6 +423,9 @@ static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, 
     }
     if ((int64_t)(d->T + 64) * d->dy_t + d->M + 256 > 0x7fffffffLL || (int64_t)(d->T + 64) * d->x_t + d->C + 256 > 0x7fffffffLL) { *err = "wgrad: rows too long for 32-bit in-row offsets"; return AERO_ERR_UNSUPPORTED; }
     if ((int64_t)d->B * d->Fout * ((d->T + 63) / 64) > 0x3fffffffLL) { *err = "wgrad: too many positions"; return AERO_ERR_UNSUPPORTED; }
+    if (!d->slabs && (d->store || d->dw_layout)) { *err = "wgrad: store / dw_layout need the slab workspace"; return AERO_ERR_ARG; }
+    if (d->dw_layout < 0 || d->dw_layout > 1 || d->dw_rowlen < 0 || d->dw_coff < 0 || (d->dw_rowlen && d->dw_coff + d->C > d->dw_rowlen) ||
+        (!d->dw_rowlen && d->dw_coff) || (int64_t)d->M * d->C > 0x7fffffffLL) { *err = "wgrad: bad destination layout"; return AERO_ERR_ARG; }
     AeroWgradK p;
     p.d = *d;
     static const int abl = [] { const char* e = getenv("AERO_WGRAD_ABL"); return e ? atoi(e) : 0; }();
@@ -430,9 +451,13 @@ static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, 
     if (big) AERO_LAUNCH_DYN(aero_conv_wgrad256_kernel, dim3((unsigned)nb), dim3(512), (size_t)128 * 1024, stream, p);
     else AERO_LAUNCH(aero_conv_wgrad_kernel, dim3((unsigned)nb), dim3(256), stream, p);
     if (d->slabs) {
-        const int64_t n = p.sl_stride;
-        const int64_t fb = (n / 4 + 31) / 32;
-        AERO_LAUNCH(aero_wgrad_finish_kernel, dim3((unsigned)fb), dim3(256), stream, (const float*)d->slabs, p.nchunk, p.sl_stride, d->dw, p.w_n, d->db, n);
+        AeroWgradFinishK f;
+        f.slabs = d->slabs; f.dw = d->dw; f.db = d->db;
+        f.stride = p.sl_stride; f.w_n = p.w_n; f.n = p.sl_stride;
+        f.nslab = p.nchunk; f.store = d->store; f.layout = d->dw_layout; f.ntaps = d->ntaps; f.MC = d->M * d->C; f.C = d->C;
+        f.rowlen = d->dw_rowlen ? d->dw_rowlen : d->C; f.coff = d->dw_coff;
+        const int64_t fb = (f.n / 4 + 31) / 32;
+        AERO_LAUNCH(aero_wgrad_finish_kernel, dim3((unsigned)fb), dim3(256), stream, f);
     }
     return AERO_OK;
 }

@@ -50,11 +50,30 @@ class FlatAdam:
                 p.data = self.flat_p[o:o + sz].view_as(p)
                 p.grad = self.flat_g[o:o + sz].view_as(p)
         self.step_count = 0
+        self.fresh = True                                        # flat_g is all zeros (nothing accumulated since zero_grad)
+        if model is not None:                                    # the HIP backward writes its gradients straight into flat_g
+            import weakref
+            for m in (model, getattr(model, 'module', None)):    # (distrib.DataParallel: the wrapper and the generator inside)
+                if isinstance(m, torch.nn.Module):
+                    object.__setattr__(m, '_grad_sink', weakref.ref(self))
 
     def zero_grad(self, set_to_none=False):
         """(gradients stay views of the flat buffer: set_to_none is accepted for API compatibility and ignored)"""
         self.flat_g.zero_()
         self._reattach()
+        self.fresh = True
+
+    def accepts(self, param_ptrs, offs, n, dev):
+        """aero_amd.train.AeroFunction: are these (data pointers of) parameters exactly the ones of this optimizer, laid out in its
+        flat buffers at these offsets, with their .grad still views of flat_g?  Then the backward may write into flat_g directly."""
+        if n != self.n or len(param_ptrs) != len(self.params) or list(offs) != self._offs or self.flat_g.device != dev:
+            return False
+        esz, bp, bg = 4, self.flat_p.data_ptr(), self.flat_g.data_ptr()
+        for p, ptr, o in zip(self.params, param_ptrs, self._offs):
+            g = p.grad
+            if ptr != bp + o * esz or g is None or g.data_ptr() != bg + o * esz:
+                return False
+        return True
 
     def _reattach(self):
         """The kernel reads ONLY the flat buffers.  `module.zero_grad()` (set_to_none=True is torch's default), `model.to()` or

@@ -525,6 +525,54 @@ class TrainEngine:
         elif unboost:
             TO.scale_f32(self.ops, dst, self._factor(self._unboost, dst.device))
 
+    def _wgrad_to(self, wname, bname, dy, x, df, dt, fstride=1, coff=0):
+        """weight (and bias) gradient of a convolution whose weight parameter `wname` is [M, Ctot, taps...] with its taps in the order
+        of df / dt: ADDED straight into the flat gradient buffer (zero at the start of the backward), in the parameter's own layout at
+        column offset `coff`, when the operands' 8-aligned channel counts are the parameter's; through a temporary otherwise (padded
+        channels: the FTB's 5, DConv hidden widths that are not multiples of 8, the 2-channel ends of the net)."""
+        gw = self.g[wname]
+        gb = self.g[bname] if bname else None
+        M, Cx, nt, rowlen = dy.shape[-1], x.shape[-1], len(df), gw.shape[1]
+        if bw.wgrad_direct_ok(dy, x) and gw.shape[0] == M and gw[0, 0].numel() == nt and coff + Cx <= rowlen:
+            bw.conv_wgrad(self.ops, dy, x, df, dt, fstride=fstride, bias=gb is not None, dw_out=gw, db_out=gb, layout=1, rowlen=rowlen, coff=coff)
+        else:
+            dw, db = bw.conv_wgrad(self.ops, dy, x, df, dt, fstride=fstride, bias=gb is not None)
+            Mp, Cp = gw.shape[0], min(Cx, rowlen - coff)
+            gw.view(Mp, rowlen, nt)[:, coff:coff + Cp].copy_(dw[:, :Mp, :Cp].permute(1, 2, 0))
+            if gb is not None:
+                gb.copy_(db[:Mp])
+        if self._unboost != 1.0 and self._range_of is None:
+            for t in (gw, gb):
+                if t is not None:
+                    TO.scale_f32(self.ops, t, self._factor(self._unboost, t.device))
+
+    def _norm_bwd_to(self, names, x, dy, stats, G, per_row, gamma, beta, act, **kw):
+        """bw.norm_bwd with the parameter gradients accumulated straight into the flat gradient buffer: names = the parameters of
+        (gamma, beta[, LayerScale[, Snake a]]) -- None to skip one; a parameter narrower than the kernel's (zero-padded) channel count
+        goes through a temporary.  Returns dx."""
+        keys = ('dgamma', 'dbeta', 'dls', 'dsn')
+        want = (x.shape[-1], x.shape[-1], x.shape[-1] // 2, x.shape[1])
+        out, late = {}, []
+        for k, nme, n in zip(keys, names, want):
+            if nme is None:
+                continue
+            if self.g[nme].numel() == n:
+                out[k] = self.g[nme].view(-1)
+            else:
+                late.append((k, nme))
+        res = bw.norm_bwd(self.ops, x, dy, stats, G, per_row, gamma, beta, act, out=out, **kw)
+        by_key = dict(zip(('dgamma', 'dbeta', 'dls', 'dsn'), res[1:] + (None,) * 4))
+        for k, nme in late:
+            self._put(nme, by_key[k][:self.g[nme].numel()], unboost=(k != 'dls'))
+        if self._unboost != 1.0:
+            for k, t in out.items():
+                if self._range_of is not None:
+                    if k == 'dls':                               # (see _put: pre-multiplied so that the layer's range pass restores it)
+                        TO.scale_f32(self.ops, t, self._factor(1.0 / self._unboost, t.device))
+                elif k != 'dls':
+                    TO.scale_f32(self.ops, t, self._factor(self._unboost, t.device))
+        return res[0]
+
     # ------------------------------------------------------------------ decoder layer
     def _dec_bwd(self, j, dec, r, dout, B, T):
         ops, dev = self.ops, dout.device
@@ -539,25 +587,24 @@ class TrainEngine:
             if dec.norm:
                 dfull = torch.zeros(B, r.Fu, T, M, dtype=torch.float16, device=dev)      # dL/d(GELU output) is zero on the trimmed rows
                 dfull[:, pad:pad + r.Ft].copy_(dout)
-                res = bw.norm_bwd(ops, r.z, dfull, r.st2, dec.norm_groups, 0, self.w(f'{p}.norm2.weight'), self.w(f'{p}.norm2.bias'), ACT_GELU)
-                self._put(f'{p}.norm2.weight', res[1])
-                self._put(f'{p}.norm2.bias', res[2])
-                dz, pad_eff, Fz = res[0], 0, r.Fu
+                dz = self._norm_bwd_to((f'{p}.norm2.weight', f'{p}.norm2.bias'), r.z, dfull, r.st2, dec.norm_groups, 0,
+                                       self.w(f'{p}.norm2.weight'), self.w(f'{p}.norm2.bias'), ACT_GELU)
+                pad_eff, Fz = 0, r.Fu
             else:
                 zt = r.z[:, pad:pad + r.Ft]
                 dz = bw.norm_bwd(ops, zt, dout.contiguous(), None, 1, 0, None, None, ACT_GELU)[0]
                 pad_eff, Fz = pad, r.Ft
         dyv = ops.conv(self.spec(p + f'.tr_dgrad{pad_eff}', lambda: bw.dgrad_convtr(w_tr, s, pad_eff, dev)), dz, None, B, Fz, Fq, T)
-        dw, _ = bw.conv_wgrad(ops, r.y, dz, [kk - pad_eff for kk in range(K)], [0] * K, fstride=s, bias=False)
-        self._put(f'{p}.conv_tr.weight', dw.permute(1, 2, 0))
-        _, db = bw.conv_wgrad(ops, dz, dz[..., :8] if dz.shape[-1] >= 8 else dz, [0], [0], bias=True)
-        self._put(f'{p}.conv_tr.bias', db)
+        self._wgrad_to(f'{p}.conv_tr.weight', None, r.y, dz, [kk - pad_eff for kk in range(K)], [0] * K, fstride=s)     # [Cin, Cout, K, 1]
+        if dz.shape[-1] % 8 == 0:                               # (the bias sum rides on a product with 8 of dz's own channels)
+            bw.conv_wgrad(ops, dz, dz[..., :8], [0], [0], bias=True, db_out=self.g[f'{p}.conv_tr.bias'])
+        else:
+            _, db = bw.conv_wgrad(ops, dz, dz, [0], [0], bias=True)
+            self._put(f'{p}.conv_tr.bias', db)
         # norm1 + GLU
         if dec.norm:
-            res = bw.norm_bwd(ops, r.r, dyv, r.st1, dec.norm_groups, 0, self.w(f'{p}.norm1.weight'), self.w(f'{p}.norm1.bias'), ACT_GLU)
-            self._put(f'{p}.norm1.weight', res[1])
-            self._put(f'{p}.norm1.bias', res[2])
-            dr = res[0]
+            dr = self._norm_bwd_to((f'{p}.norm1.weight', f'{p}.norm1.bias'), r.r, dyv, r.st1, dec.norm_groups, 0,
+                                   self.w(f'{p}.norm1.weight'), self.w(f'{p}.norm1.bias'), ACT_GLU)
         else:
             dr = bw.norm_bwd(ops, r.r, dyv, None, 1, 0, None, None, ACT_GLU)[0]
         # rewrite 3x3 over cat(x, skip) (aero.py:195-198)
@@ -565,16 +612,11 @@ class TrainEngine:
         half = dec.chin // 2
         ctxp = dec.context
         spec_rw = self.spec(p + '.rewrite', None)
-        dws, db = bw.conv_wgrad(ops, dr, r.skip, spec_rw.df, spec_rw.dt)
-        kF = kT = 1 + 2 * ctxp
-        gw = self.g[f'{p}.rewrite.weight']                        # [2chin, chin, kF, kT]
-        gw[:, half:].copy_(dws.view(kF, kT, dws.shape[1], half).permute(2, 3, 0, 1))
+        # [2chin, chin, kF, kT]: columns [half:] see the skip, [:half] the decoder path (the first decoder's x is zeros, aero.py:484:
+        # those columns keep the zero they start with)
+        self._wgrad_to(f'{p}.rewrite.weight', f'{p}.rewrite.bias', dr, r.skip, spec_rw.df, spec_rw.dt, coff=half)
         if r.x is not None:
-            dwx, _ = bw.conv_wgrad(ops, dr, r.x, spec_rw.df, spec_rw.dt, bias=False)
-            gw[:, :half].copy_(dwx.view(kF, kT, dwx.shape[1], half).permute(2, 3, 0, 1))
-        else:
-            gw[:, :half].zero_()                                 # the first decoder's x is zeros (aero.py:484)
-        self._put(f'{p}.rewrite.bias', db)
+            self._wgrad_to(f'{p}.rewrite.weight', None, dr, r.x, spec_rw.df, spec_rw.dt, coff=0)
         dskip = ops.conv(self.spec(p + '.rw_dgrad_s', lambda: bw.dgrad_conv2d(w_rw[:, half:], ctxp, ctxp, dev)), dr, None, B, Fq, Fq, T)
         dxp = None
         if r.x is not None:
@@ -592,19 +634,14 @@ class TrainEngine:
             TO.sum_bt(ops, dout.contiguous(), ge, float(m.freq_emb.scale * m.freq_emb_scale))
         # norm2 + GLU, rewrite
         if enc.norm:
-            res = bw.norm_bwd(ops, r.r, dout, r.st_rw, enc.norm_groups, 0, self.w(f'{p}.norm2.weight'), self.w(f'{p}.norm2.bias'), ACT_GLU)
-            self._put(f'{p}.norm2.weight', res[1])
-            self._put(f'{p}.norm2.bias', res[2])
-            dr = res[0]
+            dr = self._norm_bwd_to((f'{p}.norm2.weight', f'{p}.norm2.bias'), r.r, dout, r.st_rw, enc.norm_groups, 0,
+                                   self.w(f'{p}.norm2.weight'), self.w(f'{p}.norm2.bias'), ACT_GLU)
         else:
             dr = bw.norm_bwd(ops, r.r, dout, None, 1, 0, None, None, ACT_GLU)[0]
         w_rw = self.w(f'{p}.rewrite.weight')
         c = enc.context
         spec_rw = self.spec(p + '.rewrite', None)
-        dw, db = bw.conv_wgrad(ops, dr, r.x_rw, spec_rw.df, spec_rw.dt)
-        kk = 1 + 2 * c
-        self._put(f'{p}.rewrite.weight', dw.view(kk, kk, dw.shape[1], dw.shape[2]).permute(2, 3, 0, 1))
-        self._put(f'{p}.rewrite.bias', db)
+        self._wgrad_to(f'{p}.rewrite.weight', f'{p}.rewrite.bias', dr, r.x_rw, spec_rw.df, spec_rw.dt)
         dx = ops.conv(self.spec(p + '.rw_dgrad', lambda: bw.dgrad_conv2d(w_rw, c, c, dev)), dr, None, B, Fo, Fo, T)
         # DConv residual branch
         if enc.dconv is not None:
@@ -612,17 +649,13 @@ class TrainEngine:
                 dx = self._dconv_layer_bwd(f'{p}.dconv.layers.{d_}', enc.dconv, d_, r.dconv[d_], dx, B, Fo, T)
         # norm1 + GELU, the strided frequency conv
         if enc.norm:
-            res = bw.norm_bwd(ops, r.yc, dx, r.stc, enc.norm_groups, 0, self.w(f'{p}.norm1.weight'), self.w(f'{p}.norm1.bias'), ACT_GELU)
-            self._put(f'{p}.norm1.weight', res[1])
-            self._put(f'{p}.norm1.bias', res[2])
-            dyc = res[0]
+            dyc = self._norm_bwd_to((f'{p}.norm1.weight', f'{p}.norm1.bias'), r.yc, dx, r.stc, enc.norm_groups, 0,
+                                    self.w(f'{p}.norm1.weight'), self.w(f'{p}.norm1.bias'), ACT_GELU)
         else:
             dyc = bw.norm_bwd(ops, r.yc, dx, None, 1, 0, None, None, ACT_GELU)[0]
         w_c = self.w(f'{p}.conv.weight')
         spec_c = self.spec(p + '.conv', None)
-        dw, db = bw.conv_wgrad(ops, dyc, r.x_conv, spec_c.df, spec_c.dt, fstride=enc.stride)
-        self._put(f'{p}.conv.weight', dw.permute(1, 2, 0))
-        self._put(f'{p}.conv.bias', db)
+        self._wgrad_to(f'{p}.conv.weight', f'{p}.conv.bias', dyc, r.x_conv, spec_c.df, spec_c.dt, fstride=enc.stride)
         need_dx = enc.freq_attn or enc.is_first or i > 0
         if not need_dx:
             return None
@@ -632,9 +665,7 @@ class TrainEngine:
         if enc.freq_attn:
             dxc = self._ftb_bwd(p + '.freq_attn_block', enc.freq_attn_block, r.ftb, dxc, B, Fq, T)
         if enc.is_first:
-            dw, db = bw.conv_wgrad(ops, dxc, r.x_in, [0], [0])
-            self._put(f'{p}.pre_conv.weight', dw.permute(1, 2, 0))
-            self._put(f'{p}.pre_conv.bias', db)
+            self._wgrad_to(f'{p}.pre_conv.weight', f'{p}.pre_conv.bias', dxc, r.x_in, [0], [0])
             return None
         return dxc
 
@@ -643,17 +674,10 @@ class TrainEngine:
         Cc, rch, rp = ftb.in_channel, ftb.r_channel, r.rp
         x = r.x
         # conv2 -> BN -> ReLU
-        res = bw.norm_bwd(ops, r.y3, dout, r.st3, Cc, 2, r.g3, r.b3, ACT_RELU, eps=ftb.conv2[1].eps)
-        self._put(f'{q}.conv2.1.weight', res[1])
-        self._put(f'{q}.conv2.1.bias', res[2])
-        dy3 = res[0]
+        dy3 = self._norm_bwd_to((f'{q}.conv2.1.weight', f'{q}.conv2.1.bias'), r.y3, dout, r.st3, Cc, 2, r.g3, r.b3, ACT_RELU, eps=ftb.conv2[1].eps)
         w2 = self.w(f'{q}.conv2.0.weight')                                              # [C, 2C, 1, 1]: [att | inputs]
-        dwa, db = bw.conv_wgrad(ops, dy3, r.fc, [0], [0])
-        dwb, _ = bw.conv_wgrad(ops, dy3, x, [0], [0], bias=False)
-        gw = self.g[f'{q}.conv2.0.weight']
-        gw[:, :Cc, 0, 0].copy_(dwa[0])
-        gw[:, Cc:, 0, 0].copy_(dwb[0])
-        self._put(f'{q}.conv2.0.bias', db)
+        self._wgrad_to(f'{q}.conv2.0.weight', f'{q}.conv2.0.bias', dy3, r.fc, [0], [0], coff=0)
+        self._wgrad_to(f'{q}.conv2.0.weight', None, dy3, x, [0], [0], coff=Cc)
         dfc = ops.conv(self.spec(q + '.c2_dgrad_a', lambda: bw.dgrad_conv2d(w2[:, :Cc], 0, 0, dev)), dy3, None, B, Fq, Fq, T)
         dxa = ops.conv(self.spec(q + '.c2_dgrad_b', lambda: bw.dgrad_conv2d(w2[:, Cc:], 0, 0, dev)), dy3, None, B, Fq, Fq, T)
         # freq_fc and the gate product
@@ -665,10 +689,8 @@ class TrainEngine:
         v = ops.freqfc(dfc, self.spec(q + '.fc', None)[1], self._tables[okey])
         dxb, dgate = TO.ftb_gate_bwd(ops, v, x, r.gate, add=dxa)
         # conv1d -> BN -> ReLU (the gate)
-        res = bw.norm_bwd(ops, r.y2, dgate.view(B, 1, T, Cc), r.st2, Cc, 2, r.g2, r.b2, ACT_RELU, eps=ftb.conv1d[1].eps)
-        self._put(f'{q}.conv1d.1.weight', res[1])
-        self._put(f'{q}.conv1d.1.bias', res[2])
-        dy2 = res[0]
+        dy2 = self._norm_bwd_to((f'{q}.conv1d.1.weight', f'{q}.conv1d.1.bias'), r.y2, dgate.view(B, 1, T, Cc), r.st2, Cc, 2, r.g2, r.b2, ACT_RELU,
+                                eps=ftb.conv1d[1].eps)
         spec1d = self.spec(q + '.c1d', None)
         k9 = len(spec1d.dt)
         img = r.c1.view(B, 1, T, Fq * rp)
@@ -686,13 +708,8 @@ class TrainEngine:
         dc1 = ops.conv(self.spec(q + '.c1d_dgrad', b_dg1d), dy2, None, B, 1, 1, T)      # [B,1,T,F*rp]
         # conv1 -> BN -> ReLU (dy arrives in the [B,T,F*rp] image layout)
         dimg = dc1.view(B, T, Fq, rp).permute(0, 2, 1, 3)                               # [B,F,T,rp] strided view
-        res = bw.norm_bwd(ops, r.y1, dimg, r.st1, rp, 2, r.g1, r.b1, ACT_RELU, eps=ftb.conv1[1].eps)
-        self._put(f'{q}.conv1.1.weight', res[1][:rch])
-        self._put(f'{q}.conv1.1.bias', res[2][:rch])
-        dy1 = res[0]
-        dw, db = bw.conv_wgrad(ops, dy1, x, [0], [0])
-        self._put(f'{q}.conv1.0.weight', dw[0, :rch])
-        self._put(f'{q}.conv1.0.bias', db[:rch])
+        dy1 = self._norm_bwd_to((f'{q}.conv1.1.weight', f'{q}.conv1.1.bias'), r.y1, dimg, r.st1, rp, 2, r.g1, r.b1, ACT_RELU, eps=ftb.conv1[1].eps)
+        self._wgrad_to(f'{q}.conv1.0.weight', f'{q}.conv1.0.bias', dy1, x, [0], [0])
 
         def b_dg1():
             w = self.w(f'{q}.conv1.0.weight')
@@ -709,31 +726,20 @@ class TrainEngine:
         bst = r.boost
         self._unboost = 1.0 / bst                               # applied by _put to every parameter gradient inside the branch
         try:
-            res = bw.norm_bwd(ops, r.h2, dy, r.st2, 1, 1, self.w(f'{q}.conv2.1.weight'), self.w(f'{q}.conv2.1.bias'), ACT_GLU,
-                              layer_scale=self.w(f'{q}.conv2.3.scale') * bst)
-            dh2 = res[0]                                        # = boost * dL/dh2
-            self._put(f'{q}.conv2.1.weight', res[1])
-            self._put(f'{q}.conv2.1.bias', res[2])
-            self._put(f'{q}.conv2.3.scale', res[3], unboost=False)      # sum dy * GLU(.): does not pass through the scale
-            dw2, db2 = bw.conv_wgrad(ops, dh2, r.a, [0], [0])
-            self._put(f'{q}.conv2.0.weight', dw2.permute(1, 2, 0)[:, :hid])
-            self._put(f'{q}.conv2.0.bias', db2)
+            # dh2 = boost * dL/dh2; LayerScale's own gradient (sum dy * GLU(.)) does not pass through the scale
+            dh2 = self._norm_bwd_to((f'{q}.conv2.1.weight', f'{q}.conv2.1.bias', f'{q}.conv2.3.scale'), r.h2, dy, r.st2, 1, 1,
+                                    self.w(f'{q}.conv2.1.weight'), self.w(f'{q}.conv2.1.bias'), ACT_GLU, layer_scale=self.w(f'{q}.conv2.3.scale') * bst)
+            self._wgrad_to(f'{q}.conv2.0.weight', f'{q}.conv2.0.bias', dh2, r.a, [0], [0])
             w2p = self.spec(q + '.c2', None)[1]
             da = ops.conv(self.spec(q + '.c2_dgrad', lambda: bw.dgrad_conv1d(w2p, 1, 0, dev)), dh2, None, B, Fo, Fo, T)
             if r.attn is not None:
                 da = self._attn_bwd(q + '.time_attn', hid, r.attn, da, B, Fo, T)
             if r.lstm is not None:
                 da = self._blstm_bwd(q + '.lstm', hid, r.lstm, da, B, Fo, T)
-            res = bw.norm_bwd(ops, r.h1, da, r.st1, 1, 1, r.g1, r.be1, r.act, stat_count=T * hid, snake_a=r.snake_a)
-            dh1 = res[0]
-            self._put(f'{q}.conv1.1.weight', res[1][:hid])
-            self._put(f'{q}.conv1.1.bias', res[2][:hid])
-            if r.act == ACT_SNAKE:
-                self._put(f'{q}.act.a', res[4])
+            dh1 = self._norm_bwd_to((f'{q}.conv1.1.weight', f'{q}.conv1.1.bias', None, f'{q}.act.a' if r.act == ACT_SNAKE else None),
+                                    r.h1, da, r.st1, 1, 1, r.g1, r.be1, r.act, stat_count=T * hid, snake_a=r.snake_a)
             spec1, w1p = self.spec(q + '.c1', None)
-            dw1, db1 = bw.conv_wgrad(ops, dh1, r.x, spec1.df, spec1.dt)
-            self._put(f'{q}.conv1.0.weight', dw1.permute(1, 2, 0)[:hid])
-            self._put(f'{q}.conv1.0.bias', db1[:hid])
+            self._wgrad_to(f'{q}.conv1.0.weight', f'{q}.conv1.0.bias', dh1, r.x, spec1.df, spec1.dt)
             dxb = ops.conv(self.spec(q + '.c1_dgrad', lambda: bw.dgrad_conv1d(w1p, r.dil, r.dil * (k // 2), dev)), dh1, None, B, Fo, Fo, T)
             if self._range_of is not None and bst != 1.0:
                 TO.scale_f32(ops, self._range_of(q + '.'), self._factor(1.0 / bst, dev))
@@ -745,9 +751,7 @@ class TrainEngine:
         ops, dev = self.ops, dy.device
         qk, pj, wq, wp = self.spec(q + '.specs', None)
         R = B * Fo
-        dw, db = bw.conv_wgrad(ops, dy, r.att.view(B, Fo, T, Cc), [0], [0])
-        self._put(f'{q}.proj.weight', dw[0])
-        self._put(f'{q}.proj.bias', db)
+        self._wgrad_to(f'{q}.proj.weight', f'{q}.proj.bias', dy, r.att.view(B, Fo, T, Cc), [0], [0])
         datt = ops.conv(self.spec(q + '.proj_dgrad', lambda: bw.dgrad_conv1d(wp[:, :, None], 1, 0, dev)), dy, None, B, Fo, Fo, T)
         dsc = 4096.0                                             # own power-of-two scale of the decay columns (~1e-6 below dQ / dK / dV)
         dqkvd = TO.localstate_bwd(ops, r.qkvd.view(R, T, -1), r.att, datt.view(R, T, Cc), R, T, Cc, r.heads, r.ndecay, decay_scale=dsc)
@@ -772,9 +776,7 @@ class TrainEngine:
         ops, dev = self.ops, dy.device
         layers, whh_t, lin, sdl = self._lstm_specs(q, H, dev)
         R = B * Fo
-        dw, db = bw.conv_wgrad(ops, dy, r.out1s.view(B, Fo, T, 2 * H), [0], [0])
-        self._put(f'{q}.linear.weight', dw[0])
-        self._put(f'{q}.linear.bias', db)
+        self._wgrad_to(f'{q}.linear.weight', f'{q}.linear.bias', dy, r.out1s.view(B, Fo, T, 2 * H), [0], [0])
         wl = self.w(f'{q}.linear.weight')
         dout = ops.conv(self.spec(q + '.lin_dgrad', lambda: bw.dgrad_conv1d(wl[:, :, None], 1, 0, dev)), dy, None, B, Fo, Fo, T).view(R, T, 2 * H)
         xs = [r.fr0, r.outs[0]]
@@ -803,6 +805,7 @@ class AeroFunction(torch.autograd.Function):
             y, spec_out, lr_spec, c = engine.forward(mix)
         ctx.engine, ctx.c, ctx.names = engine, c, names
         ctx.shapes = [p.shape for p in params]
+        ctx.param_ptrs = [p.data_ptr() for p in params]
         ctx.mark_non_differentiable(spec_out, lr_spec)
         return y, spec_out, lr_spec
 
@@ -814,7 +817,17 @@ class AeroFunction(torch.autograd.Function):
         for s in ctx.shapes:
             offs.append(n)
             n += (s.numel() + 3) // 4 * 4
-        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # FlatAdam (aero_amd/optim.py) keeps every parameter's .grad as a view of ONE flat buffer with this same layout: the backward
+        # then works IN that buffer (freshly zeroed by zero_grad) and hands autograd no per-parameter gradients at all -- its
+        # AccumulateGrad nodes were ~300 little `grad += g` launches per step; a buffer that already holds gradients gets one flat add
+        sink = getattr(eng.model, '_grad_sink', None)
+        sink = sink() if sink is not None else None              # (a weak reference: the optimizer may be gone)
+        if sink is not None and not sink.accepts(ctx.param_ptrs, offs, n, dev):
+            sink = None
+        direct = sink is not None and sink.fresh
+        flat = sink.flat_g if direct else torch.zeros(n, dtype=torch.float32, device=dev)
+        if sink is not None:
+            sink.fresh = False
         views = [flat[o:o + s.numel()].view(s) for o, s in zip(offs, ctx.shapes)]
         grads = dict(zip(ctx.names, views))
         sync = getattr(eng.model, '_grad_sync', None)            # distrib.wrap(): gradient all-reduce over RCCL, overlapped with the backward
@@ -854,6 +867,10 @@ class AeroFunction(torch.autograd.Function):
             if sync is not None:
                 sync.wait()
         ctx.c = None
+        if sink is not None:
+            if not direct:
+                sink.flat_g.add_(flat)
+            return (None, None, None) + (None,) * len(views)
         return (None, None, None) + tuple(views)
 
 

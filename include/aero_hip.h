@@ -340,6 +340,11 @@ typedef struct {
     int32_t B, Fin, Fout, T, M, C, ntaps, fstride;
     int32_t df[9], dt[9];
     float* slabs; int32_t nslab;
+    /* with slabs only.  store != 0: dw / db are WRITTEN (dw = sum of the chunk partials) instead of added to -- no zero fill needed.
+     * dw_layout 1: dw is addressed in the layout of an nn.Conv2d / Conv1d / ConvTranspose2d weight whose taps are in raster order,
+     * dw[((m * dw_rowlen + dw_coff + c) * ntaps) + j]  (dw_rowlen 0 = C: the c-extent of the destination rows; dw_coff: first column --
+     * the two sources of a concatenated input write the two column ranges of one weight); 0: [ntaps][M][C] as above. */
+    int32_t store, dw_layout, dw_rowlen, dw_coff;
 } aero_wgrad_desc;
 int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream);
 int aero_conv_wgrad_chunks(int32_t M, int32_t C, int32_t ntaps, int32_t nrows, int32_t T);

@@ -549,6 +549,16 @@ def case_wgrad_conv2d(lib, dev, Cin, Cout, kF, kT, Fr, T, B=2, seed=82):
     got = dw.cpu().view(kF, kT, Cout, Cin).permute(2, 3, 0, 1)
     assert rel_l2(got, gw) < TOL16, rel_l2(got, gw)
     assert rel_l2(db.cpu(), gb) < TOL16
+    if bw.wgrad_direct_ok(cl(dy), cl(x)):
+        # straight into a destination in the nn.Conv2d weight's own layout (a column range of a wider weight, as the two sources of
+        # a concatenated input use it) and into a bias destination: added in place, same sums bit for bit
+        wfull = torch.full((Cout, Cin + 8, kF, kT), 0.5, device=dev)
+        bfull = torch.full((Cout,), 0.25, device=dev)
+        bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt, dw_out=wfull, db_out=bfull, layout=1, rowlen=Cin + 8, coff=8)
+        dw3, db3 = bw.conv_wgrad(ops, cl(dy).to(dev), cl(x).to(dev), df, dt)           # (same tile choice as the call above)
+        got3 = dw3.cpu().view(kF, kT, Cout, Cin).permute(2, 3, 0, 1)
+        assert torch.equal(wfull[:, 8:].cpu(), got3 + 0.5) and bool((wfull[:, :8] == 0.5).all())
+        assert torch.equal(bfull.cpu(), db3.cpu() + 0.25)
 
 
 def case_wgrad_conv1d(lib, dev, Cin, Cout, k, dil, R, T, seed=85):
