@@ -183,6 +183,7 @@ _PROTOS = {
     'aero_add_f16': (i32, [vp, vp, vp, i64, C.c_float, vp]),
     'aero_scale_cast': (i32, [fp, i32, i64, fp, vp, C.c_float, vp, fp, vp]),
     'aero_scale_f32': (i32, [fp, i64, fp, vp]),
+    'aero_gather_pack': (i32, [vp, vp, i32, vp, vp, i64, i32, vp]),
     'aero_rescale_f16': (i32, [vp, fp, vp, fp, i64, vp, C.c_float, vp, fp, vp]),
     'aero_gconv1d_fwd': (i32, [C.POINTER(GconvDesc), vp]),
     'aero_leaky_relu': (i32, [vp, i64, C.c_float, vp]),

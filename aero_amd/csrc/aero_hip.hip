@@ -338,6 +338,13 @@ int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const fl
     return aero_finish(rc, err);
 }
 
+int aero_gather_pack(const void* ptrs, const int32_t* starts, int32_t nparam, const int32_t* table, void* dst, int64_t n, int32_t dst_f16,
+                     void* stream) {
+    const char* err = "";
+    int rc = aero_gather_pack_launch((const float* const*)ptrs, starts, nparam, table, dst, n, dst_f16, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream) {
     const char* err = "";
     int rc = aero_scale_f32_launch(x, n, scale, (hipStream_t)stream, &err);

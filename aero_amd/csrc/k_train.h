@@ -1141,6 +1141,65 @@ static int aero_scale_f32_launch(float* x, int64_t n, const float* scale, hipStr
     return AERO_OK;
 }
 
+// Re-packing of the weight images after an optimizer step.  Every packed image of the training engine (padded / tiled / flipped /
+// interleaved fp16 or fp32 copies of parameters, aero_amd/pack.py, backward.py) is pure data movement: element i of the arena is
+// element table[i] of the parameters laid end to end (or zero, table[i] < 0).  The parameters need not be contiguous in memory:
+// `ptrs[p]` is the base of parameter p and `starts[p]` its first flat index (starts[nparam] = total).  One launch per arena replaces
+// the ~700 little layout kernels torch ran per step for the same bytes (aero_amd/repack.py builds and checks the tables).
+#define AERO_GATHER_MAXP 1024
+__global__ __launch_bounds__(256) void aero_gather_pack_kernel(const float* const* ptrs, const int* starts, int nparam, const int* table,
+                                                               h16* dst16, float* dst32, int64_t n) {
+    __shared__ int st[AERO_GATHER_MAXP + 1];
+    __shared__ const float* pp[AERO_GATHER_MAXP];
+    for (int i = threadIdx.x; i <= nparam; i += 256) st[i] = starts[i];
+    for (int i = threadIdx.x; i < nparam; i += 256) pp[i] = ptrs[i];
+    __syncthreads();
+    int p = 0;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (int64_t)gridDim.x * 1024) {
+        const int nv = n - i0 < 4 ? (int)(n - i0) : 4;        // (arenas are padded to multiples of 4: nv == 4 in practice)
+        int idx[4];
+        if (nv == 4) {
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const i32x4 t = *(const i32x4*)(table + i0);
+            idx[0] = t[0]; idx[1] = t[1]; idx[2] = t[2]; idx[3] = t[3];
+        } else {
+            for (int j = 0; j < 4; ++j) idx[j] = j < nv ? table[i0 + j] : -1;
+        }
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int fi = idx[j];
+            if (fi < 0) { v[j] = 0.f; continue; }
+            if (fi < st[p] || fi >= st[p + 1]) {               // neighbours mostly come from the same parameter
+                int lo = 0, hi = nparam - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (st[mid] <= fi) lo = mid; else hi = mid - 1;
+                }
+                p = lo;
+            }
+            v[j] = pp[p][fi - st[p]];
+        }
+        if (dst16) {
+            for (int j = 0; j < nv; ++j) dst16[i0 + j] = (h16)v[j];
+        } else {
+            for (int j = 0; j < nv; ++j) dst32[i0 + j] = v[j];
+        }
+    }
+}
+
+static int aero_gather_pack_launch(const float* const* ptrs, const int* starts, int nparam, const int* table, void* dst, int64_t n, int dst_f16,
+                                   hipStream_t stream, const char** err) {
+    if (!ptrs || !starts || !table || !dst || n < 1 || nparam < 1) { *err = "gather_pack: bad arguments"; return AERO_ERR_ARG; }
+    if (nparam > AERO_GATHER_MAXP) { *err = "gather_pack: more than 1024 parameters"; return AERO_ERR_UNSUPPORTED; }
+    if (((uintptr_t)table & 15) || ((uintptr_t)dst & 15)) { *err = "gather_pack: table / dst must be 16-byte aligned"; return AERO_ERR_ARG; }
+    int64_t nb = (n + 1023) / 1024;
+    if (nb > 8192) nb = 8192;
+    AERO_LAUNCH(aero_gather_pack_kernel, dim3((unsigned)nb), dim3(256), stream, ptrs, starts, nparam, table, dst_f16 ? (h16*)dst : nullptr,
+                dst_f16 ? nullptr : (float*)dst, n);
+    return AERO_OK;
+}
+
 // Re-normalisation of an fp16 gradient between stages of the backward: v = a / Sa + b / Sb (b optional), S = 2^floor(log2(target / max|v|)),
 // out = fp16(v * S), scale_out = {S, 1/S}.  sa / sb: the {S, 1/S} pairs the operands carry (device memory; NULL = 1).  Powers of two: exact
 // unless a value leaves the fp16 range, which is what this pass prevents (gradients may grow or shrink by orders of magnitude from

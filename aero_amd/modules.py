@@ -306,6 +306,7 @@ class Aero(nn.Module):
         st = self.__dict__.copy()
         st['_engine'] = None
         st.pop('_train_engine', None)
+        st.pop('_grad_sink', None)                               # (a weak reference to the optimizer: FlatAdam re-registers itself)
         return st
 
     def _spec(self, x, scale=False):

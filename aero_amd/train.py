@@ -17,6 +17,8 @@ un-scaled in fp32 at the end (`aero_scale_f32`), so nothing depends on the magni
 """
 import math
 
+import os
+
 import torch
 
 from . import _lib, backward as bw, pack, train_ops as TO
@@ -78,6 +80,7 @@ class TrainEngine:
         self._tables = {}
         self._epoch = 0
         self._boosts, self._nfwd = {}, 0
+        self._builders = {}
 
     # ------------------------------------------------------------------ weights (packed on the device, per parameter version)
     def invalidate(self):
@@ -85,9 +88,33 @@ class TrainEngine:
 
     def _sync_weights(self, dev):
         key = (str(dev), self._epoch) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
-        if key != self._key:
-            self._cache, self._key = {}, key
-            self.sd = {k: v.detach() for k, v in self.model.state_dict(keep_vars=True).items()}
+        if key == self._key:
+            return
+        first = self._key is None
+        self._key = key
+        self.sd = {k: v.detach() for k, v in self.model.state_dict(keep_vars=True).items()}
+        rp = self._replay
+        if rp is not None and (self._replay_dev != str(dev) or not rp.matches(self.sd)):
+            rp, self._replay, self._builders = None, None, {}
+        if rp is None and not first and self._builders and self.replay_enabled and not (
+                self.sd and next(iter(self.sd.values())).is_cuda and torch.cuda.is_current_stream_capturing()):
+            # the weights changed for the first time since the images were built (an optimizer step): from now on the images are
+            # re-packed by one gather launch per arena instead of by their closures (aero_amd/repack.py)
+            from .repack import WeightReplay
+            rp = WeightReplay(self.lib, self.ops.stream)
+            rp.compile(self.sd, self._builders, lambda d: setattr(self, 'sd', d))
+            self._replay, self._replay_dev = rp, str(dev)
+            if os.environ.get('AERO_REPACK_DEBUG'):
+                print(f'[repack] {len(rp.objects)} image sets replayed by gather, {len(rp.skipped)} rebuilt by their closures:')
+                for k, why in rp.skipped.items():
+                    print(f'[repack]   {k}: {why}')
+            self._cache = dict(rp.objects)
+        elif rp is not None:
+            self._cache = dict(rp.refresh(self.sd))
+        else:
+            self._cache = {}
+
+    _replay, _replay_dev, replay_enabled = None, None, os.environ.get('AERO_REPACK_GATHER', '1') != '0'
 
     def w(self, name):
         return self.sd[name].float()
@@ -96,6 +123,8 @@ class TrainEngine:
         s = self._cache.get(key)
         if s is None:
             s = self._cache[key] = build()
+            if key not in self._builders:
+                self._builders[key] = build
         return s
 
     def _window(self, win, dev):
@@ -594,7 +623,7 @@ class TrainEngine:
                 zt = r.z[:, pad:pad + r.Ft]
                 dz = bw.norm_bwd(ops, zt, dout.contiguous(), None, 1, 0, None, None, ACT_GELU)[0]
                 pad_eff, Fz = pad, r.Ft
-        dyv = ops.conv(self.spec(p + f'.tr_dgrad{pad_eff}', lambda: bw.dgrad_convtr(w_tr, s, pad_eff, dev)), dz, None, B, Fz, Fq, T)
+        dyv = ops.conv(self.spec(p + f'.tr_dgrad{pad_eff}', lambda: bw.dgrad_convtr(self.w(f'{p}.conv_tr.weight'), s, pad_eff, dev)), dz, None, B, Fz, Fq, T)
         self._wgrad_to(f'{p}.conv_tr.weight', None, r.y, dz, [kk - pad_eff for kk in range(K)], [0] * K, fstride=s)     # [Cin, Cout, K, 1]
         if dz.shape[-1] % 8 == 0:                               # (the bias sum rides on a product with 8 of dz's own channels)
             bw.conv_wgrad(ops, dz, dz[..., :8], [0], [0], bias=True, db_out=self.g[f'{p}.conv_tr.bias'])
@@ -617,10 +646,10 @@ class TrainEngine:
         self._wgrad_to(f'{p}.rewrite.weight', f'{p}.rewrite.bias', dr, r.skip, spec_rw.df, spec_rw.dt, coff=half)
         if r.x is not None:
             self._wgrad_to(f'{p}.rewrite.weight', None, dr, r.x, spec_rw.df, spec_rw.dt, coff=0)
-        dskip = ops.conv(self.spec(p + '.rw_dgrad_s', lambda: bw.dgrad_conv2d(w_rw[:, half:], ctxp, ctxp, dev)), dr, None, B, Fq, Fq, T)
+        dskip = ops.conv(self.spec(p + '.rw_dgrad_s', lambda: bw.dgrad_conv2d(self.w(f'{p}.rewrite.weight')[:, half:], ctxp, ctxp, dev)), dr, None, B, Fq, Fq, T)
         dxp = None
         if r.x is not None:
-            dxp = ops.conv(self.spec(p + '.rw_dgrad_x', lambda: bw.dgrad_conv2d(w_rw[:, :half], ctxp, ctxp, dev)), dr, None, B, Fq, Fq, T)
+            dxp = ops.conv(self.spec(p + '.rw_dgrad_x', lambda: bw.dgrad_conv2d(self.w(f'{p}.rewrite.weight')[:, :half], ctxp, ctxp, dev)), dr, None, B, Fq, Fq, T)
         return dxp, dskip
 
     # ------------------------------------------------------------------ encoder layer
@@ -642,7 +671,7 @@ class TrainEngine:
         c = enc.context
         spec_rw = self.spec(p + '.rewrite', None)
         self._wgrad_to(f'{p}.rewrite.weight', f'{p}.rewrite.bias', dr, r.x_rw, spec_rw.df, spec_rw.dt)
-        dx = ops.conv(self.spec(p + '.rw_dgrad', lambda: bw.dgrad_conv2d(w_rw, c, c, dev)), dr, None, B, Fo, Fo, T)
+        dx = ops.conv(self.spec(p + '.rw_dgrad', lambda: bw.dgrad_conv2d(self.w(f'{p}.rewrite.weight'), c, c, dev)), dr, None, B, Fo, Fo, T)
         # DConv residual branch
         if enc.dconv is not None:
             for d_ in reversed(range(enc.dconv.depth)):
@@ -660,7 +689,7 @@ class TrainEngine:
         if not need_dx:
             return None
         K, s = enc.kernel_size, enc.stride
-        dxc = ops.conv(self.spec(p + '.conv_dgrad', lambda: bw.dgrad_conv_fstride(w_c, s, dev)), dyc, None, B, Fo, (Fo - 1) * s + K, T,
+        dxc = ops.conv(self.spec(p + '.conv_dgrad', lambda: bw.dgrad_conv_fstride(self.w(f'{p}.conv.weight'), s, dev)), dyc, None, B, Fo, (Fo - 1) * s + K, T,
                        dst_f_off=enc.pad, dst_F=Fq)
         if enc.freq_attn:
             dxc = self._ftb_bwd(p + '.freq_attn_block', enc.freq_attn_block, r.ftb, dxc, B, Fq, T)
@@ -678,8 +707,8 @@ class TrainEngine:
         w2 = self.w(f'{q}.conv2.0.weight')                                              # [C, 2C, 1, 1]: [att | inputs]
         self._wgrad_to(f'{q}.conv2.0.weight', f'{q}.conv2.0.bias', dy3, r.fc, [0], [0], coff=0)
         self._wgrad_to(f'{q}.conv2.0.weight', None, dy3, x, [0], [0], coff=Cc)
-        dfc = ops.conv(self.spec(q + '.c2_dgrad_a', lambda: bw.dgrad_conv2d(w2[:, :Cc], 0, 0, dev)), dy3, None, B, Fq, Fq, T)
-        dxa = ops.conv(self.spec(q + '.c2_dgrad_b', lambda: bw.dgrad_conv2d(w2[:, Cc:], 0, 0, dev)), dy3, None, B, Fq, Fq, T)
+        dfc = ops.conv(self.spec(q + '.c2_dgrad_a', lambda: bw.dgrad_conv2d(self.w(f'{q}.conv2.0.weight')[:, :Cc], 0, 0, dev)), dy3, None, B, Fq, Fq, T)
+        dxa = ops.conv(self.spec(q + '.c2_dgrad_b', lambda: bw.dgrad_conv2d(self.w(f'{q}.conv2.0.weight')[:, Cc:], 0, 0, dev)), dy3, None, B, Fq, Fq, T)
         # freq_fc and the gate product
         gfc = self.g[f'{q}.freq_fc.weight']
         gfc.copy_(TO.freqfc_wgrad(ops, dfc, x, r.gate))
@@ -730,17 +759,26 @@ class TrainEngine:
             dh2 = self._norm_bwd_to((f'{q}.conv2.1.weight', f'{q}.conv2.1.bias', f'{q}.conv2.3.scale'), r.h2, dy, r.st2, 1, 1,
                                     self.w(f'{q}.conv2.1.weight'), self.w(f'{q}.conv2.1.bias'), ACT_GLU, layer_scale=self.w(f'{q}.conv2.3.scale') * bst)
             self._wgrad_to(f'{q}.conv2.0.weight', f'{q}.conv2.0.bias', dh2, r.a, [0], [0])
-            w2p = self.spec(q + '.c2', None)[1]
-            da = ops.conv(self.spec(q + '.c2_dgrad', lambda: bw.dgrad_conv1d(w2p, 1, 0, dev)), dh2, None, B, Fo, Fo, T)
+            def b_dg2():                                        # (every image closure reads the parameters through self.w: repack.py)
+                wp = torch.zeros(2 * Cc, hp, 1, device=dev)
+                wp[:, :hid] = self.w(f'{q}.conv2.0.weight')
+                return bw.dgrad_conv1d(wp, 1, 0, dev)
+            da = ops.conv(self.spec(q + '.c2_dgrad', b_dg2), dh2, None, B, Fo, Fo, T)
             if r.attn is not None:
                 da = self._attn_bwd(q + '.time_attn', hid, r.attn, da, B, Fo, T)
             if r.lstm is not None:
                 da = self._blstm_bwd(q + '.lstm', hid, r.lstm, da, B, Fo, T)
             dh1 = self._norm_bwd_to((f'{q}.conv1.1.weight', f'{q}.conv1.1.bias', None, f'{q}.act.a' if r.act == ACT_SNAKE else None),
                                     r.h1, da, r.st1, 1, 1, r.g1, r.be1, r.act, stat_count=T * hid, snake_a=r.snake_a)
-            spec1, w1p = self.spec(q + '.c1', None)
+            spec1, _ = self.spec(q + '.c1', None)
             self._wgrad_to(f'{q}.conv1.0.weight', f'{q}.conv1.0.bias', dh1, r.x, spec1.df, spec1.dt)
-            dxb = ops.conv(self.spec(q + '.c1_dgrad', lambda: bw.dgrad_conv1d(w1p, r.dil, r.dil * (k // 2), dev)), dh1, None, B, Fo, Fo, T)
+            dil = r.dil
+
+            def b_dg1():
+                wp = torch.zeros(hp, Cc, k, device=dev)
+                wp[:hid] = self.w(f'{q}.conv1.0.weight')
+                return bw.dgrad_conv1d(wp, dil, dil * (k // 2), dev)
+            dxb = ops.conv(self.spec(q + '.c1_dgrad', b_dg1), dh1, None, B, Fo, Fo, T)
             if self._range_of is not None and bst != 1.0:
                 TO.scale_f32(ops, self._range_of(q + '.'), self._factor(1.0 / bst, dev))
         finally:
@@ -752,7 +790,7 @@ class TrainEngine:
         qk, pj, wq, wp = self.spec(q + '.specs', None)
         R = B * Fo
         self._wgrad_to(f'{q}.proj.weight', f'{q}.proj.bias', dy, r.att.view(B, Fo, T, Cc), [0], [0])
-        datt = ops.conv(self.spec(q + '.proj_dgrad', lambda: bw.dgrad_conv1d(wp[:, :, None], 1, 0, dev)), dy, None, B, Fo, Fo, T)
+        datt = ops.conv(self.spec(q + '.proj_dgrad', lambda: bw.dgrad_conv1d(self.w(f'{q}.proj.weight'), 1, 0, dev)), dy, None, B, Fo, Fo, T)
         dsc = 4096.0                                             # own power-of-two scale of the decay columns (~1e-6 below dQ / dK / dV)
         dqkvd = TO.localstate_bwd(ops, r.qkvd.view(R, T, -1), r.att, datt.view(R, T, Cc), R, T, Cc, r.heads, r.ndecay, decay_scale=dsc)
         dqk = dqkvd.view(B, Fo, T, -1)
@@ -778,7 +816,7 @@ class TrainEngine:
         R = B * Fo
         self._wgrad_to(f'{q}.linear.weight', f'{q}.linear.bias', dy, r.out1s.view(B, Fo, T, 2 * H), [0], [0])
         wl = self.w(f'{q}.linear.weight')
-        dout = ops.conv(self.spec(q + '.lin_dgrad', lambda: bw.dgrad_conv1d(wl[:, :, None], 1, 0, dev)), dy, None, B, Fo, Fo, T).view(R, T, 2 * H)
+        dout = ops.conv(self.spec(q + '.lin_dgrad', lambda: bw.dgrad_conv1d(self.w(f'{q}.linear.weight')[:, :, None], 1, 0, dev)), dy, None, B, Fo, Fo, T).view(R, T, 2 * H)
         xs = [r.fr0, r.outs[0]]
         for l in (1, 0):
             stitched = r.framed and l == 1

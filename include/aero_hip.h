@@ -447,6 +447,12 @@ int aero_add_f16(const void* a, const void* b, void* dst, int64_t n, float scale
 int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const float* item_scale, void* amax, float target, void* dst,
                     float* scale_out, void* stream);
 int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream);
+/* Weight images re-packed after an optimizer step (the training engine re-packs every step; torch's layout ops for the same bytes were
+ * ~700 launches): dst[i] = table[i] >= 0 ? P[table[i]] : 0 for i < n, converted to fp16 (dst_f16 != 0) or kept fp32, where P is the
+ * parameters laid end to end: ptrs = device array of nparam (<= 1024) fp32 base pointers, starts = device int32 [nparam + 1] of their
+ * first flat indices.  table / dst 16-byte aligned.  aero_amd/repack.py derives the tables from the packing code itself and verifies them. */
+int aero_gather_pack(const void* ptrs, const int32_t* starts, int32_t nparam, const int32_t* table, void* dst, int64_t n, int32_t dst_f16,
+                     void* stream);
 /* re-normalisation between stages of the backward: v = a / Sa + b / Sb (b may be NULL), S = 2^floor(log2(target / max|v|)),
  * out = fp16(v * S), scale_out = {S, 1/S}; sa / sb: the {S, 1/S} pairs of the operands (device floats, NULL = 1); amax: one zeroed
  * uint32 of scratch.  out may alias a. */

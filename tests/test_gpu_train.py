@@ -87,6 +87,37 @@ def test_config5_training_steps(meta):
     assert hist[2] < hist[0], hist
 
 
+def test_weight_images_replayed_by_gather_match_their_closures():
+    """aero_gather_pack on the device: every replayed weight image == its packing closure's output, bit for bit, after each step"""
+    assert tc.case_weight_replay('cuda') > 50
+
+
+def test_config5_weight_replay_covers_the_model(meta):
+    """the full-size music model: which image sets the replay declines (and keeps rebuilding with their closures) is a short, known list"""
+    from aero_amd import Aero, losses
+    from aero_amd.optim import FlatAdam
+    from aero_amd.repack import _flatten
+    torch.manual_seed(2036)
+    m = Aero(**meta['music_cfg']).cuda().train()
+    opt = FlatAdam(m.parameters(), lr=3e-4, model=m)
+    crit = losses.MultiResolutionSTFTLoss(factor_sc=0.5, factor_mag=0.5)
+    lr, hr = seeded((1, 1, 22050), 1).cuda(), (0.1 * seeded((1, 1, 88200), 2)).cuda()
+    for _ in range(2):
+        y = m(lr)
+        sc, mg = crit(y.squeeze(1), hr.squeeze(1))
+        opt.zero_grad()
+        (sc + mg).backward()
+        opt.step()
+    eng = m._get_train_engine()
+    eng._sync_weights(torch.device('cuda'))
+    rp = eng._replay
+    assert rp is not None and len(rp.objects) > 100
+    assert all(k.endswith('lstm.specs') or k.endswith('qkvd_dgrad') for k in rp.skipped), rp.skipped
+    for key, obj in rp.objects.items():
+        for a, b in zip(_flatten(obj, []), _flatten(eng._builders[key](), [])):
+            assert torch.equal(a, b), key
+
+
 def test_captured_training_step_matches_eager(meta):
     """aero_amd.train.CapturedStep: the whole step (forward, loss, backward, fused Adam with the step count advancing) replayed as one HIP
     graph follows the eager loop on the same data: same losses step by step (to the atomics' rounding), same weights afterwards"""

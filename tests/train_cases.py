@@ -123,3 +123,51 @@ def case_training_step_small(dev, lib=None, L=400):
     finally:
         if lib is not None:
             losses.use_library(None)
+
+
+def case_weight_replay(dev, lib=None, steps=3):
+    """After the first optimizer step the training engine stops re-packing its weight images with torch ops and replays them with
+    aero_gather_pack (aero_amd/repack.py).  A few training steps of the small model; after every optimizer step each replayed image
+    must equal, bit for bit, what its packing closure builds from the weights as they are now (the closures are what ran before, and
+    what still runs for the images the replay declines: summed LSTM biases, the scaled decay rows of the LocalState data gradient)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from aero_amd import losses
+    from aero_amd.optim import FlatAdam
+    from aero_amd.repack import _flatten
+    meta = json.load(open(os.path.join(GOLDEN, 'meta.json')))
+    m = build_model(meta, 'small').train()
+    if lib is not None:
+        from aero_amd.engine import HipEngine
+        object.__setattr__(m, '_engine', HipEngine(m, lib=lib))
+        losses.use_library(lib)
+    try:
+        m.to(dev)
+        eng = m._get_train_engine()
+        opt = FlatAdam(m.parameters(), lr=1e-3, model=m, lib=lib)
+        crit = losses.MultiResolutionSTFTLoss()
+        x, hr = seeded((2, 1, 400), 100).to(dev), (seeded((2, 1, 1600), 200) * 0.1).to(dev)
+        hist = []
+        for it in range(steps):
+            y = m(x)
+            sc, mg = crit(y.squeeze(1), hr.squeeze(1))
+            opt.zero_grad()
+            (sc + mg).backward()
+            hist.append(float((sc + mg).detach()))
+            opt.step()
+            eng._sync_weights(torch.device(dev))                 # what the next forward does first: images of the new weights
+            if it == 0:
+                assert eng._replay is not None and len(eng._replay.objects) > 50, (eng._replay and eng._replay.skipped)
+                assert all(k.endswith('lstm.specs') or k.endswith('qkvd_dgrad') for k in eng._replay.skipped), eng._replay.skipped
+            for key, obj in eng._replay.objects.items():
+                assert eng._cache[key] is obj
+                fresh, have = _flatten(eng._builders[key](), []), _flatten(obj, [])
+                assert len(fresh) == len(have)
+                for a, b in zip(have, fresh):
+                    assert a.dtype == b.dtype and torch.equal(a, b), (it, key)
+        assert hist[-1] < hist[0]                                # (and the model does train on them)
+        return len(eng._replay.objects)
+    finally:
+        if lib is not None:
+            losses.use_library(None)

@@ -63,7 +63,8 @@ def main():
         (sc + mg).backward()
         if opt is not None:
             opt.step()
-    step()
+    for _ in range(3):                                      # (the second step compiles the weight replay, aero_amd/repack.py)
+        step()
     a = Audit()
     with a:
         step()
