@@ -94,7 +94,8 @@ class TrainEngine:
         self._key = key
         self.sd = {k: v.detach() for k, v in self.model.state_dict(keep_vars=True).items()}
         rp = self._replay
-        if rp is not None and (self._replay_dev != str(dev) or not rp.matches(self.sd)):
+        sd_dev = str(next(iter(self.sd.values())).device)
+        if rp is not None and (self._replay_dev != sd_dev or not rp.matches(self.sd)):
             rp, self._replay, self._builders = None, None, {}
         if rp is None and not first and self._builders and self.replay_enabled and not (
                 self.sd and next(iter(self.sd.values())).is_cuda and torch.cuda.is_current_stream_capturing()):
@@ -103,7 +104,7 @@ class TrainEngine:
             from .repack import WeightReplay
             rp = WeightReplay(self.lib, self.ops.stream)
             rp.compile(self.sd, self._builders, lambda d: setattr(self, 'sd', d))
-            self._replay, self._replay_dev = rp, str(dev)
+            self._replay, self._replay_dev = rp, sd_dev
             if os.environ.get('AERO_REPACK_DEBUG'):
                 print(f'[repack] {len(rp.objects)} image sets replayed by gather, {len(rp.skipped)} rebuilt by their closures:')
                 for k, why in rp.skipped.items():

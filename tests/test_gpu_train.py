@@ -109,7 +109,7 @@ def test_config5_weight_replay_covers_the_model(meta):
         (sc + mg).backward()
         opt.step()
     eng = m._get_train_engine()
-    eng._sync_weights(torch.device('cuda'))
+    eng._sync_weights(lr.device)
     rp = eng._replay
     assert rp is not None and len(rp.objects) > 100
     assert all(k.endswith('lstm.specs') or k.endswith('qkvd_dgrad') for k in rp.skipped), rp.skipped

@@ -156,7 +156,7 @@ def case_weight_replay(dev, lib=None, steps=3):
             (sc + mg).backward()
             hist.append(float((sc + mg).detach()))
             opt.step()
-            eng._sync_weights(torch.device(dev))                 # what the next forward does first: images of the new weights
+            eng._sync_weights(x.device)                 # what the next forward does first: images of the new weights
             if it == 0:
                 assert eng._replay is not None and len(eng._replay.objects) > 50, (eng._replay and eng._replay.skipped)
                 assert all(k.endswith('lstm.specs') or k.endswith('qkvd_dgrad') for k in eng._replay.skipped), eng._replay.skipped
