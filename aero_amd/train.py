@@ -15,8 +15,8 @@ the fused forms never write.  Activations and their gradients are fp16 (fp32 acc
 multiplied by a power-of-two loss scale chosen from its own maximum (`aero_scale_cast`) and every parameter gradient is
 un-scaled in fp32 at the end (`aero_scale_f32`), so nothing depends on the magnitude of the loss.
 """
+import contextlib
 import math
-
 import os
 
 import torch
@@ -33,37 +33,23 @@ def _r8(n):
     return (n + 7) // 8 * 8
 
 
-def lstm_param_grads(ops, da, x, out, sd, layer, H, nseq, W, in_ch, dev):
-    """Parameter and input gradients of one bidirectional nn.LSTM layer from da = d(gate pre-activations) (aero_lstm_bwd):
-    da fp16 [nseq*W, 2, 4H] (column 4j + gate), x fp16 [nseq, W, in_ch] the layer input, out fp16 [nseq, W, 2H] its output;
-    sd: the nn.LSTM state dict (`weight_ih_l{layer}[_reverse]`, ...).  Returns {parameter name: fp32 gradient, 'dx': fp16 [nseq, W, in_ch]}."""
-    npos = nseq * W
+def lstm_param_grads(ops, da, x, out, layer, H, nseq, W, in_ch, dev, put):
+    """Parameter gradients of one bidirectional nn.LSTM layer from da = d(gate pre-activations) (aero_lstm_bwd): da fp16 [nseq*W, 2, 4H]
+    (column 4j + gate), x fp16 [nseq, W, in_ch] the layer input, out fp16 [nseq, W, 2H] its output.  put(name, rows, perm) receives
+    the gradient of nn.LSTM parameter `name` as rows in KERNEL order: destination row perm[i] = rows[i]."""
     H4 = 4 * H
     perm = pack.lstm_gate_perm(H, dev)                       # kernel row 4j+g <- nn.LSTM row g*H+j
-    g = {}
-    dw, db = bw.conv_wgrad(ops, da.view(nseq, 1, W, 2 * H4), x.reshape(nseq, 1, W, in_ch), [0], [0])      # [1, 8H, in_ch], [8H] (a row per sequence: the kernel cuts rows into parallel chunks)
-    w_t = []
+    dw, db = bw.conv_wgrad(ops, da.view(nseq, 1, W, 2 * H4), x.reshape(nseq, 1, W, in_ch), [0], [0])      # [1, 8H, in_ch], [8H]
     for dr, sfx in enumerate(('', '_reverse')):
-        gi = torch.empty(H4, in_ch, dtype=torch.float32, device=dev)
-        gi[perm] = dw[0, dr * H4:(dr + 1) * H4]
-        g[f'weight_ih_l{layer}{sfx}'] = gi
-        gb = torch.empty(H4, dtype=torch.float32, device=dev)
-        gb[perm] = db[dr * H4:(dr + 1) * H4]
-        g[f'bias_ih_l{layer}{sfx}'] = gb
-        g[f'bias_hh_l{layer}{sfx}'] = gb
+        put(f'weight_ih_l{layer}{sfx}', dw[0, dr * H4:(dr + 1) * H4], perm)
+        put(f'bias_ih_l{layer}{sfx}', db[dr * H4:(dr + 1) * H4], perm)
+        put(f'bias_hh_l{layer}{sfx}', db[dr * H4:(dr + 1) * H4], perm)
         dav = da.view(nseq, W, 2, H4)[:, :, dr, :].unsqueeze(1)                       # [nseq, 1, W, 4H] strided
         hv = out.view(nseq, W, 2 * H)[:, :, dr * H:(dr + 1) * H].unsqueeze(1)         # h of this direction
         if H % 8:
             dav, hv = dav.contiguous(), hv.contiguous()
         dwh, _ = bw.conv_wgrad(ops, dav, hv, [0], [1 if dr else -1], bias=False)      # h_{prev}: the step before in this direction
-        gh = torch.empty(H4, H, dtype=torch.float32, device=dev)
-        gh[perm] = dwh[0]
-        g[f'weight_hh_l{layer}{sfx}'] = gh
-        w_t.append(sd[f'weight_ih_l{layer}{sfx}'].detach().float().to(dev)[perm])   # [4H, in] kernel row order
-    wt = torch.cat(w_t, 0).t().contiguous()                                          # [in_ch, 8H]
-    spec = pack.make_conv_spec(wt[None, :, None, :], None, 2 * H4, 0, [0], [0], dev)
-    g['dx'] = ops.conv(spec, da.view(1, 1, npos, 2 * H4), None, 1, 1, 1, npos).view(nseq, W, in_ch)
-    return g
+        put(f'weight_hh_l{layer}{sfx}', dwh[0], perm)
 
 
 class _Ctx:
@@ -501,6 +487,15 @@ class TrainEngine:
         dev = dy.device
         B, T, F0 = ctx.B, ctx.T, ctx.F0
         self.g = grads
+        self._side = self._param_stream(dev)
+        try:
+            self._backward(ctx, dy, stage_done, m, ops, dev, B, T, F0)
+        finally:
+            if self._side is not None:
+                torch.cuda.current_stream(dev).wait_stream(self._side)
+            self._side = None
+
+    def _backward(self, ctx, dy, stage_done, m, ops, dev, B, T, F0):
         dz = bw.istft_bwd(ops, dy.reshape(B, ctx.Lout).contiguous().float(), m.nfft, ctx.hop_o, self._window(ctx.win_o, dev),
                           self._inv_env(ctx.win_o, ctx.hop_o, T, dev), T)                               # fp32 [B,F0,T,2]
         # adjoint of x * std + mean (aero.py:497-498) and the fp32 -> fp16 boundary with the loss scale
@@ -534,6 +529,35 @@ class TrainEngine:
 
     _unboost = 1.0
     _range_of = None             # AeroFunction: prefix -> contiguous fp32 view of the flat gradient buffer covering those parameters
+    _side = None                 # the parameter-gradient stream of the backward pass that is running (None: everything on one stream)
+    _side_streams = None
+
+    def _param_stream(self, dev):
+        if dev.type != 'cuda' or os.environ.get('AERO_TRAIN_STREAMS', '2') == '1':
+            return None
+        if self._side_streams is None:
+            self._side_streams = {}
+        if dev not in self._side_streams:
+            self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        return self._side_streams[dev]
+
+    @contextlib.contextmanager
+    def on_param_stream(self, *tensors):
+        """Parameter-gradient work (weight gradients, their un-scaling, the gradient all-reduce) goes to a SECOND HIP stream: nothing on the
+        activation-gradient chain waits for it, and at BASELINE config 5's per-GPU batch that chain is a string of latency-bound
+        launches (LSTM / LocalState backward: 9-18 blocks on 256 CUs) under which the weight-gradient GEMMs fit.  Entering waits for
+        everything the main stream has issued so far; `tensors` (allocated on the main stream, read here) are kept from being
+        recycled until this stream is done with them; backward() joins the two streams before it returns."""
+        side = self._side
+        if side is None:
+            yield
+            return
+        side.wait_stream(torch.cuda.current_stream(side.device))
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            yield
 
     def _factor(self, f, dev):
         key = ('factor', f, str(dev))
@@ -563,18 +587,19 @@ class TrainEngine:
         gw = self.g[wname]
         gb = self.g[bname] if bname else None
         M, Cx, nt, rowlen = dy.shape[-1], x.shape[-1], len(df), gw.shape[1]
-        if bw.wgrad_direct_ok(dy, x) and gw.shape[0] == M and gw[0, 0].numel() == nt and coff + Cx <= rowlen:
-            bw.conv_wgrad(self.ops, dy, x, df, dt, fstride=fstride, bias=gb is not None, dw_out=gw, db_out=gb, layout=1, rowlen=rowlen, coff=coff)
-        else:
-            dw, db = bw.conv_wgrad(self.ops, dy, x, df, dt, fstride=fstride, bias=gb is not None)
-            Mp, Cp = gw.shape[0], min(Cx, rowlen - coff)
-            gw.view(Mp, rowlen, nt)[:, coff:coff + Cp].copy_(dw[:, :Mp, :Cp].permute(1, 2, 0))
-            if gb is not None:
-                gb.copy_(db[:Mp])
-        if self._unboost != 1.0 and self._range_of is None:
-            for t in (gw, gb):
-                if t is not None:
-                    TO.scale_f32(self.ops, t, self._factor(self._unboost, t.device))
+        with self.on_param_stream(dy, x):
+            if bw.wgrad_direct_ok(dy, x) and gw.shape[0] == M and gw[0, 0].numel() == nt and coff + Cx <= rowlen:
+                bw.conv_wgrad(self.ops, dy, x, df, dt, fstride=fstride, bias=gb is not None, dw_out=gw, db_out=gb, layout=1, rowlen=rowlen, coff=coff)
+            else:
+                dw, db = bw.conv_wgrad(self.ops, dy, x, df, dt, fstride=fstride, bias=gb is not None)
+                Mp, Cp = gw.shape[0], min(Cx, rowlen - coff)
+                gw.view(Mp, rowlen, nt)[:, coff:coff + Cp].copy_(dw[:, :Mp, :Cp].permute(1, 2, 0))
+                if gb is not None:
+                    gb.copy_(db[:Mp])
+            if self._unboost != 1.0 and self._range_of is None:
+                for t in (gw, gb):
+                    if t is not None:
+                        TO.scale_f32(self.ops, t, self._factor(self._unboost, t.device))
 
     def _norm_bwd_to(self, names, x, dy, stats, G, per_row, gamma, beta, act, **kw):
         """bw.norm_bwd with the parameter gradients accumulated straight into the flat gradient buffer: names = the parameters of
@@ -626,11 +651,12 @@ class TrainEngine:
                 pad_eff, Fz = pad, r.Ft
         dyv = ops.conv(self.spec(p + f'.tr_dgrad{pad_eff}', lambda: bw.dgrad_convtr(self.w(f'{p}.conv_tr.weight'), s, pad_eff, dev)), dz, None, B, Fz, Fq, T)
         self._wgrad_to(f'{p}.conv_tr.weight', None, r.y, dz, [kk - pad_eff for kk in range(K)], [0] * K, fstride=s)     # [Cin, Cout, K, 1]
-        if dz.shape[-1] % 8 == 0:                               # (the bias sum rides on a product with 8 of dz's own channels)
-            bw.conv_wgrad(ops, dz, dz[..., :8], [0], [0], bias=True, db_out=self.g[f'{p}.conv_tr.bias'])
-        else:
-            _, db = bw.conv_wgrad(ops, dz, dz, [0], [0], bias=True)
-            self._put(f'{p}.conv_tr.bias', db)
+        with self.on_param_stream(dz):
+            if dz.shape[-1] % 8 == 0:                           # (the bias sum rides on a product with 8 of dz's own channels)
+                bw.conv_wgrad(ops, dz, dz[..., :8], [0], [0], bias=True, db_out=self.g[f'{p}.conv_tr.bias'])
+            else:
+                _, db = bw.conv_wgrad(ops, dz, dz, [0], [0], bias=True)
+                self._put(f'{p}.conv_tr.bias', db)
         # norm1 + GLU
         if dec.norm:
             dr = self._norm_bwd_to((f'{p}.norm1.weight', f'{p}.norm1.bias'), r.r, dyv, r.st1, dec.norm_groups, 0,
@@ -660,8 +686,10 @@ class TrainEngine:
         Fq, Fo = r.Fq, r.Fo
         if i == 0 and m.freq_emb is not None:
             ge = self.g['freq_emb.embedding.weight']
-            ge.zero_()
-            TO.sum_bt(ops, dout.contiguous(), ge, float(m.freq_emb.scale * m.freq_emb_scale))
+            dout = dout.contiguous()
+            with self.on_param_stream(dout):
+                ge.zero_()
+                TO.sum_bt(ops, dout, ge, float(m.freq_emb.scale * m.freq_emb_scale))
         # norm2 + GLU, rewrite
         if enc.norm:
             dr = self._norm_bwd_to((f'{p}.norm2.weight', f'{p}.norm2.bias'), r.r, dout, r.st_rw, enc.norm_groups, 0,
@@ -712,7 +740,8 @@ class TrainEngine:
         dxa = ops.conv(self.spec(q + '.c2_dgrad_b', lambda: bw.dgrad_conv2d(self.w(f'{q}.conv2.0.weight')[:, Cc:], 0, 0, dev)), dy3, None, B, Fq, Fq, T)
         # freq_fc and the gate product
         gfc = self.g[f'{q}.freq_fc.weight']
-        gfc.copy_(TO.freqfc_wgrad(ops, dfc, x, r.gate))
+        with self.on_param_stream(dfc, x, r.gate):
+            gfc.copy_(TO.freqfc_wgrad(ops, dfc, x, r.gate))
         okey = ('ones', B, T, Cc, str(dev))
         if okey not in self._tables:
             self._tables[okey] = torch.ones(B, T, Cc, dtype=torch.float16, device=dev)
@@ -724,10 +753,11 @@ class TrainEngine:
         spec1d = self.spec(q + '.c1d', None)
         k9 = len(spec1d.dt)
         img = r.c1.view(B, 1, T, Fq * rp)
-        dw, db = bw.conv_wgrad(ops, dy2, img, spec1d.df, spec1d.dt)                     # [k9, C, F*rp], ours channel f*rp + c
-        dw = dw.view(k9, Cc, Fq, rp)[..., :rch].permute(1, 3, 2, 0)                     # -> [C, r, F, k]: reference channel c*F + f
-        self._put(f'{q}.conv1d.0.weight', dw)
-        self._put(f'{q}.conv1d.0.bias', db)
+        with self.on_param_stream(dy2, img):
+            dw, db = bw.conv_wgrad(ops, dy2, img, spec1d.df, spec1d.dt)                 # [k9, C, F*rp], ours channel f*rp + c
+            dw = dw.view(k9, Cc, Fq, rp)[..., :rch].permute(1, 3, 2, 0)                 # -> [C, r, F, k]: reference channel c*F + f
+            self._put(f'{q}.conv1d.0.weight', dw)
+            self._put(f'{q}.conv1d.0.bias', db)
 
         def b_dg1d():
             w = self.w(f'{q}.conv1d.0.weight')
@@ -781,7 +811,8 @@ class TrainEngine:
                 return bw.dgrad_conv1d(wp, dil, dil * (k // 2), dev)
             dxb = ops.conv(self.spec(q + '.c1_dgrad', b_dg1), dh1, None, B, Fo, Fo, T)
             if self._range_of is not None and bst != 1.0:
-                TO.scale_f32(ops, self._range_of(q + '.'), self._factor(1.0 / bst, dev))
+                with self.on_param_stream():                    # (after every gradient of the layer, on either stream)
+                    TO.scale_f32(ops, self._range_of(q + '.'), self._factor(1.0 / bst, dev))
         finally:
             self._unboost = 1.0
         return TO.add_f16(ops, dy, dxb, scale_b=1.0 / bst)      # skip path + the branch, un-boosted in fp32
@@ -795,15 +826,16 @@ class TrainEngine:
         dsc = 4096.0                                             # own power-of-two scale of the decay columns (~1e-6 below dQ / dK / dV)
         dqkvd = TO.localstate_bwd(ops, r.qkvd.view(R, T, -1), r.att, datt.view(R, T, Cc), R, T, Cc, r.heads, r.ndecay, decay_scale=dsc)
         dqk = dqkvd.view(B, Fo, T, -1)
-        dw, db = bw.conv_wgrad(ops, dqk, r.a, [0], [0])
         nd = r.heads * r.ndecay
-        dw[0, 3 * Cc:3 * Cc + nd] *= 1.0 / dsc                    # (parameter-sized fp32 rows: exact power of two)
-        db[3 * Cc:3 * Cc + nd] *= 1.0 / dsc
-        o = 0
-        for nme, n in (('query', Cc), ('key', Cc), ('content', Cc), ('query_decay', nd)):
-            self._put(f'{q}.{nme}.weight', dw[0, o:o + n])
-            self._put(f'{q}.{nme}.bias', db[o:o + n])
-            o += n
+        with self.on_param_stream(dqk, r.a):
+            dw, db = bw.conv_wgrad(ops, dqk, r.a, [0], [0])
+            dw[0, 3 * Cc:3 * Cc + nd] *= 1.0 / dsc                # (parameter-sized fp32 rows: exact power of two)
+            db[3 * Cc:3 * Cc + nd] *= 1.0 / dsc
+            o = 0
+            for nme, n in (('query', Cc), ('key', Cc), ('content', Cc), ('query_decay', nd)):
+                self._put(f'{q}.{nme}.weight', dw[0, o:o + n])
+                self._put(f'{q}.{nme}.bias', db[o:o + n])
+                o += n
 
         def b_dg():
             w = wq.clone()
@@ -824,11 +856,18 @@ class TrainEngine:
             da = TO.lstm_bwd(ops, dout, whh_t[l], r.saves[l][0], r.saves[l][1], H, r.nseq, r.W, out_mode=1 if stitched else 0,
                              nframes=r.nf, S=r.S, T=T)
             xin = xs[l].reshape(r.nseq, r.W, -1)
-            g = lstm_param_grads(ops, da, xin, r.outs[l], sdl, l, H, r.nseq, r.W, xin.shape[-1], dev)
-            for kname, v in g.items():
-                if kname != 'dx':
-                    self._put(f'{q}.lstm.{kname}', v)
-            dout = g['dx']
+            in_ch, npos = xin.shape[-1], r.nseq * r.W
+
+            def b_ih(l=l):                                       # dx = da W_ih: the input projection's data gradient, both directions
+                perm = pack.lstm_gate_perm(H, dev)
+                wt = torch.cat([self.w(f'{q}.lstm.weight_ih_l{l}{sfx}')[perm] for sfx in ('', '_reverse')], 0).t().contiguous()   # [in_ch, 8H]
+                return pack.make_conv_spec(wt[None, :, None, :], None, 8 * H, 0, [0], [0], dev)
+            dout = ops.conv(self.spec(q + f'.ih_dgrad{l}', b_ih), da.view(1, 1, npos, 8 * H), None, 1, 1, 1, npos).view(r.nseq, r.W, in_ch)
+
+            def put(kname, rows, perm):                          # scattered straight into the flat gradient buffer (zero before)
+                self.g[f'{q}.lstm.{kname}'].index_copy_(0, perm, rows)
+            with self.on_param_stream(da, xin, r.outs[l]):
+                lstm_param_grads(ops, da, xin, r.outs[l], l, H, r.nseq, r.W, in_ch, dev, put)
         dfr = dout                                               # [nseq, W, H]
         da_in = TO.frames_op(ops, dfr.contiguous(), 1, R, T, H, r.nf, r.W, r.S) if r.framed else dfr
         return TO.add_f16(ops, dy.contiguous(), da_in.reshape(dy.shape).contiguous())
@@ -880,20 +919,21 @@ class AeroFunction(torch.autograd.Function):
 
         def stage_done(prefix, scale):
             prefixes = [prefix] + (['freq_emb.'] if prefix == 'encoder.0.' and any(nme.startswith('freq_emb.') for nme in names) else [])
-            for pf in prefixes:
-                a, b = span(pf)
-                TO.scale_f32(eng.ops, flat[a:b], sync.unscale(scale) if sync is not None else scale[1:])
-            if sync is None:
-                return
-            # all-reduce in a few flat segments as stages complete: the whole decoder once its last layer is done (it overlaps with the
-            # encoders' backward, the bulk of the time), then each encoder level
-            if prefix == 'decoder.0.':
-                a, b = span('decoder.')
-                sync.reduce_async(flat[a:b])
-            elif prefix.startswith('encoder.'):
+            with eng.on_param_stream(scale):                     # (after every gradient of the stage, whichever stream produced it)
                 for pf in prefixes:
                     a, b = span(pf)
+                    TO.scale_f32(eng.ops, flat[a:b], sync.unscale(scale) if sync is not None else scale[1:])
+                if sync is None:
+                    return
+                # all-reduce in a few flat segments as stages complete: the whole decoder once its last layer is done (it overlaps with
+                # the encoders' backward, the bulk of the time), then each encoder level
+                if prefix == 'decoder.0.':
+                    a, b = span('decoder.')
                     sync.reduce_async(flat[a:b])
+                elif prefix.startswith('encoder.'):
+                    for pf in prefixes:
+                        a, b = span(pf)
+                        sync.reduce_async(flat[a:b])
         def range_of(prefix):
             a, b = span(prefix)
             return flat[a:b]

@@ -1023,8 +1023,20 @@ def case_lstm_bwd(lib, dev, H, nseq, W, in_ch=None, seed=240, framed_T=None):
 
 
 def lstm_layer_grads(ops, da, x, out, sd, pre, layer, H, nseq, W, in_ch, dev):
+    """parameter gradients (aero_amd.train.lstm_param_grads, scattered into zeroed nn.LSTM-shaped buffers as the engine does into its
+    flat buffer) and dx = da W_ih (the engine's `.ih_dgrad` image)"""
     from aero_amd.train import lstm_param_grads
-    return lstm_param_grads(ops, da, x, out, {k[len(pre) + 1:]: v for k, v in sd.items()}, layer, H, nseq, W, in_ch, dev)
+    sdl = {k[len(pre) + 1:]: v for k, v in sd.items()}
+    g = {}
+
+    def put(name, rows, perm):
+        g.setdefault(name, torch.zeros(sdl[name].shape, dtype=torch.float32, device=dev)).index_copy_(0, perm, rows)
+    lstm_param_grads(ops, da, x, out, layer, H, nseq, W, in_ch, dev, put)
+    perm = pack.lstm_gate_perm(H, dev)
+    wt = torch.cat([sdl[f'weight_ih_l{layer}{sfx}'].detach().float().to(dev)[perm] for sfx in ('', '_reverse')], 0).t().contiguous()
+    spec = pack.make_conv_spec(wt[None, :, None, :], None, 8 * H, 0, [0], [0], dev)
+    g['dx'] = ops.conv(spec, da.view(1, 1, nseq * W, 8 * H), None, 1, 1, 1, nseq * W).view(nseq, W, in_ch)
+    return g
 
 
 def case_localstate_bwd(lib, dev, Cc, heads, R, T, seed=250):
