@@ -351,6 +351,10 @@ int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream) {
     return aero_finish(rc, err);
 }
 
+int aero_gconv1d_mfma_ok(int32_t Cin, int32_t Cout, int32_t groups, int32_t K, int32_t stride, int32_t pad, int32_t reflect) {
+    return aero_gconv4_ok(Cin, Cout, groups, K, stride, pad, reflect);
+}
+
 int aero_gconv1d_fwd(const aero_gconv_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_gconv1d_launch(d, (hipStream_t)stream, &err);

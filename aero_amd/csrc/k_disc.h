@@ -12,6 +12,7 @@
 // owns 64 output steps of one group chunk; the input span and the group's weights sit in LDS as fp32.
 #pragma once
 #include "aero_common.h"
+#include "k_gconv_mfma.h"
 
 struct AeroGconvK {
     const h16* x; const h16* w; const float* bias; h16* y;
@@ -94,6 +95,19 @@ static int aero_gconv1d_launch(const aero_gconv_desc* d, hipStream_t stream, con
     p.reflect = d->reflect; p.slope = d->slope;
     p.Tout = (d->Tin + 2 * d->pad - d->K) / d->stride + 1;
     if (p.Tout < 1) { *err = "gconv1d: kernel longer than the padded input"; return AERO_ERR_ARG; }
+    if (d->w_mfma && aero_gconv4_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad, d->reflect) && d->B <= 65535) {
+        if (((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->w_mfma | (uintptr_t)d->bias) & 15) { *err = "gconv1d: 16-byte aligned tensors required"; return AERO_ERR_ARG; }
+        AeroGconv4K m;
+        m.src = (const h16*)d->x; m.act = nullptr; m.wimg = (const h16*)d->w_mfma; m.bias = d->bias; m.dst = (h16*)d->y;
+        m.B = d->B; m.Ts = d->Tin; m.Cs = d->Cin; m.Td = p.Tout; m.Cd = d->Cout; m.groups = d->groups; m.pad = d->pad; m.slope = d->slope;
+        aero_gconv4_tile(d->groups, &m.GPB, &m.NT);
+        m.ROWS = m.NT * 4 + 48;
+        const size_t lds = (size_t)m.GPB * m.ROWS * 4 * sizeof(h16);
+        dim3 grid((unsigned)((p.Tout + m.NT - 1) / m.NT), (unsigned)(d->groups / m.GPB), (unsigned)d->B);
+        if (d->Cout / d->groups == 16) AERO_LAUNCH_DYN(aero_gconv4_fwd_kernel<16>, grid, dim3(256), lds, stream, m);
+        else AERO_LAUNCH_DYN(aero_gconv4_fwd_kernel<4>, grid, dim3(256), lds, stream, m);
+        return AERO_OK;
+    }
     p.cig = d->Cin / d->groups;
     p.cog = d->Cout / d->groups;
     p.cob = p.cog < 64 ? p.cog : 64;
@@ -327,7 +341,20 @@ static int aero_gconv1d_bwd_launch(const aero_gconv_bwd_desc* d, hipStream_t str
     if (p.cog > 64) { *err = "gconv1d_bwd: more than 64 output channels per group"; return AERO_ERR_UNSUPPORTED; }
     p.ntile = (p.Tout + AERO_GCONV_TO - 1) / AERO_GCONV_TO;
     p.tiles_per_block = 1;
-    if (d->dx) {
+    if (d->dx && d->w_dgrad_mfma && aero_gconv4_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad, d->reflect)) {
+        if (((uintptr_t)d->dx | (uintptr_t)d->dy | (uintptr_t)d->y | (uintptr_t)d->w_dgrad_mfma) & 15) { *err = "gconv1d_bwd: 16-byte aligned tensors required"; return AERO_ERR_ARG; }
+        AeroGconv4K m;
+        m.src = (const h16*)d->dy; m.act = (const h16*)d->y; m.wimg = (const h16*)d->w_dgrad_mfma; m.bias = nullptr; m.dst = (h16*)d->dx;
+        m.B = d->B; m.Ts = p.Tout; m.Cs = d->Cout; m.Td = d->Tin; m.Cd = d->Cin; m.groups = d->groups; m.pad = d->pad; m.slope = d->slope;
+        aero_gconv4_tile(d->groups, &m.GPB, &m.NT);
+        const int cog = d->Cout / d->groups;
+        m.ROWS = m.NT + (cog == 16 ? 12 : 16);
+        const size_t lds = (size_t)m.GPB * m.ROWS * cog * sizeof(h16);
+        const int umax = ((d->Tin - 1 + d->pad) >> 2) + 1;
+        dim3 grid((unsigned)((umax + m.NT - 1) / m.NT), (unsigned)(d->groups / m.GPB), (unsigned)d->B);
+        if (cog == 16) AERO_LAUNCH_DYN(aero_gconv4_dgrad_kernel<16>, grid, dim3(256), lds, stream, m);
+        else AERO_LAUNCH_DYN(aero_gconv4_dgrad_kernel<4>, grid, dim3(256), lds, stream, m);
+    } else if (d->dx) {
         const size_t lds = (size_t)p.cog * p.K * AERO_GCONV_CIC * sizeof(float);
         if (lds > 150 * 1024) { *err = "gconv1d_bwd: weights exceed the LDS"; return AERO_ERR_UNSUPPORTED; }
         AERO_LAUNCH_DYN(aero_gconv1d_dgrad_kernel, dim3((unsigned)((p.Tin + 255) / 256), (unsigned)d->groups, (unsigned)d->B), dim3(256), lds, stream, p);

@@ -67,6 +67,28 @@ class NLayerDiscriminator(nn.Module):
         raise RuntimeError('run the critic through Discriminator.forward (HIP kernels)')
 
 
+def gconv_mfma_images(w, groups, dev):
+    """weights [Cout, 4, K] of a grouped stride-4 Conv1d (weight norm applied) -> the two fp16 images of the MFMA kernels
+    (include/aero_hip.h, aero_gconv_desc.w_mfma / aero_gconv_bwd_desc.w_dgrad_mfma; csrc/k_gconv_mfma.h)"""
+    Cout, cig, K = w.shape
+    cog = Cout // groups
+    assert cig == 4 and cog in (4, 16) and K <= 44
+    wg = w.view(groups, cog, 4, K)
+    fwd = torch.zeros(groups, 16, 192, dtype=torch.float32, device=w.device)
+    fwd[:, :cog, :4 * K] = wg.permute(0, 1, 3, 2).reshape(groups, cog, 4 * K)             # column 4 k + c
+    wp = torch.zeros(groups, cog, 4, 48, dtype=torch.float32, device=w.device)
+    wp[..., :K] = wg
+    t = wp.view(groups, cog, 4, 12, 4).permute(0, 4, 2, 3, 1)                             # [g, r, c, j, o] = W[o][c][r + 4 j]
+    if cog == 16:
+        dg = t.reshape(groups, 16, 192)                                                   # column 16 j + o
+    else:
+        t = t.reshape(groups, 16, 6, 2, 4).flip(3)                                        # octet m: (j = 2m + 1, o), (j = 2m, o)
+        dg = torch.zeros(groups, 16, 64, dtype=torch.float32, device=w.device)
+        dg[:, :, :48] = t.reshape(groups, 16, 48)
+    cvt = lambda a: a.to(device=dev, dtype=torch.float16).contiguous()                    # noqa: E731
+    return cvt(fwd), cvt(dg)
+
+
 class Discriminator(nn.Module):
     @capture_init
     def __init__(self, num_D, ndf, n_layers, downsampling_factor):
@@ -109,6 +131,8 @@ class Discriminator(nn.Module):
                     ent['spec'] = pack.make_conv_spec(taps, conv.bias.detach().float(), cig, 0, df, dt, dev)
                 else:
                     ent['w'] = w.permute(0, 2, 1).contiguous().to(device=dev, dtype=torch.float16)      # [Cout][K][Cin/groups]
+                    if self._get_ops().lib.cdll.aero_gconv1d_mfma_ok(ent['Cin'], Cout, g['groups'], K, g['stride'], g['pad'], int(g['reflect'])):
+                        ent['w_mfma'], ent['w_dgrad_mfma'] = gconv_mfma_images(w, g['groups'], dev)
                 layers.append(ent)
             packed.append(layers)
         self._packed, self._key = packed, key
@@ -143,6 +167,7 @@ class Discriminator(nn.Module):
                     d.B, d.Tin, d.Cin, d.Cout, d.groups, d.K, d.stride, d.pad, d.reflect = B, Tc, ent['Cin'], ent['Cout'], ent['groups'], ent['K'], \
                         ent['stride'], ent['pad'], ent['reflect']
                     d.slope = ent['slope']
+                    d.w_mfma = _ptr(ent.get('w_mfma'))
                     ops.lib.call('aero_gconv1d_fwd', C.byref(d), ops.stream(y))
                 recs.append((ent, h, y))
                 h, Tc = y, To
@@ -217,6 +242,7 @@ class Discriminator(nn.Module):
                     d.B, d.Tin, d.Cin, d.Cout, d.groups, d.K, d.stride, d.pad, d.reflect = B, Tin, ent['Cin'], ent['Cout'], ent['groups'], ent['K'], \
                         ent['stride'], ent['pad'], ent['reflect']
                     d.slope = ent['slope']
+                    d.w_dgrad_mfma = _ptr(ent.get('w_dgrad_mfma'))
                     ops.lib.call('aero_gconv1d_bwd', C.byref(d), ops.stream(g))
                     if want_params:
                         dwt = dwk.permute(0, 2, 1).contiguous()                     # [Cout, Cin/groups, K]

@@ -469,8 +469,13 @@ typedef struct {
     const void* x; const void* w; const float* bias; void* y;
     int32_t B, Tin, Cin, Cout, groups, K, stride, pad, reflect;
     float slope;
+    /* optional MFMA form (layers with 4 input channels and 16 or 4 output channels per group, stride 4, zero padding, K <= 44:
+     * aero_gconv1d_mfma_ok): the same weights as fp16 [groups][16][192], row o < Cout/groups, column 4 k + c, zero elsewhere.  NULL (or a
+     * geometry the MFMA form does not take): the VALU kernel. */
+    const void* w_mfma;
 } aero_gconv_desc;
 int aero_gconv1d_fwd(const aero_gconv_desc* d, void* stream);
+int aero_gconv1d_mfma_ok(int32_t Cin, int32_t Cout, int32_t groups, int32_t K, int32_t stride, int32_t pad, int32_t reflect);
 int aero_leaky_relu(void* x, int64_t n, float slope, void* stream);                      /* fp16 [n], in place */
 /* nn.AvgPool1d(4, stride=2, padding=1, count_include_pad=False) (discriminators.py:70): x fp16 [B][T] -> y fp16 [B][(T-2)/2+1] */
 int aero_avgpool1d(const void* x, void* y, int32_t B, int32_t T, void* stream);
@@ -486,6 +491,10 @@ typedef struct {
     const void* x; const void* w; const void* y; const void* dy; void* dx; float* dw; float* db;
     int32_t B, Tin, Cin, Cout, groups, K, stride, pad, reflect;
     float slope;
+    /* optional MFMA form of the data gradient (same geometries as aero_gconv_desc.w_mfma): fp16 [groups][16][KD], row 4 r + c, with
+     * cog = Cout/groups = 16: KD = 192, column 16 j + o; cog = 4: KD = 64, column 8 m + e = (j = 2m + 1, o = e) for e < 4, (j = 2m, o = e - 4)
+     * otherwise; value W[g cog + o][c][r + 4 j] (zero where r + 4 j >= K). */
+    const void* w_dgrad_mfma;
 } aero_gconv_bwd_desc;
 int aero_gconv1d_bwd(const aero_gconv_bwd_desc* d, void* stream);
 /* gradients of the loss terms as fp16: mode 0 g = coef * sign * [1 + sign a > 0] (hinge, solver.py:489-496,508), mode 1

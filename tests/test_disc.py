@@ -81,13 +81,26 @@ def _gconv_case(lib, dev, B, Cin, Cout, groups, K, stride, pad, T, reflect=0, sl
     assert rel_l2(dx.float().cpu().permute(0, 2, 1), x.grad) < 2e-3
     # (fp32 atomics over up to ~5e4 positions per output: the sum order is not fixed)
     assert rel_l2(dw.cpu().permute(0, 2, 1), w.grad) < 2e-4 and rel_l2(db.cpu(), b.grad) < 2e-4
+    if lib.cdll.aero_gconv1d_mfma_ok(Cin, Cout, groups, K, stride, pad, reflect):
+        # the MFMA forms of the same layer (csrc/k_gconv_mfma.h): forward and data gradient from the two weight images
+        from aero_amd.discriminators import gconv_mfma_images
+        wf, wd = gconv_mfma_images(w.detach(), groups, dev)
+        y2 = torch.full_like(yk, float('nan'))
+        d.y, d.w_mfma = _ptr(y2), _ptr(wf)
+        lib.call('aero_gconv1d_fwd', C.byref(d), stream)
+        assert rel_l2(y2.float().cpu().permute(0, 2, 1), y.detach()) < 5e-4 and rel_l2(y2.float().cpu(), yk.float().cpu()) < 5e-4
+        dx2 = torch.full_like(dx, float('nan'))
+        bd.dx, bd.dw, bd.db, bd.w_dgrad_mfma = _ptr(dx2), None, None, _ptr(wd)
+        lib.call('aero_gconv1d_bwd', C.byref(bd), stream)
+        assert bool(torch.isfinite(dx2).all())                   # every input step written
+        assert rel_l2(dx2.float().cpu().permute(0, 2, 1), x.grad) < 2e-3 and rel_l2(dx2.float().cpu(), dx.float().cpu()) < 1e-3
 
 
-GCONV = [(2, 16, 64, 4, 41, 4, 20, 300), (2, 256, 256, 64, 41, 4, 20, 16), (2, 1, 16, 1, 15, 1, 7, 200, 1), (2, 128, 1, 1, 3, 1, 1, 9, 0, 1.0),
+GCONV = [(2, 16, 64, 4, 41, 4, 20, 300), (2, 256, 256, 64, 41, 4, 20, 16), (1, 64, 256, 16, 41, 4, 20, 139), (2, 1, 16, 1, 15, 1, 7, 200, 1), (2, 128, 1, 1, 3, 1, 1, 9, 0, 1.0),
          (2, 4, 16, 1, 41, 4, 20, 2048)]
 
 
-@pytest.mark.parametrize('a', GCONV[:4])
+@pytest.mark.parametrize('a', GCONV[:5])
 def test_grouped_conv_op(a):
     from aero_amd import _lib
     from emu.build_emu import build
