@@ -100,10 +100,13 @@ class Discriminator(nn.Module):
         self.downsample = nn.AvgPool1d(4, stride=2, padding=1, count_include_pad=False)
         self.apply(weights_init)
         self._ops, self._packed, self._key = None, None, None
+        self._pair, self._epoch = None, 0
 
     def repack(self):
         """the weights were edited behind autograd's version counters (FlatAdam's fused step): re-pack on the next forward"""
         self._key = None
+        self._pair = None
+        self._epoch += 1
 
     def use_library(self, lib):
         """tests: an explicitly loaded library (the CPU-emulated test double)"""
@@ -178,6 +181,24 @@ class Discriminator(nn.Module):
                 ops.lib.call('aero_avgpool1d', _ptr(cur), _ptr(nxt), B, T, ops.stream(cur))
                 cur = nxt
         return scales
+
+    def _run_pair(self, fake, real):
+        """D(fake) and D(real) as ONE batch of 2B signals (the reference runs the critic twice per loss, solver.py:478-480,505-506: the
+        same arithmetic per signal, half the launches), kept until the weights or the signals change: the critic's own step
+        (solver.py:607-611) evaluates D on exactly the signals and weights the generator's adversarial / feature losses just used, so
+        its forward pass is this record again.  Returns (record of the 2B batch, B)."""
+        if fake.shape != real.shape:
+            raise ValueError('fake and real must have the same shape')
+        key = (fake.data_ptr(), fake._version, real.data_ptr(), real._version, tuple(fake.shape), str(fake.device)) + \
+            tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self._epoch,)
+        if self._pair is None or self._pair[0] != key:
+            self._pair = (key, self._run(torch.cat([fake.detach(), real.detach()], 0)))
+        return self._pair[1], fake.shape[0]
+
+    @staticmethod
+    def _half(runs, lo, hi):
+        """the record of batch items [lo, hi) of a run (views)"""
+        return [(cur[lo:hi], [(ent, h[lo:hi], y[lo:hi]) for (ent, h, y) in recs]) for (cur, recs) in runs]
 
     def forward(self, x):
         """x [B, 1, T] float waveform on the device -> list over scales of [fmap_0 .. fmap_5, logits], each [B, C, T'] (values; the
@@ -276,41 +297,57 @@ class Discriminator(nn.Module):
         return v * (gg / v.flatten(1).norm(dim=1).view(-1, 1, 1))
 
 
-def _scaled_grad(ops, a, b, n_mean, sign, coef, mode):
+def _scaled_grad(ops, a, b, n_mean, sign, coef, mode, out=None):
     """gradient of coef * mean(...) as fp16 with a host-chosen power-of-two scale: returns (tensor, {S, 1/S} on the device)"""
     import math
     c = coef / n_mean
     S = 2.0 ** round(math.log2(32.0 / max(abs(c), 1e-30)))
-    g = torch.empty(a.shape, dtype=torch.float16, device=a.device)
+    g = torch.empty(a.shape, dtype=torch.float16, device=a.device) if out is None else out
+    assert a.is_contiguous() and g.is_contiguous() and (b is None or b.is_contiguous())
     ops.lib.call('aero_loss_grad', _ptr(a), _ptr(b), a.numel(), C.c_float(sign), C.c_float(c * S), mode, _ptr(g), ops.stream(a))
-    return g, torch.tensor([S, 1.0 / S], dtype=torch.float32, device=a.device)
+    return g, _scale_pair(S, a.device)
+
+
+_SCALES = {}
+
+
+def _scale_pair(S, dev):
+    """{S, 1/S} on the device (cached: host-chosen powers of two, a handful of distinct values)"""
+    key = (S, str(dev))
+    if key not in _SCALES:
+        _SCALES[key] = torch.tensor([S, 1.0 / S], dtype=torch.float32, device=dev)
+    return _SCALES[key]
 
 
 class _CriticLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, disc, names, fake, real, *params):
         ops = disc._get_ops()
-        rf, rr = disc._run(fake), disc._run(real)
+        runs, B = disc._run_pair(fake, real)
         acc = torch.zeros(2, dtype=torch.float64, device=fake.device)
         loss = torch.zeros((), dtype=torch.float64, device=fake.device)
-        for (_, a), (_, b) in zip(rf, rr):
+        for (_, recs) in runs:
+            logits = recs[-1][2]
             acc.zero_()
-            _loss_sum(ops, a[-1][2], None, 1.0, 0, acc[0:1])
-            _loss_sum(ops, b[-1][2], None, -1.0, 0, acc[1:2])
-            loss = loss + acc[0] / a[-1][2].numel() + acc[1] / b[-1][2].numel()
-        ctx.disc, ctx.names, ctx.runs = disc, names, (rf, rr)
+            _loss_sum(ops, logits[:B], None, 1.0, 0, acc[0:1])
+            _loss_sum(ops, logits[B:], None, -1.0, 0, acc[1:2])
+            loss = loss + (acc[0] + acc[1]) / logits[:B].numel()
+        ctx.disc, ctx.names, ctx.runs, ctx.B = disc, names, runs, B
         return loss.float()
 
     @staticmethod
     def backward(ctx, gl):
         disc, ops = ctx.disc, ctx.disc._get_ops()
-        rf, rr = ctx.runs
-        total = {}
-        for runs, sign in ((rf, 1.0), (rr, -1.0)):
-            dtop = [_scaled_grad(ops, recs[-1][2], None, recs[-1][2].numel(), sign, 1.0, 0) for (_, recs) in runs]
-            grads, _ = disc._backward(runs, dtop, None, True, False)
-            for k, v in grads.items():
-                total[k] = v if k not in total else total[k] + v
+        B = ctx.B
+        # one backward pass over the 2B batch: d relu(1 + D(fake)).mean() on the first half, d relu(1 - D(real)).mean() on the second
+        dtop = []
+        for (_, recs) in ctx.runs:
+            logits = recs[-1][2]
+            g = torch.empty_like(logits)
+            _, sc = _scaled_grad(ops, logits[:B], None, logits[:B].numel(), 1.0, 1.0, 0, out=g[:B])
+            _scaled_grad(ops, logits[B:], None, logits[B:].numel(), -1.0, 1.0, 0, out=g[B:])
+            dtop.append((g, sc))
+        total, _ = disc._backward(ctx.runs, dtop, None, True, False)
         ctx.runs = None
         g = gl.float()
         return (None, None, None, None) + tuple(total[n] * g for n in ctx.names)
@@ -320,7 +357,8 @@ class _GeneratorLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, disc, fake, real, n_layers, lam):
         ops = disc._get_ops()
-        rf, rr = disc._run(fake), disc._run(real)
+        runs, B = disc._run_pair(fake, real)
+        rf, rr = disc._half(runs, 0, B), disc._half(runs, B, 2 * B)
         num_D = len(rf)
         w_feat = (4.0 / (n_layers + 1)) * (1.0 / num_D)
         acc = torch.zeros(1, dtype=torch.float64, device=fake.device)

@@ -36,7 +36,43 @@ class Audit(TorchDispatchMode):
         return func(*args, **(kwargs or {}))
 
 
+def critic():
+    """the same count for the MelGAN critic: generator_losses (forward + backward to the fake waveform) and the critic's own step"""
+    from conftest import seeded
+    from emu.build_emu import build
+    from aero_amd import _lib
+    from aero_amd.discriminators import Discriminator
+    from aero_amd.optim import FlatAdam
+    lib = _lib.load(build())
+    torch.manual_seed(3)
+    d = Discriminator(num_D=3, ndf=16, n_layers=4, downsampling_factor=4)
+    d.use_library(lib)
+    opt = FlatAdam(d.parameters(), lr=1e-4, model=d, lib=lib)
+    fake = (seeded((2, 1, 4096), 1) * 0.3).requires_grad_()
+    real = seeded((2, 1, 4096), 2) * 0.3
+
+    def step():
+        fake.grad = None
+        adv, feat = d.generator_losses(fake, real, n_layers=4, features_loss_lambda=100.0)
+        (adv + feat).backward()
+        dl = d.discriminator_loss(fake.detach(), real)
+        opt.zero_grad()
+        dl.backward()
+        opt.step()
+    for _ in range(2):
+        step()
+    a = Audit()
+    with a:
+        step()
+    tot = sum(sum(c.values()) for c in a.sites.values())
+    print(f'critic: {tot} torch ops with a kernel behind them in one generator-loss + critic step')
+    for k, c in sorted(a.sites.items(), key=lambda kv: -sum(kv[1].values()))[:45]:
+        print(f'{sum(c.values()):5d}  {k:48s} ' + ', '.join(f'{n} x{v}' for n, v in c.most_common(5)))
+
+
 def main():
+    if '--gan' in sys.argv:
+        return critic()
     from conftest import GOLDEN, build_model, seeded
     from emu.build_emu import build
     from aero_amd import _lib, losses
