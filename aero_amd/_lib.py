@@ -100,7 +100,7 @@ class GconvDesc(C.Structure):
 class GconvBwdDesc(C.Structure):
     _fields_ = [('x', vp), ('w', vp), ('y', vp), ('dy', vp), ('dx', vp), ('dw', fp), ('db', fp),
                 ('B', i32), ('Tin', i32), ('Cin', i32), ('Cout', i32), ('groups', i32), ('K', i32), ('stride', i32), ('pad', i32),
-                ('reflect', i32), ('slope', C.c_float), ('w_dgrad_mfma', vp)]
+                ('reflect', i32), ('slope', C.c_float), ('w_dgrad_mfma', vp), ('slabs', fp), ('nslab', i32)]
 
 
 class FreqFcDesc(C.Structure):
@@ -185,6 +185,7 @@ _PROTOS = {
     'aero_scale_f32': (i32, [fp, i64, fp, vp]),
     'aero_gather_pack': (i32, [vp, vp, i32, vp, vp, i64, i32, vp]),
     'aero_gconv1d_mfma_ok': (i32, [i32, i32, i32, i32, i32, i32, i32]),
+    'aero_gconv1d_wgrad_slabs': (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32]),
     'aero_rescale_f16': (i32, [vp, fp, vp, fp, i64, vp, C.c_float, vp, fp, vp]),
     'aero_gconv1d_fwd': (i32, [C.POINTER(GconvDesc), vp]),
     'aero_leaky_relu': (i32, [vp, i64, C.c_float, vp]),

@@ -355,6 +355,16 @@ int aero_gconv1d_mfma_ok(int32_t Cin, int32_t Cout, int32_t groups, int32_t K, i
     return aero_gconv4_ok(Cin, Cout, groups, K, stride, pad, reflect);
 }
 
+int aero_gconv1d_wgrad_slabs(int32_t B, int32_t Tin, int32_t Cin, int32_t Cout, int32_t groups, int32_t K, int32_t stride, int32_t pad,
+                             int32_t reflect) {
+    if (B < 1 || Tin < 1 || !aero_gconv4_ok(Cin, Cout, groups, K, stride, pad, reflect)) return 0;
+    const int Tout = (Tin + 2 * pad - K) / stride + 1;
+    if (Tout < 1) return 0;
+    int ntile, tpc, nchunk;
+    aero_gconv4_wgrad_plan(B, Tout, groups, &ntile, &tpc, &nchunk);
+    return B * nchunk;
+}
+
 int aero_gconv1d_fwd(const aero_gconv_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_gconv1d_launch(d, (hipStream_t)stream, &err);

@@ -359,7 +359,41 @@ static int aero_gconv1d_bwd_launch(const aero_gconv_bwd_desc* d, hipStream_t str
         if (lds > 150 * 1024) { *err = "gconv1d_bwd: weights exceed the LDS"; return AERO_ERR_UNSUPPORTED; }
         AERO_LAUNCH_DYN(aero_gconv1d_dgrad_kernel, dim3((unsigned)((p.Tin + 255) / 256), (unsigned)d->groups, (unsigned)d->B), dim3(256), lds, stream, p);
     }
-    if (d->dw) {
+    if (d->dw && d->slabs && aero_gconv4_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad, d->reflect)) {
+        AeroGconv4WK m;
+        int NT;
+        aero_gconv4_tile(d->groups, &m.GPB, &NT);
+        aero_gconv4_wgrad_plan(d->B, p.Tout, d->groups, &m.ntile, &m.tiles_per_chunk, &m.nchunk);
+        if ((long)d->B * m.nchunk > d->nslab) { *err = "gconv1d_bwd: slab workspace smaller than aero_gconv1d_wgrad_slabs()"; return AERO_ERR_ARG; }
+        if (((uintptr_t)d->x | (uintptr_t)d->dy | (uintptr_t)d->y | (uintptr_t)d->slabs | (uintptr_t)d->dw | (uintptr_t)d->db) & 15) {
+            *err = "gconv1d_bwd: 16-byte aligned tensors required"; return AERO_ERR_ARG;
+        }
+        const int cog = d->Cout / d->groups;
+        m.x = (const h16*)d->x; m.dy = (const h16*)d->dy; m.y = (const h16*)d->y; m.slabs = d->slabs;
+        m.B = d->B; m.Tin = d->Tin; m.Cin = d->Cin; m.Tout = p.Tout; m.Cout = d->Cout; m.groups = d->groups; m.K = d->K; m.pad = d->pad;
+        m.slope = d->slope;
+        m.DS = m.GPB * cog + 4;
+        m.XG = 1360;                                            // skewed span of 4 * 64 + 44 rows x 4 channels
+        m.w_n = (int64_t)d->Cout * d->K * 4;
+        m.sl_stride = m.w_n + d->Cout;
+        const size_t lds = ((size_t)64 * m.DS + (size_t)m.GPB * m.XG) * sizeof(h16);
+        dim3 grid((unsigned)m.nchunk, (unsigned)(d->groups / m.GPB), (unsigned)d->B);
+        const int gpw = m.GPB / 4;
+        if (cog == 16) {
+            if (gpw == 4) AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<16, 4>), grid, dim3(256), lds, stream, m);
+            else if (gpw == 2) AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<16, 2>), grid, dim3(256), lds, stream, m);
+            else AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<16, 1>), grid, dim3(256), lds, stream, m);
+        } else {
+            if (gpw == 4) AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<4, 4>), grid, dim3(256), lds, stream, m);
+            else if (gpw == 2) AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<4, 2>), grid, dim3(256), lds, stream, m);
+            else AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<4, 1>), grid, dim3(256), lds, stream, m);
+        }
+        AeroWgradFinishK f;
+        f.slabs = d->slabs; f.dw = d->dw; f.db = d->db;
+        f.stride = m.sl_stride; f.w_n = m.w_n; f.n = d->db ? m.sl_stride : m.w_n;
+        f.nslab = d->B * m.nchunk; f.store = 0; f.layout = 0; f.ntaps = 1; f.MC = 0; f.C = 0; f.rowlen = 0; f.coff = 0;
+        AERO_LAUNCH(aero_wgrad_finish_kernel, dim3((unsigned)((f.n / 4 + 31) / 32)), dim3(256), stream, f);
+    } else if (d->dw) {
         const int span = (AERO_GCONV_TO - 1) * p.stride + p.K;
         const size_t lds = ((size_t)span * AERO_GCONV_CIC + (size_t)AERO_GCONV_TO * p.cog) * sizeof(float);
         if (lds > 150 * 1024) { *err = "gconv1d_bwd: tile exceeds the LDS"; return AERO_ERR_UNSUPPORTED; }

@@ -146,3 +146,134 @@ static void aero_gconv4_tile(int groups, int* GPB, int* NT) {
     *GPB = groups < 16 ? groups : 16;
     *NT = 1024 / *GPB;                                          // 64 steps x 16 groups, 256 x 4
 }
+
+// Weight gradient of the same layers.   dw[o][kk] = sum_{b, to} dy'[to][o] X[to][kk],  X[to][4k + c] = x[4 to - pad + k][c]:
+// per group a 16 x 164 product whose contraction runs over the output steps -- the slow index of both channels-last operands.  With
+// the group's input span in LDS as a flat array xs[row * 4 + c], element (to, kk) is simply xs[16 to + kk]: an MFMA B fragment ("8
+// consecutive steps of column kk") is 8 two-byte LDS reads at a stride of 16 elements, an A fragment 8 reads down a column of the
+// staged dy' tile; 11 column tiles of 16 share one A fragment.  LDS-read bound (96 two-byte reads per 11 MFMAs) -- at ~20 % of the
+// MFMA rate still two orders of magnitude above the VALU kernel with its fp32 atomics (9.7 of the 15.4 ms of a critic step).
+// A block owns GPB groups of one batch item and a chunk of 64-step tiles; each wave keeps the 11 accumulator tiles of its groups in
+// registers across the chunk and stores them to the chunk's slab (plain stores; aero_wgrad_finish_kernel adds the slabs in order).
+struct AeroGconv4WK {
+    const h16* x; const h16* dy; const h16* y; float* slabs;
+    int B, Tin, Cin, Tout, Cout, groups, K, pad, GPB, ntile, tiles_per_chunk, nchunk, DS, XG;
+    float slope;
+    int64_t sl_stride, w_n;
+};
+
+static __device__ __forceinline__ int aero_gw_skew(int i) { return i + ((i >> 7) << 4); }     // 16 halves of padding per 128: the four k-octets of a fragment read hit disjoint banks
+
+template <int COG, int GPW>
+__global__ __launch_bounds__(256) void aero_gconv4_wgrad_kernel(AeroGconv4WK p) {
+    constexpr int NP = 64;
+    h16* dyps = (h16*)AERO_DYN_SMEM;                            // [NP][DS]
+    h16* xs = dyps + NP * p.DS;                                  // [GPB][XG] (skewed flat spans)
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int q = lane >> 4, col = lane & 15;
+    const int chunk = blockIdx.x, g0 = blockIdx.y * p.GPB, b = blockIdx.z;
+    const int nrow_x = 4 * NP + 44;
+    f32x4 acc[GPW][11];
+    float bsum[GPW];
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+        bsum[gi] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 11; ++nt) acc[gi][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const h16* dyb = p.dy + (int64_t)b * p.Tout * p.Cout + g0 * COG;
+    const h16* yb = p.y + (int64_t)b * p.Tout * p.Cout + g0 * COG;
+    const h16* xb = p.x + (int64_t)b * p.Tin * p.Cin + g0 * 4;
+    const int pcs_d = p.GPB * COG / 8, pcs_x = p.GPB / 2;
+    const int t_lo = chunk * p.tiles_per_chunk;
+    const int t_hi = t_lo + p.tiles_per_chunk < p.ntile ? t_lo + p.tiles_per_chunk : p.ntile;
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int to0 = tile * NP;
+        __syncthreads();
+        for (int idx = tid; idx < NP * pcs_d; idx += 256) {
+            const int row = idx / pcs_d, v = idx - row * pcs_d;
+            const int t = to0 + row;
+            h16x8 val = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (t < p.Tout) {
+                const h16x8 dv = *(const h16x8*)(dyb + (int64_t)t * p.Cout + v * 8);
+                const h16x8 yv = *(const h16x8*)(yb + (int64_t)t * p.Cout + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] = (float)yv[e] > 0.f ? dv[e] : (h16)((float)dv[e] * p.slope);
+            }
+            *(h16x4*)(dyps + row * p.DS + v * 8) = (h16x4){val[0], val[1], val[2], val[3]};
+            *(h16x4*)(dyps + row * p.DS + v * 8 + 4) = (h16x4){val[4], val[5], val[6], val[7]};
+        }
+        const int ti0 = 4 * to0 - p.pad;
+        for (int idx = tid; idx < nrow_x * pcs_x; idx += 256) {
+            const int row = idx / pcs_x, v = idx - row * pcs_x;
+            const int t = ti0 + row;
+            h16x8 val = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (t >= 0 && t < p.Tin) val = *(const h16x8*)(xb + (int64_t)t * p.Cin + v * 8);
+            const int o = aero_gw_skew(4 * row);
+            *(h16x4*)(xs + (2 * v) * p.XG + o) = (h16x4){val[0], val[1], val[2], val[3]};
+            *(h16x4*)(xs + (2 * v + 1) * p.XG + o) = (h16x4){val[4], val[5], val[6], val[7]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+            const int gl = wave + 4 * gi;
+            const h16* xg = xs + gl * p.XG;
+            const bool arow = COG == 16 || col < COG;
+#pragma unroll
+            for (int ks = 0; ks < NP / 32; ++ks) {
+                const int p0 = ks * 32 + 8 * q;
+                h16x8 A = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (arow) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) A[e] = dyps[(p0 + e) * p.DS + gl * COG + col];
+                }
+                float s8 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s8 += (float)A[e];
+                bsum[gi] += s8;
+#pragma unroll
+                for (int nt = 0; nt < 11; ++nt) {
+                    const int kk = nt * 16 + col;
+                    h16x8 Bf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) Bf[e] = xg[aero_gw_skew(16 * (p0 + e) + kk)];
+                    acc[gi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, Bf, acc[gi][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // the chunk's partial sums -> its slab: [Cout][4K] weights, then [Cout] bias sums
+    float* sl = p.slabs + ((int64_t)b * p.nchunk + chunk) * p.sl_stride;
+    const int K4 = 4 * p.K;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+        const int g = g0 + wave + 4 * gi;
+#pragma unroll
+        for (int nt = 0; nt < 11; ++nt) {
+            const int kk = nt * 16 + col;
+            if (kk < K4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * q + i;
+                    if (o < COG) sl[(int64_t)(g * COG + o) * K4 + kk] = acc[gi][nt][i];
+                }
+            }
+        }
+        float s = bsum[gi];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (q == 0 && col < COG) sl[p.w_n + g * COG + col] = s;
+    }
+}
+
+// chunks of 64-step tiles per (batch item, group block) of the MFMA weight gradient: ~1024 blocks in all
+static void aero_gconv4_wgrad_plan(int B, int Tout, int groups, int* ntile, int* tpc, int* nchunk) {
+    int GPB, NT;
+    aero_gconv4_tile(groups, &GPB, &NT);
+    *ntile = (Tout + 63) / 64;
+    long want = 1024 / ((long)B * (groups / GPB));
+    if (want < 1) want = 1;
+    if (want > *ntile) want = *ntile;
+    *tpc = (int)((*ntile + want - 1) / want);
+    *nchunk = (*ntile + *tpc - 1) / *tpc;
+}

@@ -264,6 +264,12 @@ class Discriminator(nn.Module):
                         ent['stride'], ent['pad'], ent['reflect']
                     d.slope = ent['slope']
                     d.w_dgrad_mfma = _ptr(ent.get('w_dgrad_mfma'))
+                    if want_params and 'w_mfma' in ent:          # MFMA weight gradient: per-chunk slabs, added in order
+                        nsl = ops.lib.cdll.aero_gconv1d_wgrad_slabs(B, Tin, ent['Cin'], ent['Cout'], ent['groups'], ent['K'], ent['stride'], ent['pad'],
+                                                                    int(ent['reflect']))
+                        if nsl > 0:
+                            slabs = torch.empty(nsl, ent['Cout'] * (4 * ent['K'] + 1), dtype=torch.float32, device=g.device)
+                            d.slabs, d.nslab = _ptr(slabs), nsl
                     ops.lib.call('aero_gconv1d_bwd', C.byref(d), ops.stream(g))
                     if want_params:
                         dwt = dwk.permute(0, 2, 1).contiguous()                     # [Cout, Cin/groups, K]

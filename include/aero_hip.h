@@ -495,8 +495,14 @@ typedef struct {
      * cog = Cout/groups = 16: KD = 192, column 16 j + o; cog = 4: KD = 64, column 8 m + e = (j = 2m + 1, o = e) for e < 4, (j = 2m, o = e - 4)
      * otherwise; value W[g cog + o][c][r + 4 j] (zero where r + 4 j >= K). */
     const void* w_dgrad_mfma;
+    /* optional MFMA form of the weight / bias gradient (same geometries): a workspace of nslab >= aero_gconv1d_wgrad_slabs(...) slabs
+     * of (Cout * K * 4 + Cout) floats each; position chunks store their partial sums there and a second kernel adds them to dw / db in
+     * order (deterministic).  NULL: the VALU kernel with fp32 atomics. */
+    float* slabs; int32_t nslab;
 } aero_gconv_bwd_desc;
 int aero_gconv1d_bwd(const aero_gconv_bwd_desc* d, void* stream);
+int aero_gconv1d_wgrad_slabs(int32_t B, int32_t Tin, int32_t Cin, int32_t Cout, int32_t groups, int32_t K, int32_t stride, int32_t pad,
+                             int32_t reflect);    /* 0: the MFMA form does not take this layer */
 /* gradients of the loss terms as fp16: mode 0 g = coef * sign * [1 + sign a > 0] (hinge, solver.py:489-496,508), mode 1
  * g = coef * sgn(a - b) (L1, solver.py:505), mode 2 g = a * (b > 0 ? 1 : coef) (LeakyReLU backward: a = dy, b = y, coef = slope) */
 int aero_loss_grad(const void* a, const void* b, int64_t n, float sign, float coef, int32_t mode, void* g, void* stream);
