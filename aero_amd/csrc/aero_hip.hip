@@ -357,7 +357,14 @@ int aero_gconv1d_mfma_ok(int32_t Cin, int32_t Cout, int32_t groups, int32_t K, i
 
 int aero_gconv1d_wgrad_slabs(int32_t B, int32_t Tin, int32_t Cin, int32_t Cout, int32_t groups, int32_t K, int32_t stride, int32_t pad,
                              int32_t reflect) {
-    if (B < 1 || Tin < 1 || !aero_gconv4_ok(Cin, Cout, groups, K, stride, pad, reflect)) return 0;
+    if (B < 1 || Tin < 1) return 0;
+    const bool c1 = aero_edge_c1_ok(Cin, Cout, groups, K, stride, pad);
+    if (c1 || aero_edge_o1_ok(Cin, Cout, groups, K, stride, pad, reflect)) {
+        int nb, per;
+        aero_edge_wgrad_plan(c1, B, Tin, &nb, &per);
+        return B * nb;
+    }
+    if (!aero_gconv4_ok(Cin, Cout, groups, K, stride, pad, reflect)) return 0;
     const int Tout = (Tin + 2 * pad - K) / stride + 1;
     if (Tout < 1) return 0;
     int ntile, tpc, nchunk;

@@ -13,6 +13,7 @@
 #pragma once
 #include "aero_common.h"
 #include "k_gconv_mfma.h"
+#include "k_gconv_edge.h"
 
 struct AeroGconvK {
     const h16* x; const h16* w; const float* bias; h16* y;
@@ -95,6 +96,21 @@ static int aero_gconv1d_launch(const aero_gconv_desc* d, hipStream_t stream, con
     p.reflect = d->reflect; p.slope = d->slope;
     p.Tout = (d->Tin + 2 * d->pad - d->K) / d->stride + 1;
     if (p.Tout < 1) { *err = "gconv1d: kernel longer than the padded input"; return AERO_ERR_ARG; }
+    if (aero_edge_c1_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad) || aero_edge_o1_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad, d->reflect)) {
+        if (((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->w) & 15) { *err = "gconv1d: 16-byte aligned tensors required"; return AERO_ERR_ARG; }
+        if (d->B > 65535) { *err = "gconv1d: grid too large"; return AERO_ERR_ARG; }
+        AeroEdgeK e = {};
+        e.x = (const h16*)d->x; e.w = (const h16*)d->w; e.bias = d->bias; e.out = (h16*)d->y;
+        e.B = d->B; e.T = d->Tin; e.K = d->K; e.pad = d->pad; e.reflect = d->reflect; e.slope = d->slope;
+        if (d->Cin == 1) {
+            e.C = d->Cout;
+            AERO_LAUNCH(aero_gconv_c1_fwd_kernel, dim3((unsigned)((d->Tin + 255) / 256), (unsigned)d->B), dim3(256), stream, e);
+        } else {
+            e.C = d->Cin;
+            AERO_LAUNCH(aero_gconv_o1_fwd_kernel, dim3((unsigned)((d->Tin + 3) / 4), (unsigned)d->B), dim3(256), stream, e);
+        }
+        return AERO_OK;
+    }
     if (d->w_mfma && aero_gconv4_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad, d->reflect) && d->B <= 65535) {
         if (((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->w_mfma | (uintptr_t)d->bias) & 15) { *err = "gconv1d: 16-byte aligned tensors required"; return AERO_ERR_ARG; }
         AeroGconv4K m;
@@ -341,6 +357,38 @@ static int aero_gconv1d_bwd_launch(const aero_gconv_bwd_desc* d, hipStream_t str
     if (p.cog > 64) { *err = "gconv1d_bwd: more than 64 output channels per group"; return AERO_ERR_UNSUPPORTED; }
     p.ntile = (p.Tout + AERO_GCONV_TO - 1) / AERO_GCONV_TO;
     p.tiles_per_block = 1;
+    const bool edge_c1 = aero_edge_c1_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad);
+    const bool edge_o1 = aero_edge_o1_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad, d->reflect);
+    if ((edge_c1 || edge_o1) && (!d->dw || d->slabs)) {
+        if (((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->dy | (uintptr_t)d->dx | (uintptr_t)d->w | (uintptr_t)d->slabs | (uintptr_t)d->dw | (uintptr_t)d->db) & 15) {
+            *err = "gconv1d_bwd: 16-byte aligned tensors required"; return AERO_ERR_ARG;
+        }
+        AeroEdgeK e = {};
+        e.x = (const h16*)d->x; e.w = (const h16*)d->w; e.y = (const h16*)d->y; e.dy = (const h16*)d->dy; e.out = (h16*)d->dx; e.slabs = d->slabs;
+        e.B = d->B; e.T = d->Tin; e.K = d->K; e.pad = d->pad; e.reflect = d->reflect; e.slope = d->slope;
+        e.C = edge_c1 ? d->Cout : d->Cin;
+        if (d->dx) {
+            if (edge_c1) AERO_LAUNCH(aero_gconv_c1_dgrad_kernel, dim3((unsigned)((d->Tin + 255) / 256), (unsigned)d->B), dim3(256), stream, e);
+            else AERO_LAUNCH(aero_gconv_o1_dgrad_kernel, dim3((unsigned)(((int64_t)d->Tin * (d->Cin / 8) + 255) / 256), (unsigned)d->B), dim3(256), stream, e);
+        }
+        if (d->dw) {
+            int nb, per;
+            aero_edge_wgrad_plan(edge_c1, d->B, d->Tin, &nb, &per);
+            if ((long)d->B * nb > d->nslab) { *err = "gconv1d_bwd: slab workspace smaller than aero_gconv1d_wgrad_slabs()"; return AERO_ERR_ARG; }
+            const int64_t w_n = (int64_t)d->Cout * d->K * (d->Cin / d->groups);
+            e.sl_stride = w_n + (d->Cout < 4 ? 4 : d->Cout);
+            e.tiles_per_block = per;
+            e.ntile = (d->Tin + 255) / 256;
+            if (edge_c1) AERO_LAUNCH(aero_gconv_c1_wgrad_kernel, dim3((unsigned)nb, (unsigned)d->B), dim3(256), stream, e);
+            else AERO_LAUNCH(aero_gconv_o1_wgrad_kernel, dim3((unsigned)nb, (unsigned)d->B), dim3(256), stream, e);
+            AeroWgradFinishK f;
+            f.slabs = d->slabs; f.dw = d->dw; f.db = d->db;
+            f.stride = e.sl_stride; f.w_n = w_n; f.n = d->db ? e.sl_stride : w_n;
+            f.nslab = d->B * nb; f.store = 0; f.layout = 0; f.ntaps = 1; f.MC = 0; f.C = 0; f.rowlen = 0; f.coff = 0;
+            AERO_LAUNCH(aero_wgrad_finish_kernel, dim3((unsigned)((f.n / 4 + 31) / 32)), dim3(256), stream, f);
+        }
+        return AERO_OK;
+    }
     if (d->dx && d->w_dgrad_mfma && aero_gconv4_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad, d->reflect)) {
         if (((uintptr_t)d->dx | (uintptr_t)d->dy | (uintptr_t)d->y | (uintptr_t)d->w_dgrad_mfma) & 15) { *err = "gconv1d_bwd: 16-byte aligned tensors required"; return AERO_ERR_ARG; }
         AeroGconv4K m;
@@ -361,8 +409,7 @@ static int aero_gconv1d_bwd_launch(const aero_gconv_bwd_desc* d, hipStream_t str
     }
     if (d->dw && d->slabs && aero_gconv4_ok(d->Cin, d->Cout, d->groups, d->K, d->stride, d->pad, d->reflect)) {
         AeroGconv4WK m;
-        int NT;
-        aero_gconv4_tile(d->groups, &m.GPB, &NT);
+        m.GPB = AERO_GCONV4_WGRAD_GPB;
         aero_gconv4_wgrad_plan(d->B, p.Tout, d->groups, &m.ntile, &m.tiles_per_chunk, &m.nchunk);
         if ((long)d->B * m.nchunk > d->nslab) { *err = "gconv1d_bwd: slab workspace smaller than aero_gconv1d_wgrad_slabs()"; return AERO_ERR_ARG; }
         if (((uintptr_t)d->x | (uintptr_t)d->dy | (uintptr_t)d->y | (uintptr_t)d->slabs | (uintptr_t)d->dw | (uintptr_t)d->db) & 15) {
@@ -378,16 +425,8 @@ static int aero_gconv1d_bwd_launch(const aero_gconv_bwd_desc* d, hipStream_t str
         m.sl_stride = m.w_n + d->Cout;
         const size_t lds = ((size_t)64 * m.DS + (size_t)m.GPB * m.XG) * sizeof(h16);
         dim3 grid((unsigned)m.nchunk, (unsigned)(d->groups / m.GPB), (unsigned)d->B);
-        const int gpw = m.GPB / 4;
-        if (cog == 16) {
-            if (gpw == 4) AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<16, 4>), grid, dim3(256), lds, stream, m);
-            else if (gpw == 2) AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<16, 2>), grid, dim3(256), lds, stream, m);
-            else AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<16, 1>), grid, dim3(256), lds, stream, m);
-        } else {
-            if (gpw == 4) AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<4, 4>), grid, dim3(256), lds, stream, m);
-            else if (gpw == 2) AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<4, 2>), grid, dim3(256), lds, stream, m);
-            else AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<4, 1>), grid, dim3(256), lds, stream, m);
-        }
+        if (cog == 16) AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<16, 1>), grid, dim3(256), lds, stream, m);
+        else AERO_LAUNCH_DYN((aero_gconv4_wgrad_kernel<4, 1>), grid, dim3(256), lds, stream, m);
         AeroWgradFinishK f;
         f.slabs = d->slabs; f.dw = d->dw; f.db = d->db;
         f.stride = m.sl_stride; f.w_n = m.w_n; f.n = d->db ? m.sl_stride : m.w_n;

@@ -267,9 +267,11 @@ __global__ __launch_bounds__(256) void aero_gconv4_wgrad_kernel(AeroGconv4WK p) 
 }
 
 // chunks of 64-step tiles per (batch item, group block) of the MFMA weight gradient: ~1024 blocks in all
+// (four groups per block, one per wave: 44 accumulator registers.  Sixteen groups per block -- 176 accumulator registers per wave --
+// ran 8x slower per MAC than the four-group form of the first grouped layer.)
+#define AERO_GCONV4_WGRAD_GPB 4
 static void aero_gconv4_wgrad_plan(int B, int Tout, int groups, int* ntile, int* tpc, int* nchunk) {
-    int GPB, NT;
-    aero_gconv4_tile(groups, &GPB, &NT);
+    const int GPB = AERO_GCONV4_WGRAD_GPB;
     *ntile = (Tout + 63) / 64;
     long want = 1024 / ((long)B * (groups / GPB));
     if (want < 1) want = 1;

@@ -257,18 +257,19 @@ class Discriminator(nn.Module):
                     dx = torch.empty(B, Tin, ent['Cin'], dtype=torch.float16, device=g.device) if need_dx else None
                     if want_params:
                         dwk = torch.zeros(ent['Cout'], ent['K'], ent['Cin'] // ent['groups'], dtype=torch.float32, device=g.device)
-                        db = torch.zeros(ent['Cout'], dtype=torch.float32, device=g.device)
+                        db = torch.zeros(max(ent['Cout'], 4), dtype=torch.float32, device=g.device)[:ent['Cout']]   # (room for a float4)
                     d.x, d.w, d.y, d.dy, d.dx = _ptr(h), _ptr(ent['w']), _ptr(y), _ptr(g), _ptr(dx)
                     d.dw, d.db = (_ptr(dwk), _ptr(db)) if want_params else (None, None)
                     d.B, d.Tin, d.Cin, d.Cout, d.groups, d.K, d.stride, d.pad, d.reflect = B, Tin, ent['Cin'], ent['Cout'], ent['groups'], ent['K'], \
                         ent['stride'], ent['pad'], ent['reflect']
                     d.slope = ent['slope']
                     d.w_dgrad_mfma = _ptr(ent.get('w_dgrad_mfma'))
-                    if want_params and 'w_mfma' in ent:          # MFMA weight gradient: per-chunk slabs, added in order
+                    if want_params:                              # per-chunk slabs added in order, where the library has that form
                         nsl = ops.lib.cdll.aero_gconv1d_wgrad_slabs(B, Tin, ent['Cin'], ent['Cout'], ent['groups'], ent['K'], ent['stride'], ent['pad'],
                                                                     int(ent['reflect']))
                         if nsl > 0:
-                            slabs = torch.empty(nsl, ent['Cout'] * (4 * ent['K'] + 1), dtype=torch.float32, device=g.device)
+                            slabs = torch.empty(nsl, ent['Cout'] * ent['K'] * (ent['Cin'] // ent['groups']) + max(ent['Cout'], 4),
+                                                dtype=torch.float32, device=g.device)
                             d.slabs, d.nslab = _ptr(slabs), nsl
                     ops.lib.call('aero_gconv1d_bwd', C.byref(d), ops.stream(g))
                     if want_params:

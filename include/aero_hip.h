@@ -496,8 +496,10 @@ typedef struct {
      * otherwise; value W[g cog + o][c][r + 4 j] (zero where r + 4 j >= K). */
     const void* w_dgrad_mfma;
     /* optional MFMA form of the weight / bias gradient (same geometries): a workspace of nslab >= aero_gconv1d_wgrad_slabs(...) slabs
-     * of (Cout * K * 4 + Cout) floats each; position chunks store their partial sums there and a second kernel adds them to dw / db in
-     * order (deterministic).  NULL: the VALU kernel with fp32 atomics. */
+     * of (Cout * K * Cin/groups + max(Cout, 4)) floats each; position chunks store their partial sums there and a second kernel adds
+     * them to dw / db in order (deterministic).  Also taken by the two edge layers (1 -> 8|16 channels, k <= 15, and 512 n -> 1 channel,
+     * k <= 3, both stride 1 with pad = (K - 1) / 2), whose forward and data gradient have dedicated kernels as well; db must then have
+     * room for 4 floats (added as whole float4s).  NULL: the VALU kernel with fp32 atomics. */
     float* slabs; int32_t nslab;
 } aero_gconv_bwd_desc;
 int aero_gconv1d_bwd(const aero_gconv_bwd_desc* d, void* stream);

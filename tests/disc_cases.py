@@ -103,7 +103,7 @@ def case_critic_backward(dev, lib=None, T=1024):
     d.to(dev)
     errs = {}
     loss = d.discriminator_loss(xf.to(dev), xr.to(dev))
-    errs['d_loss'] = abs(float(loss) - float(dl)) / float(dl)
+    errs["d_loss"] = abs(float(loss.detach()) - float(dl.detach())) / float(dl.detach())
     loss.backward()
     for n, p in d.named_parameters():
         errs['d.' + n] = float((p.grad.cpu().double() - ref['d'][n].double()).norm()) / max(ref['dn'][n], 1e-30)
