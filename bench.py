@@ -175,6 +175,45 @@ def extra_configs(dev, steps, warmup):
                                            'losses: [stft]; the msd_melgan critic (tools/config5.py --gan) is not part of this line', 'frames': 1724}})
     except Exception as e:
         out.append({'config': 'BASELINE config 5 (training step)', 'error': repr(e)})
+    try:
+        # the experiment file's own recipe (conf/experiment/aero_11-44_512_256.yaml: adversarial: true, msd_melgan): solver.py:296-320 +
+        # 602-611 -- generator forward, MR-STFT + adversarial + feature-matching losses, backward, Adam; then the critic's hinge step
+        from aero_amd.discriminators import Discriminator
+        del m, opt
+        torch.manual_seed(2036)
+        m = Aero(**dict(FULL_CFG, nfft=512, hop_length=256, lr_sr=11025, hr_sr=44100)).to(dev).train()
+        opt = FlatAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.999), model=m)
+        disc = Discriminator(num_D=3, ndf=16, n_layers=4, downsampling_factor=4).to(dev)
+        opt_d = FlatAdam(disc.parameters(), lr=3e-4, betas=(0.9, 0.999), model=disc)
+
+        def gan_step():
+            y = m(lr_)
+            sc, mg = crit(y.squeeze(1), hr_.squeeze(1))
+            adv, feat = disc.generator_losses(y, hr_, n_layers=4, features_loss_lambda=100.0)
+            opt.zero_grad()
+            (sc + mg + adv + feat).backward()
+            opt.step()
+            d_loss = disc.discriminator_loss(y.detach(), hr_)
+            opt_d.zero_grad()
+            d_loss.backward()
+            opt_d.step()
+            return (sc + mg + adv + feat).detach(), d_loss.detach()
+        for _ in range(2):
+            gan_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k5):
+            lg, ld = gan_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out.append({'metric': 'adversarial training steps per second per GPU (generator step with MR-STFT + adversarial + feature losses, then the '
+                              'msd_melgan critic step), 11.025->44.1kHz nfft=512 hop=256, 2 x 10-s clips',
+                    'value': round(k5 / dt, 3), 'unit': 'steps/s', 'n_gpus': 1, 'steps': k5, 'ms_per_step': round(dt / k5 * 1e3, 2), 'dtype': 'f16',
+                    'data': 'synthetic', 'audio_sec_per_wall_sec': round(2 * 10.0 * k5 / dt, 1), 'g_loss': round(float(lg), 5), 'd_loss': round(float(ld), 5),
+                    'config': {'workload': "BASELINE config 5 as its experiment file trains it (adversarial: true, discriminator_models: [msd_melgan]), "
+                                           "one GPU's share (2 of the 16 clips)", 'frames': 1724}})
+    except Exception as e:
+        out.append({'config': 'BASELINE config 5 (adversarial training step)', 'error': repr(e)})
     return out
 
 

@@ -20,7 +20,15 @@ timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.log 
 timeout 200 python tools/launch_table.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_launch_table.txt
 timeout 200 python tools/profile_train.py 2 2>&1 | grep -v "amdgpu.ids\|Warn" > gpurun_out/${TAG}_train_profile_b2.txt
 timeout 200 python tools/profile_train.py 16 2>&1 | grep -v "amdgpu.ids\|Warn" > gpurun_out/${TAG}_train_profile_b16.txt
-timeout 300 python tools/config5.py 2 4 --gan 2>&1 | grep step > gpurun_out/${TAG}_config5_gan_b2.txt
+timeout 300 python tools/config5.py 2 6 2>&1 | grep "^step" > gpurun_out/${TAG}_config5_b2.txt
+timeout 300 python tools/config5.py 16 4 2>&1 | grep "^step" > gpurun_out/${TAG}_config5_b16.txt
+timeout 300 python tools/config5.py 2 6 --gan 2>&1 | grep "^step" > gpurun_out/${TAG}_config5_gan_b2.txt
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_tl" -o tl -- python "$GRAFT_REPO_ROOT/tools/config5.py" 2 6 > /dev/null 2>&1 )
+python tools/step_timeline.py $(find gpurun_out/${TAG}_tl -name "*kernel_trace.csv" | head -1) > gpurun_out/${TAG}_step_timeline_b2.txt 2>&1
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_tlg" -o tl -- python "$GRAFT_REPO_ROOT/tools/config5.py" 2 6 --gan > /dev/null 2>&1 )
+python tools/step_timeline.py $(find gpurun_out/${TAG}_tlg -name "*kernel_trace.csv" | head -1) > gpurun_out/${TAG}_step_timeline_gan_critic_b2.txt 2>&1
+rm -rf gpurun_out/${TAG}_tl gpurun_out/${TAG}_tlg
+timeout 200 python tools/torch_glue.py 2 2>&1 | grep "torch kernels" > gpurun_out/${TAG}_torch_glue_b2.txt
 tail -3 gpurun_out/${TAG}_pytest_gpu.log; tail -2 gpurun_out/${TAG}_smoke.log; grep '^{' gpurun_out/${TAG}_bench.log | cut -c1-700
 head -3 gpurun_out/${TAG}_train_profile_b2.txt; cat gpurun_out/${TAG}_config5_gan_b2.txt | tail -1
 ls gpurun_out/${TAG}_prof gpurun_out/${TAG}_prof_train | head
