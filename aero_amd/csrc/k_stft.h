@@ -270,17 +270,19 @@ __global__ __launch_bounds__(256) void aero_spec_normalize_kernel(const float* s
 struct AeroIstftK {
     const float* spec; const float* window; const float* inv_env; float* y;
     int nsig, F, T, n_fft, hop, hsh, Lout, FPB, SEG;         // hsh = log2(hop) if hop is a power of two, else -1
+    int abl;                                                 // timing ablations (AERO_ISTFT_ABL): 1 no spectrum loads, 2 no FFT, 4 no overlap-add
 };
 
 static inline int aero_istft_fpb(int n) { int f = 4096 / n; return f > 32 ? 32 : f; }   // frame ring (power of two)
 
-// dynamic LDS: tw[n] | fbuf[FPB][n + 1] | sbuf[4][n]   (f32x2)   then   wl[n_fft]   (float)
-static inline size_t aero_istft_lds_bytes(int n_fft, int fpb) {
-    return ((size_t)(n_fft / 2) * (5 + fpb) + fpb) * sizeof(f32x2) + (size_t)n_fft * sizeof(float);
+// dynamic LDS: tw[n] | fbuf[FPB][n + 1] | sbuf[NW][n]   (f32x2)   then   wl[n_fft]   (float)
+static inline size_t aero_istft_lds_bytes(int n_fft, int fpb, int nw = 4) {
+    return ((size_t)(n_fft / 2) * (1 + nw + fpb) + fpb) * sizeof(f32x2) + (size_t)n_fft * sizeof(float);
 }
 
-template <int LOGN>
-__global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
+template <int LOGN, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void aero_istft_kernel(AeroIstftK p) {
+    constexpr int NT = NW * 64;
     const int n = LOGN ? (1 << LOGN) : (p.n_fft >> 1);
     const int n_fft = 2 * n;
     const int FPB = LOGN ? ((4096 >> LOGN) > 32 ? 32 : (4096 >> LOGN)) : p.FPB;
@@ -288,10 +290,13 @@ __global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
     f32x2* tw = (f32x2*)AERO_DYN_SMEM;
     f32x2* fbuf = tw + n;                                  // [FPB][n + 1]
     f32x2* sbuf0 = fbuf + FPB * fs;
-    float* wl = (float*)(sbuf0 + 4 * n);
+    float* wl = (float*)(sbuf0 + NW * n);
     const int lane = aero_lane(), wave = aero_uniform(aero_wave());
-    const int sig = blockIdx.y;
-    const int o0 = blockIdx.x * p.SEG;
+    // neighbouring segments of a signal share half of their frames: give each XCD (private L2) a contiguous run of (signal, segment)
+    // blocks, so the second reader of a frame finds it in L2 (PMC: 259 MB fetched per launch for 66 MB of spectrogram)
+    const int lin = aero_xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    const int sig = lin / (int)gridDim.x;
+    const int o0 = (lin - sig * (int)gridDim.x) * p.SEG;
     const int i0 = o0 + n;                                  // first overlap-add index of this block
     auto div_hop = [&](int v) { return p.hsh >= 0 ? v >> p.hsh : v / p.hop; };      // v >= 0
     const int num = i0 - n_fft + p.hop;
@@ -299,8 +304,9 @@ __global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
     int t_hi = div_hop(i0 + p.SEG - 1);
     if (t_hi > p.T - 1) t_hi = p.T - 1;
     const int nfr = t_hi - t_lo + 1;                        // <= FPB by construction of SEG
-    aero_fft_init_twiddles(tw, n_fft);
-    for (int i = threadIdx.x; i < n_fft; i += 256) wl[i] = p.window[i];
+    if (p.abl & 8) return;
+    if (!(p.abl & 16)) aero_fft_init_twiddles(tw, n_fft);
+    for (int i = threadIdx.x; i < n_fft; i += NT) wl[i] = p.window[i];
     __syncthreads();
     const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * p.T + t_lo;
     // phase 1: Hermitian unpack of each frame into conj(Z), Z = E + iO  (frames are the fast index: runs of FPB frames
@@ -314,17 +320,17 @@ __global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
     };
     const int npair = ((n >> 1) + 1) << lf;
 #pragma unroll 4
-    for (int idx = threadIdx.x; idx < npair; idx += 256) {
+    for (int idx = threadIdx.x; idx < npair; idx += NT) {
         const int fr = idx & (FPB - 1), k = idx >> lf;
         const bool livef = fr < nfr;
         const int t = livef ? fr : 0;
-        f32x2 xa = X[k * p.T + t];
+        f32x2 xa = (p.abl & 1) ? (f32x2){1.f, 0.f} : X[k * p.T + t];
         if (k == 0) {                                       // pairs with the implicit zero Nyquist bin X[n]
             xa[1] = 0.f;                                    // irfft ignores the imaginary part of DC
             const f32x2 z = unpack(xa, (f32x2){0.f, 0.f}, 0);
             fbuf[fr * fs] = livef ? z : (f32x2){0.f, 0.f};
         } else {
-            const f32x2 xq = X[(n - k) * p.T + t];
+            const f32x2 xq = (p.abl & 1) ? (f32x2){0.5f, 0.f} : X[(n - k) * p.T + t];
             const f32x2 z0 = unpack(xa, (f32x2){xq[0], -xq[1]}, k);
             const f32x2 z1 = unpack(xq, (f32x2){xa[0], -xa[1]}, n - k);
             fbuf[fr * fs + k] = livef ? z0 : (f32x2){0.f, 0.f};
@@ -333,11 +339,11 @@ __global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
     }
     __syncthreads();
     // phase 2: one frame per wave per round
-    const int rounds = (FPB + 3) / 4;
+    const int rounds = (FPB + NW - 1) / NW;
     f32x2* sb = sbuf0 + wave * n;
 #pragma unroll(LOGN ? 2 : 1)
-    for (int r = 0; r < rounds; ++r) {
-        const int fr = r * 4 + wave;
+    for (int r = 0; r < ((p.abl & 2) ? 0 : rounds); ++r) {
+        const int fr = r * NW + wave;
         f32x2* a = fr < FPB ? fbuf + fr * fs : sb;          // (FPB is a multiple of 4 in practice)
         f32x2* R = aero_fft_wave<LOGN>(a, sb, n, tw);
         if (R != a) {
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
     // phase 3: output-stationary overlap-add
     const float scale = sqrtf((float)n_fft) / (float)n;
     float* ys = p.y + (int64_t)sig * p.Lout;
-    for (int o = threadIdx.x; o < p.SEG; o += 256) {
+    for (int o = threadIdx.x; o < p.SEG; o += NT) {
         const int oo = o0 + o;
         if (oo >= p.Lout) break;
         const int i = oo + n;
@@ -359,6 +365,7 @@ __global__ __launch_bounds__(256) void aero_istft_kernel(AeroIstftK p) {
         int tb = div_hop(i);
         if (tb > t_hi) tb = t_hi;
         float acc = 0.f;
+        if (p.abl & 4) tb = ta - 1;
         for (int t = ta; t <= tb; ++t) {
             const int ni = i - t * p.hop;
             const f32x2 R = fbuf[(t - t_lo) * fs + (ni >> 1)];
@@ -619,7 +626,24 @@ static int aero_istft_launch(const float* spec, int nsig, int F, int T, int n_ff
     p.FPB = fpb;
     p.SEG = (fpb - need) * hop;
     p.hsh = (hop & (hop - 1)) == 0 ? aero_ilog2(hop) : -1;
+    static const int abl = [] { const char* e = getenv("AERO_ISTFT_ABL"); return e ? atoi(e) : 0; }();
+    p.abl = abl;
     dim3 grid((unsigned)((Lout + p.SEG - 1) / p.SEG), (unsigned)nsig), block(256);
+    // eight waves per block for the two common sizes: two frames per wave instead of four, twice the lanes in the unpack and overlap-add
+    // phases (78.9 -> 61.5 us at B = 64 with the XCD-aware block order; sixteen waves: 70 us).  Ablations (AERO_ISTFT_ABL) at eight
+    // waves: empty kernel 7 us, no loads / FFT / overlap-add 24 us, no FFT 41 us, no loads 58 us, all 64 us -- the frame FFTs (23 us) and
+    // the per-block skeleton (window, unpack, barriers: 17 us) are what is left, not the 259 MB it fetches.
+    static const int waves = [] { const char* e = getenv("AERO_ISTFT_WAVES"); return e ? atoi(e) : 8; }();
+    if (waves == 8 && (n == 256 || n == 512)) {
+        const size_t lds8 = aero_istft_lds_bytes(n_fft, fpb, 8);
+        if (n == 256) AERO_LAUNCH_DYN((aero_istft_kernel<8, 8>), grid, dim3(512), lds8, stream, p);
+        else AERO_LAUNCH_DYN((aero_istft_kernel<9, 8>), grid, dim3(512), lds8, stream, p);
+        return AERO_OK;
+    }
+    if (waves == 16 && n == 256) {
+        AERO_LAUNCH_DYN((aero_istft_kernel<8, 16>), grid, dim3(1024), aero_istft_lds_bytes(n_fft, fpb, 16), stream, p);
+        return AERO_OK;
+    }
     const size_t lds = aero_istft_lds_bytes(n_fft, fpb);
     switch (n) {
         case 64: AERO_LAUNCH_DYN(aero_istft_kernel<6>, grid, block, lds, stream, p); break;

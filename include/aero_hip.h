@@ -22,7 +22,8 @@
  *       AERO_LSTM_RING, AERO_LSTM_WIDE                                          (recurrent kernel form)
  *       AERO_ATTN_FOLD                                                          (LocalState: folded vs streaming kernel)
  *       AERO_NORM_CHUNK_KB                                                      (GroupNorm work-item size)
- *       AERO_STFT_DFT_BLOCKS                                                    (GEMM-form STFT: blocks per (signal, table quarter))
+ *       AERO_STFT_DFT_BLOCKS, AERO_ISTFT_WAVES, AERO_ISTFT_ABL                  (GEMM-form STFT: blocks per (signal, table quarter);
+ *                                                                                iSTFT waves per block, timing ablations)
  *       AERO_WGRAD_ABL                                                          (weight-gradient ablations; AERO_WGRAD_256 -- the tile
  *                                                                                choice -- is the one switch read at every call)
  *       AERO_ATTN_BWD_VALU, AERO_RING_TILE192                                   (LocalState backward form; ring-tile A/B)
