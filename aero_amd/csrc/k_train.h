@@ -389,6 +389,183 @@ __global__ __launch_bounds__(512) void aero_lstm_bwd_kernel(AeroLstmBwdK p) {
     }
 }
 
+// Ring form of the BPTT kernel (what the engine runs for H % 16 == 0).  The step-wise kernel above fetches a step's saved activations
+// one step ahead and `__syncthreads()` then waits for those loads (and for the previous step's da stores) at EVERY step: 2.2-2.5 us per
+// step, almost all of it one global round trip -- the launch has only nseq/16 x 2 blocks of 3-6 waves, so nothing else hides it.  Here,
+// as in the forward ring kernel (k_lstm.h), all global reads move in GROUPS of G steps: the saved gates / cell states / dout rows of group
+// g+1 are loaded into registers at the START of group g (15 sixteen-byte loads per lane) and parked in LDS at its END, G steps later;
+// the step loop itself contains LDS reads, the MFMA chain (two accumulators), the cell algebra, one LDS write, one LDS-only barrier
+// (lgkmcnt + s_barrier: the da stores of the step stay in flight) -- the vector-memory counter is waited for once per group.
+// LDS: gates [G][H][16 x 4 fp16, rows padded to 160 B], cell states [G + 1][H][16 fp32, rows padded to 80 B] (the extra row is c of the
+// step after the group: c_prev of its last step), dout [G][16][H + 4] fp16; paddings chosen so that the four k-octets of a wave read
+// disjoint banks.
+template <int KT4, int G>
+__global__ __launch_bounds__(512) void aero_lstm_bwd_ring_kernel(AeroLstmBwdK p) {
+    constexpr int K4P = KT4 * 32, LD = K4P + 8;
+    constexpr int GS = 80, CS = 20;                              // row strides: gates (h16), cell states (float)
+    const aero_lstm_bwd_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int NT = blockDim.x;
+    const int dir = blockIdx.y;
+    const int seq0 = blockIdx.x * 16;
+    const int H = d.H, W = d.W, H4 = 4 * H, H2 = 2 * H;
+    const int q = lane >> 4, col = lane & 15;
+    const int HP = ((H + 15) / 16) * 16;
+    const int DYS = H + 4;
+    h16* dabuf = (h16*)AERO_DYN_SMEM;                            // [2][16 * LD]
+    h16* gring = dabuf + 2 * 16 * LD;                            // [G][H][GS]
+    float* cring = (float*)(gring + G * H * GS);                 // [G + 1][H][CS]
+    h16* dyring = (h16*)(cring + (G + 1) * H * CS);              // [G][16][DYS]
+    const h16* WT = (const h16*)d.whh_t + (int64_t)dir * HP * K4P;
+    h16x8 wf[KT4];
+#pragma unroll
+    for (int kt = 0; kt < KT4; ++kt) wf[kt] = *(const h16x8*)(WT + (int64_t)(wave * 16 + col) * K4P + kt * 32 + q * 8);
+    for (int idx = tid; idx < 2 * 16 * LD; idx += NT) dabuf[idx] = (h16)0;
+
+    const h16* dout = (const h16*)d.dout;
+    const h16* gs = (const h16*)d.save_gates + ((int64_t)blockIdx.x * 2 + dir) * W * ((int64_t)H * 64);
+    const float* cs = d.save_c + ((int64_t)blockIdx.x * 2 + dir) * W * ((int64_t)H * 16);
+    h16* da_out = (h16*)d.da;
+    // Pieces (16 bytes) of a group, with NT = 4 H threads (H a multiple of 16): per step 8H = 2 NT of gates (two per thread), 4H = NT
+    // of cell states (one per thread), 2H = NT / 2 of dout rows (one per thread every other step); plus one more row of cell states (the
+    // step after the group).  So a thread's 3.5 G + 1 pieces have compile-time step indices and per-thread constant offsets.
+    // Every piece is ONE unconditional load: what must read as zero -- steps past the end, sequences past nseq, dout rows outside a
+    // frame's kept range -- reads the zero page (`cond ? load : 0` made the compiler wait for each load where it was issued).
+    constexpr int NG = 2 * G, NC = G + 1, ND = G / 2;
+    h16x8 rg[NG], rc[NC], rd[ND];
+    const h16* zpage = aero_zero_page;
+    const int hsel = tid >= (NT >> 1) ? 1 : 0;                   // dout: which of the pair of steps this thread copies
+    const int r2 = tid - hsel * (NT >> 1);
+    const int dsl = r2 / (H >> 3), de = r2 - dsl * (H >> 3);
+    const int dseq = seq0 + dsl;
+    int d_lo = 0, d_hi = dseq < d.nseq ? W : -1, d_tmax = 0x7fffffff;
+    int64_t d_base = (int64_t)dseq * W * H2 + dir * H + de * 8;
+    if (d.out_mode == 1 && dseq < d.nseq) {
+        const int r = dseq / d.nframes, k = dseq - r * d.nframes;
+        const int lim = d.S / 2;
+        d_lo = (k == 0) ? 0 : lim;
+        d_hi = (k == d.nframes - 1 && k != 0) ? W : W - lim;
+        d_tmax = d.T - k * d.S;                                   // tau must stay below it
+        d_base = ((int64_t)r * d.T + k * d.S) * H2 + dir * H + de * 8;
+    }
+    auto tau_of = [&](int step) { return dir ? step : W - 1 - step; };
+    auto load_group = [&](int g) {
+#pragma unroll
+        for (int v = 0; v < NG; ++v) {
+            const int step = g * G + (v >> 1);
+            const h16* src = step < W ? gs + (int64_t)tau_of(step) * H * 64 + (tid + (v & 1) * NT) * 8 : zpage;
+            rg[v] = *(const h16x8*)src;
+        }
+#pragma unroll
+        for (int v = 0; v < NC; ++v) {
+            const int step = g * G + v;
+            const h16* src = step < W ? (const h16*)(cs + (int64_t)tau_of(step) * H * 16) + tid * 8 : zpage;
+            rc[v] = *(const h16x8*)src;
+        }
+#pragma unroll
+        for (int v = 0; v < ND; ++v) {
+            const int step = g * G + 2 * v + hsel;
+            const int tau = tau_of(step);
+            const bool ok = step < W && tau >= d_lo && tau < d_hi && tau < d_tmax;
+            const h16* src = ok ? dout + d_base + (int64_t)tau * H2 : zpage;
+            rd[v] = *(const h16x8*)src;
+        }
+    };
+    auto park_group = [&]() {
+#pragma unroll
+        for (int v = 0; v < NG; ++v) {
+            const int rem = tid + (v & 1) * NT;
+            *(h16x8*)(gring + ((v >> 1) * H + (rem >> 3)) * GS + (rem & 7) * 8) = rg[v];
+        }
+#pragma unroll
+        for (int v = 0; v < NC; ++v) *(h16x8*)((h16*)(cring + (v * H + (tid >> 2)) * CS) + (tid & 3) * 8) = rc[v];
+#pragma unroll
+        for (int v = 0; v < ND; ++v) {
+            const h16x8 x = rd[v];                              // (row stride H + 4 halves: 8-byte aligned)
+            h16* dst = dyring + ((2 * v + hsel) * 16 + dsl) * DYS + de * 8;
+            *(h16x4*)dst = (h16x4){x[0], x[1], x[2], x[3]};
+            *(h16x4*)(dst + 4) = (h16x4){x[4], x[5], x[6], x[7]};
+        }
+    };
+    const int j0 = wave * 16 + q * 4;                          // this lane's 4 hidden units
+    const bool seq_ok = seq0 + col < d.nseq;
+    float dc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int vec = 8, per = H4 / vec;
+    const int ngroups = (W + G - 1) / G;
+    load_group(0);
+    park_group();
+    __syncthreads();
+    int cur = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        if (g + 1 < ngroups) load_group(g + 1);
+        const int nst = W - g * G < G ? W - g * G : G;
+        for (int i = 0; i < nst; ++i) {
+            const int step = g * G + i;
+            const int tau = tau_of(step);
+            // every LDS read of the step first (one latency, not one per MFMA pair / per hidden unit), then the two MFMA chains, then the
+            // four units' cell algebra as straight-line code: H is a multiple of 16 here, so every lane's four units exist, and a lane of
+            // a sequence past nseq computes on whatever its rows hold -- its column of the MFMA never meets another column and the store
+            // loop below skips it.  (With `if (j < H && seq_ok)` around each unit the compiler emitted four separate blocks, each
+            // waiting for its own LDS reads and its own exp -> rcp chain: 1.7 us per step.)
+            h16x8 bf[KT4];
+#pragma unroll
+            for (int kt = 0; kt < KT4; ++kt) bf[kt] = *(const h16x8*)&dabuf[cur * 16 * LD + col * LD + kt * 32 + q * 8];
+            h16x4 g4[4];
+            float ct[4], cp[4], dyv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + r;
+                g4[r] = *(const h16x4*)(gring + (i * H + j) * GS + col * 4);
+                ct[r] = cring[(i * H + j) * CS + col];
+                cp[r] = cring[((i + 1) * H + j) * CS + col];
+            }
+            {
+                const h16x4 d4 = *(const h16x4*)(dyring + (i * 16 + col) * DYS + j0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dyv[r] = (float)d4[r];
+            }
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int kt = 0; kt < KT4; ++kt) {
+                if (kt & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt], bf[kt], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kt], bf[kt], acc0, 0, 0, 0);
+            }
+            const f32x4 acc = acc0 + acc1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dh = acc[r] + dyv[r];
+                const float ig = (float)g4[r][0], fg = (float)g4[r][1], gg = (float)g4[r][2], og = (float)g4[r][3];
+                const float th = aero_tanh(ct[r]);
+                const float d_o = dh * th;
+                const float dct = dc[r] + dh * og * (1.f - th * th);
+                const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cp[r];
+                dc[r] = dct * fg;
+                const h16x4 dav = (h16x4){(h16)(d_i * ig * (1.f - ig)), (h16)(d_f * fg * (1.f - fg)), (h16)(d_g * (1.f - gg * gg)), (h16)(d_o * og * (1.f - og))};
+                *(h16x4*)&dabuf[(cur ^ 1) * 16 * LD + col * LD + (j0 + r) * 4] = dav;
+            }
+            aero_phase_barrier();                               // LDS only: the da stores below (and the group loads) stay in flight
+            for (int idx = tid; idx < 16 * per; idx += NT) {
+                const int sl = idx / per, e = idx - sl * per;
+                const int s2 = seq0 + sl;
+                if (s2 >= d.nseq) continue;
+                h16* dst = da_out + (((int64_t)s2 * W + tau) * 2 + dir) * H4 + e * vec;
+                *(h16x8*)dst = *(const h16x8*)&dabuf[(cur ^ 1) * 16 * LD + sl * LD + e * 8];
+            }
+            cur ^= 1;
+        }
+        if (g + 1 < ngroups) {
+            // every read of this group's rings happened before the last step's barrier; the store loop above reads dabuf only
+            park_group();
+            aero_phase_barrier();
+        }
+    }
+}
+
+static size_t aero_lstm_bwd_ring_lds(int H, int kt4, int G) {
+    const int LD = kt4 * 32 + 8;
+    return (size_t)2 * 16 * LD * 2 + (size_t)G * H * 80 * 2 + (size_t)(G + 1) * H * 20 * 4 + (size_t)G * 16 * (H + 4) * 2;
+}
+
 static int aero_lstm_bwd_kt4(int H) {
     const int need = (4 * H + 31) / 32;
     const int opts[8] = {1, 2, 3, 4, 6, 8, 12, 16};
@@ -408,6 +585,30 @@ static int aero_lstm_bwd_launch(const aero_lstm_bwd_desc* d, hipStream_t stream,
     p.K4P = kt4 * 32;
     const int nw = (d->H + 15) / 16;
     dim3 grid((unsigned)((d->nseq + 15) / 16), 2), block((unsigned)(nw * 64));
+    static const int ring = [] { const char* e = getenv("AERO_LSTM_BWD_RING"); return e ? atoi(e) : 1; }();
+    if (ring && d->H % 16 == 0 && (((uintptr_t)d->dout | (uintptr_t)d->save_gates | (uintptr_t)d->save_c | (uintptr_t)d->da) & 15) == 0) {
+        const size_t l4 = aero_lstm_bwd_ring_lds(d->H, kt4, 4), l2 = aero_lstm_bwd_ring_lds(d->H, kt4, 2);
+        const bool g4 = l4 <= 150 * 1024;
+        if (g4 || l2 <= 150 * 1024) {
+#define AERO_LSTM_BWD_RING_GO(KT_)                                                                                                   \
+            do {                                                                                                                     \
+                if (g4) AERO_LAUNCH_DYN((aero_lstm_bwd_ring_kernel<KT_, 4>), grid, block, l4, stream, p);                           \
+                else AERO_LAUNCH_DYN((aero_lstm_bwd_ring_kernel<KT_, 2>), grid, block, l2, stream, p);                              \
+            } while (0)
+            switch (kt4) {
+                case 1: AERO_LSTM_BWD_RING_GO(1); break;
+                case 2: AERO_LSTM_BWD_RING_GO(2); break;
+                case 3: AERO_LSTM_BWD_RING_GO(3); break;
+                case 4: AERO_LSTM_BWD_RING_GO(4); break;
+                case 6: AERO_LSTM_BWD_RING_GO(6); break;
+                case 8: AERO_LSTM_BWD_RING_GO(8); break;
+                case 12: AERO_LSTM_BWD_RING_GO(12); break;
+                default: AERO_LSTM_BWD_RING_GO(16); break;
+            }
+#undef AERO_LSTM_BWD_RING_GO
+            return AERO_OK;
+        }
+    }
     switch (kt4) {
         case 1: AERO_LAUNCH(aero_lstm_bwd_kernel<1>, grid, block, stream, p); break;
         case 2: AERO_LAUNCH(aero_lstm_bwd_kernel<2>, grid, block, stream, p); break;
