@@ -279,7 +279,12 @@ struct AeroLstmRingGeom {
     static constexpr size_t BYTES = (size_t)(2 * G * 16 * HS + 2 * G * 16 * XS) * sizeof(h16);
 };
 
-template <int NW, int TPW, int KT, int KTI, int G>
+// SAVE: the training-mode forward -- the gate activations (fp16 [H][16][4]) and the cell state (fp32 [H][16]) of every step go to
+// d.save_gates / d.save_c for aero_lstm_bwd (k_train.h).  They are written straight from registers (no extra reciprocal: sigmoid(i),
+// tanh(g) and sigmoid(o) fall out of the shared reciprocals of the gate math), and the step barrier becomes LDS-only (lgkmcnt + s_barrier)
+// so that the stores stay in flight: with `__syncthreads()` every step waited for their acknowledgement (the step-wise kernel's 2.5 us
+// per step).
+template <int NW, int TPW, int KT, int KTI, int G, bool SAVE = false>
 __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
     constexpr int R = 2 * G;
     constexpr int KP = KT * 32, HS = KP + 8, KPI = KTI * 32, XS = KPI + 8, SPR = KTI * 4, NT = NW * 64;
@@ -491,6 +496,17 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
                 const float ec = aero_exp2(aero_med3(c[t] * (2.f * L2E), NOLIM, LIM));
                 const float r2 = aero_rcp((1.f + eo) * (ec + 1.f));
                 hq[t] = fmaf(ec, r2, -r2);                                              // sigmoid(o) * tanh(c)
+                if constexpr (SAVE) {
+                    const int j = (wave * TPW + t) * 4 + q;
+                    if (j < H) {
+                        const int tau_s = dir ? W - 1 - s : s;
+                        const int64_t sb = ((int64_t)blockIdx.x * 2 + dir) * W + tau_s;
+                        const float sig_i = r1 * (eg + 1.f), tanh_g = (eg - 1.f) * r1 * (1.f + ei);
+                        const float sig_f = aero_rcp(1.f + ef), sig_o = r2 * (ec + 1.f);
+                        *(h16x4*)((h16*)d.save_gates + sb * H * 64 + ((int64_t)j * 16 + col) * 4) = (h16x4){(h16)sig_i, (h16)sig_f, (h16)tanh_g, (h16)sig_o};
+                        d.save_c[sb * H * 16 + j * 16 + col] = c[t];
+                    }
+                }
             }
 #ifndef AERO_EMU
 #pragma unroll
@@ -505,7 +521,8 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
             // MFMAs fill the pipes while the other waves finish their gate math
             if (i + 1 < nst) project(xring + (((g & 1) * G + i + 1) * 16 + col) * XS);
             else if (g + 1 < ngroups) park_x((g + 1) & 1);              // loads issued G steps ago
-            __syncthreads();
+            if constexpr (SAVE) aero_phase_barrier();
+            else __syncthreads();
         }
     }
     store_group(ngroups - 1);
@@ -545,6 +562,19 @@ static int aero_lstm_launch(const aero_lstm_desc* d, hipStream_t stream, const c
                         (AeroLstmRingGeom<KT_, KTI_, G_>::BYTES), stream, p);                                           \
     } while (0)
     if ((d->save_gates == nullptr) != (d->save_c == nullptr)) { *err = "lstm: save_gates and save_c go together"; return AERO_ERR_ARG; }
+    if (fused && ring && d->save_gates && wide && (nw == 6 || (nw == 8 && tpw == 3))) {
+        // training-mode forward on the ring kernel (the hidden sizes of the reference configs: 48 -> 12 x 1 tiles, 96 -> 12 x 2)
+#define AERO_LSTM_RING_SAVE(NW_, TPW_, KT_, KTI_, G_)                                                                   \
+    do {                                                                                                                \
+        block = dim3(NW_ * 64);                                                                                         \
+        AERO_LAUNCH_DYN((aero_lstm_ring_kernel<NW_, TPW_, KT_, KTI_, G_, true>), grid, block,                           \
+                        (AeroLstmRingGeom<KT_, KTI_, G_>::BYTES), stream, p);                                           \
+    } while (0)
+        if (nw == 6) { if (kti == 2) AERO_LSTM_RING_SAVE(12, 1, 2, 2, 4); else AERO_LSTM_RING_SAVE(12, 1, 2, 3, 4); }
+        else { if (kti == 3) AERO_LSTM_RING_SAVE(12, 2, 3, 3, 8); else AERO_LSTM_RING_SAVE(12, 2, 3, 6, 4); }
+#undef AERO_LSTM_RING_SAVE
+        return AERO_OK;
+    }
     if (fused && ring && !d->save_gates) {
         if (nw == 4 && tpw == 1) AERO_LSTM_RING_GO(4, 1, 1, 1, 4);
         else if (nw == 4 && tpw == 2) { if (kti == 1) AERO_LSTM_RING_GO(4, 2, 1, 1, 4); else AERO_LSTM_RING_GO(4, 2, 1, 2, 4); }
