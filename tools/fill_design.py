@@ -19,6 +19,9 @@ def mean_field(rows, pat):
     return sum(v) / len(v)
 
 
+FWD, BWD, CRIT = r'forward ([0-9.]+) ms', r'loss\+backward ([0-9.]+) ms', r'critic step ([0-9.]+) ms'
+
+
 def main():
     tag = sys.argv[1]
     P = lambda name: os.path.join(ROOT, 'profiles', f'{tag}_{name}')   # noqa: E731
@@ -44,16 +47,16 @@ def main():
     }
     if os.path.exists(P('config5_b2.txt')):
         rows = last_steps(P('config5_b2.txt'))
-        v['T2FWD'] = f"{mean_field(rows, r'forward ([0-9.]+) ms'):.1f}"
-        v['T2BWD'] = f"{mean_field(rows, r'loss\+backward ([0-9.]+) ms'):.1f}"
+        v['T2FWD'] = f"{mean_field(rows, FWD):.1f}"
+        v['T2BWD'] = f"{mean_field(rows, BWD):.1f}"
     if os.path.exists(P('config5_b16.txt')):
         rows = last_steps(P('config5_b16.txt'))
-        f, b = mean_field(rows, r'forward ([0-9.]+) ms'), mean_field(rows, r'loss\+backward ([0-9.]+) ms')
+        f, b = mean_field(rows, FWD), mean_field(rows, BWD)
         v['T16FWD'], v['T16BWD'], v['T16'] = f'{f:.1f}', f'{b:.1f}', f'{f + b + 0.5:.0f}'
     if os.path.exists(P('config5_gan_b2.txt')):
         rows = last_steps(P('config5_gan_b2.txt'))
-        v['GANGEN'] = f"{mean_field(rows, r'loss\+backward ([0-9.]+) ms'):.1f}"
-        v['GANCRIT'] = f"{mean_field(rows, r'critic step ([0-9.]+) ms'):.1f}"
+        v['GANGEN'] = f"{mean_field(rows, BWD):.1f}"
+        v['GANCRIT'] = f"{mean_field(rows, CRIT):.1f}"
     if os.path.exists(P('train_profile_b2.txt')):
         m = re.search(r'([0-9.]+) ms\s+\d+ calls\s+aero_conv_wgrad', open(P('train_profile_b2.txt')).read())
         if m:
