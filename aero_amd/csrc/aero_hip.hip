@@ -372,6 +372,13 @@ int aero_gconv1d_wgrad_slabs(int32_t B, int32_t Tin, int32_t Cin, int32_t Cout, 
     return B * nchunk;
 }
 
+int aero_weightnorm_bwd(const float* dw, int64_t so, int64_t sc, int64_t sk, const float* v, const float* g, const float* db, const float* inv_scale,
+                        const float* gl, float* dg, float* dv, float* dbias, int32_t Cout, int32_t cig, int32_t K, int32_t accumulate, void* stream) {
+    const char* err = "";
+    int rc = aero_weightnorm_bwd_launch(dw, so, sc, sk, v, g, db, inv_scale, gl, dg, dv, dbias, Cout, cig, K, accumulate, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 int aero_gconv1d_fwd(const aero_gconv_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_gconv1d_launch(d, (hipStream_t)stream, &err);

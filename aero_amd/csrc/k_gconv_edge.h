@@ -268,3 +268,64 @@ static void aero_edge_wgrad_plan(bool c1, int B, int T, int* nb, int* per) {
     *per = (int)((total + want - 1) / want);
     *nb = (int)((total + *per - 1) / *per);
 }
+
+// Weight-norm chain rule of one convolution (torch.nn.utils.weight_norm, dim 0: w[o] = g[o] v[o] / |v[o]|), with the un-scaling of
+// the fp16 gradient path and the upstream loss factor folded in -- one launch instead of ~20 parameter-sized torch kernels per conv:
+//   dg[o] (+)= a * <dw[o], v[o]> / |v[o]|,   dv[o] (+)= a * g[o] / |v[o]| * (dw[o] - v[o] <dw[o], v[o]> / |v[o]|^2),   dbias[o] (+)= a * db[o]
+// a = inv_scale[0] * (gl ? gl[0] : 1).  dw is addressed by strides (element (o, c, k) at o*so + c*sc + k*sk): the kernels leave it as
+// [Cout][K][cig] (grouped / edge layers) or [K][Cout][Cin] (aero_conv_wgrad); v, dv are the parameter's [Cout][cig][K].
+struct AeroWnBwdK {
+    const float* dw; const float* v; const float* g; const float* db; const float* inv_scale; const float* gl;
+    float* dg; float* dv; float* dbias;
+    int64_t so, sc, sk;
+    int Cout, cig, K, accumulate;
+};
+
+__global__ __launch_bounds__(256) void aero_weightnorm_bwd_kernel(AeroWnBwdK p) {
+    __shared__ float red[2][4];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const int L = p.cig * p.K;
+    const float* vr = p.v + (int64_t)o * L;
+    float nv2 = 0.f, dot = 0.f;
+    for (int i = tid; i < L; i += 256) {
+        const int c = i / p.K, k = i - c * p.K;
+        const float vv = vr[i], d = p.dw[(int64_t)o * p.so + (int64_t)c * p.sc + (int64_t)k * p.sk];
+        nv2 = fmaf(vv, vv, nv2);
+        dot = fmaf(d, vv, dot);
+    }
+    nv2 = aero_wave_sum(nv2);
+    dot = aero_wave_sum(dot);
+    if (aero_lane() == 0) { red[0][aero_wave()] = nv2; red[1][aero_wave()] = dot; }
+    __syncthreads();
+    nv2 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    dot = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float a = p.inv_scale[0] * (p.gl ? p.gl[0] : 1.f);
+    const float inv = 1.f / sqrtf(nv2), gg = p.g[o];
+    const float cg = a * gg * inv, cv = dot / nv2;
+    for (int i = tid; i < L; i += 256) {
+        const int c = i / p.K, k = i - c * p.K;
+        const float d = p.dw[(int64_t)o * p.so + (int64_t)c * p.sc + (int64_t)k * p.sk];
+        const float r = cg * (d - vr[i] * cv);
+        float* dst = p.dv + (int64_t)o * L + i;
+        *dst = p.accumulate ? *dst + r : r;
+    }
+    if (tid == 0) {
+        const float rg = a * dot * inv;
+        p.dg[o] = p.accumulate ? p.dg[o] + rg : rg;
+        if (p.db && p.dbias) {
+            const float rb = a * p.db[o];
+            p.dbias[o] = p.accumulate ? p.dbias[o] + rb : rb;
+        }
+    }
+}
+
+static int aero_weightnorm_bwd_launch(const float* dw, int64_t so, int64_t sc, int64_t sk, const float* v, const float* g, const float* db,
+                                      const float* inv_scale, const float* gl, float* dg, float* dv, float* dbias, int Cout, int cig, int K,
+                                      int accumulate, hipStream_t stream, const char** err) {
+    if (!dw || !v || !g || !inv_scale || !dg || !dv || Cout < 1 || cig < 1 || K < 1) { *err = "weightnorm_bwd: bad arguments"; return AERO_ERR_ARG; }
+    AeroWnBwdK p;
+    p.dw = dw; p.v = v; p.g = g; p.db = db; p.inv_scale = inv_scale; p.gl = gl; p.dg = dg; p.dv = dv; p.dbias = dbias;
+    p.so = so; p.sc = sc; p.sk = sk; p.Cout = Cout; p.cig = cig; p.K = K; p.accumulate = accumulate;
+    AERO_LAUNCH(aero_weightnorm_bwd_kernel, dim3((unsigned)Cout), dim3(256), stream, p);
+    return AERO_OK;
+}

@@ -216,9 +216,11 @@ class Discriminator(nn.Module):
         """solver.py:498-520: (adversarial = sum relu(1 - D(fake)).mean(), lambda * feature matching); differentiable w.r.t. `fake`"""
         return _GeneratorLoss.apply(self, fake, real.detach(), n_layers, features_loss_lambda)
 
-    def _backward(self, runs, dtop, dfeat, want_params, want_input):
+    def _backward(self, runs, dtop, dfeat, want_params, want_input, out=None, gl=None):
         """runs: _run() record; dtop[s]: (gradient of scale s's logits fp16 [B,T',1], {S,1/S}); dfeat[s][j]: the same for feature map j
-        or None.  Returns ({parameter name: fp32 gradient of weight_g / weight_v / bias}, d waveform fp32 [B,T] or None)."""
+        or None.  Returns ({parameter name: fp32 gradient of weight_g / weight_v / bias}, d waveform fp32 [B,T] or None).
+        out: {parameter name: fp32 destination} the parameter gradients are ADDED to (views of a flat gradient buffer) instead of being
+        returned as new tensors; gl: 0-dim fp32 device tensor, the upstream factor of the loss (folded into the same kernel)."""
         from . import backward as bw, train_ops as TO
         ops = self._get_ops()
         grads = {}
@@ -248,8 +250,8 @@ class Discriminator(nn.Module):
                     w = self._wn(conv)
                     if want_params:
                         spec = ent['spec']
-                        dw, db = bw.conv_wgrad(ops, dyp.view(B, 1, To, ent['Cout']), h.view(B, 1, Tin, ent['Cin']), spec.df, spec.dt)
-                        dwt = dw.permute(1, 2, 0).contiguous()                     # [Cout, Cin, K]
+                        dwk, db = bw.conv_wgrad(ops, dyp.view(B, 1, To, ent['Cout']), h.view(B, 1, Tin, ent['Cin']), spec.df, spec.dt)
+                        dw_strides = (ent['Cin'], 1, ent['Cout'] * ent['Cin'])      # [K, Cout, Cin]: element (o, c, k)
                     dx = ops.conv(bw.dgrad_conv1d(w, 1, ent['pad'], g.device), dyp.view(B, 1, To, ent['Cout']), None, B, 1, 1, To).view(B, Tin, ent['Cin']) \
                         if need_dx else None
                 else:
@@ -273,17 +275,23 @@ class Discriminator(nn.Module):
                             d.slabs, d.nslab = _ptr(slabs), nsl
                     ops.lib.call('aero_gconv1d_bwd', C.byref(d), ops.stream(g))
                     if want_params:
-                        dwt = dwk.permute(0, 2, 1).contiguous()                     # [Cout, Cin/groups, K]
+                        cig_ = ent['Cin'] // ent['groups']
+                        dw_strides = (ent['K'] * cig_, 1, cig_)                      # [Cout, K, cig]: element (o, c, k)
                 if want_params:
-                    TO.scale_f32(ops, dwt, sc[1:])
-                    TO.scale_f32(ops, db, sc[1:])
-                    # weight norm (w = g v / |v| per output channel): parameter-sized bookkeeping of torch.nn.utils.weight_norm
-                    v, gg = conv.weight_v.detach().float(), conv.weight_g.detach().float()
-                    nv = v.flatten(1).norm(dim=1).view(-1, 1, 1)
-                    dot = (dwt * v).flatten(1).sum(1).view(-1, 1, 1)
-                    grads[prefix + 'weight_g'] = dot / nv
-                    grads[prefix + 'weight_v'] = gg / nv * (dwt - v * dot / (nv * nv))
-                    grads[prefix + 'bias'] = db
+                    # weight norm (w = g v / |v| per output channel), the 1 / S of the fp16 gradient path and the upstream loss factor in
+                    # ONE launch (aero_weightnorm_bwd) -- the same bookkeeping in torch ops was ~20 parameter-sized kernels per conv
+                    v, gg = conv.weight_v.detach(), conv.weight_g.detach()
+                    assert v.dtype == torch.float32 and v.is_contiguous() and gg.is_contiguous()
+                    names3 = (prefix + 'weight_g', prefix + 'weight_v', prefix + 'bias')
+                    if out is not None:
+                        dg_, dv_, dbias_ = (out[n] for n in names3)
+                        acc = 1
+                    else:
+                        dg_, dv_, dbias_ = torch.empty_like(gg), torch.empty_like(v), torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
+                        acc = 0
+                        grads[names3[0]], grads[names3[1]], grads[names3[2]] = dg_, dv_, dbias_
+                    ops.lib.call('aero_weightnorm_bwd', _ptr(dwk), dw_strides[0], dw_strides[1], dw_strides[2], _ptr(v), _ptr(gg), _ptr(db),
+                                 sc[1:].data_ptr(), _ptr(gl), _ptr(dg_), _ptr(dv_), _ptr(dbias_), v.shape[0], v.shape[1], v.shape[2], acc, ops.stream(v))
             if want_input:
                 dxw = dx.view(B, -1)                             # gradient of this scale's waveform
                 if dwave is not None:                            # + the coarser scales through the AvgPool1d between them
@@ -340,6 +348,7 @@ class _CriticLoss(torch.autograd.Function):
             _loss_sum(ops, logits[B:], None, -1.0, 0, acc[1:2])
             loss = loss + (acc[0] + acc[1]) / logits[:B].numel()
         ctx.disc, ctx.names, ctx.runs, ctx.B = disc, names, runs, B
+        ctx.param_ptrs, ctx.shapes = [p.data_ptr() for p in params], [p.shape for p in params]
         return loss.float()
 
     @staticmethod
@@ -354,10 +363,25 @@ class _CriticLoss(torch.autograd.Function):
             _, sc = _scaled_grad(ops, logits[:B], None, logits[:B].numel(), 1.0, 1.0, 0, out=g[:B])
             _scaled_grad(ops, logits[B:], None, logits[B:].numel(), -1.0, 1.0, 0, out=g[B:])
             dtop.append((g, sc))
-        total, _ = disc._backward(ctx.runs, dtop, None, True, False)
+        # FlatAdam keeps every parameter's .grad as a view of one flat buffer: write there (freshly zeroed by zero_grad) and hand autograd no
+        # per-parameter gradients (its AccumulateGrad nodes were one `grad += g` launch per parameter) -- as aero_amd.train.AeroFunction does
+        glf = gl.detach().float().contiguous()
+        sink = getattr(disc, '_grad_sink', None)
+        sink = sink() if sink is not None else None
+        offs, n = [], 0
+        for shp in ctx.shapes:
+            offs.append(n)
+            n += (shp.numel() + 3) // 4 * 4
+        params = dict(disc.named_parameters())
+        if sink is not None and sink.accepts(ctx.param_ptrs, offs, n, glf.device):
+            out = {nme: params[nme].grad for nme in ctx.names}
+            sink.fresh = False
+            disc._backward(ctx.runs, dtop, None, True, False, out=out, gl=glf)
+            ctx.runs = None
+            return (None, None, None, None) + (None,) * len(ctx.names)
+        total, _ = disc._backward(ctx.runs, dtop, None, True, False, gl=glf)
         ctx.runs = None
-        g = gl.float()
-        return (None, None, None, None) + tuple(total[n] * g for n in ctx.names)
+        return (None, None, None, None) + tuple(total[n] for n in ctx.names)
 
 
 class _GeneratorLoss(torch.autograd.Function):

@@ -504,6 +504,13 @@ typedef struct {
     float* slabs; int32_t nslab;
 } aero_gconv_bwd_desc;
 int aero_gconv1d_bwd(const aero_gconv_bwd_desc* d, void* stream);
+/* weight-norm chain rule of one convolution (torch.nn.utils.weight_norm on dim 0, discriminators.py:10-11: w[o] = g[o] v[o] / |v[o]|):
+ *   dg[o] = a <dw[o], v[o]> / |v[o]|,  dv[o] = a g[o] / |v[o]| (dw[o] - v[o] <dw[o], v[o]> / |v[o]|^2),  dbias[o] = a db[o],
+ * a = inv_scale[0] * (gl ? gl[0] : 1) (device scalars: the 1/S of the fp16 gradient path, the upstream loss factor).  dw fp32, element
+ * (o, c, k) at o*so + c*sc + k*sk; v / dv fp32 [Cout][cig][K]; g / dg, db / dbias fp32 [Cout] (db, dbias may be NULL).  accumulate != 0:
+ * added to dg / dv / dbias (views of a flat gradient buffer), else written. */
+int aero_weightnorm_bwd(const float* dw, int64_t so, int64_t sc, int64_t sk, const float* v, const float* g, const float* db, const float* inv_scale,
+                        const float* gl, float* dg, float* dv, float* dbias, int32_t Cout, int32_t cig, int32_t K, int32_t accumulate, void* stream);
 int aero_gconv1d_wgrad_slabs(int32_t B, int32_t Tin, int32_t Cin, int32_t Cout, int32_t groups, int32_t K, int32_t stride, int32_t pad,
                              int32_t reflect);    /* 0: the MFMA form does not take this layer */
 /* gradients of the loss terms as fp16: mode 0 g = coef * sign * [1 + sign a > 0] (hinge, solver.py:489-496,508), mode 1

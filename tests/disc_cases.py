@@ -113,4 +113,15 @@ def case_critic_backward(dev, lib=None, T=1024):
     errs['feat'] = abs(float(f2) - float(feat)) / float(feat)
     (a2 + f2).backward()
     errs['dx'] = rel_l2(xh.grad.cpu(), ref['dx'])
+    # with FlatAdam attached the backward writes the same gradients straight into the optimizer's flat buffer (no per-parameter
+    # tensors through autograd): identical values; a second backward without zero_grad accumulates
+    from aero_amd.optim import FlatAdam
+    plain = {n: p.grad.detach().clone() for n, p in d.named_parameters()}
+    opt = FlatAdam(d.parameters(), lr=1e-4, model=d, lib=lib)
+    opt.zero_grad()
+    d.discriminator_loss(xf.to(dev), xr.to(dev)).backward()
+    errs['sink'] = max(rel_l2(p.grad.cpu(), plain[n].cpu()) for n, p in d.named_parameters())
+    assert all(p.grad.data_ptr() >= opt.flat_g.data_ptr() for p in d.parameters())
+    (2.0 * d.discriminator_loss(xf.to(dev), xr.to(dev))).backward()
+    errs['sink_acc'] = max(rel_l2(p.grad.cpu(), 3.0 * plain[n].cpu()) for n, p in d.named_parameters())
     return errs
