@@ -191,9 +191,9 @@ _PROTOS = {
     'aero_gconv1d_fwd': (i32, [C.POINTER(GconvDesc), vp]),
     'aero_leaky_relu': (i32, [vp, i64, C.c_float, vp]),
     'aero_avgpool1d': (i32, [vp, vp, i32, i32, vp]),
-    'aero_loss_sum': (i32, [vp, vp, i64, C.c_float, i32, dp, i32, dp, vp]),
+    'aero_loss_sum': (i32, [vp, vp, i64, C.c_float, i32, dp, i32, dp, C.c_double, vp]),
     'aero_gconv1d_bwd': (i32, [C.POINTER(GconvBwdDesc), vp]),
-    'aero_loss_grad': (i32, [vp, vp, i64, C.c_float, C.c_float, i32, vp, vp]),
+    'aero_loss_grad': (i32, [vp, vp, i64, C.c_float, C.c_float, i32, vp, fp, vp]),
     'aero_avgpool1d_bwd': (i32, [vp, vp, i32, i32, vp]),
 }
 

@@ -397,9 +397,10 @@ int aero_avgpool1d(const void* x, void* y, int32_t B, int32_t T, void* stream) {
     return aero_finish(rc, err);
 }
 
-int aero_loss_sum(const void* a, const void* b, int64_t n, float sign, int32_t mode, double* part, int32_t npart, double* out, void* stream) {
+int aero_loss_sum(const void* a, const void* b, int64_t n, float sign, int32_t mode, double* part, int32_t npart, double* out, double weight,
+                  void* stream) {
     const char* err = "";
-    int rc = aero_loss_sum_launch(a, b, n, sign, mode, part, npart, out, (hipStream_t)stream, &err);
+    int rc = aero_loss_sum_launch(a, b, n, sign, mode, part, npart, out, weight, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 
@@ -416,9 +417,9 @@ int aero_gconv1d_bwd(const aero_gconv_bwd_desc* d, void* stream) {
     return aero_finish(rc, err);
 }
 
-int aero_loss_grad(const void* a, const void* b, int64_t n, float sign, float coef, int32_t mode, void* g, void* stream) {
+int aero_loss_grad(const void* a, const void* b, int64_t n, float sign, float coef, int32_t mode, void* g, const float* gl, void* stream) {
     const char* err = "";
-    int rc = aero_loss_grad_launch(a, b, n, sign, coef, mode, g, (hipStream_t)stream, &err);
+    int rc = aero_loss_grad_launch(a, b, n, sign, coef, mode, g, gl, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 

@@ -190,21 +190,21 @@ __global__ __launch_bounds__(256) void aero_loss_sum_kernel(const h16* a, const 
     if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void aero_loss_sum_finish_kernel(const double* part, int nblk, double* out) {
+__global__ void aero_loss_sum_finish_kernel(const double* part, int nblk, double* out, double weight) {
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int k = 0; k < nblk; ++k) s += part[k];
-        out[0] += s;
+        out[0] += weight * s;
     }
 }
 
-static int aero_loss_sum_launch(const void* a, const void* b, int64_t n, float sign, int mode, double* part, int npart, double* out, hipStream_t stream,
-                                const char** err) {
+static int aero_loss_sum_launch(const void* a, const void* b, int64_t n, float sign, int mode, double* part, int npart, double* out, double weight,
+                                hipStream_t stream, const char** err) {
     if (!a || (mode == 1 && !b) || !part || !out || n < 1 || npart < 1 || mode < 0 || mode > 1) { *err = "loss_sum: bad arguments"; return AERO_ERR_ARG; }
     int64_t nb = (n + 255) / 256;
     if (nb > npart) nb = npart;
     AERO_LAUNCH(aero_loss_sum_kernel, dim3((unsigned)nb), dim3(256), stream, (const h16*)a, (const h16*)b, n, sign, mode, part);
-    AERO_LAUNCH(aero_loss_sum_finish_kernel, dim3(1), dim3(64), stream, (const double*)part, (int)nb, out);
+    AERO_LAUNCH(aero_loss_sum_finish_kernel, dim3(1), dim3(64), stream, (const double*)part, (int)nb, out, weight);
     return AERO_OK;
 }
 
@@ -451,7 +451,8 @@ static int aero_gconv1d_bwd_launch(const aero_gconv_bwd_desc* d, hipStream_t str
 //   mode 0 (hinge)  g[i] = coef * sign * [1 + sign * a[i] > 0]                  d/da of coef * relu(1 + sign * a)
 //   mode 1 (L1)     g[i] = coef * sgn(a[i] - b[i])                              d/da of coef * |a - b|
 //   mode 2          g[i] = dy[i] * (y[i] > 0 ? 1 : slope)   (a = dy, b = y, coef = slope): LeakyReLU backward for the dense layer
-__global__ __launch_bounds__(256) void aero_loss_grad_kernel(const h16* a, const h16* b, int64_t n, float sign, float coef, int mode, h16* g) {
+__global__ __launch_bounds__(256) void aero_loss_grad_kernel(const h16* a, const h16* b, int64_t n, float sign, float coef, int mode, h16* g, const float* gl) {
+    if (gl && mode < 2) coef *= gl[0];                           // the upstream factor of the loss, a device scalar (no host read)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float v;
         if (mode == 0) v = (1.f + sign * (float)a[i] > 0.f) ? coef * sign : 0.f;
@@ -461,11 +462,12 @@ __global__ __launch_bounds__(256) void aero_loss_grad_kernel(const h16* a, const
     }
 }
 
-static int aero_loss_grad_launch(const void* a, const void* b, int64_t n, float sign, float coef, int mode, void* g, hipStream_t stream, const char** err) {
+static int aero_loss_grad_launch(const void* a, const void* b, int64_t n, float sign, float coef, int mode, void* g, const float* gl, hipStream_t stream,
+                                 const char** err) {
     if (!a || !g || n < 1 || mode < 0 || mode > 2 || (mode >= 1 && !b)) { *err = "loss_grad: bad arguments"; return AERO_ERR_ARG; }
     int64_t nb = (n + 255) / 256;
     if (nb > 4096) nb = 4096;
-    AERO_LAUNCH(aero_loss_grad_kernel, dim3((unsigned)nb), dim3(256), stream, (const h16*)a, (const h16*)b, n, sign, coef, mode, (h16*)g);
+    AERO_LAUNCH(aero_loss_grad_kernel, dim3((unsigned)nb), dim3(256), stream, (const h16*)a, (const h16*)b, n, sign, coef, mode, (h16*)g, gl);
     return AERO_OK;
 }
 

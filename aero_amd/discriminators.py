@@ -246,7 +246,7 @@ class Discriminator(nn.Module):
                 need_dx = want_input or j > 0
                 if 'spec' in ent:
                     dyp = torch.empty_like(g)
-                    ops.lib.call('aero_loss_grad', _ptr(g), _ptr(y), g.numel(), C.c_float(0.0), C.c_float(ent['slope']), 2, _ptr(dyp), ops.stream(g))
+                    ops.lib.call('aero_loss_grad', _ptr(g), _ptr(y), g.numel(), C.c_float(0.0), C.c_float(ent['slope']), 2, _ptr(dyp), None, ops.stream(g))
                     w = self._wn(conv)
                     if want_params:
                         spec = ent['spec']
@@ -312,14 +312,14 @@ class Discriminator(nn.Module):
         return v * (gg / v.flatten(1).norm(dim=1).view(-1, 1, 1))
 
 
-def _scaled_grad(ops, a, b, n_mean, sign, coef, mode, out=None):
+def _scaled_grad(ops, a, b, n_mean, sign, coef, mode, out=None, gl=None):
     """gradient of coef * mean(...) as fp16 with a host-chosen power-of-two scale: returns (tensor, {S, 1/S} on the device)"""
     import math
     c = coef / n_mean
     S = 2.0 ** round(math.log2(32.0 / max(abs(c), 1e-30)))
     g = torch.empty(a.shape, dtype=torch.float16, device=a.device) if out is None else out
     assert a.is_contiguous() and g.is_contiguous() and (b is None or b.is_contiguous())
-    ops.lib.call('aero_loss_grad', _ptr(a), _ptr(b), a.numel(), C.c_float(sign), C.c_float(c * S), mode, _ptr(g), ops.stream(a))
+    ops.lib.call('aero_loss_grad', _ptr(a), _ptr(b), a.numel(), C.c_float(sign), C.c_float(c * S), mode, _ptr(g), _ptr(gl), ops.stream(a))
     return g, _scale_pair(S, a.device)
 
 
@@ -339,17 +339,15 @@ class _CriticLoss(torch.autograd.Function):
     def forward(ctx, disc, names, fake, real, *params):
         ops = disc._get_ops()
         runs, B = disc._run_pair(fake, real)
-        acc = torch.zeros(2, dtype=torch.float64, device=fake.device)
-        loss = torch.zeros((), dtype=torch.float64, device=fake.device)
+        loss = torch.zeros(1, dtype=torch.float64, device=fake.device)
         for (_, recs) in runs:
             logits = recs[-1][2]
-            acc.zero_()
-            _loss_sum(ops, logits[:B], None, 1.0, 0, acc[0:1])
-            _loss_sum(ops, logits[B:], None, -1.0, 0, acc[1:2])
-            loss = loss + (acc[0] + acc[1]) / logits[:B].numel()
+            w = 1.0 / logits[:B].numel()                         # (the means and the sum over scales accumulate in one device scalar)
+            _loss_sum(ops, logits[:B], None, 1.0, 0, loss, w)
+            _loss_sum(ops, logits[B:], None, -1.0, 0, loss, w)
         ctx.disc, ctx.names, ctx.runs, ctx.B = disc, names, runs, B
         ctx.param_ptrs, ctx.shapes = [p.data_ptr() for p in params], [p.shape for p in params]
-        return loss.float()
+        return loss[0].float()
 
     @staticmethod
     def backward(ctx, gl):
@@ -392,19 +390,14 @@ class _GeneratorLoss(torch.autograd.Function):
         rf, rr = disc._half(runs, 0, B), disc._half(runs, B, 2 * B)
         num_D = len(rf)
         w_feat = (4.0 / (n_layers + 1)) * (1.0 / num_D)
-        acc = torch.zeros(1, dtype=torch.float64, device=fake.device)
-        adv = torch.zeros((), dtype=torch.float64, device=fake.device)
-        feat = torch.zeros((), dtype=torch.float64, device=fake.device)
+        acc = torch.zeros(2, dtype=torch.float64, device=fake.device)        # {adversarial, lambda * feature matching}
         for (_, a), (_, b) in zip(rf, rr):
-            acc.zero_()
-            _loss_sum(ops, a[-1][2], None, -1.0, 0, acc)
-            adv = adv + acc[0] / a[-1][2].numel()
+            _loss_sum(ops, a[-1][2], None, -1.0, 0, acc[0:1], 1.0 / a[-1][2].numel())
             for j in range(len(a) - 1):
-                acc.zero_()
-                _loss_sum(ops, a[j][2], b[j][2], 0.0, 1, acc)
-                feat = feat + w_feat * acc[0] / a[j][2].numel()
+                _loss_sum(ops, a[j][2], b[j][2], 0.0, 1, acc[1:2], lam * w_feat / a[j][2].numel())
         ctx.disc, ctx.runs, ctx.cfg, ctx.shape = disc, (rf, rr), (w_feat, lam), fake.shape
-        return adv.float(), (lam * feat).float()
+        out = acc.float()
+        return out[0], out[1]
 
     @staticmethod
     def backward(ctx, gadv, gfeat):
@@ -412,22 +405,24 @@ class _GeneratorLoss(torch.autograd.Function):
         disc, ops = ctx.disc, ctx.disc._get_ops()
         rf, rr = ctx.runs
         w_feat, lam = ctx.cfg
-        ga, gf = float(gadv), float(gfeat)                       # (upstream scalars: 1 in solver.py:314-316)
-        dtop = [_scaled_grad(ops, recs[-1][2], None, recs[-1][2].numel(), -1.0, ga, 0) for (_, recs) in rf]
-        dfeat = [[_scaled_grad(ops, ra[j][2], rb[j][2], ra[j][2].numel(), 0.0, gf * lam * w_feat, 1) for j in range(len(ra) - 1)]
+        # the upstream factors (1 in solver.py:314-316) stay on the device: the loss-gradient kernel multiplies them in (a float() here
+        # would stall the host in the middle of the generator's backward until the device had caught up)
+        ga, gf = gadv.detach().float().contiguous(), gfeat.detach().float().contiguous()
+        dtop = [_scaled_grad(ops, recs[-1][2], None, recs[-1][2].numel(), -1.0, 1.0, 0, gl=ga) for (_, recs) in rf]
+        dfeat = [[_scaled_grad(ops, ra[j][2], rb[j][2], ra[j][2].numel(), 0.0, lam * w_feat, 1, gl=gf) for j in range(len(ra) - 1)]
                  for (_, ra), (_, rb) in zip(rf, rr)]
         _, dx = disc._backward(rf, dtop, dfeat, False, True)
         ctx.runs = None
         return None, dx.view(ctx.shape), None, None, None
 
 
-def _loss_sum(ops, a, b, sign, mode, out):
+def _loss_sum(ops, a, b, sign, mode, out, weight=1.0):
     a = a.contiguous()
     b = None if b is None else b.contiguous()                    # (named: the buffers must outlive the call)
     n = a.numel()
     npart = min(1024, (n + 255) // 256)
     part = torch.empty(npart, dtype=torch.float64, device=a.device)
-    ops.lib.call('aero_loss_sum', _ptr(a), _ptr(b), n, C.c_float(sign), mode, _ptr(part), npart, _ptr(out), ops.stream(a))
+    ops.lib.call('aero_loss_sum', _ptr(a), _ptr(b), n, C.c_float(sign), mode, _ptr(part), npart, _ptr(out), C.c_double(weight), ops.stream(a))
 
 
 def melgan_losses(disc, fake, real, n_layers=4, num_D=3, features_loss_lambda=100.0):

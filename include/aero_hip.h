@@ -480,9 +480,10 @@ int aero_gconv1d_mfma_ok(int32_t Cin, int32_t Cout, int32_t groups, int32_t K, i
 int aero_leaky_relu(void* x, int64_t n, float slope, void* stream);                      /* fp16 [n], in place */
 /* nn.AvgPool1d(4, stride=2, padding=1, count_include_pad=False) (discriminators.py:70): x fp16 [B][T] -> y fp16 [B][(T-2)/2+1] */
 int aero_avgpool1d(const void* x, void* y, int32_t B, int32_t T, void* stream);
-/* reductions of the hinge / feature-matching losses (solver.py:489-512): out[0] += sum relu(1 + sign * a[i]) (mode 0) or
- * sum |a[i] - b[i]| (mode 1); a, b fp16 [n]; part: scratch of npart doubles; block partials added in order (deterministic). */
-int aero_loss_sum(const void* a, const void* b, int64_t n, float sign, int32_t mode, double* part, int32_t npart, double* out, void* stream);
+/* reductions of the hinge / feature-matching losses (solver.py:489-512): out[0] += weight * sum relu(1 + sign * a[i]) (mode 0) or
+ * weight * sum |a[i] - b[i]| (mode 1) -- the weight carries the 1 / numel of the mean and the loss coefficients, so a whole loss is one scalar; a, b fp16 [n]; part: scratch of npart doubles; block partials added in order (deterministic). */
+int aero_loss_sum(const void* a, const void* b, int64_t n, float sign, int32_t mode, double* part, int32_t npart, double* out, double weight,
+                  void* stream);
 
 /* Backward of aero_gconv1d_fwd (solver.py:602-611).  y: the layer's post-activation output, dy: its gradient (fp16 [B][Tout][Cout]); the
  * LeakyReLU derivative is read off y.  dx (fp16 [B][Tin][Cin], may be NULL) is WRITTEN -- with reflect != 0 the contributions of the
@@ -515,7 +516,8 @@ int aero_gconv1d_wgrad_slabs(int32_t B, int32_t Tin, int32_t Cin, int32_t Cout, 
                              int32_t reflect);    /* 0: the MFMA form does not take this layer */
 /* gradients of the loss terms as fp16: mode 0 g = coef * sign * [1 + sign a > 0] (hinge, solver.py:489-496,508), mode 1
  * g = coef * sgn(a - b) (L1, solver.py:505), mode 2 g = a * (b > 0 ? 1 : coef) (LeakyReLU backward: a = dy, b = y, coef = slope) */
-int aero_loss_grad(const void* a, const void* b, int64_t n, float sign, float coef, int32_t mode, void* g, void* stream);
+int aero_loss_grad(const void* a, const void* b, int64_t n, float sign, float coef, int32_t mode, void* g, const float* gl, void* stream);
+/* (gl: optional device scalar multiplied into coef for modes 0 / 1 -- the upstream factor of the loss, read on the device) */
 int aero_avgpool1d_bwd(const void* dy, void* dx, int32_t B, int32_t T, void* stream);      /* adjoint of aero_avgpool1d */
 
 #ifdef __cplusplus
