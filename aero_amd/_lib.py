@@ -185,6 +185,7 @@ _PROTOS = {
     'aero_scale_f32': (i32, [fp, i64, fp, vp]),
     'aero_gather_pack': (i32, [vp, vp, i32, vp, vp, i64, i32, vp]),
     'aero_gconv1d_mfma_ok': (i32, [i32, i32, i32, i32, i32, i32, i32]),
+    'aero_weightnorm_fwd': (i32, [fp, fp, fp, i32, i32, vp]),
     'aero_weightnorm_bwd': (i32, [fp, i64, i64, i64, fp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, vp]),
     'aero_gconv1d_wgrad_slabs': (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32]),
     'aero_rescale_f16': (i32, [vp, fp, vp, fp, i64, vp, C.c_float, vp, fp, vp]),

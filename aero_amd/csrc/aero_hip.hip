@@ -372,6 +372,12 @@ int aero_gconv1d_wgrad_slabs(int32_t B, int32_t Tin, int32_t Cin, int32_t Cout, 
     return B * nchunk;
 }
 
+int aero_weightnorm_fwd(const float* v, const float* g, float* w, int32_t Cout, int32_t L, void* stream) {
+    if (!v || !g || !w || Cout < 1 || L < 1) return aero_fail(AERO_ERR_ARG, "weightnorm_fwd: bad arguments");
+    AERO_LAUNCH(aero_weightnorm_fwd_kernel, dim3((unsigned)Cout), dim3(256), (hipStream_t)stream, v, g, w, L);
+    return aero_finish(AERO_OK, "");
+}
+
 int aero_weightnorm_bwd(const float* dw, int64_t so, int64_t sc, int64_t sk, const float* v, const float* g, const float* db, const float* inv_scale,
                         const float* gl, float* dg, float* dv, float* dbias, int32_t Cout, int32_t cig, int32_t K, int32_t accumulate, void* stream) {
     const char* err = "";

@@ -329,3 +329,18 @@ static int aero_weightnorm_bwd_launch(const float* dw, int64_t so, int64_t sc, i
     AERO_LAUNCH(aero_weightnorm_bwd_kernel, dim3((unsigned)Cout), dim3(256), stream, p);
     return AERO_OK;
 }
+
+// w[o][:] = g[o] * v[o][:] / |v[o]|  (fp32 rows of L elements; one block per output channel): the forward of torch's weight_norm for one conv
+__global__ __launch_bounds__(256) void aero_weightnorm_fwd_kernel(const float* v, const float* g, float* w, int L) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const float* vr = v + (int64_t)o * L;
+    float nv2 = 0.f;
+    for (int i = tid; i < L; i += 256) nv2 = fmaf(vr[i], vr[i], nv2);
+    nv2 = aero_wave_sum(nv2);
+    if (aero_lane() == 0) red[aero_wave()] = nv2;
+    __syncthreads();
+    nv2 = red[0] + red[1] + red[2] + red[3];
+    const float sc = g[o] / sqrtf(nv2);
+    for (int i = tid; i < L; i += 256) w[(int64_t)o * L + i] = vr[i] * sc;
+}

@@ -101,10 +101,10 @@ class Discriminator(nn.Module):
         self.apply(weights_init)
         self._ops, self._packed, self._key = None, None, None
         self._pair, self._epoch = None, 0
+        self._builders = {}
 
     def repack(self):
         """the weights were edited behind autograd's version counters (FlatAdam's fused step): re-pack on the next forward"""
-        self._key = None
         self._pair = None
         self._epoch += 1
 
@@ -118,28 +118,73 @@ class Discriminator(nn.Module):
         return self._ops
 
     def _pack(self, dev):
-        key = (str(dev),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """the layers' device images for the current weights.  Weight norm first (w = g v / |v|, one launch per conv into a persistent
+        flat fp32 buffer), then every image -- fp16 [Cout][K][cig], the MFMA images of the grouped layers, the dense layer's conv and
+        data-gradient images -- is pure data movement of w and the biases: built by their closures once, and from the first weight
+        change on replayed by one gather launch per arena (aero_amd/repack.py), as the generator's training engine does."""
+        key = (str(dev),) + tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self._epoch,)
         if key == self._key:
             return self._packed
-        packed = []
-        for disc in self.model.values():
-            layers = []
-            for conv, g in zip(disc.convs(), disc.geom):
-                v, gg = conv.weight_v.detach().float(), conv.weight_g.detach().float()
-                w = v * (gg / v.flatten(1).norm(dim=1).view(-1, 1, 1))                 # weight norm (torch.nn.utils.weight_norm, dim 0)
+        first = self._packed is None
+        ops = self._get_ops()
+        convs = [(si, j, conv, g) for si, disc in enumerate(self.model.values()) for j, (conv, g) in enumerate(zip(disc.convs(), disc.geom))]
+        if self._wflat is None or self._wflat.device != torch.device(dev):
+            offs, n = [], 0
+            for _, _, conv, _ in convs:
+                offs.append(n)
+                n += (conv.weight_v.numel() + 3) // 4 * 4
+            self._wflat, self._woffs = torch.empty(n, dtype=torch.float32, device=dev), offs
+            self._replay, self._builders = None, {}
+        sd = {}
+        for (si, j, conv, g), o in zip(convs, self._woffs):
+            v, gg = conv.weight_v.detach(), conv.weight_g.detach()
+            w = self._wflat[o:o + v.numel()].view(v.shape)
+            ops.lib.call('aero_weightnorm_fwd', _ptr(v.contiguous()), _ptr(gg.contiguous()), _ptr(w), v.shape[0], v.shape[1] * v.shape[2], ops.stream(w))
+            sd[f'{si}.{j}.w'], sd[f'{si}.{j}.b'] = w, conv.bias.detach()
+        self._sd = sd
+
+        def builder(si, j, g):
+            def build():
+                w, b = self._sd[f'{si}.{j}.w'], self._sd[f'{si}.{j}.b']
                 Cout, cig, K = w.shape
-                ent = dict(g, Cout=Cout, Cin=cig * g['groups'], bias=conv.bias.detach().float().to(dev).contiguous())
+                ent = dict(g, Cout=Cout, Cin=cig * g['groups'], bias=b.float().to(dev).contiguous())
                 if g['groups'] == 1 and cig >= 64 and Cout >= 64:                        # the dense k = 5 layer: MFMA conv family
+                    from . import backward as bw
                     taps, df, dt = pack.conv1d_taps(w, 1, g['pad'])
-                    ent['spec'] = pack.make_conv_spec(taps, conv.bias.detach().float(), cig, 0, df, dt, dev)
+                    ent['spec'] = pack.make_conv_spec(taps, b.float(), cig, 0, df, dt, dev)
+                    ent['dgrad_spec'] = bw.dgrad_conv1d(w, 1, g['pad'], dev)
                 else:
                     ent['w'] = w.permute(0, 2, 1).contiguous().to(device=dev, dtype=torch.float16)      # [Cout][K][Cin/groups]
-                    if self._get_ops().lib.cdll.aero_gconv1d_mfma_ok(ent['Cin'], Cout, g['groups'], K, g['stride'], g['pad'], int(g['reflect'])):
+                    if ops.lib.cdll.aero_gconv1d_mfma_ok(ent['Cin'], Cout, g['groups'], K, g['stride'], g['pad'], int(g['reflect'])):
                         ent['w_mfma'], ent['w_dgrad_mfma'] = gconv_mfma_images(w, g['groups'], dev)
-                layers.append(ent)
-            packed.append(layers)
+                return ent
+            return build
+        rp = self._replay
+        if rp is None and not first and self._builders and self.replay_enabled and not (
+                self._wflat.is_cuda and torch.cuda.is_current_stream_capturing()):
+            from .repack import WeightReplay
+            rp = WeightReplay(ops.lib, ops.stream)
+            rp.compile(sd, self._builders, lambda d: setattr(self, '_sd', d))
+            self._replay = rp
+            ents = dict(rp.objects)
+        elif rp is not None:
+            ents = dict(rp.refresh(sd))
+        else:
+            ents = {}
+        packed = []
+        for si, j, conv, g in convs:
+            if j == 0:
+                packed.append([])
+            k = f'{si}.{j}'
+            if k not in ents:
+                if k not in self._builders:
+                    self._builders[k] = builder(si, j, g)
+                ents[k] = self._builders[k]()
+            packed[-1].append(ents[k])
         self._packed, self._key = packed, key
         return packed
+
+    _wflat, _woffs, _replay, _builders, _sd, replay_enabled = None, None, None, {}, None, True
 
     def _run(self, x):
         """-> per scale: (waveform fp16 [B, T_s], [(layer entry, input h [B,T,Cin], output y [B,T',Cout]) ...])"""
@@ -247,12 +292,11 @@ class Discriminator(nn.Module):
                 if 'spec' in ent:
                     dyp = torch.empty_like(g)
                     ops.lib.call('aero_loss_grad', _ptr(g), _ptr(y), g.numel(), C.c_float(0.0), C.c_float(ent['slope']), 2, _ptr(dyp), None, ops.stream(g))
-                    w = self._wn(conv)
                     if want_params:
                         spec = ent['spec']
                         dwk, db = bw.conv_wgrad(ops, dyp.view(B, 1, To, ent['Cout']), h.view(B, 1, Tin, ent['Cin']), spec.df, spec.dt)
                         dw_strides = (ent['Cin'], 1, ent['Cout'] * ent['Cin'])      # [K, Cout, Cin]: element (o, c, k)
-                    dx = ops.conv(bw.dgrad_conv1d(w, 1, ent['pad'], g.device), dyp.view(B, 1, To, ent['Cout']), None, B, 1, 1, To).view(B, Tin, ent['Cin']) \
+                    dx = ops.conv(ent['dgrad_spec'], dyp.view(B, 1, To, ent['Cout']), None, B, 1, 1, To).view(B, Tin, ent['Cin']) \
                         if need_dx else None
                 else:
                     d = _lib.GconvBwdDesc()

@@ -512,6 +512,8 @@ int aero_gconv1d_bwd(const aero_gconv_bwd_desc* d, void* stream);
  * added to dg / dv / dbias (views of a flat gradient buffer), else written. */
 int aero_weightnorm_bwd(const float* dw, int64_t so, int64_t sc, int64_t sk, const float* v, const float* g, const float* db, const float* inv_scale,
                         const float* gl, float* dg, float* dv, float* dbias, int32_t Cout, int32_t cig, int32_t K, int32_t accumulate, void* stream);
+/* ... and its forward: w[o][:] = g[o] v[o][:] / |v[o]| (fp32 rows of L = cig * K elements) */
+int aero_weightnorm_fwd(const float* v, const float* g, float* w, int32_t Cout, int32_t L, void* stream);
 int aero_gconv1d_wgrad_slabs(int32_t B, int32_t Tin, int32_t Cin, int32_t Cout, int32_t groups, int32_t K, int32_t stride, int32_t pad,
                              int32_t reflect);    /* 0: the MFMA form does not take this layer */
 /* gradients of the loss terms as fp16: mode 0 g = coef * sign * [1 + sign a > 0] (hinge, solver.py:489-496,508), mode 1

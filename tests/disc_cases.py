@@ -125,3 +125,37 @@ def case_critic_backward(dev, lib=None, T=1024):
     (2.0 * d.discriminator_loss(xf.to(dev), xr.to(dev))).backward()
     errs['sink_acc'] = max(rel_l2(p.grad.cpu(), 3.0 * plain[n].cpu()) for n, p in d.named_parameters())
     return errs
+
+
+def case_critic_replay(dev, lib=None, steps=3, ndf=16, T=2048):
+    """the critic's device images (fp16 weights, MFMA images, the dense layer's conv / data-gradient images) after optimizer steps:
+    replayed by aero_gather_pack from the weight-normed weights, bit-identical to what the packing closures build"""
+    from aero_amd.discriminators import Discriminator
+    from aero_amd.optim import FlatAdam
+    from aero_amd.repack import _flatten
+    torch.manual_seed(11)
+    d = Discriminator(num_D=3, ndf=ndf, n_layers=4, downsampling_factor=4)
+    if lib is not None:
+        d.use_library(lib)
+    d.to(dev)
+    opt = FlatAdam(d.parameters(), lr=1e-3, model=d, lib=lib)
+    xf, xr = (seeded((1, 1, T), 1) * 0.3).to(dev), (seeded((1, 1, T), 2) * 0.3).to(dev)
+    for it in range(steps):
+        loss = d.discriminator_loss(xf, xr)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        packed = d._pack(torch.device(dev) if isinstance(dev, str) else dev)
+        if it >= 1:
+            assert d._replay is not None and len(d._replay.objects) == 21 and not d._replay.skipped, d._replay and d._replay.skipped
+        k = 0
+        for si, layers in enumerate(packed):
+            for j, ent in enumerate(layers):
+                fresh = _flatten(d._builders[f'{si}.{j}'](), [])
+                have = _flatten(ent, [])
+                assert len(fresh) == len(have)
+                for a, b in zip(have, fresh):
+                    assert a.dtype == b.dtype and torch.equal(a, b), (it, si, j)
+                k += 1
+        assert k == 21
+    return k

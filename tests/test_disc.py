@@ -44,6 +44,17 @@ def test_critic_backward_on_the_mi355x():
     _check_bwd(dc.case_critic_backward('cuda', T=8192))
 
 
+def test_critic_images_replayed_by_gather_on_the_emulator():
+    from aero_amd import _lib
+    from emu.build_emu import build
+    assert dc.case_critic_replay('cpu', lib=_lib.load(build()), ndf=4, T=1024) == 21       # (a narrow critic: the emulated dense layer is slow)
+
+
+@pytest.mark.gpu
+def test_critic_images_replayed_by_gather_on_the_mi355x():
+    assert dc.case_critic_replay('cuda') == 21
+
+
 def _gconv_case(lib, dev, B, Cin, Cout, groups, K, stride, pad, T, reflect=0, slope=0.2, seed=0):
     """aero_gconv1d_fwd / aero_gconv1d_bwd against torch.nn.functional.conv1d + autograd on fp16-rounded operands"""
     import ctypes as C
