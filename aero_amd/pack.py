@@ -175,7 +175,10 @@ def pack_lstm_layer(lib, sd, prefix, layer, H, device):
     w_ih, b, w_hh = [], [], []
     for sfx in ('', '_reverse'):
         w_ih.append(sd[f'{prefix}.weight_ih_l{layer}{sfx}'].float()[perm])
-        b.append((sd[f'{prefix}.bias_ih_l{layer}{sfx}'].float() + sd[f'{prefix}.bias_hh_l{layer}{sfx}'].float())[perm])
+        bsum = sd.get(f'{prefix}.bias_sum_l{layer}{sfx}')        # (the training engine keeps b_ih + b_hh as a derived entry: pure data movement from there on)
+        if bsum is None:
+            bsum = sd[f'{prefix}.bias_ih_l{layer}{sfx}'].float() + sd[f'{prefix}.bias_hh_l{layer}{sfx}'].float()
+        b.append(bsum.float()[perm])
         w_hh.append(sd[f'{prefix}.weight_hh_l{layer}{sfx}'].float()[perm])
     w_ih = torch.cat(w_ih, 0)                                  # [8H, in]
     b = torch.cat(b, 0)

@@ -79,6 +79,15 @@ class TrainEngine:
         first = self._key is None
         self._key = key
         self.sd = {k: v.detach() for k, v in self.model.state_dict(keep_vars=True).items()}
+        # derived entries: b_ih + b_hh of every LSTM layer / direction, in a persistent buffer (stable pointers): with them every weight
+        # image of an LSTM is pure data movement too, and is replayed like the rest
+        ih = [k for k in self.sd if '.bias_ih_l' in k]
+        if ih:
+            if self._bias_sums is None or self._bias_sums[0].device != self.sd[ih[0]].device or len(self._bias_sums) != len(ih):
+                self._bias_sums = [torch.empty_like(self.sd[k], dtype=torch.float32) for k in ih]
+            for k, out in zip(ih, self._bias_sums):
+                torch.add(self.sd[k].float(), self.sd[k.replace('.bias_ih_l', '.bias_hh_l')].float(), out=out)
+                self.sd[k.replace('.bias_ih_l', '.bias_sum_l')] = out
         rp = self._replay
         sd_dev = str(next(iter(self.sd.values())).device)
         if rp is not None and (self._replay_dev != sd_dev or not rp.matches(self.sd)):
@@ -102,6 +111,7 @@ class TrainEngine:
             self._cache = {}
 
     _replay, _replay_dev, replay_enabled = None, None, os.environ.get('AERO_REPACK_GATHER', '1') != '0'
+    _bias_sums = None
 
     def w(self, name):
         return self.sd[name].float()
