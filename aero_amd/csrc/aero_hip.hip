@@ -338,6 +338,14 @@ int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const fl
     return aero_finish(rc, err);
 }
 
+int aero_bn_running_update(const double* stats, int32_t nc, double count, float momentum, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, void* stream) {
+    if (!stats || !running_mean || !running_var || nc < 1 || count < 1.0) return aero_fail(AERO_ERR_ARG, "bn_running_update: bad arguments");
+    AERO_LAUNCH(aero_bn_running_kernel, dim3(1), dim3(256), (hipStream_t)stream, stats, nc, count, momentum, running_mean, running_var,
+                (long long*)num_batches_tracked);
+    return aero_finish(AERO_OK, "");
+}
+
 int aero_gather_pack(const void* ptrs, const int32_t* starts, int32_t nparam, const int32_t* table, void* dst, int64_t n, int32_t dst_f16,
                      void* stream) {
     const char* err = "";

@@ -1342,6 +1342,21 @@ static int aero_scale_f32_launch(float* x, int64_t n, const float* scale, hipStr
     return AERO_OK;
 }
 
+// Running-statistics bookkeeping of nn.BatchNorm in training mode (torch/nn/modules/batchnorm.py: running = (1 - m) running + m batch,
+// the variance unbiased, num_batches_tracked += 1) from the fp64 channel sums the norm kernels accumulated: one launch instead of a
+// dozen parameter-sized torch kernels per BatchNorm layer.
+__global__ __launch_bounds__(256) void aero_bn_running_kernel(const double* st, int nc, double n, float mom, float* rm, float* rv, long long* nbt) {
+    for (int c = threadIdx.x; c < nc; c += 256) {
+        const double mean = st[2 * c] / n;
+        double var = st[2 * c + 1] / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double unb = var * (n / (n - 1.0 > 1.0 ? n - 1.0 : 1.0));
+        rm[c] = rm[c] * (1.f - mom) + mom * (float)mean;
+        rv[c] = rv[c] * (1.f - mom) + mom * (float)unb;
+    }
+    if (threadIdx.x == 0 && nbt) nbt[0] += 1;
+}
+
 // Re-packing of the weight images after an optimizer step.  Every packed image of the training engine (padded / tiled / flipped /
 // interleaved fp16 or fp32 copies of parameters, aero_amd/pack.py, backward.py) is pure data movement: element i of the arena is
 // element table[i] of the parameters laid end to end (or zero, table[i] < 0).  The parameters need not be contiguous in memory:

@@ -16,6 +16,7 @@ multiplied by a power-of-two loss scale chosen from its own maximum (`aero_scale
 un-scaled in fp32 at the end (`aero_scale_f32`), so nothing depends on the magnitude of the loss.
 """
 import contextlib
+import ctypes as C
 import math
 import os
 
@@ -152,19 +153,28 @@ class TrainEngine:
         Bq, Fy, Ty, Cy = y.shape
         gamma, beta = self.w(prefix + '.weight'), self.w(prefix + '.bias')
         if Cy > gamma.numel():                                  # zero-padded channels (r_channel 5 -> 8): gamma = beta = 0 there
-            gamma = torch.cat([gamma, gamma.new_zeros(Cy - gamma.numel())])
-            beta = torch.cat([beta, beta.new_zeros(Cy - beta.numel())])
+            def b_pad():                                         # (an image like the others: replayed after optimizer steps)
+                gm, bt = self.w(prefix + '.weight'), self.w(prefix + '.bias')
+                return torch.cat([gm, gm.new_zeros(Cy - gm.numel())]), torch.cat([bt, bt.new_zeros(Cy - bt.numel())])
+            gamma, beta = self.spec(prefix + f'.pad{Cy}', b_pad)
         out = self.ops.norm_act(y, Cy, 2, gamma, beta, ACT_RELU, eps=bnmod.eps, dst=dst, dst_strides=dst_strides)
         st = self.ops._last_stats
         n = float(Bq * Fy * Ty)
         nc = bnmod.running_mean.numel()
-        with torch.no_grad():                                   # buffer bookkeeping of nn.BatchNorm (not the data path)
-            mean = st[:nc, 0] / n
-            var = (st[:nc, 1] / n - mean * mean).clamp_min(0)
-            mom = bnmod.momentum
-            bnmod.running_mean.mul_(1 - mom).add_(mean.to(bnmod.running_mean.dtype), alpha=mom)
-            bnmod.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(bnmod.running_var.dtype), alpha=mom)
-            bnmod.num_batches_tracked.add_(1)
+        rm, rv, nbt = bnmod.running_mean, bnmod.running_var, bnmod.num_batches_tracked
+        if rm.dtype == torch.float32 and rv.dtype == torch.float32 and rm.is_contiguous() and rv.is_contiguous() and nbt.dtype == torch.int64 \
+                and bnmod.momentum is not None:
+            # buffer bookkeeping of nn.BatchNorm (not the data path): one launch
+            self.lib.call('aero_bn_running_update', st.data_ptr(), nc, C.c_double(n), C.c_float(bnmod.momentum), rm.data_ptr(), rv.data_ptr(),
+                          nbt.data_ptr(), self.ops.stream(y))
+        else:
+            with torch.no_grad():
+                mean = st[:nc, 0] / n
+                var = (st[:nc, 1] / n - mean * mean).clamp_min(0)
+                mom = bnmod.momentum if bnmod.momentum is not None else 1.0 / float(nbt + 1)
+                rm.mul_(1 - mom).add_(mean.to(rm.dtype), alpha=mom)
+                rv.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(rv.dtype), alpha=mom)
+                nbt.add_(1)
         return out, st, gamma, beta
 
     # ================================================================== forward

@@ -448,6 +448,11 @@ int aero_add_f16(const void* a, const void* b, void* dst, int64_t n, float scale
 int aero_scale_cast(const float* x, int32_t nitems, int64_t n_per_item, const float* item_scale, void* amax, float target, void* dst,
                     float* scale_out, void* stream);
 int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream);
+/* running statistics of nn.BatchNorm in training mode (the FTB's BatchNorms, modules.py:287,293,300) from the fp64 channel sums
+ * {sum, sum of squares} [nc][2] of `count` values per channel: running = (1 - momentum) running + momentum * {mean, unbiased variance};
+ * num_batches_tracked += 1 (may be NULL). */
+int aero_bn_running_update(const double* stats, int32_t nc, double count, float momentum, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, void* stream);
 /* Weight images re-packed after an optimizer step (the training engine re-packs every step; torch's layout ops for the same bytes were
  * ~700 launches): dst[i] = table[i] >= 0 ? P[table[i]] : 0 for i < n, converted to fp16 (dst_f16 != 0) or kept fp32, where P is the
  * parameters laid end to end: ptrs = device array of nparam (<= 1024) fp32 base pointers, starts = device int32 [nparam + 1] of their

@@ -1300,3 +1300,21 @@ def case_module_golden(lib, dev, tag):
     else:
         raise KeyError(tag)
     return errs
+
+
+def case_bn_running_update(lib, dev, nc=37, n=1234.0, mom=0.1, seed=400):
+    """aero_bn_running_update against the bookkeeping of torch.nn.BatchNorm in training mode"""
+    import ctypes as C
+    x = _rand((int(n), nc), seed, 1.3) + 0.4
+    bn = torch.nn.BatchNorm1d(nc, momentum=mom)
+    with torch.no_grad():
+        bn.running_mean.copy_(_rand((nc,), seed + 1, 0.2))
+        bn.running_var.copy_(_rand((nc,), seed + 2, 0.2).abs() + 0.5)
+    rm, rv, nbt = bn.running_mean.clone().to(dev), bn.running_var.clone().to(dev), bn.num_batches_tracked.clone().to(dev)
+    bn.train()
+    bn(x)
+    st = torch.stack([x.double().sum(0), (x.double() ** 2).sum(0)], 1).contiguous().to(dev)
+    stream = torch.cuda.current_stream().cuda_stream if str(dev) != 'cpu' else 0
+    lib.call('aero_bn_running_update', st.data_ptr(), nc, C.c_double(n), C.c_float(mom), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), stream)
+    assert torch.allclose(rm.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(rv.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    assert int(nbt) == int(bn.num_batches_tracked) == 1

@@ -352,3 +352,7 @@ def test_localstate_bwd_valu_form():
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_ATTN_BWD_VALU': '1'}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
+
+
+def test_bn_running_update(emu):
+    oc.case_bn_running_update(emu, DEV)

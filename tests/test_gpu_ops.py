@@ -301,3 +301,7 @@ def test_reference_module_vectors(lib, tag):
     DConv with BLSTM + LocalState, HEncLayer, HDecLayer) reproduced by the HIP kernels: <= 1e-3 (VERDICT r2 missing #5)"""
     errs = oc.case_module_golden(lib, DEV, tag)
     assert errs and max(errs.values()) < 1e-3, errs
+
+
+def test_bn_running_update(lib):
+    oc.case_bn_running_update(lib, DEV)
