@@ -113,6 +113,7 @@ class TrainEngine:
 
     _replay, _replay_dev, replay_enabled = None, None, os.environ.get('AERO_REPACK_GATHER', '1') != '0'
     _bias_sums = None
+    _stat_need = 0
 
     def w(self, name):
         return self.sd[name].float()
@@ -190,8 +191,10 @@ class TrainEngine:
         self._nfwd += 1
         B, _, L = mix.shape
         mix = mix.contiguous()
-        ops.begin_step(dev)
-        ops._cur = None                                          # statistics are kept for the backward: no shared arena
+        # the GroupNorm / BatchNorm accumulators of this forward are slices of ONE zero-filled buffer (kept alive by the slices the
+        # backward holds on to -- not the inference engine's per-stream arena, which the next forward zeroes again)
+        ar = [torch.zeros(max(self._stat_need, 1 << 12), dtype=torch.float64, device=dev), 0, 0]
+        ops._cur = ar
         ctx = _Ctx()
         hop, win = m.hop_length, m.win_length
         padn = (hop - L % hop) % hop
@@ -216,6 +219,7 @@ class TrainEngine:
         spec_out = x
         hop_o, win_o = int(m.hop_length * m.scale), int(m.win_length * m.scale)
         Lout = min(hop_o * (T - 1), int(L * m.scale))
+        self._stat_need, ops._cur = ar[2], None
         y = ops.istft(spec_out, m.nfft, hop_o, self._window(win_o, dev), self._inv_env(win_o, hop_o, T, dev), Lout)
         ctx.Lout, ctx.hop_o, ctx.win_o = Lout, hop_o, win_o
         return y.view(B, 1, Lout), spec_out, torch.view_as_complex(z).view(B, 1, F0, T), ctx
@@ -350,7 +354,7 @@ class TrainEngine:
             out = torch.zeros(hp, device=dev)
             out[:hid] = v
             return out
-        r.g1, r.be1 = padded(f'{q}.conv1.1.weight'), padded(f'{q}.conv1.1.bias')
+        r.g1, r.be1 = self.spec(q + '.gn1pad', lambda: (padded(f'{q}.conv1.1.weight'), padded(f'{q}.conv1.1.bias')))   # (replayed images)
         act = {'snake': ACT_SNAKE, 'gelu': ACT_GELU}.get(dc.act_func, ACT_RELU)
         r.act = act
         r.snake_a = self.w(f'{q}.act.a').reshape(-1).contiguous() if act == ACT_SNAKE else None
