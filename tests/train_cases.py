@@ -125,7 +125,7 @@ def case_training_step_small(dev, lib=None, L=400):
             losses.use_library(None)
 
 
-def case_weight_replay(dev, lib=None, steps=3):
+def case_weight_replay(dev, lib=None, steps=2):
     """After the first optimizer step the training engine stops re-packing its weight images with torch ops and replays them with
     aero_gather_pack (aero_amd/repack.py).  A few training steps of the small model; after every optimizer step each replayed image
     must equal, bit for bit, what its packing closure builds from the weights as they are now (the closures are what ran before, and
