@@ -122,13 +122,16 @@ class Discriminator(nn.Module):
         flat fp32 buffer), then every image -- fp16 [Cout][K][cig], the MFMA images of the grouped layers, the dense layer's conv and
         data-gradient images -- is pure data movement of w and the biases: built by their closures once, and from the first weight
         change on replayed by one gather launch per arena (aero_amd/repack.py), as the generator's training engine does."""
+        dev = torch.device(dev)
+        if dev.type == 'cuda' and dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
         key = (str(dev),) + tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self._epoch,)
         if key == self._key:
             return self._packed
         first = self._packed is None
         ops = self._get_ops()
         convs = [(si, j, conv, g) for si, disc in enumerate(self.model.values()) for j, (conv, g) in enumerate(zip(disc.convs(), disc.geom))]
-        if self._wflat is None or self._wflat.device != torch.device(dev):
+        if self._wflat is None or self._wflat.device != dev:
             offs, n = [], 0
             for _, _, conv, _ in convs:
                 offs.append(n)

@@ -145,7 +145,7 @@ def case_critic_replay(dev, lib=None, steps=3, ndf=16, T=2048):
         opt.zero_grad()
         loss.backward()
         opt.step()
-        packed = d._pack(torch.device(dev) if isinstance(dev, str) else dev)
+        packed = d._pack(xf.device)
         if it >= 1:
             assert d._replay is not None and len(d._replay.objects) == 21 and not d._replay.skipped, d._replay and d._replay.skipped
         k = 0
