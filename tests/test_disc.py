@@ -28,7 +28,8 @@ def _check_bwd(errs):
     the grouped-conv kernels themselves are exact to fp32 rounding: test_grouped_conv_op)"""
     assert errs['d_loss'] < 1e-4 and errs['adv'] < 1e-4 and errs['feat'] < 1e-3, errs
     assert errs['dx'] < 1e-2, errs['dx']
-    assert errs['sink'] < 1e-6 and errs['sink_acc'] < 1e-6, (errs['sink'], errs['sink_acc'])
+    # (same kernels, same data; the narrow test critic's grouped layers take the VALU weight-gradient kernel with fp32 atomics: 1.5e-6 run to run)
+    assert errs['sink'] < 1e-5 and errs['sink_acc'] < 1e-5, (errs['sink'], errs['sink_acc'])
     bad = {k: v for k, v in errs.items() if k.startswith('d.') and not v < 3e-2}       # (keys 'sink*' are checked above)
     assert not bad, bad
 
