@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void aero_spec_normalize_kernel(const float* s
 struct AeroIstftK {
     const float* spec; const float* window; const float* inv_env; float* y;
     int nsig, F, T, n_fft, hop, hsh, Lout, FPB, SEG;         // hsh = log2(hop) if hop is a power of two, else -1
-    int abl;                                                 // timing ablations (AERO_ISTFT_ABL): 1 no spectrum loads, 2 no FFT, 4 no overlap-add
+    int abl;                                                 // timing ablations (AERO_ISTFT_ABL): 1 no spectrum loads, 2 no FFT, 4 no overlap-add, 8 empty kernel
 };
 
 static inline int aero_istft_fpb(int n) { int f = 4096 / n; return f > 32 ? 32 : f; }   // frame ring (power of two)
@@ -305,13 +305,7 @@ __global__ __launch_bounds__(NW * 64) void aero_istft_kernel(AeroIstftK p) {
     if (t_hi > p.T - 1) t_hi = p.T - 1;
     const int nfr = t_hi - t_lo + 1;                        // <= FPB by construction of SEG
     if (p.abl & 8) return;
-    if (p.abl & 32) {                                       // (debug: poison the whole allocation first -- an uninitialised read shows up as NaN)
-        float* all = (float*)AERO_DYN_SMEM;
-        const int nfl = (int)(((size_t)n * (1 + NW + FPB) + FPB) * 2 + n_fft);
-        for (int i = threadIdx.x; i < nfl; i += NT) all[i] = __builtin_nanf("");
-        __syncthreads();
-    }
-    if (!(p.abl & 16)) aero_fft_init_twiddles(tw, n_fft);
+    aero_fft_init_twiddles(tw, n_fft);
     for (int i = threadIdx.x; i < n_fft; i += NT) wl[i] = p.window[i];
     __syncthreads();
     const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * p.T + t_lo;
@@ -330,13 +324,13 @@ __global__ __launch_bounds__(NW * 64) void aero_istft_kernel(AeroIstftK p) {
         const int fr = idx & (FPB - 1), k = idx >> lf;
         const bool livef = fr < nfr;
         const int t = livef ? fr : 0;
-        f32x2 xa = (p.abl & 1) ? (f32x2){1.f, 0.f} : ((p.abl & 64) ? __builtin_nontemporal_load(&X[k * p.T + t]) : X[k * p.T + t]);
+        f32x2 xa = (p.abl & 1) ? (f32x2){1.f, 0.f} : X[k * p.T + t];
         if (k == 0) {                                       // pairs with the implicit zero Nyquist bin X[n]
             xa[1] = 0.f;                                    // irfft ignores the imaginary part of DC
             const f32x2 z = unpack(xa, (f32x2){0.f, 0.f}, 0);
             fbuf[fr * fs] = livef ? z : (f32x2){0.f, 0.f};
         } else {
-            const f32x2 xq = (p.abl & 1) ? (f32x2){0.5f, 0.f} : ((p.abl & 64) ? __builtin_nontemporal_load(&X[(n - k) * p.T + t]) : X[(n - k) * p.T + t]);
+            const f32x2 xq = (p.abl & 1) ? (f32x2){0.5f, 0.f} : X[(n - k) * p.T + t];
             const f32x2 z0 = unpack(xa, (f32x2){xq[0], -xq[1]}, k);
             const f32x2 z1 = unpack(xq, (f32x2){xa[0], -xa[1]}, n - k);
             fbuf[fr * fs + k] = livef ? z0 : (f32x2){0.f, 0.f};
