@@ -240,7 +240,9 @@ class Discriminator(nn.Module):
         key = (fake.data_ptr(), fake._version, real.data_ptr(), real._version, tuple(fake.shape), str(fake.device)) + \
             tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self._epoch,)
         if self._pair is None or self._pair[0] != key:
-            self._pair = (key, self._run(torch.cat([fake.detach(), real.detach()], 0)))
+            # (the record keeps the two signals alive: while it is cached their memory cannot be recycled for other data at the same
+            # address and version -- a key built from pointers alone would then hit a stale record, e.g. in a validation loop)
+            self._pair = (key, self._run(torch.cat([fake.detach(), real.detach()], 0)), fake.detach(), real.detach())
         return self._pair[1], fake.shape[0]
 
     @staticmethod
