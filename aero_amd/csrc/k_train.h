@@ -14,7 +14,9 @@
 //   aero_axpy_f16, aero_scale_cast, aero_absmax_f32, aero_scale_f32     element-wise plumbing of the gradient path
 //                          (sum of two gradient paths, the fp32 -> fp16 boundary with the loss scale, un-scaling)
 //
-// First versions: written for correctness and a sane memory access pattern, not yet tuned.
+// State at the end of round 3: the LSTM backward runs in ring form (group-wise loads, LDS-only barriers), the LocalState
+// backward on MFMA; the streaming kernels (loss, frames, scaling, gather re-pack) are bound by the bytes they move; what bounds a
+// training step at the per-GPU batch is the chain of latency-bound launches, not any one of these.
 #pragma once
 #include "aero_common.h"
 #include "k_stft.h"
