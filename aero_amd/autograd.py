@@ -3,8 +3,9 @@ forward AND backward on the HIP kernels -- conv (aero_conv_fwd) -> GroupNorm -> 
 aero_norm_bwd_* -> data gradient (aero_conv_fwd on re-packed weights) + aero_conv_wgrad.  Tensors are channels-last fp16
 [B, F, T, C] on the device; parameters and their gradients are fp32 in the nn.Module layout (aero.py:86-101,172-179).
 
-First version: the weight image is re-packed on every call, and LSTM / attention / FTB / STFT have no backward yet, so this does
-not train the whole model."""
+These per-block Functions are the building blocks the op-level gradient tests drive (tests/op_cases.py); the whole model trains
+through aero_amd/train.py (TrainEngine + AeroFunction: one hand-written reverse walk, weight images replayed after optimizer steps),
+which is what `Aero.forward` uses under autograd."""
 import torch
 
 from . import _lib, backward as bw, pack
