@@ -160,6 +160,8 @@ def case_weight_replay(dev, lib=None, steps=2):
             if it == 0:
                 assert eng._replay is not None and len(eng._replay.objects) > 50, (eng._replay and eng._replay.skipped)
                 assert all(k.endswith('lstm.specs') or k.endswith('qkvd_dgrad') for k in eng._replay.skipped), eng._replay.skipped
+            if it < steps - 1:                                   # (the images are rebuilt by their closures for the comparison: once, after a refresh)
+                continue
             for key, obj in eng._replay.objects.items():
                 assert eng._cache[key] is obj
                 fresh, have = _flatten(eng._builders[key](), []), _flatten(obj, [])
