@@ -184,6 +184,7 @@ _PROTOS = {
     'aero_scale_cast': (i32, [fp, i32, i64, fp, vp, C.c_float, vp, fp, vp]),
     'aero_scale_f32': (i32, [fp, i64, fp, vp]),
     'aero_gather_pack': (i32, [vp, vp, i32, vp, vp, i64, i32, vp]),
+    'aero_debug_probe': (i32, [vp, i32, i32, i32, vp, vp]),
     'aero_bn_running_update': (i32, [dp, i32, C.c_double, C.c_float, fp, fp, vp, vp]),
     'aero_gconv1d_mfma_ok': (i32, [i32, i32, i32, i32, i32, i32, i32]),
     'aero_weightnorm_fwd': (i32, [fp, fp, fp, i32, i32, vp]),

@@ -1464,3 +1464,24 @@ static int aero_rescale_f16_launch(const void* a, const float* sa, const void* b
                 (h16*)out, scale_out);
     return AERO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Diagnostic (tools/istft_concurrency.py): a bystander kernel that shares CUs with whatever runs on another stream and
+// counts (0) words of its OWN LDS allocation that changed under it and (1) global loads of a constant pattern that came back wrong.
+__global__ __launch_bounds__(256) void aero_probe_kernel(const unsigned* pattern, int npat, int rounds, unsigned long long* counters) {
+    unsigned* lds = (unsigned*)AERO_DYN_SMEM;
+    const int nw = 12 * 1024;                                   // 48 KiB
+    for (int i = threadIdx.x; i < nw; i += 256) lds[i] = (unsigned)i * 2654435761u ^ blockIdx.x;
+    __syncthreads();
+    unsigned long long bad_lds = 0, bad_ld = 0;
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = threadIdx.x; i < nw; i += 256) bad_lds += lds[i] != ((unsigned)i * 2654435761u ^ blockIdx.x);
+        for (int j = 0; j < 8; ++j) {
+            const int idx = (int)(((long long)blockIdx.x * 977 + (long long)r * 131 + j * 4099) % (npat / 256)) * 256 + threadIdx.x;
+            bad_ld += pattern[idx] != (unsigned)idx * 2246822519u;
+        }
+        __syncthreads();
+    }
+    if (bad_lds) atomicAdd(counters, bad_lds);
+    if (bad_ld) atomicAdd(counters + 1, bad_ld);
+}
