@@ -348,7 +348,7 @@ int aero_bn_running_update(const double* stats, int32_t nc, double count, float 
 
 int aero_debug_probe(const void* pattern, int32_t npat, int32_t blocks, int32_t rounds, void* counters, void* stream) {
     if (!pattern || !counters || npat < 256 || blocks < 1 || rounds < 1) return aero_fail(AERO_ERR_ARG, "debug_probe: bad arguments");
-    AERO_LAUNCH_DYN(aero_probe_kernel, dim3((unsigned)blocks), dim3(256), (size_t)48 * 1024, (hipStream_t)stream, (const unsigned*)pattern, npat, rounds,
+    AERO_LAUNCH_DYN(aero_probe_kernel, dim3((unsigned)blocks), dim3(256), (size_t)50 * 1024, (hipStream_t)stream, (const unsigned*)pattern, npat, rounds,
                     (unsigned long long*)counters);
     return aero_finish(AERO_OK, "");
 }

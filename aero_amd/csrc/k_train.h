@@ -1473,15 +1473,43 @@ __global__ __launch_bounds__(256) void aero_probe_kernel(const unsigned* pattern
     const int nw = 12 * 1024;                                   // 48 KiB
     for (int i = threadIdx.x; i < nw; i += 256) lds[i] = (unsigned)i * 2654435761u ^ blockIdx.x;
     __syncthreads();
-    unsigned long long bad_lds = 0, bad_ld = 0;
+    unsigned long long bad_lds = 0, bad_ld = 0, bad_tw = 0;
     for (int r = 0; r < rounds; ++r) {
         for (int i = threadIdx.x; i < nw; i += 256) bad_lds += lds[i] != ((unsigned)i * 2654435761u ^ blockIdx.x);
-        for (int j = 0; j < 8; ++j) {
-            const int idx = (int)(((long long)blockIdx.x * 977 + (long long)r * 131 + j * 4099) % (npat / 256)) * 256 + threadIdx.x;
-            bad_ld += pattern[idx] != (unsigned)idx * 2246822519u;
+        for (int j = 0; j < 8; ++j) {                           // 8-byte loads at an odd 4008-byte row pitch, as the iSTFT's unpack issues them
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const int row = (int)(((long long)blockIdx.x * 977 + (long long)r * 131 + j * 4099) % 500);
+            const int idx = row * 1002 + 2 * (threadIdx.x & 15) + 34 * (threadIdx.x >> 4);       // 16 lanes = 128 contiguous bytes
+            if (idx + 1 < npat) {
+                const u32x2 v = *(const u32x2*)(pattern + idx);
+                bad_ld += (v[0] != (unsigned)idx * 2246822519u) + (v[1] != (unsigned)(idx + 1) * 2246822519u);
+            }
         }
         __syncthreads();
+        // the iSTFT's twiddle table: thread k writes exp(-2 pi i k / 512) computed on the spot, everybody reads entries others wrote
+        {
+            f32x2* tw = (f32x2*)(lds + nw);                     // 2 KiB behind the pattern words
+            float sn, cs;
+#ifdef AERO_EMU
+            sn = (float)sin(-2.0 * 3.14159265358979323846 * threadIdx.x / 512.0); cs = (float)cos(-2.0 * 3.14159265358979323846 * threadIdx.x / 512.0);
+#else
+            sincospif(-2.0f * (float)threadIdx.x / 512.f, &sn, &cs);
+#endif
+            tw[threadIdx.x] = (f32x2){cs, sn};
+            __syncthreads();
+            const int k2 = (threadIdx.x * 7 + r) & 255;
+            float sn2, cs2;
+#ifdef AERO_EMU
+            sn2 = (float)sin(-2.0 * 3.14159265358979323846 * k2 / 512.0); cs2 = (float)cos(-2.0 * 3.14159265358979323846 * k2 / 512.0);
+#else
+            sincospif(-2.0f * (float)k2 / 512.f, &sn2, &cs2);
+#endif
+            const f32x2 t = tw[k2];
+            bad_tw += (t[0] != cs2) + (t[1] != sn2);
+            __syncthreads();
+        }
     }
     if (bad_lds) atomicAdd(counters, bad_lds);
     if (bad_ld) atomicAdd(counters + 1, bad_ld);
+    if (bad_tw) atomicAdd(counters + 2, bad_tw);
 }

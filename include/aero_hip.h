@@ -453,9 +453,10 @@ int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream);
  * num_batches_tracked += 1 (may be NULL). */
 int aero_bn_running_update(const double* stats, int32_t nc, double count, float momentum, float* running_mean, float* running_var,
                            int64_t* num_batches_tracked, void* stream);
-/* diagnostic bystander kernel (tools/istft_concurrency.py): `blocks` blocks of 256 threads with 48 KiB of LDS each check, `rounds` times,
+/* diagnostic bystander kernel (tools/istft_concurrency.py): `blocks` blocks of 256 threads with 50 KiB of LDS each check, `rounds` times,
  * that their own LDS still holds what they wrote and that loads of pattern[i] == i * 2246822519u (uint32 [npat], npat a multiple of 256)
- * return that; counters uint64 [2] += {changed LDS words, wrong loads}. */
+ * return that, and that a twiddle table written by the block (sincospif per thread, as the iSTFT builds it) reads back as recomputed;
+ * counters uint64 [3] += {changed LDS words, wrong loads, wrong twiddles}. */
 int aero_debug_probe(const void* pattern, int32_t npat, int32_t blocks, int32_t rounds, void* counters, void* stream);
 /* Weight images re-packed after an optimizer step (the training engine re-packs every step; torch's layout ops for the same bytes were
  * ~700 launches): dst[i] = table[i] >= 0 ? P[table[i]] : 0 for i < n, converted to fp16 (dst_f16 != 0) or kept fp32, where P is the

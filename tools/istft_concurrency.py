@@ -20,7 +20,7 @@ with torch.no_grad():
     lib = _lib.load()
     pat = (torch.arange(1 << 20, dtype=torch.int64, device='cuda') * 2246822519 % (1 << 32)).to(torch.int64)
     pat = (pat - (pat >= (1 << 31)).to(torch.int64) * (1 << 32)).to(torch.int32)
-    cnt = torch.zeros(2, dtype=torch.int64, device='cuda')
+    cnt = torch.zeros(3, dtype=torch.int64, device='cuda')
     bad = 0
     mode = sys.argv[1] if len(sys.argv) > 1 else 'istft_vs_forward'
     for it in range(200):
@@ -57,4 +57,4 @@ with torch.no_grad():
                 print('  block', c, s0_, 'nonzero diffs', int((dd.abs()>1e-7).sum()), 'first idx', (dd.abs()>1e-7).nonzero().flatten()[:8].tolist(), 'last', (dd.abs()>1e-7).nonzero().flatten()[-4:].tolist())
                 print('  diff[::32]', [f'{v:.1e}' for v in dd[::32].tolist()])
                 print('  ref [::32]', [f'{v:.1e}' for v in rr[::32].tolist()])
-    print(mode, 'bad', bad, 'of 200', '| probe counters {changed LDS words, wrong loads}:', cnt.tolist())
+    print(mode, 'bad', bad, 'of 200', '| probe counters {changed LDS words, wrong loads, wrong twiddles}:', cnt.tolist())
