@@ -151,6 +151,7 @@ static inline T __shfl(T v, int src) { return emu::shfl_idx(v, src); }
 
 static inline float atomicAdd(float* a, float v) { return emu::atomic_add_cas(a, v); }
 static inline double atomicAdd(double* a, double v) { return emu::atomic_add_cas(a, v); }
+static inline unsigned long long atomicAdd(unsigned long long* a, unsigned long long v) { return __atomic_fetch_add(a, v, __ATOMIC_RELAXED); }
 static inline unsigned int atomicMax(unsigned int* a, unsigned int v) {
     unsigned int old = __atomic_load_n(a, __ATOMIC_RELAXED);
     while (old < v && !__atomic_compare_exchange_n(a, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
