@@ -6,7 +6,9 @@ same RNG stream at construction (so a seed reproduces the reference's initial we
 kernels of csrc/k_disc.h (grouped strided Conv1d with bias + LeakyReLU fused, the dense k = 5 layer on aero_conv_fwd, AvgPool1d
 between the scales) and returns the reference's structure: a list (scales) of lists (7 feature maps, the last one the logits),
 each [B, C, T] like nn.Conv1d's output (fp16 values, channels-last storage viewed in the reference layout).
-Forward only: the critic's backward (solver.py:607-611) is not built yet."""
+The critic's own step (solver.py:607-611) and the generator's adversarial / feature-matching losses are the autograd functions
+`discriminator_loss` / `generator_losses` below, whose backward runs on the same kernel family; wrapped by `distrib.wrap` (solver.py:51
+wraps every model) the parameter gradients are averaged over the ranks inside that backward (`_grad_sync`, one flat all-reduce)."""
 import ctypes as C
 
 import torch
@@ -90,6 +92,8 @@ def gconv_mfma_images(w, groups, dev):
 
 
 class Discriminator(nn.Module):
+    _supports_grad_sync = True                                   # distrib.wrap: the backward of `discriminator_loss` averages the gradients itself
+
     @capture_init
     def __init__(self, num_D, ndf, n_layers, downsampling_factor):
         super().__init__()
@@ -413,6 +417,14 @@ class _CriticLoss(torch.autograd.Function):
         # FlatAdam keeps every parameter's .grad as a view of one flat buffer: write there (freshly zeroed by zero_grad) and hand autograd no
         # per-parameter gradients (its AccumulateGrad nodes were one `grad += g` launch per parameter) -- as aero_amd.train.AeroFunction does
         glf = gl.detach().float().contiguous()
+        # distrib.wrap(critic) (solver.py:51): the mean over ranks.  1 / world rides in the upstream factor the weight-norm kernel
+        # multiplies in anyway; the sum is ONE all-reduce over the flat gradient range once the pass is done (the critic's backward is a
+        # few milliseconds: nothing to overlap it with but the optimizer step that needs its result)
+        sync = getattr(disc, '_grad_sync', None)
+        if sync is not None and not sync.active():
+            sync = None
+        if sync is not None:
+            glf = glf * sync.mean_factor()
         sink = getattr(disc, '_grad_sink', None)
         sink = sink() if sink is not None else None
         offs, n = [], 0
@@ -420,14 +432,27 @@ class _CriticLoss(torch.autograd.Function):
             offs.append(n)
             n += (shp.numel() + 3) // 4 * 4
         params = dict(disc.named_parameters())
-        if sink is not None and sink.accepts(ctx.param_ptrs, offs, n, glf.device):
+        # (a buffer that already holds gradients must not go through the collective a second time: then this pass gets its own tensors)
+        if sink is not None and sink.accepts(ctx.param_ptrs, offs, n, glf.device) and (sync is None or sink.fresh):
             out = {nme: params[nme].grad for nme in ctx.names}
             sink.fresh = False
             disc._backward(ctx.runs, dtop, None, True, False, out=out, gl=glf)
             ctx.runs = None
+            if sync is not None:
+                sync.reduce_async(sink.flat_g)
+                sync.wait()
             return (None, None, None, None) + (None,) * len(ctx.names)
         total, _ = disc._backward(ctx.runs, dtop, None, True, False, gl=glf)
         ctx.runs = None
+        if sync is not None:
+            flat = torch.cat([total[nme].reshape(-1) for nme in ctx.names])
+            sync.reduce_async(flat)
+            sync.wait()
+            o = 0
+            for nme in ctx.names:
+                k = total[nme].numel()
+                total[nme] = flat[o:o + k].view_as(total[nme])
+                o += k
         return (None, None, None, None) + tuple(total[n] for n in ctx.names)
 
 

@@ -159,6 +159,12 @@ class GradSync:
         self._work = []
         self.launched = 0
 
+    def active(self):
+        return world_size > 1 and is_initialized()
+
+    def mean_factor(self):
+        return 1.0 / world_size
+
     def unscale(self, scale):
         """{S, 1/S} of this rank's backward -> the device factor 1 / (S * world_size)"""
         return scale[1:] * (1.0 / world_size)
@@ -220,11 +226,19 @@ class DataParallel(torch.nn.Module):
 
 
 def wrap(model):
-    """distrib.py:59-69.  Inference needs no wrapper (weights are replicated, clips are independent); for training the generator is
-    wrapped in `DataParallel` (gradient all-reduce in flat segments overlapped with the HIP backward, BatchNorm buffers from rank 0)."""
+    """distrib.py:59-69.  Inference needs no wrapper (weights are replicated, clips are independent); for training the generator and the
+    critic (solver.py:51 wraps every model) are wrapped in `DataParallel`: their HIP backward passes average the gradients over the
+    ranks themselves (`_grad_sync`: flat all-reduce segments overlapped with the generator's backward, one flat all-reduce after the
+    critic's), BatchNorm buffers follow rank 0.  A module WITHOUT that protocol (anything that is not one of this package's models)
+    gets torch's DistributedDataParallel, as in the reference: its gradients must not silently stay per-rank."""
     if world_size == 1:
         return model
-    return DataParallel(model)
+    if getattr(model, '_supports_grad_sync', False):
+        return DataParallel(model)
+    from torch.nn.parallel import DistributedDataParallel
+    if _dist().get_backend() == 'nccl':
+        return DistributedDataParallel(model, device_ids=[torch.cuda.current_device()], output_device=torch.cuda.current_device())
+    return DistributedDataParallel(model)
 
 
 def loader(dataset, *args, shuffle=False, klass=None, **kwargs):

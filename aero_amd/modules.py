@@ -222,6 +222,7 @@ def rescale_module(module, reference):
 class Aero(nn.Module):
     """Drop-in for ``src.models.aero.Aero`` (aero.py:218-523): same 35 ctor kwargs, attributes,
     state_dict keys and ``forward`` signature; the arithmetic runs on gfx950 through the C-ABI."""
+    _supports_grad_sync = True                                   # distrib.wrap: AeroFunction.backward averages the gradients over the ranks itself
 
     @capture_init
     def __init__(self, in_channels=1, out_channels=1, audio_channels=2, channels=48, growth=2, nfft=512,

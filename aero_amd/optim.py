@@ -59,8 +59,8 @@ class FlatAdam:
 
     def zero_grad(self, set_to_none=False):
         """(gradients stay views of the flat buffer: set_to_none is accepted for API compatibility and ignored)"""
+        self._reattach(drop_stray_grads=True)                    # (first: a stray p.grad must not be copied into the zeroed buffer)
         self.flat_g.zero_()
-        self._reattach()
         self.fresh = True
 
     def accepts(self, param_ptrs, offs, n, dev):
@@ -75,7 +75,7 @@ class FlatAdam:
                 return False
         return True
 
-    def _reattach(self):
+    def _reattach(self, drop_stray_grads=False):
         """The kernel reads ONLY the flat buffers.  `module.zero_grad()` (set_to_none=True is torch's default), `model.to()` or
         `load_state_dict(assign=True)` replace `p.grad` / `p.data` by fresh tensors that are no longer views of them: copy such
         strays in and re-home the parameter, so that a step always follows the gradients autograd produced.  A gradient that is
@@ -93,7 +93,8 @@ class FlatAdam:
                     self.flat_g[o:o + sz].zero_()
                     p.grad = self.flat_g[o:o + sz].view_as(p)
                 elif g.data_ptr() != self.flat_g.data_ptr() + o * esz:
-                    self.flat_g[o:o + sz].copy_(g.detach().reshape(-1).to(self.flat_g.dtype))
+                    if not drop_stray_grads:
+                        self.flat_g[o:o + sz].copy_(g.detach().reshape(-1).to(self.flat_g.dtype))
                     p.grad = self.flat_g[o:o + sz].view_as(p)
 
     def step(self, grad_scale=1.0):
@@ -123,18 +124,34 @@ class FlatAdam:
     # ---- HIP-graph replay (aero_amd.train.CapturedStep)
     _bc = None
 
+    _BC_SLOTS = 8
+
     def prepare_capture(self):
         """allocate the device-side bias-correction pair the captured step reads"""
         if self._bc is None:
             self._bc = torch.ones(2, dtype=torch.float32, device=self.flat_p.device)
-            self._bc_host = torch.ones(2, dtype=torch.float32).pin_memory() if self.flat_p.is_cuda else torch.ones(2)
+            # a RING of pinned upload slots: replays are asynchronous, and a host that runs ahead would overwrite a single pinned pair
+            # before the copy of the previous replay has executed.  A slot is reused only after the event behind its last copy is done.
+            host = torch.ones(self._BC_SLOTS, 2, dtype=torch.float32)
+            self._bc_host = host.pin_memory() if self.flat_p.is_cuda else host
+            self._bc_events = [None] * self._BC_SLOTS
+            self._bc_slot = 0
 
     def before_replay(self):
         """advance the step count and upload {1 - beta1^t, sqrt(1 - beta2^t)} for the replay that follows"""
         self.step_count += 1
-        self._bc_host[0] = 1.0 - self.betas[0] ** self.step_count
-        self._bc_host[1] = (1.0 - self.betas[1] ** self.step_count) ** 0.5
-        self._bc.copy_(self._bc_host, non_blocking=True)
+        i = self._bc_slot
+        self._bc_slot = (i + 1) % self._BC_SLOTS
+        if self._bc_events[i] is not None:
+            self._bc_events[i].synchronize()
+        slot = self._bc_host[i]
+        slot[0] = 1.0 - self.betas[0] ** self.step_count
+        slot[1] = (1.0 - self.betas[1] ** self.step_count) ** 0.5
+        self._bc.copy_(slot, non_blocking=True)
+        if self.flat_p.is_cuda:
+            ev = self._bc_events[i] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat_p.device))
+            self._bc_events[i] = ev
 
     # ---- checkpoints: the schema of torch.optim.Adam.state_dict() (the reference stores it under the checkpoint's optimizer entry,
     # src/solver.py:111-118 / model_serializer.py), so checkpoints move both ways between the two optimizers

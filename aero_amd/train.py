@@ -989,8 +989,10 @@ class CapturedStep:
         loss = cap(lr, hr)                                                    # copies into the static inputs, replays
     """
 
-    def __init__(self, step_fn, *example_inputs, warmup=2, optimizers=()):
+    def __init__(self, step_fn, *example_inputs, warmup=2, optimizers=(), modules=()):
         self.optimizers = list(optimizers)                       # FlatAdam instances stepped inside step_fn
+        # every module whose weights the captured step changes: the optimizers' models plus any named explicitly
+        self.modules = [m for m in list(modules) + [getattr(o, 'model', None) for o in self.optimizers] if m is not None and hasattr(m, 'repack')]
         for o in self.optimizers:
             o.prepare_capture()
         self.static_in = [t.clone() for t in example_inputs]
@@ -1011,4 +1013,9 @@ class CapturedStep:
         for o in self.optimizers:
             o.before_replay()
         self.graph.replay()
+        # the replay stepped the weights (and re-packed the TRAINING images, captured with the step) behind every cache key kept on the
+        # host: bump them, so that an eval-mode forward, an eager step or the critic's cached record re-pack instead of running on the
+        # weights of capture time
+        for m in self.modules:
+            m.repack()
         return self.static_out

@@ -1,10 +1,4 @@
-"""get_model(args) as the reference's factory (modelFactory.py:6-12) for the generator.  The GAN critics and the
-Seanet baseline are training-only / off the hot path and are not part of this package."""
-from aero_amd.modules import Aero
-
-
-def get_model(args):
-    exp = args.experiment
-    if exp.model != 'aero':
-        raise NotImplementedError(f"model '{exp.model}': only the AERO generator is implemented on MI355X")
-    return {'generator': Aero(**exp.aero)}
+"""get_model(args) as the reference's factory (modelFactory.py:6-29): the AERO generator and, for `adversarial: true` experiments, the
+MelGAN multi-scale critic (`msd_melgan`, the critic of every aero experiment file).  Seanet and the HiFi-GAN critics are in no aero
+config and raise NotImplementedError."""
+from aero_amd.trainer import build_models as get_model  # noqa: F401

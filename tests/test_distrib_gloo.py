@@ -200,3 +200,110 @@ def test_two_rank_training_matches_one_process():
     assert not torch.equal(l0, l1)
     mean = 0.5 * (l0 + l1)
     assert torch.allclose(g0, mean, rtol=1e-4, atol=1e-6 * float(mean.abs().max())), float((g0 - mean).abs().max())   # (two separate backward passes: atomics order)
+
+
+# ---- the adversarial step of `train.py ddp=true` (config 5): generator AND critic through distrib.wrap (solver.py:51) ----------------
+def _adv_args():
+    from aero_amd.config import _wrap
+    gen = dict(channels=16, nfft=128, hop_length=32, lr_sr=4000, hr_sr=16000, enc_freq_attn=4)      # no FTB (index >= 4): no BatchNorm, clips do not interact
+    # (l1 instead of the MR-STFT criterion: its 2048-point resolution needs > 1024 samples, 4x the emulator time, and its spectral-
+    # convergence term is a ratio of BATCH norms -- not a mean over clips, so not what one-process equivalence can be shown on)
+    return _wrap(dict(optim='adam', lr=1e-3, beta2=0.999, losses=['l1'], stft_sc_factor=0.5, stft_mag_factor=0.5,
+                      experiment=dict(model='aero', aero=gen, adversarial=True, features_loss_lambda=100, only_features_loss=False,
+                                      only_adversarial_loss=False, discriminator_models=['msd_melgan'],
+                                      melgan_discriminator=dict(n_layers=4, num_D=2, downsampling_factor=4, ndf=4))))
+
+
+def _adv_worker(rank, world, port, q, steps):
+    try:
+        _adv_worker_body(rank, world, port, q, steps)
+    except BaseException:
+        import traceback
+        q.put((rank, 'error', traceback.format_exc()))
+        raise
+
+
+def _adv_worker_body(rank, world, port, q, steps):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank),
+                      AERO_EMU_THREADS='2')
+    torch.set_num_threads(1)
+    from aero_amd import _lib, distrib, losses, trainer
+    from aero_amd.engine import HipEngine
+    from emu.build_emu import build
+    lib = _lib.load(build())
+    losses.use_library(lib)
+    if world > 1:
+        distrib.init_from_env(backend='gloo')
+    args = _adv_args()
+    torch.manual_seed(100 + (rank if world > 1 else 0))       # different initial weights per rank: wrap() must hand out rank 0's
+    models = trainer.build_models(args)
+    gen, critic = models['generator'].train(), models['msd_melgan'].train()
+    object.__setattr__(gen, '_engine', HipEngine(gen, lib=lib))
+    critic.use_library(lib)
+    opts = trainer.build_optimizers(models, args, lib=lib)
+    step = trainer.TrainStep(models, opts, args)               # (wraps both models: weights from rank 0)
+    og, od = opts['optimizer'], opts['disc_optimizer']
+    p_start = (og.flat_p.clone(), od.flat_p.clone())
+    g_first = None
+    for i in range(steps):
+        lr = torch.randn(2, 1, 136, generator=torch.Generator().manual_seed(10 + i))
+        hr = 0.1 * torch.randn(2, 1, 544, generator=torch.Generator().manual_seed(20 + i))
+        rec = step(distrib.shard_batch(lr), distrib.shard_batch(hr))
+        assert all(torch.isfinite(v) for v in rec.values()), rec
+        if i == 0:
+            g_first = (og.flat_g.clone(), od.flat_g.clone())   # (the buffers still hold the gradients the steps just used)
+    nsync = [gen._grad_sync.launched, critic._grad_sync.launched] if world > 1 else []
+    q.put((rank, og.flat_p.numpy().copy(), od.flat_p.numpy().copy(), p_start[0].numpy().copy(), p_start[1].numpy().copy(),
+           g_first[0].numpy().copy(), g_first[1].numpy().copy(), nsync))
+    if world > 1:
+        distrib.barrier()
+        distrib.close()
+
+
+def _run_adv(world, port, steps):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_adv_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r = q.get(timeout=900)
+            assert not (isinstance(r[1], str) and r[1] == 'error'), r[2]
+            res[r[0]] = [torch.from_numpy(v) if hasattr(v, 'dtype') else v for v in r]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    return res
+
+
+def test_two_rank_adversarial_steps_keep_generator_and_critic_in_sync():
+    """VERDICT r3 item 7 / ADVICE r3: adversarial steps (generator step with the critic's losses, then the critic's own step) on 2 ranks
+    over gloo, one clip of a 2-clip batch each.  Both models go through distrib.wrap as in solver.py:51; afterwards generator AND
+    critic parameters are bit-identical on the two ranks, and the gradients the first step used are those of ONE process on the whole
+    batch (every loss here is a mean over clips and no layer mixes clips) -- compared as gradients, to what fp16 activation-gradient
+    storage allows: Adam's sign-like first steps turn the rounding of a near-zero component into a full +-lr update, so the weights
+    themselves are only comparable between runs that saw bit-identical gradients, which is what the two ranks are held to."""
+    from emu.build_emu import build
+    build()
+    two = _run_adv(2, 33500 + os.getpid() % 2000, 2)
+    one = _run_adv(1, 35500 + os.getpid() % 2000, 1)      # (its first-step gradients are what is compared)
+    (_, g0, d0, gs0, ds0, gg0, gd0, n0), (_, g1, d1, gs1, ds1, gg1, gd1, n1) = two[0], two[1]
+    assert torch.equal(gs0, gs1) and torch.equal(ds0, ds1)      # wrap(): both ranks start from rank 0's weights, critic included
+    assert torch.equal(gg0, gg1) and torch.equal(gd0, gd1)      # the SAME averaged gradients on both ranks ...
+    assert torch.equal(g0, g1), float((g0 - g1).abs().max())    # ... so the generator stays in sync, bit for bit,
+    assert torch.equal(d0, d1), float((d0 - d1).abs().max())    # and the critic too (it silently drifted apart before)
+    assert n0 == n1 and n0[0] >= 6 and n0[1] == 2               # generator: several segments per step; critic: one flat all-reduce per step
+    assert not torch.equal(g0, gs0) and not torch.equal(d0, ds0)
+    _, G, D, Gs, Ds, Gg, Gd, _ = one[0]
+    assert torch.equal(Gs, gs0) and torch.equal(Ds, ds0)        # same seed as rank 0
+    cos = lambda a, b: float((a.double() * b.double()).sum() / a.double().norm() / b.double().norm())   # noqa: E731
+    cg, cd = cos(gg0, Gg), cos(gd0, Gd)
+    rg, rd = float(gg0.norm() / Gg.norm()), float(gd0.norm() / Gd.norm())
+    assert cd > 0.999 and abs(rd - 1) < 1e-2, (cd, rd)          # critic: the mean over ranks IS the one-process gradient
+    assert cg > 0.97 and abs(rg - 1) < 5e-2, (cg, rg)           # generator: to the fp16 noise of its long backward (tests/train_cases.py)

@@ -146,6 +146,15 @@ def test_captured_training_step_matches_eager(meta):
             cap = CapturedStep(step, x, hr, warmup=2, optimizers=[opt])          # two eager warm-up steps, then the capture
             for _ in range(3):
                 hist.append(float(cap(x, hr)))
+            # the replays changed the weights behind every host-side cache key -- an eval-mode forward right after them
+            # must run on the CURRENT weights (== a fresh module that loads them), not on the images of capture time
+            m.eval()
+            m2 = Aero(**cfg).cuda().eval()
+            m2.load_state_dict(m.state_dict())
+            with torch.no_grad():
+                ya, yb = m(x), m2(x)
+            assert torch.equal(ya, yb), float((ya - yb).abs().max())
+            m.train()
         else:
             for i in range(5):
                 v = float(step(x, hr))
