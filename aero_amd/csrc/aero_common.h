@@ -27,7 +27,11 @@
 #define aero_med3(x, lo, hi) __builtin_amdgcn_fmed3f((x), (lo), (hi))   /* one-instruction clamp */
 #include <hip/hip_runtime.h>
 // every launch records which instantiation it was: aero_last_kernel_name() (profiling labels that match rocprofv3)
+#ifdef AERO_PART
+extern thread_local const void* aero_last_kernel_ptr_;      /* the library is built in parts (aero_hip.hip): defined in part 0 */
+#else
 static thread_local const void* aero_last_kernel_ptr_ = nullptr;
+#endif
 #define AERO_LAUNCH(kern, grid, block, stream, ...)                                  \
     do {                                                                             \
         aero_last_kernel_ptr_ = (const void*)(kern);                                 \
@@ -49,6 +53,14 @@ extern __shared__ __attribute__((aligned(16))) char aero_dyn_smem_[];
 #endif
 
 #include "../../include/aero_hip.h"
+
+// The library is ONE source (aero_hip.hip) compiled in parts (-DAERO_PART=k, __graft_entry__.build): a host function one part
+// calls in another has external linkage there, and is a file-local static when the whole library is a single unit.
+#ifdef AERO_PART
+#define AERO_XPART
+#else
+#define AERO_XPART static
+#endif
 
 typedef _Float16 h16;
 typedef h16 h16x8 __attribute__((ext_vector_type(8)));
@@ -103,6 +115,37 @@ static __device__ __forceinline__ void aero_wave_sync() {
     emu::wave_barrier();
 #else
     __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+static __device__ __forceinline__ void aero_sched_fence() {
+#ifndef AERO_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <int N>
+static __device__ __forceinline__ void aero_wait_vm() {
+#ifndef AERO_EMU
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+// end of a phase: this wave's LDS reads have returned (their slot may be refilled) and every wave's landed copies are
+// visible to the others.  Not __syncthreads(): that would also drain the copies still in flight (vmcnt).
+static __device__ __forceinline__ void aero_phase_barrier() {
+#ifdef AERO_EMU
+    __syncthreads();
+#else
+    // the BUILTIN wait (not inline asm) so that hipcc's own scoreboard knows the operand registers fetched during this
+    // phase are ready: with an asm wait it re-waits `lgkmcnt(0)` in front of the next phase's first MFMA, i.e. also for
+    // the fragment reads just issued for the phase after -- the prefetch would never overlap the MFMAs.
+    // sched_barrier(0): nothing moves across -- hipcc otherwise hoists register-only MFMAs of the next phase over the
+    // s_barrier (legal, but it then waits for this phase's prefetch reads in front of them)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0); vmcnt / expcnt fields at their maxima
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #endif
 }
 

@@ -1,23 +1,45 @@
 // aero_hip.hip -- the C-ABI shared library (include/aero_hip.h) over the gfx950 kernels.
-// Built with:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC  (see __graft_entry__.build()).
 // gfx950 only: no other offload arch, no CUDA path, no CPU fallback.  (tests/emu builds the same
 // translation unit against a CPU emulation of the HIP subset, as a test double -- never loaded by
 // the product.)
+//
+// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DAERO_PART=k  for k = 0..6 (no 5), IN PARALLEL,
+// then one link into aero_amd/libaero_hip.so.  The library is ONE source file cut into six independently compiled parts (each
+// kernel header belongs to exactly one part; a part holds the entry points over its kernels): as a single translation unit it took
+// four minutes to compile; now a change to one header rebuilds one part.  Without -DAERO_PART (the emulator's build, or a plain
+// `hipcc -c aero_hip.hip`) the file is the whole library in one unit, as before.
 #include "aero_common.h"
+#ifdef AERO_PART
+#define AERO_IN(p) (AERO_PART == (p))
+#else
+#define AERO_IN(p) 1
+#endif
+#if AERO_IN(0)
 #include "k_attn.h"
-#include "k_conv.h"
-#include "k_conv_ring.h"
-#include "k_ftb.h"
-#include "k_enc0.h"
-#include "k_dconv.h"
 #include "k_lstm.h"
 #include "k_norm.h"
 #include "k_gram.h"
-#include "k_stft.h"
 #include "k_optim.h"
-#include "k_bwd.h"
+#endif
+#if AERO_IN(1)
+#include "k_stft.h"
 #include "k_train.h"
+#endif
+#if AERO_IN(2)
+#include "k_conv.h"
+#endif
+#if AERO_IN(6)
+#include "k_conv_ring.h"
+#endif
+#if AERO_IN(3)
+#include "k_ftb.h"
+#include "k_enc0.h"
+#include "k_dconv.h"
+#endif
+#if AERO_IN(4)
+#include "k_bwd.h"
 #include "k_disc.h"
+#endif
 
 #include <stdio.h>
 #include <string.h>
@@ -25,7 +47,18 @@
 #include <cxxabi.h>
 #endif
 
+// the last error text of the calling thread: one buffer for the whole library (defined in part 0)
+#ifdef AERO_PART
+extern thread_local char g_err[512];
+#if AERO_IN(0)
+thread_local char g_err[512] = "";
+#ifndef AERO_EMU
+thread_local const void* aero_last_kernel_ptr_ = nullptr;
+#endif
+#endif
+#else
 static thread_local char g_err[512] = "";
+#endif
 
 static int aero_fail(int rc, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "unknown error");
@@ -43,6 +76,10 @@ static int aero_finish(int rc, const char* err) {
 }
 
 extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------
+// part 0 -- core: version / errors / kernel names; GroupNorm, Gram statistics, LSTM, LocalState, Adam   (k_norm.h k_gram.h k_lstm.h k_attn.h k_optim.h)
+#if AERO_IN(0)
 
 const char* aero_version(void) {
 #ifdef AERO_EMU
@@ -71,61 +108,6 @@ const char* aero_last_kernel_name(void) {
     }
 #endif
     return name;
-}
-
-int aero_stft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, const float* window,
-                  int32_t n_bins, float* spec, int32_t T, double* stats, int32_t sig_per_item, void* stream) {
-    const char* err = "";
-    int rc = aero_stft_launch(x, nsig, L, Lp, n_fft, hop, window, n_bins, spec, T, stats, sig_per_item,
-                              (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int64_t aero_stft_dft_table_bytes(int32_t n_fft) { return (int64_t)aero_stft_dft_tbytes((int)n_fft); }
-
-int aero_stft_dft_table(const float* window, int32_t n_fft, int32_t win_off, void* table, void* stream) {
-    const char* err = "";
-    int rc = aero_stft_dft_table_launch(window, n_fft, win_off, table, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_stft_dft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, int32_t win_off, const void* table,
-                      float* spec, int32_t T, double* stats, int32_t sig_per_item, void* stream) {
-    const char* err = "";
-    int rc = aero_stft_dft_launch(x, nsig, L, Lp, n_fft, hop, win_off, table, spec, T, stats, sig_per_item, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_spec_normalize(const float* spec, int32_t nitems, int64_t n_per_item, const double* stats, void* xn,
-                        float* mean_std, void* stream) {
-    const char* err = "";
-    int rc = aero_spec_normalize_launch(spec, nitems, n_per_item, stats, xn, mean_std, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_istft_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_t n_fft, int32_t hop, const float* window,
-                   const float* inv_env, float* y, int32_t Lout, void* stream) {
-    const char* err = "";
-    int rc = aero_istft_launch(spec, nsig, F, T, n_fft, hop, window, inv_env, y, Lout, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_conv_fwd(const aero_conv_desc* d, void* stream) {
-    const char* err = "";
-    int rc = aero_conv_launch(d, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_conv_tile_m(int32_t M) { return aero_conv_pick_bm(M, (M + 127) / 128 * 128); }
-
-int aero_conv_ring_bm(int32_t M, int32_t Ktot) { return aero_conv_ring_pick_bm(M, Ktot); }
-
-int aero_conv_kernel_name(const aero_conv_desc* d, char* name, int32_t cap) {
-    if (!name || cap < 96) return aero_fail(AERO_ERR_ARG, "conv_kernel_name: buffer of >= 96 bytes required");
-    const char* err = "";
-    name[0] = 0;
-    int rc = aero_conv_launch(d, nullptr, &err, name);
-    return rc == AERO_OK ? AERO_OK : aero_fail(rc, err);
 }
 
 int aero_norm_stats(const aero_norm_desc* d, void* stream) {
@@ -173,12 +155,6 @@ int aero_localstate_fwd(const aero_attn_desc* d, void* stream) {
     return aero_finish(rc, err);
 }
 
-int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream) {
-    const char* err = "";
-    int rc = aero_freqfc_launch(d, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
 int aero_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int32_t step,
                    float grad_scale, void* stream) {
     const char* err = "";
@@ -194,67 +170,46 @@ int aero_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, 
     return aero_finish(rc, err);
 }
 
-int aero_split_finish(const float* acc, int32_t nsplit, const float* bias, int32_t act, void* dst, int64_t npos, int32_t M, void* stream) {
+#endif  // part 0
+
+// ---------------------------------------------------------------------------------------------------------------
+// part 1 -- STFT / iSTFT front-end and the training-step kernels that share its FFT core   (k_stft.h k_train.h)
+#if AERO_IN(1)
+
+int aero_stft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, const float* window,
+                  int32_t n_bins, float* spec, int32_t T, double* stats, int32_t sig_per_item, void* stream) {
     const char* err = "";
-    int rc = aero_split_finish_launch(acc, nsplit, bias, act, dst, npos, M, (hipStream_t)stream, &err);
+    int rc = aero_stft_launch(x, nsig, L, Lp, n_fft, hop, window, n_bins, spec, T, stats, sig_per_item,
+                              (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 
-int aero_dconv_row_fwd(const aero_dconv_desc* d, void* stream) {
+int64_t aero_stft_dft_table_bytes(int32_t n_fft) { return (int64_t)aero_stft_dft_tbytes((int)n_fft); }
+
+int aero_stft_dft_table(const float* window, int32_t n_fft, int32_t win_off, void* table, void* stream) {
     const char* err = "";
-    int rc = aero_dconv_launch(d, (hipStream_t)stream, &err);
+    int rc = aero_stft_dft_table_launch(window, n_fft, win_off, table, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 
-int aero_dconv_row_fits(int T, int C, int hidden, int max_dilation) { return aero_dconv_row_fits_impl(T, C, hidden, max_dilation); }
-
-int aero_enc0_fwd(const aero_enc0_desc* d, void* stream) {
+int aero_stft_dft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, int32_t win_off, const void* table,
+                      float* spec, int32_t T, double* stats, int32_t sig_per_item, void* stream) {
     const char* err = "";
-    int rc = aero_enc0_launch(d, (hipStream_t)stream, &err);
+    int rc = aero_stft_dft_launch(x, nsig, L, Lp, n_fft, hop, win_off, table, spec, T, stats, sig_per_item, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 
-int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream) {
+int aero_spec_normalize(const float* spec, int32_t nitems, int64_t n_per_item, const double* stats, void* xn,
+                        float* mean_std, void* stream) {
     const char* err = "";
-    int rc = aero_conv_wgrad_launch(d, (hipStream_t)stream, &err);
+    int rc = aero_spec_normalize_launch(spec, nitems, n_per_item, stats, xn, mean_std, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 
-int aero_conv_wgrad_chunks(int32_t M, int32_t C, int32_t ntaps, int32_t nrows, int32_t T) {
-    if (M < 1 || C < 1 || ntaps < 1 || nrows < 1 || T < 1) return 1;
-    bool big;
-    int nchunk, SC;
-    aero_wgrad_plan(M, C, ntaps, nrows, T, &big, &nchunk, &SC);
-    return nchunk;
-}
-
-int aero_norm_bwd_reduce(const aero_norm_bwd_desc* d, void* stream) {
+int aero_istft_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_t n_fft, int32_t hop, const float* window,
+                   const float* inv_env, float* y, int32_t Lout, void* stream) {
     const char* err = "";
-    int rc = aero_norm_bwd_launch(d, 0, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_norm_bwd_apply(const aero_norm_bwd_desc* d, void* stream) {
-    const char* err = "";
-    int rc = aero_norm_bwd_launch(d, 1, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_istft_bwd_prep(const float* dy, const float* inv_env, float* s, int32_t nsig, int32_t L, int32_t Ls, int32_t off, int32_t env_off, void* stream) {
-    const char* err = "";
-    int rc = aero_istft_bwd_prep_launch(dy, inv_env, s, nsig, L, Ls, off, env_off, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_istft_bwd_pack(const float* spec, float* dz, int32_t nsig, int32_t nbins, int32_t Tsrc, int32_t T, int32_t t_off, void* stream) {
-    const char* err = "";
-    int rc = aero_istft_bwd_pack_launch(spec, dz, nsig, nbins, Tsrc, T, t_off, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
-int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream) {
-    const char* err = "";
-    int rc = aero_ftb_first_launch(d, (hipStream_t)stream, &err);
+    int rc = aero_istft_launch(spec, nsig, F, T, n_fft, hop, window, inv_env, y, Lout, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
 
@@ -366,6 +321,123 @@ int aero_scale_f32(float* x, int64_t n, const float* scale, void* stream) {
     return aero_finish(rc, err);
 }
 
+int aero_rescale_f16(const void* a, const float* sa, const void* b, const float* sb, int64_t n, void* amax, float target, void* out,
+                     float* scale_out, void* stream) {
+    const char* err = "";
+    int rc = aero_rescale_f16_launch(a, sa, b, sb, n, (unsigned int*)amax, target, out, scale_out, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+#endif  // part 1
+
+// ---------------------------------------------------------------------------------------------------------------
+// part 2 -- convolution family incl. the software-pipelined ring kernel   (k_conv.h k_conv_ring.h)
+#if AERO_IN(2)
+
+int aero_conv_fwd(const aero_conv_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_conv_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_conv_tile_m(int32_t M) { return aero_conv_pick_bm(M, (M + 127) / 128 * 128); }
+
+int aero_conv_kernel_name(const aero_conv_desc* d, char* name, int32_t cap) {
+    if (!name || cap < 96) return aero_fail(AERO_ERR_ARG, "conv_kernel_name: buffer of >= 96 bytes required");
+    const char* err = "";
+    name[0] = 0;
+    int rc = aero_conv_launch(d, nullptr, &err, name);
+    return rc == AERO_OK ? AERO_OK : aero_fail(rc, err);
+}
+
+int aero_split_finish(const float* acc, int32_t nsplit, const float* bias, int32_t act, void* dst, int64_t npos, int32_t M, void* stream) {
+    const char* err = "";
+    int rc = aero_split_finish_launch(acc, nsplit, bias, act, dst, npos, M, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+#endif  // part 2
+
+// ---------------------------------------------------------------------------------------------------------------
+// part 3 -- FTB, fused encoder 0, row-resident DConv   (k_ftb.h k_enc0.h k_dconv.h)
+#if AERO_IN(3)
+
+int aero_freqfc_fwd(const aero_freqfc_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_freqfc_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_dconv_row_fwd(const aero_dconv_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_dconv_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_dconv_row_fits(int T, int C, int hidden, int max_dilation) { return aero_dconv_row_fits_impl(T, C, hidden, max_dilation); }
+
+int aero_enc0_fwd(const aero_enc0_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_enc0_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_ftb_first_fwd(const aero_ftb_first_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_ftb_first_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+#endif  // part 3
+
+// ---------------------------------------------------------------------------------------------------------------
+// part 4 -- backward of the conv / norm blocks   (k_bwd.h)
+#if AERO_IN(4)
+
+int aero_conv_wgrad(const aero_wgrad_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_conv_wgrad_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_conv_wgrad_chunks(int32_t M, int32_t C, int32_t ntaps, int32_t nrows, int32_t T) {
+    if (M < 1 || C < 1 || ntaps < 1 || nrows < 1 || T < 1) return 1;
+    bool big;
+    int nchunk, SC;
+    aero_wgrad_plan(M, C, ntaps, nrows, T, &big, &nchunk, &SC);
+    return nchunk;
+}
+
+int aero_norm_bwd_reduce(const aero_norm_bwd_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_norm_bwd_launch(d, 0, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_norm_bwd_apply(const aero_norm_bwd_desc* d, void* stream) {
+    const char* err = "";
+    int rc = aero_norm_bwd_launch(d, 1, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_istft_bwd_prep(const float* dy, const float* inv_env, float* s, int32_t nsig, int32_t L, int32_t Ls, int32_t off, int32_t env_off, void* stream) {
+    const char* err = "";
+    int rc = aero_istft_bwd_prep_launch(dy, inv_env, s, nsig, L, Ls, off, env_off, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_istft_bwd_pack(const float* spec, float* dz, int32_t nsig, int32_t nbins, int32_t Tsrc, int32_t T, int32_t t_off, void* stream) {
+    const char* err = "";
+    int rc = aero_istft_bwd_pack_launch(spec, dz, nsig, nbins, Tsrc, T, t_off, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+#endif  // part 4
+
+// ---------------------------------------------------------------------------------------------------------------
+// part 5 -- MelGAN critic   (k_disc.h k_gconv_mfma.h k_gconv_edge.h)
+#if AERO_IN(4)
+
 int aero_gconv1d_mfma_ok(int32_t Cin, int32_t Cout, int32_t groups, int32_t K, int32_t stride, int32_t pad, int32_t reflect) {
     return aero_gconv4_ok(Cin, Cout, groups, K, stride, pad, reflect);
 }
@@ -425,13 +497,6 @@ int aero_loss_sum(const void* a, const void* b, int64_t n, float sign, int32_t m
     return aero_finish(rc, err);
 }
 
-int aero_rescale_f16(const void* a, const float* sa, const void* b, const float* sb, int64_t n, void* amax, float target, void* out,
-                     float* scale_out, void* stream) {
-    const char* err = "";
-    int rc = aero_rescale_f16_launch(a, sa, b, sb, n, (unsigned int*)amax, target, out, scale_out, (hipStream_t)stream, &err);
-    return aero_finish(rc, err);
-}
-
 int aero_gconv1d_bwd(const aero_gconv_bwd_desc* d, void* stream) {
     const char* err = "";
     int rc = aero_gconv1d_bwd_launch(d, (hipStream_t)stream, &err);
@@ -449,5 +514,15 @@ int aero_avgpool1d_bwd(const void* dy, void* dx, int32_t B, int32_t T, void* str
     int rc = aero_avgpool1d_bwd_launch(dy, dx, B, T, (hipStream_t)stream, &err);
     return aero_finish(rc, err);
 }
+
+#endif  // part 5 (compiled with part 4: the critic's weight gradients end in k_bwd.h's slab-finish kernel)
+
+// ---------------------------------------------------------------------------------------------------------------
+// part 6 -- the software-pipelined ring kernel (k_conv_ring.h), entered from part 2's aero_conv_launch through aero_conv_ring_try
+#if AERO_IN(6)
+
+int aero_conv_ring_bm(int32_t M, int32_t Ktot) { return aero_conv_ring_pick_bm(M, Ktot); }
+
+#endif  // part 6
 
 }  // extern "C"

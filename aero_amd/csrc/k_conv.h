@@ -1538,7 +1538,7 @@ static int aero_split_finish_launch(const float* acc, int nsplit, const float* b
 }
 
 // k_conv_ring.h: the software-pipelined 8-wave kernel for the wide contractions; returns true if it took the launch
-static bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStream_t stream, char* name);
+AERO_XPART bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStream_t stream, char* name);
 
 static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const char** err, char* name = nullptr) {
     if (!d || !d->weight || (!d->dst && d->stat_mode != 2 && d->tap_split <= 1)) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }

@@ -59,37 +59,6 @@ struct AeroRingGeom {
     }
 };
 
-static __device__ __forceinline__ void aero_sched_fence() {
-#ifndef AERO_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-template <int N>
-static __device__ __forceinline__ void aero_wait_vm() {
-#ifndef AERO_EMU
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
-}
-// end of a phase: this wave's LDS reads have returned (their slot may be refilled) and every wave's landed copies are
-// visible to the others.  Not __syncthreads(): that would also drain the copies still in flight (vmcnt).
-static __device__ __forceinline__ void aero_phase_barrier() {
-#ifdef AERO_EMU
-    __syncthreads();
-#else
-    // the BUILTIN wait (not inline asm) so that hipcc's own scoreboard knows the operand registers fetched during this
-    // phase are ready: with an asm wait it re-waits `lgkmcnt(0)` in front of the next phase's first MFMA, i.e. also for
-    // the fragment reads just issued for the phase after -- the prefetch would never overlap the MFMAs.
-    // sched_barrier(0): nothing moves across -- hipcc otherwise hoists register-only MFMAs of the next phase over the
-    // s_barrier (legal, but it then waits for this phase's prefetch reads in front of them)
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0); vmcnt / expcnt fields at their maxima
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
 // SM = 1: GroupNorm statistics (sum, sum of squares of conv + bias, per (item, group)) ride along in fp32 per lane, are
 // folded over the wave's row blocks of one group, reduced over the wave in fp64 and added with one fp64 atomic pair per
 // (wave, group): the separate read-only statistics pass over the stored tensor (80 us for the first decoder's 394 MB)
@@ -565,7 +534,7 @@ static void aero_conv_ring_go(AeroConvK& p, hipStream_t stream, char* name) {
 }
 
 #ifndef AERO_RING_ONLY
-static bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStream_t stream, char* name) {
+AERO_XPART bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStream_t stream, char* name) {
     const int mode = aero_conv_ring_mode();
     if (!mode) return false;
     // what the lean epilogue of this kernel covers: bias, activation, fp16 channels-last rows, no trim / residual /
