@@ -206,6 +206,15 @@ int aero_spec_normalize(const float* spec, int32_t nitems, int64_t n_per_item, c
     return aero_finish(rc, err);
 }
 
+#ifdef AERO_ISTFT_DEBUG
+// tools/dbg builds only: counters (6 x u64 on the device, zeroed by the caller) and mode bits of the iSTFT's load checks (k_stft.h)
+int aero_istft_debug_set(void* counters, int32_t mode) {
+    aero_istft_dbg_ptr = (unsigned long long*)counters;
+    aero_istft_dbg_mode = mode;
+    return AERO_OK;
+}
+#endif
+
 int aero_istft_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_t n_fft, int32_t hop, const float* window,
                    const float* inv_env, float* y, int32_t Lout, void* stream) {
     const char* err = "";

@@ -270,8 +270,23 @@ __global__ __launch_bounds__(256) void aero_spec_normalize_kernel(const float* s
 struct AeroIstftK {
     const float* spec; const float* window; const float* inv_env; float* y;
     int nsig, F, T, n_fft, hop, hsh, Lout, FPB, SEG;         // hsh = log2(hop) if hop is a power of two, else -1
-    int abl;                                                 // timing ablations (AERO_ISTFT_ABL): 1 no spectrum loads, 2 no FFT, 4 no overlap-add, 8 empty kernel
+#ifdef AERO_ISTFT_DEBUG
+    // tools/dbg builds only (never the product library): bit 0 = re-read every spectrum value past the caches (sc0 sc1) and count the
+    // values that differ from the ordinary load in dbg[0] (first mismatch: dbg[1..5]); bit 1 = take the cache-bypassing loads as THE loads
+    unsigned long long* dbg; int dbg_mode;
+#endif
 };
+
+#ifdef AERO_ISTFT_DEBUG
+static unsigned long long* aero_istft_dbg_ptr = nullptr;
+static int aero_istft_dbg_mode = 0;
+// 8-byte load with system scope: misses in the vector L1 and in this XCD's L2 (the data comes from the memory side)
+static __device__ __forceinline__ f32x2 aero_load_bypass(const f32x2* ptr) {
+    f32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+#endif
 
 static inline int aero_istft_fpb(int n) { int f = 4096 / n; return f > 32 ? 32 : f; }   // frame ring (power of two)
 
@@ -304,7 +319,6 @@ __global__ __launch_bounds__(NW * 64) void aero_istft_kernel(AeroIstftK p) {
     int t_hi = div_hop(i0 + p.SEG - 1);
     if (t_hi > p.T - 1) t_hi = p.T - 1;
     const int nfr = t_hi - t_lo + 1;                        // <= FPB by construction of SEG
-    if (p.abl & 8) return;
     aero_fft_init_twiddles(tw, n_fft);
     for (int i = threadIdx.x; i < n_fft; i += NT) wl[i] = p.window[i];
     __syncthreads();
@@ -324,13 +338,45 @@ __global__ __launch_bounds__(NW * 64) void aero_istft_kernel(AeroIstftK p) {
         const int fr = idx & (FPB - 1), k = idx >> lf;
         const bool livef = fr < nfr;
         const int t = livef ? fr : 0;
-        f32x2 xa = (p.abl & 1) ? (f32x2){1.f, 0.f} : X[k * p.T + t];
+#ifdef AERO_ISTFT_DEBUG
+        f32x2 xa = (p.dbg_mode & 2) ? aero_load_bypass(X + k * p.T + t) : X[k * p.T + t];
+        if (p.dbg_mode & 1) {
+            const f32x2 chk = aero_load_bypass(X + k * p.T + t);
+            if (__float_as_uint(chk[0]) != __float_as_uint(xa[0]) || __float_as_uint(chk[1]) != __float_as_uint(xa[1])) {
+                if (atomicAdd(p.dbg, 1ull) == 0) {
+                    p.dbg[1] = (unsigned long long)(uintptr_t)(X + k * p.T + t);
+                    p.dbg[2] = ((unsigned long long)__float_as_uint(xa[0]) << 32) | __float_as_uint(xa[1]);
+                    p.dbg[3] = ((unsigned long long)__float_as_uint(chk[0]) << 32) | __float_as_uint(chk[1]);
+                    p.dbg[4] = ((unsigned long long)blockIdx.x << 32) | ((unsigned long long)blockIdx.y << 16) | threadIdx.x;
+                    p.dbg[5] = ((unsigned long long)k << 32) | (unsigned)fr;
+                }
+            }
+        }
+#else
+        f32x2 xa = X[k * p.T + t];
+#endif
         if (k == 0) {                                       // pairs with the implicit zero Nyquist bin X[n]
             xa[1] = 0.f;                                    // irfft ignores the imaginary part of DC
             const f32x2 z = unpack(xa, (f32x2){0.f, 0.f}, 0);
             fbuf[fr * fs] = livef ? z : (f32x2){0.f, 0.f};
         } else {
-            const f32x2 xq = (p.abl & 1) ? (f32x2){0.5f, 0.f} : X[(n - k) * p.T + t];
+#ifdef AERO_ISTFT_DEBUG
+            const f32x2 xq = (p.dbg_mode & 2) ? aero_load_bypass(X + (n - k) * p.T + t) : X[(n - k) * p.T + t];
+            if (p.dbg_mode & 1) {
+                const f32x2 chk = aero_load_bypass(X + (n - k) * p.T + t);
+                if (__float_as_uint(chk[0]) != __float_as_uint(xq[0]) || __float_as_uint(chk[1]) != __float_as_uint(xq[1])) {
+                    if (atomicAdd(p.dbg, 1ull) == 0) {
+                        p.dbg[1] = (unsigned long long)(uintptr_t)(X + (n - k) * p.T + t);
+                        p.dbg[2] = ((unsigned long long)__float_as_uint(xq[0]) << 32) | __float_as_uint(xq[1]);
+                        p.dbg[3] = ((unsigned long long)__float_as_uint(chk[0]) << 32) | __float_as_uint(chk[1]);
+                        p.dbg[4] = ((unsigned long long)blockIdx.x << 32) | ((unsigned long long)blockIdx.y << 16) | threadIdx.x;
+                        p.dbg[5] = ((unsigned long long)(n - k) << 32) | (unsigned)fr;
+                    }
+                }
+            }
+#else
+            const f32x2 xq = X[(n - k) * p.T + t];
+#endif
             const f32x2 z0 = unpack(xa, (f32x2){xq[0], -xq[1]}, k);
             const f32x2 z1 = unpack(xq, (f32x2){xa[0], -xa[1]}, n - k);
             fbuf[fr * fs + k] = livef ? z0 : (f32x2){0.f, 0.f};
@@ -342,7 +388,7 @@ __global__ __launch_bounds__(NW * 64) void aero_istft_kernel(AeroIstftK p) {
     const int rounds = (FPB + NW - 1) / NW;
     f32x2* sb = sbuf0 + wave * n;
 #pragma unroll(LOGN ? 2 : 1)
-    for (int r = 0; r < ((p.abl & 2) ? 0 : rounds); ++r) {
+    for (int r = 0; r < rounds; ++r) {
         const int fr = r * NW + wave;
         f32x2* a = fr < FPB ? fbuf + fr * fs : sb;          // (FPB is a multiple of 4 in practice)
         f32x2* R = aero_fft_wave<LOGN>(a, sb, n, tw);
@@ -365,7 +411,6 @@ __global__ __launch_bounds__(NW * 64) void aero_istft_kernel(AeroIstftK p) {
         int tb = div_hop(i);
         if (tb > t_hi) tb = t_hi;
         float acc = 0.f;
-        if (p.abl & 4) tb = ta - 1;
         for (int t = ta; t <= tb; ++t) {
             const int ni = i - t * p.hop;
             const f32x2 R = fbuf[(t - t_lo) * fs + (ni >> 1)];
@@ -626,13 +671,15 @@ static int aero_istft_launch(const float* spec, int nsig, int F, int T, int n_ff
     p.FPB = fpb;
     p.SEG = (fpb - need) * hop;
     p.hsh = (hop & (hop - 1)) == 0 ? aero_ilog2(hop) : -1;
-    static const int abl = [] { const char* e = getenv("AERO_ISTFT_ABL"); return e ? atoi(e) : 0; }();
-    p.abl = abl;
+#ifdef AERO_ISTFT_DEBUG
+    p.dbg = aero_istft_dbg_ptr;
+    p.dbg_mode = aero_istft_dbg_ptr ? aero_istft_dbg_mode : (aero_istft_dbg_mode & 2);
+#endif
     dim3 grid((unsigned)((Lout + p.SEG - 1) / p.SEG), (unsigned)nsig), block(256);
     // eight waves per block for the two common sizes: two frames per wave instead of four, twice the lanes in the unpack and overlap-add
-    // phases (78.9 -> 61.5 us at B = 64 with the XCD-aware block order; sixteen waves: 70 us).  Ablations (AERO_ISTFT_ABL) at eight
+    // phases (78.9 -> 61.5 us at B = 64 with the XCD-aware block order; sixteen waves: 70 us).  Ablation builds of round 3 at eight
     // waves: empty kernel 7 us, no loads / FFT / overlap-add 24 us, no FFT 41 us, no loads 58 us, all 64 us -- the frame FFTs (23 us) and
-    // the per-block skeleton (window, unpack, barriers: 17 us) are what is left, not the 259 MB it fetches.
+    // the per-block skeleton (window, unpack, barriers: 17 us) are what is left, not the bytes it fetches.
     static const int waves = [] { const char* e = getenv("AERO_ISTFT_WAVES"); return e ? atoi(e) : 8; }();
     if (waves == 8 && (n == 256 || n == 512)) {
         const size_t lds8 = aero_istft_lds_bytes(n_fft, fpb, 8);
