@@ -48,7 +48,8 @@ def overlapped(victim, disturber, iters, n_disturb=24, compare=None):
     """victim() -> tensor or tuple of tensors.  Reference = victim() alone; then `iters` rounds of {disturber on stream A, victim on
     stream B}.  Returns (number of rounds whose result differs in any bit, description of the first difference)."""
     def as_tuple(r):
-        return tuple(t for t in (r if isinstance(r, (tuple, list)) else (r,)) if t is not None)
+        r = tuple(t for t in (r if isinstance(r, (tuple, list)) else (r,)) if t is not None)
+        return tuple(torch.view_as_real(t) if t.is_complex() else t for t in r)
     with torch.no_grad():
         ref = tuple(t.clone() for t in as_tuple(victim()))
         torch.cuda.synchronize()

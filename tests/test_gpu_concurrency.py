@@ -69,16 +69,19 @@ def test_two_stream_forward_equals_one_stream_100_times(rig):
 
 def test_training_step_gradients_do_not_depend_on_the_second_stream(meta):
     """the training backward issues its weight-gradient GEMMs on a second stream beside the main stream's ring / norm / recurrent
-    kernels (train.py: on_param_stream).  Every parameter whose gradient is bit-reproducible from run to run in the single-stream order
-    (AERO_TRAIN_STREAMS=1) -- all convolution / linear / LSTM weights: `aero_conv_wgrad` adds its slabs in a fixed order; the few
-    norm-parameter sums that go through float atomics are not -- must come out bit-identical with the second stream on, 20 times"""
+    kernels (train.py: on_param_stream).  The backward is not bit-reproducible from run to run even on ONE stream (its loss-scale
+    maxima and a few parameter sums go through atomics, and every later stage inherits the last bit), so the fence is statistical:
+    per parameter, the distance of a two-stream gradient from a single-stream one (AERO_TRAIN_STREAMS=1) must stay within the
+    run-to-run distance of single-stream gradients among themselves (x 4, floor 2e-6) -- a damaged 128-byte line in a weight
+    gradient is 1e-3 .. 1e-1 of it, three orders above that floor"""
     import os
     from aero_amd import Aero, losses
     from aero_amd.optim import FlatAdam
+    from conftest import rel_l2
     cfg = dict(meta['small_cfg'])
     x, hr = seeded((2, 1, 2003), 1).cuda(), (0.1 * seeded((2, 1, 8012), 2)).cuda()
     grads, names = {}, None
-    for mode, reps in (('1', 3), ('2', 20)):
+    for mode, reps in (('1', 6), ('2', 20)):
         os.environ['AERO_TRAIN_STREAMS'] = mode
         try:
             torch.manual_seed(3)
@@ -93,13 +96,19 @@ def test_training_step_gradients_do_not_depend_on_the_second_stream(meta):
                 opt.zero_grad()
                 (sc + mg).backward()
                 torch.cuda.synchronize()
-                runs.append([p.grad.clone() for p in m.parameters()])
+                runs.append([p.grad.double().clone() for p in m.parameters()])
             grads[mode] = runs
         finally:
             os.environ.pop('AERO_TRAIN_STREAMS', None)
-    solo = grads['1']
-    stable = [i for i in range(len(names)) if all(torch.equal(r[i], solo[0][i]) for r in solo[1:])]
-    heavy = [i for i, n in enumerate(names) if solo[0][i].dim() >= 2 and solo[0][i].numel() >= 256]
-    assert len(stable) >= 0.8 * len(names) and set(heavy) <= set(stable), (len(stable), len(names), [names[i] for i in heavy if i not in stable][:6])
-    bad = sorted({names[i] for r in grads['2'] for i in stable if not torch.equal(r[i], solo[0][i])})
+    solo, two = grads['1'], grads['2']
+    gmax = max(float(g.norm()) for g in solo[0])
+    bad = []
+    for i, n in enumerate(names):
+        ref = solo[0][i]
+        if float(ref.norm()) < 1e-9 * gmax:
+            continue                                             # (mathematically zero gradients: rounding noise only)
+        floor = max(rel_l2(r[i], ref) for r in solo[1:])
+        worst = max(rel_l2(r[i], ref) for r in two)
+        if not worst <= max(4.0 * floor, 2e-6):
+            bad.append((n, f'{worst:.2e}', f'solo floor {floor:.2e}'))
     assert not bad, (len(bad), bad[:8])
