@@ -62,6 +62,16 @@ class NormBwdDesc(C.Structure):
                 ('sums', dp), ('dgamma', fp), ('dbeta', fp), ('dlayer_scale', fp), ('snake_a', fp), ('dsnake_a', fp)]
 
 
+class PwDesc(C.Structure):
+    _fields_ = [('x', vp), ('x_b', i64), ('x_f', i64), ('x_t', i64), ('C', i32),
+                ('wimg', vp), ('bias', fp),
+                ('stats', dp), ('stat_count', C.c_double), ('stat_eps', C.c_float),
+                ('gamma', fp), ('beta', fp), ('layer_scale', fp), ('post_add', fp),
+                ('res', vp), ('r_b', i64), ('r_f', i64), ('r_t', i64),
+                ('dst', vp), ('d_b', i64), ('d_f', i64), ('d_t', i64),
+                ('B', i32), ('F', i32), ('T', i32), ('M', i32), ('act', i32)]
+
+
 class GramDesc(C.Structure):
     _fields_ = [('x', vp), ('s_b', i64), ('s_f', i64), ('s_t', i64),
                 ('B', i32), ('F', i32), ('T', i32), ('C', i32),
@@ -192,6 +202,8 @@ _PROTOS = {
     'aero_gconv1d_wgrad_slabs': (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32]),
     'aero_rescale_f16': (i32, [vp, fp, vp, fp, i64, vp, C.c_float, vp, fp, vp]),
     'aero_gconv1d_fwd': (i32, [C.POINTER(GconvDesc), vp]),
+    'aero_pw_fwd': (i32, [C.POINTER(PwDesc), vp]),
+    'aero_pw_rows': (i32, [i32, i32]),
     'aero_leaky_relu': (i32, [vp, i64, C.c_float, vp]),
     'aero_avgpool1d': (i32, [vp, vp, i32, i32, vp]),
     'aero_loss_sum': (i32, [vp, vp, i64, C.c_float, i32, dp, i32, dp, C.c_double, vp]),

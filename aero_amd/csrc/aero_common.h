@@ -113,6 +113,9 @@ static __device__ __forceinline__ int aero_uniform(int x) {
 static __device__ __forceinline__ void aero_wave_sync() {
 #ifdef AERO_EMU
     emu::wave_barrier();
+#elif defined(AERO_DBG_WAVE_SYNC_WAIT)                          /* tools/dbg experiment builds only */
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
 #else
     __builtin_amdgcn_wave_barrier();
 #endif

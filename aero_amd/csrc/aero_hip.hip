@@ -3,7 +3,7 @@
 // translation unit against a CPU emulation of the HIP subset, as a test double -- never loaded by
 // the product.)
 //
-// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DAERO_PART=k  for k = 0..6 (no 5), IN PARALLEL,
+// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DAERO_PART=k  for k = 0..7 (no 5), IN PARALLEL,
 // then one link into aero_amd/libaero_hip.so.  The library is ONE source file cut into six independently compiled parts (each
 // kernel header belongs to exactly one part; a part holds the entry points over its kernels): as a single translation unit it took
 // four minutes to compile; now a change to one header rebuilds one part.  Without -DAERO_PART (the emulator's build, or a plain
@@ -30,6 +30,9 @@
 #endif
 #if AERO_IN(6)
 #include "k_conv_ring.h"
+#endif
+#if AERO_IN(7)
+#include "k_pw.h"
 #endif
 #if AERO_IN(3)
 #include "k_ftb.h"
@@ -533,5 +536,23 @@ int aero_avgpool1d_bwd(const void* dy, void* dx, int32_t B, int32_t T, void* str
 int aero_conv_ring_bm(int32_t M, int32_t Ktot) { return aero_conv_ring_pick_bm(M, Ktot); }
 
 #endif  // part 6
+
+// ---------------------------------------------------------------------------------------------------------------
+// part 7 -- streaming pointwise conv for short contractions (k_pw.h)
+#if AERO_IN(7)
+
+int aero_pw_fwd(const aero_pw_desc* d, void* stream) {
+    const char* err = "";
+    if (!d) return aero_fail(AERO_ERR_ARG, "pw: null descriptor");
+    int rc = aero_pw_launch(d, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_pw_rows(int32_t C, int32_t M) {
+    if (C < 8 || C % 8 || C > 96 || M < 16 || M % 16) return 0;
+    return 128 * aero_pw_gw(C, M);
+}
+
+#endif  // part 7
 
 }  // extern "C"

@@ -1,0 +1,276 @@
+// k_pw.h -- pointwise (1x1) convolution with a SHORT contraction (C <= 96 input channels) and a wide output, HBM-bound:
+//   * the tail of a DConv layer that has a BLSTM / LocalState in it (modules.py:240-247 via aero.py:121-131): conv2 (hidden -> 2C)
+//     -> GroupNorm(1 group, statistics already known from the Gram matrix of the input, k_gram.h) -> GLU -> LayerScale -> + x;
+//   * the encoder's `rewrite` conv + GLU (+ frequency embedding at encoder 0) where no GroupNorm sits between them (aero.py:133).
+// On the tiled conv kernels (k_conv.h) these launches ran at 0.9-2 TB/s: a 128-row x 128-step block does ONE K-chunk of MFMAs and then
+// an epilogue of coefficient loads, two LDS transposes with four barriers and the residual fetch -- all exposed latency, three M-tiles
+// re-reading the input.  Here there is no LDS staging of operands and no barrier in the loop at all:
+//   * the weights are MFMA A-fragments RESIDENT IN REGISTERS (a wave owns GW groups of 64 rows: GW*4 tiles x KS k-steps, 16 bytes each);
+//   * the B fragment of v_mfma_f32_16x16x32_f16 "lane = (time step n, k-octet q)" is one 16-byte load of x[t0 + n][32 ks + 8 q ..] straight
+//     from global memory -- channels-last rows ARE the fragment layout;
+//   * rows are PERMUTED when the weight image is packed (host, once per parameter version): tile j, row 4 q + i of a 64-row group holds
+//     logical row 16 q + 4 j + i, so the 16 accumulator values of lane (n, q) over the group's four tiles are 16 CONSECUTIVE conv rows of
+//     time step n -- after GLU 8 consecutive output channels = ONE 16-byte store (and one 16-byte residual load), no transpose;
+//   * per-row coefficients (norm scale / shift, LayerScale, frequency embedding) are computed once per block into LDS (a block works
+//     inside one (b, f) row, so GroupNorm's per-row statistics are block constants);
+//   * the next unit's loads (input fragments, residual) are issued before the current unit's MFMAs.
+// Block = 4 waves = 2 (row halves of the chunk) x 2 (alternate 16-step units); grid = (row, time split) x row chunks of 128*GW rows.
+// Roofline: HBM.  Algorithmic bytes per output position: 2 C + 2 Mout (+ 2 Mout residual).
+#pragma once
+#include "aero_common.h"
+
+struct AeroPwK {
+    aero_pw_desc d;
+    int nsplit, upb;                 // time splits per row, 16-step units per split
+    int Mout;                        // stored channels: M / 2 with GLU
+};
+
+template <int KS, int GW, int ACT, bool NORM>
+__global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
+    constexpr bool GLU = ACT == AERO_ACT_GLU;
+    constexpr int MC = 128 * GW;                                  // conv rows per chunk (block)
+    constexpr int OC = GLU ? MC / 2 : MC;                         // stored channels per chunk
+    constexpr int NV = GLU ? 1 : 2;                               // 16-byte vectors a lane stores per group
+    __shared__ AERO_LDS_ALIGN float ca[MC], cb[MC], cs[OC], cp[OC];
+    const aero_pw_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int wm = wave & 1, wt = wave >> 1;
+    const int n = lane & 15, q = lane >> 4;
+    const int chunk = blockIdx.y;
+    const int row = (int)blockIdx.x / p.nsplit, split = (int)blockIdx.x - row * p.nsplit;
+    const int b = row / d.F, f = row - b * d.F;
+    const int M = d.M, Mout = p.Mout, T = d.T;
+    const int mbase = chunk * MC, obase = chunk * OC;
+
+    // ---- block constants: v = acc * a[r] + b[r]  (bias, GroupNorm from the row's sums), LayerScale, frequency embedding row
+    {
+        float mean = 0.f, rstd = 1.f;
+        if constexpr (NORM) {
+            const double* sp = d.stats + (int64_t)row * 2;
+            const double inv = 1.0 / d.stat_count;
+            const double mu = sp[0] * inv;
+            double var = sp[1] * inv - mu * mu;
+            if (var < 0) var = 0;
+            const float vf = (float)var + d.stat_eps;
+            float rs = aero_rsqrt(vf);
+            rs = rs * (1.5f - 0.5f * vf * rs * rs);
+            mean = (float)mu;
+            rstd = rs;
+        }
+        for (int i = tid; i < MC; i += 256) {
+            const int r = mbase + i < M ? mbase + i : M - 1;
+            const float bias = d.bias ? d.bias[r] : 0.f;
+            if constexpr (NORM) {
+                const float gm = d.gamma ? d.gamma[r] * rstd : rstd;
+                ca[i] = gm;
+                cb[i] = (bias - mean) * gm + (d.gamma ? d.beta[r] : 0.f);
+            } else {
+                ca[i] = 1.f;
+                cb[i] = bias;
+            }
+        }
+        for (int i = tid; i < OC; i += 256) {
+            const int o = obase + i < Mout ? obase + i : Mout - 1;
+            cs[i] = d.layer_scale ? d.layer_scale[o] : 1.f;
+            cp[i] = d.post_add ? d.post_add[(int64_t)f * Mout + o] : 0.f;
+        }
+    }
+    // ---- the wave's weight fragments: image [chunk][wm][g][j][ks][lane][8]
+    h16x8 A[GW][4][KS];
+    {
+        const h16* w = (const h16*)d.wimg + ((int64_t)(chunk * 2 + wm) * GW * 4 * KS) * 512 + lane * 8;
+#pragma unroll
+        for (int g = 0; g < GW; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) A[g][j][ks] = *(const h16x8*)(w + ((g * 4 + j) * KS + ks) * 512);
+    }
+    __syncthreads();
+
+    const h16* xr = (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)f * d.x_f;
+    const h16* rr = d.res ? (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)f * d.r_f : nullptr;
+    h16* dr = (h16*)d.dst + (int64_t)b * d.d_b + (int64_t)f * d.d_f;
+    const int xt = (int)d.x_t, rt = (int)d.r_t, dt = (int)d.d_t;
+    const int u_lo = split * p.upb;
+    int u_hi = u_lo + p.upb;
+    const int nunit = (T + 15) >> 4;
+    if (u_hi > nunit) u_hi = nunit;
+    const h16x8 zero8 = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    // first stored channel of this lane in group g (a lane's 8 (GLU) or 16 consecutive channels)
+    const int lane_o = GLU ? 8 * q : 16 * q;
+    const int grp_o = wm * GW * (GLU ? 32 : 64);
+
+    auto load_b = [&](h16x8 (&Bf)[KS], int u) {
+        int t = u * 16 + n;
+        t = t < T ? t : T - 1;                                    // (masked at the store: the load stays in range)
+        const h16* px = xr + t * xt + 8 * q;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) Bf[ks] = (32 * ks + 8 * q < d.C) ? *(const h16x8*)(px + 32 * ks) : zero8;
+    };
+    auto load_r = [&](h16x8 (&R)[GW][NV], int u) {
+        if (!rr) return;
+        int t = u * 16 + n;
+        t = t < T ? t : T - 1;
+        const h16* pr = rr + t * rt + obase + grp_o + lane_o;
+#pragma unroll
+        for (int g = 0; g < GW; ++g)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int o = obase + grp_o + g * (GLU ? 32 : 64) + lane_o + 8 * v;
+                R[g][v] = o < Mout ? *(const h16x8*)(pr + g * (GLU ? 32 : 64) + 8 * v) : zero8;
+            }
+    };
+
+    h16x8 Bc[KS], Bn[KS], Rc[GW][NV], Rn[GW][NV];
+#pragma unroll
+    for (int g = 0; g < GW; ++g)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) Rc[g][v] = Rn[g][v] = zero8;
+    int u = u_lo + wt;
+    if (u < u_hi) {
+        load_b(Bc, u);
+        load_r(Rc, u);
+    }
+#pragma unroll 1
+    for (; u < u_hi; u += 2) {
+        if (u + 2 < u_hi) {
+            load_b(Bn, u + 2);
+            load_r(Rn, u + 2);
+        }
+        const int t = u * 16 + n;
+        const bool tin = t < T;
+#pragma unroll
+        for (int g = 0; g < GW; ++g) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[g][j][ks], Bc[ks], acc[j], 0, 0, 0);
+            // rows 16 q + 4 j + i of the group: coefficients are 4 + 4 consecutive float4 of the block's tables
+            const int ci = (wm * GW + g) * 64 + 16 * q;
+            float v[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a4 = *(const f32x4*)&ca[ci + 4 * j];
+                const f32x4 b4 = *(const f32x4*)&cb[ci + 4 * j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[j][i] = acc[j][i] * a4[i] + b4[i];
+            }
+            const int o0 = obase + grp_o + g * (GLU ? 32 : 64) + lane_o;          // first stored channel of this lane
+            const int oi = grp_o + g * (GLU ? 32 : 64) + lane_o;                  // ... inside the chunk (LDS tables)
+            if constexpr (GLU) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) o[2 * j + h] = v[j][2 * h] * aero_sigmoid(v[j][2 * h + 1]);
+                const f32x4 s0 = *(const f32x4*)&cs[oi], s1 = *(const f32x4*)&cs[oi + 4];
+                const f32x4 p0 = *(const f32x4*)&cp[oi], p1 = *(const f32x4*)&cp[oi + 4];
+                h16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sc = e < 4 ? s0[e] : s1[e - 4];
+                    const float pa = e < 4 ? p0[e] : p1[e - 4];
+                    y[e] = (h16)(o[e] * sc + (float)Rc[g][0][e] + pa);
+                }
+                if (tin && o0 < Mout) *(h16x8*)(dr + t * dt + o0) = y;
+            } else {
+#pragma unroll
+                for (int vv = 0; vv < 2; ++vv) {
+                    const f32x4 s0 = *(const f32x4*)&cs[oi + 8 * vv], s1 = *(const f32x4*)&cs[oi + 8 * vv + 4];
+                    const f32x4 p0 = *(const f32x4*)&cp[oi + 8 * vv], p1 = *(const f32x4*)&cp[oi + 8 * vv + 4];
+                    h16x8 y;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float val = v[2 * vv + (e >> 2)][e & 3];
+                        if constexpr (ACT == AERO_ACT_RELU) val = fmaxf(val, 0.f);
+                        else if constexpr (ACT == AERO_ACT_GELU) val = aero_gelu(val);
+                        const float sc = e < 4 ? s0[e] : s1[e - 4];
+                        const float pa = e < 4 ? p0[e] : p1[e - 4];
+                        y[e] = (h16)(val * sc + (float)Rc[g][NV - 1 < vv ? 0 : vv][e] + pa);
+                    }
+                    if (tin && o0 + 8 * vv < Mout) *(h16x8*)(dr + t * dt + o0 + 8 * vv) = y;
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) Bc[ks] = Bn[ks];
+#pragma unroll
+        for (int g = 0; g < GW; ++g)
+#pragma unroll
+            for (int vv = 0; vv < NV; ++vv) Rc[g][vv] = Rn[g][vv];
+    }
+}
+
+// rows per chunk (= per block) for a contraction of C channels: the register budget of the resident weight fragments
+static int aero_pw_gw(int C, int M) {
+    const int ks = (C + 31) / 32;
+    const int groups = (M + 63) / 64;
+    if (ks > 3 || ks < 1) return 0;
+    int gw = ks == 3 ? 2 : 3;                                     // 96 fragment registers per wave
+    while (gw > 1 && 2 * (gw - 1) >= groups) --gw;                // no larger than the layer needs
+    return gw;
+}
+
+static int aero_pw_ok(const aero_pw_desc* d) {
+    if (!d || !d->x || !d->wimg || !d->dst) return 0;
+    if (d->C < 8 || d->C % 8 || d->C > 96 || d->M < 16 || d->M % 16) return 0;
+    if (d->act != AERO_ACT_NONE && d->act != AERO_ACT_RELU && d->act != AERO_ACT_GELU && d->act != AERO_ACT_GLU) return 0;
+    const int Mout = d->act == AERO_ACT_GLU ? d->M / 2 : d->M;
+    if (Mout % 8) return 0;
+    auto al = [](int64_t s) { return s % 8 == 0; };
+    if (!al(d->x_b) || !al(d->x_f) || !al(d->x_t) || !al(d->d_b) || !al(d->d_f) || !al(d->d_t)) return 0;
+    if (((uintptr_t)d->x & 15) || ((uintptr_t)d->dst & 15) || ((uintptr_t)d->wimg & 15)) return 0;
+    if (d->res && (!al(d->r_b) || !al(d->r_f) || !al(d->r_t) || ((uintptr_t)d->res & 15))) return 0;
+    if ((int64_t)d->T * d->x_t >= (1ll << 31) || (int64_t)d->T * d->d_t >= (1ll << 31) || (d->res && (int64_t)d->T * d->r_t >= (1ll << 31))) return 0;
+    if (d->stats && !(d->stat_count > 0)) return 0;
+    return aero_pw_gw(d->C, d->M) > 0;
+}
+
+template <int KS, int GW>
+static void aero_pw_go(const AeroPwK& p, dim3 grid, hipStream_t stream) {
+    const bool norm = p.d.stats != nullptr;
+    const dim3 block(256);
+#define AERO_PW_CASE(ACT_)                                                                              \
+    do {                                                                                                \
+        if (norm) AERO_LAUNCH((aero_pw_kernel<KS, GW, ACT_, true>), grid, block, stream, p);            \
+        else AERO_LAUNCH((aero_pw_kernel<KS, GW, ACT_, false>), grid, block, stream, p);                \
+    } while (0)
+    switch (p.d.act) {
+        case AERO_ACT_GLU: AERO_PW_CASE(AERO_ACT_GLU); break;
+        case AERO_ACT_GELU: AERO_PW_CASE(AERO_ACT_GELU); break;
+        case AERO_ACT_RELU: AERO_PW_CASE(AERO_ACT_RELU); break;
+        default: AERO_PW_CASE(AERO_ACT_NONE); break;
+    }
+#undef AERO_PW_CASE
+}
+
+static int aero_pw_launch(const aero_pw_desc* d, hipStream_t stream, const char** err) {
+    if (!aero_pw_ok(d)) { *err = "pw: unsupported geometry (C <= 96 in steps of 8, 16-byte aligned channels-last rows, M % 16 == 0)"; return AERO_ERR_UNSUPPORTED; }
+    if (d->B < 1 || d->F < 1 || d->T < 1) { *err = "pw: empty tensor"; return AERO_ERR_ARG; }
+    AeroPwK p;
+    p.d = *d;
+    p.Mout = d->act == AERO_ACT_GLU ? d->M / 2 : d->M;
+    const int ks = (d->C + 31) / 32, gw = aero_pw_gw(d->C, d->M);
+    const int nchunk = (d->M + 128 * gw - 1) / (128 * gw);
+    const long rows = (long)d->B * d->F;
+    const int nunit = (d->T + 15) / 16;
+    // enough blocks for two per CU with something to hide latency behind; a split is a whole number of unit PAIRS (two waves alternate)
+    int nsplit = (int)((1024 + rows * nchunk - 1) / (rows * nchunk));
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 4) nsplit = 4;
+    int upb = (nunit + nsplit - 1) / nsplit;
+    upb = (upb + 1) & ~1;
+    nsplit = (nunit + upb - 1) / upb;
+    p.nsplit = nsplit;
+    p.upb = upb;
+    if (rows * nsplit > 0x7fffffffL || nchunk > 65535) { *err = "pw: too many rows for one launch"; return AERO_ERR_ARG; }
+    const dim3 grid((unsigned)(rows * nsplit), (unsigned)nchunk);
+    if (ks == 1) { if (gw == 1) aero_pw_go<1, 1>(p, grid, stream); else if (gw == 2) aero_pw_go<1, 2>(p, grid, stream); else aero_pw_go<1, 3>(p, grid, stream); }
+    else if (ks == 2) { if (gw == 1) aero_pw_go<2, 1>(p, grid, stream); else if (gw == 2) aero_pw_go<2, 2>(p, grid, stream); else aero_pw_go<2, 3>(p, grid, stream); }
+    else { if (gw == 1) aero_pw_go<3, 1>(p, grid, stream); else aero_pw_go<3, 2>(p, grid, stream); }
+    return AERO_OK;
+}

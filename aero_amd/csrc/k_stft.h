@@ -117,6 +117,9 @@ struct AeroStftK {
     const float* x; const float* window; float* spec; double* stats;
     int nsig, L, Lp, n_fft, hop, n_bins, T, sig_per_item, FPB;
     int span_cap;                                  // floats of LDS reserved for the shared signal span (0: read frames from global)
+#ifdef AERO_DBG_ZERO_LDS
+    int dbg_lds_bytes;
+#endif
 };
 
 // dynamic LDS sized by the actual n = n_fft/2 and frames per block (statically sized for n_fft = 1024 it was 62 KiB:
@@ -145,6 +148,13 @@ __global__ __launch_bounds__(256) void aero_stft_kernel(AeroStftK p) {
     const int sig = blockIdx.y;
     const int tbase = blockIdx.x * FPB;
     const float* xs = p.x + (int64_t)sig * p.L;
+#ifdef AERO_DBG_ZERO_LDS                                      /* tools/dbg experiment builds only: no stale LDS contents */
+    {
+        unsigned* z = (unsigned*)AERO_DYN_SMEM;
+        for (int i = threadIdx.x; i < (int)(p.dbg_lds_bytes >> 2); i += blockDim.x) z[i] = 0u;
+        __syncthreads();
+    }
+#endif
     const float scale = 1.0f / sqrtf((float)n_fft);
     aero_fft_init_twiddles(tw, n_fft);
     // The block's frames overlap (hop << n_fft): the window and the reflect-padded signal span they share are staged in
@@ -445,6 +455,9 @@ static int aero_stft_launch(const float* x, int nsig, int L, int Lp, int n_fft, 
     if (aero_stft_lds_bytes(n_fft, n_bins, fpb, p.span_cap) > 160 * 1024) p.span_cap = 0;
     const size_t lds = aero_stft_lds_bytes(n_fft, n_bins, fpb, p.span_cap);
     if (lds > 160 * 1024) { *err = "stft: frame buffers exceed the LDS"; return AERO_ERR_UNSUPPORTED; }
+#ifdef AERO_DBG_ZERO_LDS
+    p.dbg_lds_bytes = (int)lds;
+#endif
     switch (n) {                                            // compile-time sizes for the usual n_fft; run-time n otherwise
         case 64: AERO_LAUNCH_DYN(aero_stft_kernel<6>, grid, block, lds, stream, p); break;
         case 128: AERO_LAUNCH_DYN(aero_stft_kernel<7>, grid, block, lds, stream, p); break;

@@ -22,8 +22,8 @@
  *       AERO_LSTM_RING, AERO_LSTM_WIDE                                          (recurrent kernel form)
  *       AERO_ATTN_FOLD                                                          (LocalState: folded vs streaming kernel)
  *       AERO_NORM_CHUNK_KB                                                      (GroupNorm work-item size)
- *       AERO_STFT_DFT_BLOCKS, AERO_ISTFT_WAVES, AERO_ISTFT_ABL                  (GEMM-form STFT: blocks per (signal, table quarter);
- *                                                                                iSTFT waves per block, timing ablations)
+ *       AERO_STFT_DFT_BLOCKS, AERO_ISTFT_WAVES                                  (GEMM-form STFT: blocks per (signal, table quarter);
+ *                                                                                iSTFT waves per block)
  *       AERO_WGRAD_ABL                                                          (weight-gradient ablations; AERO_WGRAD_256 -- the tile
  *                                                                                choice -- is the one switch read at every call)
  *       AERO_ATTN_BWD_VALU, AERO_RING_TILE192                                   (LocalState backward form; ring-tile A/B)
@@ -198,6 +198,31 @@ typedef struct aero_gram_desc {
     double* stats;
 } aero_gram_desc;
 int aero_gram_stats(const aero_gram_desc* d, void* stream);
+
+/* K9' -- a pointwise (1x1) convolution with a SHORT contraction (C <= 96) and a wide output, as ONE streaming pass (k_pw.h): the tail of a
+ * DConv layer behind a BLSTM / LocalState (modules.py:240-247: Conv1d(hidden, 2C, 1) -> GroupNorm(1, 2C) -> GLU -> LayerScale, + x) and the
+ * encoder's rewrite conv + GLU (+ frequency embedding) where no GroupNorm sits between them (aero.py:133, 475-480).
+ *   x fp16 [B][F][T][C] channels-last; dst fp16 [B][F][T][Mout], Mout = M/2 with AERO_ACT_GLU (rows 2u, 2u+1 = value, gate) else M.
+ *   v[m] = W[m,:] . x + bias[m];  if stats: v = (v - mean) * rstd * gamma[m] + beta[m] with {sum, sum of squares} of ROW b*F + f at
+ *   stats[2*(b*F+f)], mean = sum / stat_count (the sums aero_gram_stats / aero_conv_fwd stat_mode 2 leave);  y = act(v) * layer_scale[c]
+ *   + res[b,f,t,c] + post_add[f][c]  (each optional).
+ *   wimg: fp16 image of W packed by the host (aero_amd/pack.py: pw_image): [chunk][2][GW][4][KS][64 lanes][8], KS = ceil(C/32),
+ *   GW = aero_pw_rows(C, M) / 128 rows-per-wave groups; element (chunk, wm, g, j, ks, lane, e) = W[r][k],
+ *   r = 128*GW*chunk + 64*(GW*wm + g) + 16*((lane & 15) >> 2) + 4*j + (lane & 3),  k = 32*ks + 8*(lane >> 4) + e  (zero outside M x C):
+ *   the row permutation that makes a lane's accumulators 16 consecutive rows of one time step (no transpose before the store). */
+typedef struct aero_pw_desc {
+    const void* x; int64_t x_b, x_f, x_t; int32_t C;
+    const void* wimg; const float* bias;
+    const double* stats; double stat_count; float stat_eps;
+    const float* gamma; const float* beta; const float* layer_scale;
+    const float* post_add;
+    const void* res; int64_t r_b, r_f, r_t;
+    void* dst; int64_t d_b, d_f, d_t;
+    int32_t B, F, T, M, act;
+} aero_pw_desc;
+int aero_pw_fwd(const aero_pw_desc* d, void* stream);
+/* conv rows one block covers (128 * GW) for a C -> M pointwise conv, 0 if the geometry is not served (C > 96, C % 8, M % 16) */
+int aero_pw_rows(int32_t C, int32_t M);
 
 /* K10 -- the recurrent part of nn.LSTM(bidirectional) inside BLSTM (modules.py:28,46), both
  * directions of ONE layer per call; the input projection is an aero_conv_fwd 1x1.
