@@ -262,7 +262,8 @@ _cached = {}
 
 
 def load(path=None):
-    path = os.path.abspath(path or DEFAULT_LIB)
+    # AERO_HIP_LIB: an experiment build of the SAME library (tools/dbg: A/B of compiler flags); never a different implementation
+    path = os.path.abspath(path or os.environ.get('AERO_HIP_LIB') or DEFAULT_LIB)
     if path not in _cached:
         _cached[path] = Lib(path)
     return _cached[path]

@@ -179,6 +179,32 @@ class Ops:
                        _ptr(spec.bias), act, _ptr(dst), B * Fout * T, spec.M, self.stream(dst))
         return dst
 
+    def pw(self, spec, x, B, F, T, res=None, post_add=None, stats=None, count=None, gamma=None, beta=None, layer_scale=None,
+           eps=1e-5, tag='aero_pw_kernel'):
+        """streaming pointwise conv (aero_pw_fwd, k_pw.h): x fp16 [B,F,T,C] (channels-last view) -> [B,F,T,Mout]; optional GroupNorm
+        from per-row sums `stats` [(B*F), 2] (count = elements per row), activation of the spec, LayerScale, residual, frequency-embedding row"""
+        Mout = spec.M // 2 if spec.act == ACT_GLU else spec.M
+        dst = torch.empty(B, F, T, Mout, dtype=torch.float16, device=x.device)
+        d = _lib.PwDesc()
+        d.x = _ptr(x)
+        d.x_b, d.x_f, d.x_t = _strides4(x)
+        d.C = spec.C
+        d.wimg, d.bias = _ptr(spec.wimg), _ptr(spec.bias)
+        d.stats = _ptr(stats)
+        d.stat_count = float(count) if stats is not None else 0.0
+        d.stat_eps = eps
+        d.gamma, d.beta, d.layer_scale, d.post_add = _ptr(gamma), _ptr(beta), _ptr(layer_scale), _ptr(post_add)
+        d.res = _ptr(res)
+        if res is not None:
+            d.r_b, d.r_f, d.r_t = _strides4(res)
+        d.dst = _ptr(dst)
+        d.d_b, d.d_f, d.d_t = _strides4(dst)
+        d.B, d.F, d.T, d.M, d.act = B, F, T, spec.M, spec.act
+        self._shape_note = f'pw M={spec.M} C={spec.C} F={F} act={spec.act} res={int(res is not None)} norm={int(stats is not None)}'
+        nb = x.numel() // x.shape[-1] * (2 * spec.C + 2 * Mout * (2 if res is not None else 1))
+        self._call('aero_pw_fwd', tag, 2.0 * B * F * T * spec.M * spec.C, nb, C.byref(d), self.stream(x))
+        return dst
+
     def begin_step(self, device):
         """Zero the statistics arena of the current stream once: the ~25 GroupNorm accumulators of a forward pass are
         slices of it instead of 25 separate torch.zeros fill launches."""
@@ -425,6 +451,7 @@ class HipEngine:
         self.fuse_lstm_proj = True         # W_ih x_t inside the recurrent kernel (no 8H-channel pre-activation tensor in HBM)
         self.collapse_first_ftb = True     # encoder-0 FTB on the 2-channel spectrogram (k_ftb.h); False = layer by layer
         self.split_taps = os.environ.get('AERO_TAP_SPLIT', '1') != '0'        # long thin FTB Conv1d: 3 x the blocks, partial sums summed in fixed order
+        self.use_pw = os.environ.get('AERO_PW', '1') != '0'                   # streaming pointwise kernel (k_pw.h) for the DConv tails / rewrite + GLU convs
         self.fuse_dconv_row = os.environ.get('AERO_DCONV_ROW', '1') != '0'    # DConv branches without LSTM / attention: one launch, the row stays in LDS (k_dconv.h)
         self.fuse_enc0 = os.environ.get('AERO_FUSE_ENC0', '1') != '0'     # ... and fused with the layer's strided conv (k_enc0.h)
 
@@ -588,6 +615,7 @@ class HipEngine:
             # recompute pair for the tail (conv2 -> GroupNorm(1) -> GLU -> LayerScale -> +skip): rows GLU-interleaved
             w, df, dt = pack.conv1d_taps(sd[f'{q}.conv2.0.weight'], 1, 0)
             L['conv2_glu'] = mk(w, sd[f'{q}.conv2.0.bias'], w.shape[-1], 0, df, dt, device, act=ACT_GLU)
+            L['pw2'] = pack.make_pw_spec(w[0, :, 0, :], sd[f'{q}.conv2.0.bias'], ACT_GLU, self.lib, device) if (dc.lstm or dc.time_attn) and dc.norm else None
             if dc.norm:
                 L['gn2_glu'] = (pack.glu_interleave(sd[f'{q}.conv2.1.weight']).to(device).contiguous(),
                                 pack.glu_interleave(sd[f'{q}.conv2.1.bias']).to(device).contiguous())
@@ -911,7 +939,10 @@ class HipEngine:
                 y = ops.norm_act(r, enc.norm_groups, False, L['norm2'][0], L['norm2'][1], ACT_GLU, stats=st)
             else:
                 ops.tag = 'stack'
-                y = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, post_add=emb)
+                if self.use_pw and L.get('rewrite_pw') is not None and y.is_contiguous():
+                    y = ops.pw(L['rewrite_pw'], y, B, Fo, T, post_add=emb)
+                else:
+                    y = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, post_add=emb)
                 ops.tag = ''
         elif i == 0 and 'freq_emb' in self.P:
             raise NotImplementedError('frequency embedding without a rewrite conv')
@@ -968,6 +999,11 @@ class HipEngine:
                     ops.gram_stats(h, L['gram'], st2)
                 else:
                     ops.conv(c2, h, None, B, Fo, Fo, T, act=ACT_NONE, stat=dict(mode=2, stats=st2, G=1, per_row=True))
+                if self.use_pw and L.get('pw2') is not None and h.is_contiguous():
+                    # the tail as ONE streaming pass: weights resident in registers, no LDS staging, no barrier (k_pw.h)
+                    x = ops.pw(L['pw2'], h, B, Fo, T, res=x, stats=st2, count=float(T * c2.M), gamma=L['gn2_glu'][0],
+                               beta=L['gn2_glu'][1], layer_scale=L['scale'])
+                    continue
                 x = ops.conv(c2, h, None, B, Fo, Fo, T, res=x,
                              stat=dict(mode=3, stats=st2, G=1, per_row=True, count=float(T * c2.M),
                                        gamma=L['gn2_glu'][0], beta=L['gn2_glu'][1], layer_scale=L['scale']))

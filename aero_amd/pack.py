@@ -68,6 +68,48 @@ def make_conv_spec(w_taps, bias, C0, C1, df, dt, device, transposed=0, fstride=1
     return spec
 
 
+class PwSpec:
+    """a pointwise conv in the form aero_pw_fwd takes (k_pw.h)"""
+    def __init__(self, wimg, bias, M, C, act):
+        self.wimg, self.bias, self.M, self.C, self.act = wimg, bias, M, C, act
+
+
+def pw_image(w, rows):
+    """w fp32/fp16 [M, C] (rows already GLU-interleaved where GLU follows) -> the fp16 image aero_pw_fwd reads (include/aero_hip.h):
+    [chunk][2][GW][4][KS][64 lanes][8], rows = 128 * GW rows per chunk; lane l of tile j holds logical row 16 * ((l & 15) >> 2) + 4 j +
+    (l & 3) of its 64-row group and the k-octet l >> 4: the permutation that leaves a lane's accumulators consecutive rows."""
+    M, C = w.shape
+    gw = rows // 128
+    ks = (C + 31) // 32
+    nchunk = (M + rows - 1) // rows
+    wp = torch.zeros(nchunk * rows, ks * 32, dtype=torch.float32, device=w.device)
+    wp[:M, :C] = w.float()
+    lane = torch.arange(64, device=w.device)
+    prow = lane & 15                                              # physical tile row of the lane's A fragment
+    koct = lane >> 4
+    j = torch.arange(4, device=w.device)
+    # logical row inside the 64-row group for (j, lane)
+    r64 = (16 * (prow >> 2))[None, :] + 4 * j[:, None] + (prow & 3)[None, :]                  # [4, 64]
+    grp = torch.arange(nchunk * 2 * gw, device=w.device)                                      # (chunk, wm, g) flattened = 64-row group index
+    rows_idx = grp[:, None, None] * 64 + r64[None]                                            # [G, 4, 64]
+    kk = torch.arange(ks, device=w.device)[:, None, None] * 32 + (koct * 8)[None, :, None] + torch.arange(8, device=w.device)[None, None, :]   # [KS, 64, 8]
+    img = wp[rows_idx[:, :, None, :, None], kk[None, None]]                                   # [G, 4, KS, 64, 8]
+    return img.to(torch.float16).contiguous()
+
+
+def make_pw_spec(w, bias, act, lib, device):
+    """w [M, C] fp32 in the reference's row order; GLU: rows / bias interleaved (value, gate) as make_conv_spec does.  None if the
+    geometry is not served by the streaming pointwise kernel."""
+    M, C = w.shape
+    rows = int(lib.cdll.aero_pw_rows(C, M))
+    if not rows:
+        return None
+    if act == _lib.ACT_GLU:
+        w = glu_interleave(w)
+        bias = None if bias is None else glu_interleave(bias)
+    return PwSpec(pw_image(w.to(device), rows), None if bias is None else bias.detach().float().to(device).contiguous(), M, C, act)
+
+
 def ring_bm(M, Ktot):
     """tile height of the software-pipelined kernel for this contraction (0: not taken) -- asks the library"""
     try:

@@ -18,6 +18,12 @@ from conftest import rel_l2
 from oracle import aero_oracle as O
 
 TOL16 = 2e-3
+PW_CASES = [dict(Cin=48, Cout=384, Fq=3, T=70, norm=True, residual=True, scale=True),            # DConv tail, encoder 2 (KS 2, GW 3)
+            dict(Cin=96, Cout=768, Fq=2, T=37, norm=True, residual=True, scale=True),            # DConv tail, encoder 3 (KS 3, GW 2, 3 chunks)
+            dict(Cin=48, Cout=96, Fq=5, T=50, post=True),                                        # encoder-0 rewrite + GLU + frequency embedding (M padded to a group)
+            dict(Cin=96, Cout=192, Fq=2, T=33),                                                  # encoder-1 rewrite + GLU
+            dict(Cin=24, Cout=64, Fq=2, T=17, act='gelu', residual=True),                        # non-GLU store path, one k-step
+            dict(Cin=16, Cout=32, Fq=1, T=5, act='none', B=1)]
 TOL32 = 2e-6
 BLSTM_TOL = 1e-3      # whole BLSTM block / LocalState block (output incl. the skip path) against the oracle: the north-star bar itself
 ATTN_TOL = 1e-3
@@ -115,6 +121,47 @@ def case_conv2d(lib, dev, Cin, Cout, kF, kT, stride, padF, padT, Fin, T, act='no
     y = ops.conv(spec, s0, s1, B, Fin, Fout, T, res=res)
     assert y.shape == (B, Fout, T, ref.shape[1])
     assert rel_l2(uncl(y.cpu()), ref) < TOL16
+
+
+def case_pw(lib, dev, Cin, Cout, Fq, T, B=2, act='glu', norm=False, residual=False, post=False, scale=False, seed=16):
+    """aero_pw_fwd (k_pw.h): 1x1 conv [-> GroupNorm(1 group per (b, f) row) from given sums] -> act [* LayerScale] [+ res] [+ frequency
+    embedding row] against fp32 torch on the fp16-rounded operands"""
+    ops = Ops(lib)
+    g = _g(seed)
+    w = torch.randn(Cout, Cin, generator=g) / math.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    x = torch.randn(B, Cin, Fq, T, generator=g)
+    actc = {'none': _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'gelu': _lib.ACT_GELU, 'glu': _lib.ACT_GLU}[act]
+    spec = pack.make_pw_spec(q16(w), b, actc, lib, dev)
+    assert spec is not None
+    v = torch.einsum('mc,bcft->bmft', q16(w), q16(x)) + b.view(1, -1, 1, 1)
+    kw = {}
+    if norm:
+        gamma, beta = 1 + 0.3 * torch.randn(Cout, generator=g), 0.2 * torch.randn(Cout, generator=g)
+        mu = v.mean(dim=(1, 3), keepdim=True)
+        var = v.var(dim=(1, 3), unbiased=False, keepdim=True)
+        st = torch.stack([v.double().sum(dim=(1, 3)), v.double().square().sum(dim=(1, 3))], -1).reshape(B * Fq, 2)   # row b*F + f
+        v = (v - mu) / torch.sqrt(var + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+        gi, bi = (pack.glu_interleave(gamma), pack.glu_interleave(beta)) if act == 'glu' else (gamma, beta)
+        kw.update(stats=st.to(dev), count=float(T * Cout), gamma=gi.to(dev).contiguous(), beta=bi.to(dev).contiguous())
+    ref = {'none': lambda u: u, 'relu': F.relu, 'gelu': F.gelu, 'glu': lambda u: F.glu(u, 1)}[act](v)
+    Mout = ref.shape[1]
+    if scale:
+        ls = 0.5 + torch.rand(Mout, generator=g)
+        ref = ref * ls.view(1, -1, 1, 1)
+        kw['layer_scale'] = ls.to(dev)
+    if residual:
+        r = torch.randn(B, Mout, Fq, T, generator=g)
+        ref = ref + q16(r)
+        kw['res'] = cl(r).to(dev)
+    if post:
+        pe = torch.randn(Fq, Mout, generator=g)
+        ref = ref + pe.t().reshape(1, Mout, Fq, 1)
+        kw['post_add'] = pe.to(dev).contiguous()
+    y = ops.pw(spec, cl(x).to(dev), B, Fq, T, **kw)
+    assert y.shape == (B, Fq, T, Mout)
+    e = rel_l2(uncl(y.cpu()), ref)
+    assert e < TOL16, e
 
 
 def case_conv_tiny(lib, dev, Cin, Cout, Fq, T, B=2, act='relu', seed=15):

@@ -82,6 +82,11 @@ def test_conv2d(emu, kw):
     oc.case_conv2d(emu, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', oc.PW_CASES)
+def test_pw(emu, kw):
+    oc.case_pw(emu, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(Cin=2, Cout=5, Fq=40, T=70), dict(Cin=2, Cout=5, Fq=64, T=64, act='none'), dict(Cin=4, Cout=6, Fq=33, T=130, B=1, act='gelu'), dict(Cin=3, Cout=3, Fq=7, T=20)])
 def test_conv_tiny(emu, kw):
     oc.case_conv_tiny(emu, DEV, **kw)

@@ -53,6 +53,11 @@ def test_conv2d(lib, kw):
     oc.case_conv2d(lib, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', oc.PW_CASES)
+def test_pw(lib, kw):
+    oc.case_pw(lib, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(Cin=2, Cout=5, Fq=256, T=501, B=4), dict(Cin=4, Cout=6, Fq=33, T=130, B=1, act='gelu'), dict(Cin=3, Cout=3, Fq=7, T=20)])
 def test_conv_tiny(lib, kw):
     oc.case_conv_tiny(lib, DEV, **kw)

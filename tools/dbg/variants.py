@@ -29,7 +29,16 @@ def build():
         g.build_library(out=lib_path(tag), objdir=os.path.join(HERE, 'build', tag), only_parts=[1], **kw)
 
 
+
+def build_nopk_all():
+    """the whole library without packed-fp32 instructions (a candidate for the release build: measured against it in the bench)"""
+    import __graft_entry__ as g
+    g.build_library(out=lib_path('nopk_all'), objdir=os.path.join(HERE, 'build', 'nopk_all'), flags=VARIANTS['nopk']['flags'])
+
+
 def main():
+    if '--build-nopk-all' in sys.argv:
+        return build_nopk_all()
     if '--build' in sys.argv:
         return build()
     import torch
@@ -67,3 +76,4 @@ def main():
 
 if __name__ == '__main__':
     main()
+
