@@ -101,24 +101,32 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
     const int lane_o = GLU ? 8 * q : 16 * q;
     const int grp_o = wm * GW * (GLU ? 32 : 64);
 
+    // Loads are UNCONDITIONAL and their values are used as they come: a predicated load becomes a branch around it, a select-to-zero
+    // behind a load is scheduled right behind it -- either way the compiler waited vmcnt(0) in front of the MFMAs, i.e. for the prefetch
+    // it had just issued (1.5 TB/s).  Padding lanes (k >= C) re-read channels 0..7 of their step: their weight columns are zero in the
+    // image, and finite x times zero is zero; lanes past Mout read a valid vector they never store.
+    const int kq = 8 * q;
     auto load_b = [&](h16x8 (&Bf)[KS], int u) {
         int t = u * 16 + n;
         t = t < T ? t : T - 1;                                    // (masked at the store: the load stays in range)
-        const h16* px = xr + t * xt + 8 * q;
+        const h16* px = xr + t * xt;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) Bf[ks] = (32 * ks + 8 * q < d.C) ? *(const h16x8*)(px + 32 * ks) : zero8;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = 32 * ks + kq;
+            Bf[ks] = *(const h16x8*)(px + (k0 < d.C ? k0 : 0));
+        }
     };
     auto load_r = [&](h16x8 (&R)[GW][NV], int u) {
-        if (!rr) return;
+        if (!rr) return;                                          // (block-uniform)
         int t = u * 16 + n;
         t = t < T ? t : T - 1;
-        const h16* pr = rr + t * rt + obase + grp_o + lane_o;
+        const h16* pr = rr + t * rt;
 #pragma unroll
         for (int g = 0; g < GW; ++g)
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int o = obase + grp_o + g * (GLU ? 32 : 64) + lane_o + 8 * v;
-                R[g][v] = o < Mout ? *(const h16x8*)(pr + g * (GLU ? 32 : 64) + 8 * v) : zero8;
+                R[g][v] = *(const h16x8*)(pr + (o < Mout ? o : 0));
             }
     };
 
@@ -132,11 +140,18 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
         load_b(Bc, u);
         load_r(Rc, u);
     }
+#ifndef AERO_EMU
+    // the loop is ENTERED with nothing in flight: otherwise hipcc merges the preheader's pending first loads into the loop header's state
+    // and waits there in every trip -- for the next unit's fragments it has just requested (the builtin, not inline asm: an asm wait
+    // is invisible to its scoreboard)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
+#endif
 #pragma unroll 1
     for (; u < u_hi; u += 2) {
-        if (u + 2 < u_hi) {
-            load_b(Bn, u + 2);
-            load_r(Rn, u + 2);
+        {
+            const int un = u + 2 < u_hi ? u + 2 : u;              // (the last trip re-reads its own unit: no branch around the prefetch)
+            load_b(Bn, un);
+            load_r(Rn, un);
         }
         const int t = u * 16 + n;
         const bool tin = t < T;
@@ -149,52 +164,53 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[g][j][ks], Bc[ks], acc[j], 0, 0, 0);
-            // rows 16 q + 4 j + i of the group: coefficients are 4 + 4 consecutive float4 of the block's tables
+            // rows 16 q + 4 j + i of the group: coefficients are 4 + 4 consecutive float4 of the block's tables, applied tile by tile IN the
+            // accumulator registers (a group's live set stays small: with everything fetched up front the three groups of a unit
+            // spilled 63 registers and every spill reload drained the next unit's prefetch: 1.5 TB/s)
             const int ci = (wm * GW + g) * 64 + 16 * q;
-            float v[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 a4 = *(const f32x4*)&ca[ci + 4 * j];
                 const f32x4 b4 = *(const f32x4*)&cb[ci + 4 * j];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[j][i] = acc[j][i] * a4[i] + b4[i];
+                for (int i = 0; i < 4; ++i) acc[j][i] = acc[j][i] * a4[i] + b4[i];
             }
             const int o0 = obase + grp_o + g * (GLU ? 32 : 64) + lane_o;          // first stored channel of this lane
             const int oi = grp_o + g * (GLU ? 32 : 64) + lane_o;                  // ... inside the chunk (LDS tables)
             if constexpr (GLU) {
-                float o[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) o[2 * j + h] = v[j][2 * h] * aero_sigmoid(v[j][2 * h + 1]);
-                const f32x4 s0 = *(const f32x4*)&cs[oi], s1 = *(const f32x4*)&cs[oi + 4];
-                const f32x4 p0 = *(const f32x4*)&cp[oi], p1 = *(const f32x4*)&cp[oi + 4];
                 h16x8 y;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float sc = e < 4 ? s0[e] : s1[e - 4];
-                    const float pa = e < 4 ? p0[e] : p1[e - 4];
-                    y[e] = (h16)(o[e] * sc + (float)Rc[g][0][e] + pa);
+                for (int hh = 0; hh < 2; ++hh) {                                  // outputs 4 hh .. 4 hh + 3 = tiles 2 hh, 2 hh + 1
+                    const f32x4 s4 = *(const f32x4*)&cs[oi + 4 * hh];
+                    const f32x4 p4 = *(const f32x4*)&cp[oi + 4 * hh];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = 2 * hh + (e >> 1), h = e & 1;
+                        const float o = acc[j][2 * h] * aero_sigmoid(acc[j][2 * h + 1]);
+                        y[4 * hh + e] = (h16)(o * s4[e] + (float)Rc[g][0][4 * hh + e] + p4[e]);
+                    }
                 }
                 if (tin && o0 < Mout) *(h16x8*)(dr + t * dt + o0) = y;
             } else {
 #pragma unroll
                 for (int vv = 0; vv < 2; ++vv) {
-                    const f32x4 s0 = *(const f32x4*)&cs[oi + 8 * vv], s1 = *(const f32x4*)&cs[oi + 8 * vv + 4];
-                    const f32x4 p0 = *(const f32x4*)&cp[oi + 8 * vv], p1 = *(const f32x4*)&cp[oi + 8 * vv + 4];
                     h16x8 y;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float val = v[2 * vv + (e >> 2)][e & 3];
-                        if constexpr (ACT == AERO_ACT_RELU) val = fmaxf(val, 0.f);
-                        else if constexpr (ACT == AERO_ACT_GELU) val = aero_gelu(val);
-                        const float sc = e < 4 ? s0[e] : s1[e - 4];
-                        const float pa = e < 4 ? p0[e] : p1[e - 4];
-                        y[e] = (h16)(val * sc + (float)Rc[g][NV - 1 < vv ? 0 : vv][e] + pa);
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const f32x4 s4 = *(const f32x4*)&cs[oi + 8 * vv + 4 * hh];
+                        const f32x4 p4 = *(const f32x4*)&cp[oi + 8 * vv + 4 * hh];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float val = acc[2 * vv + hh][e];
+                            if constexpr (ACT == AERO_ACT_RELU) val = fmaxf(val, 0.f);
+                            else if constexpr (ACT == AERO_ACT_GELU) val = aero_gelu(val);
+                            y[4 * hh + e] = (h16)(val * s4[e] + (float)Rc[g][vv][4 * hh + e] + p4[e]);
+                        }
                     }
                     if (tin && o0 + 8 * vv < Mout) *(h16x8*)(dr + t * dt + o0 + 8 * vv) = y;
                 }
             }
+            aero_sched_fence();                                                   // the next group's MFMAs and reads start after this one's store
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) Bc[ks] = Bn[ks];
@@ -259,7 +275,7 @@ static int aero_pw_launch(const aero_pw_desc* d, hipStream_t stream, const char*
     const long rows = (long)d->B * d->F;
     const int nunit = (d->T + 15) / 16;
     // enough blocks for two per CU with something to hide latency behind; a split is a whole number of unit PAIRS (two waves alternate)
-    int nsplit = (int)((1024 + rows * nchunk - 1) / (rows * nchunk));
+    int nsplit = (int)((512 + rows * nchunk - 1) / (rows * nchunk));
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 4) nsplit = 4;
     int upb = (nunit + nsplit - 1) / nsplit;

@@ -435,6 +435,7 @@ class HipEngine:
         # overlap with the MFMA / bandwidth-bound launches of the other: B = 64: 11.05 -> 10.72 ms, B = 128: 21.1 -> 20.2; neutral at 16,
         # +1..6 % at <= 8 clips, where it stays off)
         self.streams = int(os.environ.get('AERO_STREAMS', '0'))
+        self.prof_streams = False           # bench.py: keep the sub-batch streams while per-launch HIP events are recorded (each on its launch's stream)
         self.use_graph = os.environ.get('AERO_GRAPH', '0') != '0'  # replay the forward as a captured HIP graph (per input shape)
         # GroupNorm fused into conv epilogues (stat_mode 1-3 of aero_conv_fwd, lean epilogue paths).  Measured on MI355X:
         #  * DConv tail as a recompute pair (statistics pass without stores + normalise/GLU/LayerScale/skip pass): the
@@ -552,6 +553,8 @@ class HipEngine:
                                   act=ACT_NONE if enc.norm else ACT_GLU)
                 if enc.norm:
                     L['norm2'] = (sd[f'{p}.norm2.weight'].to(device), sd[f'{p}.norm2.bias'].to(device))
+                elif len(df) == 1:                                 # pointwise rewrite + GLU with no norm between: the streaming kernel (k_pw.h)
+                    L['rewrite_pw'] = pack.make_pw_spec(w[0, :, 0, :], sd[f'{p}.rewrite.bias'], ACT_GLU, self.lib, device)
             P[p] = L
         for j, dec in enumerate(m.decoder):
             p = f'decoder.{j}'
@@ -706,7 +709,7 @@ class HipEngine:
         ns = min(want, mix.shape[0]) if mix.is_cuda else 1
         if self.use_graph and mix.is_cuda and self.ops.prof is None and not self.lib.is_emulator:
             return self._forward_graph(mix, want_spec, want_lr_spec)
-        if ns <= 1 or self.ops.prof is not None:
+        if ns <= 1 or (self.ops.prof is not None and not self.prof_streams):
             return self._forward_one(mix, want_spec, want_lr_spec)
         cur = torch.cuda.current_stream(mix.device)
         key = ('streams', ns, str(mix.device))
