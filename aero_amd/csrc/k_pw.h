@@ -21,7 +21,7 @@
 
 struct AeroPwK {
     aero_pw_desc d;
-    int nsplit, upb;                 // time splits per row, 16-step units per split
+    int nsplit, upb, nchunk;         // time splits per row, 16-step units per split, row chunks (blocks) per (row, split)
     int Mout;                        // stored channels: M / 2 with GLU
 };
 
@@ -36,8 +36,11 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int wm = wave & 1, wt = wave >> 1;
     const int n = lane & 15, q = lane >> 4;
-    const int chunk = blockIdx.y;
-    const int row = (int)blockIdx.x / p.nsplit, split = (int)blockIdx.x - row * p.nsplit;
+    // the chunks of one (row, split) are NEIGHBOURS in an XCD's share of the grid: they read the same input rows, the second and third
+    // reader find them in that XCD's L2
+    const int lin = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const int rs = lin / p.nchunk, chunk = lin - rs * p.nchunk;
+    const int row = rs / p.nsplit, split = rs - row * p.nsplit;
     const int b = row / d.F, f = row - b * d.F;
     const int M = d.M, Mout = p.Mout, T = d.T;
     const int mbase = chunk * MC, obase = chunk * OC;
@@ -283,8 +286,9 @@ static int aero_pw_launch(const aero_pw_desc* d, hipStream_t stream, const char*
     nsplit = (nunit + upb - 1) / upb;
     p.nsplit = nsplit;
     p.upb = upb;
-    if (rows * nsplit > 0x7fffffffL || nchunk > 65535) { *err = "pw: too many rows for one launch"; return AERO_ERR_ARG; }
-    const dim3 grid((unsigned)(rows * nsplit), (unsigned)nchunk);
+    p.nchunk = nchunk;
+    if (rows * nsplit * nchunk > 0x7fffffffL) { *err = "pw: too many rows for one launch"; return AERO_ERR_ARG; }
+    const dim3 grid((unsigned)(rows * nsplit * nchunk));
     if (ks == 1) { if (gw == 1) aero_pw_go<1, 1>(p, grid, stream); else if (gw == 2) aero_pw_go<1, 2>(p, grid, stream); else aero_pw_go<1, 3>(p, grid, stream); }
     else if (ks == 2) { if (gw == 1) aero_pw_go<2, 1>(p, grid, stream); else if (gw == 2) aero_pw_go<2, 2>(p, grid, stream); else aero_pw_go<2, 3>(p, grid, stream); }
     else { if (gw == 1) aero_pw_go<3, 1>(p, grid, stream); else aero_pw_go<3, 2>(p, grid, stream); }

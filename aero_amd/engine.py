@@ -435,6 +435,7 @@ class HipEngine:
         # overlap with the MFMA / bandwidth-bound launches of the other: B = 64: 11.05 -> 10.72 ms, B = 128: 21.1 -> 20.2; neutral at 16,
         # +1..6 % at <= 8 clips, where it stays off)
         self.streams = int(os.environ.get('AERO_STREAMS', '0'))
+        self.stagger = int(os.environ.get('AERO_STAGGER', '0'))          # two-stream forward: start of the second half relative to the first (see forward)
         self.prof_streams = False           # bench.py: keep the sub-batch streams while per-launch HIP events are recorded (each on its launch's stream)
         self.use_graph = os.environ.get('AERO_GRAPH', '0') != '0'  # replay the forward as a captured HIP graph (per input shape)
         # GroupNorm fused into conv epilogues (stat_mode 1-3 of aero_conv_fwd, lean epilogue paths).  Measured on MI355X:
@@ -717,10 +718,24 @@ class HipEngine:
             self._tables[key] = [torch.cuda.Stream(device=mix.device) for _ in range(ns)]
         outs = []
         self._prepare(mix.device)                       # weights packed once, on the caller's stream
+        # STAGGER: sub-batch k + 1 starts when sub-batch k has finished stage `stagger` (1..4: encoder layers, 5..8: decoder layers).
+        # In lockstep the two halves run the same kernel at the same time -- two latency-bound LSTM launches next to each other hide
+        # nothing; shifted, the recurrent phase of one half runs under the MFMA / bandwidth-bound phase of the other.
+        prev_events = None
         for st, part in zip(self._tables[key], mix.chunk(ns, dim=0)):
             st.wait_stream(cur)
+            if prev_events is not None and self.stagger in prev_events:
+                st.wait_event(prev_events[self.stagger])
+            events = {}
+
+            def stage_cb(i, events=events, st=st):
+                if i == self.stagger:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    events[i] = ev
             with torch.cuda.stream(st):
-                outs.append(self._forward_one(part, want_spec, want_lr_spec, defer_istft=True))
+                outs.append(self._forward_one(part, want_spec, want_lr_spec, defer_istft=True, stage_cb=stage_cb if self.stagger else None))
+            prev_events = events
         for st in self._tables[key]:
             cur.wait_stream(st)
         # The iSTFT runs AFTER the join, on the caller's stream, never next to another stream's kernels: measured on the MI355X, an
@@ -768,7 +783,7 @@ class HipEngine:
         g.replay()
         return tuple(None if t is None else t.clone() for t in static_out)
 
-    def _forward_one(self, mix, want_spec=False, want_lr_spec=False, train=False, defer_istft=False):
+    def _forward_one(self, mix, want_spec=False, want_lr_spec=False, train=False, defer_istft=False, stage_cb=None):
         m, ops, P = self.model, self.ops, None
         self._train = train
         self._check_input(mix)
@@ -793,10 +808,14 @@ class HipEngine:
         for i, enc in enumerate(m.encoder):
             x, Fq = self._encode(i, enc, P[f'encoder.{i}'], x, B, Fq, T)
             saved.append((x, Fq))
+            if stage_cb is not None:
+                stage_cb(i + 1)
         x = None
         for j, dec in enumerate(m.decoder):
             skip, Fs = saved.pop()
             x = self._decode(j, dec, P[f'decoder.{j}'], x, skip, B, Fs, T, mean, std)
+            if stage_cb is not None:
+                stage_cb(len(m.encoder) + j + 1)
         assert not saved
         spec_out = x                                                       # fp32 [B,F0,T,2] de-normalised
         hop, win = int(m.hop_length * m.scale), int(m.win_length * m.scale)
