@@ -431,6 +431,157 @@ __global__ __launch_bounds__(NW * 64) void aero_istft_kernel(AeroIstftK p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// iSTFT, second form (round 4): a block walks a RUN of frames of one signal in groups of 16 with the overlap-add ring resident in LDS.
+// The first form (above) gives every 512-sample output segment its own block: 16 frames of which 8 are halo, twiddles / window / three
+// serial phases per block, 4032 blocks in eight rounds -- 58-65 us for 74 MB (ablations: the per-block skeleton 24 us, the doubled frame
+// FFTs 23 us; never the traffic).  Here a block owns SEGF = 64 consecutive hops of output: 72 frame transforms for 64 (an 8-frame halo
+// group once per block), setup once per 64 frames, and the spectrum values of group g + 1 are requested before the FFTs of group g and
+// unpacked from registers afterwards, so no phase waits for HBM.  512 blocks, two per CU: the whole launch is resident at once.
+//   ring:   24 frame slots (16 new + need - 1 <= 8 old), slot = (frame - first frame of the block) mod 24, rows of n + 1 complex;
+//   group:  unpack (registers -> conj(Z) rows) | barrier | request next group | FFT: wave w transforms frames 2w, 2w + 1 | barrier |
+//           overlap-add of the 16 * hop samples this group completes (each sample: its `need` frames, window, 1 / envelope) | barrier.
+// Geometry: n_fft 512 or 1024, hop a power of two dividing n_fft / 2, at most 8 frames over a sample (every configuration of the reference).
+#define AERO_ISTFT2_SLOTS 24
+#define AERO_ISTFT2_HALO 8
+#define AERO_ISTFT2_SEGF 64
+
+static inline size_t aero_istft2_lds_bytes(int n_fft) {
+    const size_t n = (size_t)n_fft / 2;
+    return (n + AERO_ISTFT2_SLOTS * (n + 1) + 8 * n) * sizeof(f32x2) + (size_t)n_fft * sizeof(float);
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(512) void aero_istft2_kernel(AeroIstftK p) {
+    constexpr int n = 1 << LOGN, n_fft = 2 * n, fs = n + 1, NP = n / 2;          // NP (k, n - k) pairs with k < n / 2; bin n / 2 pairs with itself
+    constexpr int NIT = NP * 16 / 512;                                             // pair items per thread and 16-frame group
+    f32x2* tw = (f32x2*)AERO_DYN_SMEM;
+    f32x2* ring = tw + n;                                                          // [SLOTS][n + 1]
+    f32x2* sbuf0 = ring + AERO_ISTFT2_SLOTS * fs;                                  // [8][n]
+    float* wl = (float*)(sbuf0 + 8 * n);
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int nseg = (int)gridDim.x;
+    const int lin = aero_xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    const int sig = lin / nseg, seg = lin - sig * nseg;
+    const int hop = p.hop, hsh = p.hsh, T = p.T;
+    const int need = n_fft >> hsh, h2 = n >> hsh;                                  // frames over a sample; frames before the first kept sample
+    const int F0 = seg * AERO_ISTFT2_SEGF + h2 - AERO_ISTFT2_HALO;                 // first frame this block transforms (may be < 0: zeros)
+    aero_fft_init_twiddles(tw, n_fft);
+    for (int i = tid; i < n_fft; i += 512) wl[i] = p.window[i];
+    const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * T;
+    float* ys = p.y + (int64_t)sig * p.Lout;
+    const float scale = sqrtf((float)n_fft) / (float)n;
+    const int fr = tid & 15, k0 = tid >> 4;                                         // this thread's frame of the group, first pair index
+    auto unpack = [&](f32x2 xa, f32x2 xb, int k) -> f32x2 {
+        const f32x2 E = (xa + xb) * 0.5f;
+        const f32x2 D = (xa - xb) * 0.5f;
+        const f32x2 O = aero_cmul(D, (f32x2){tw[k][0], -tw[k][1]});
+        return (f32x2){E[0] - O[1], -(E[1] + O[0])};
+    };
+    // ---- spectrum values of one group: per thread NIT pairs (k, n - k) of frame tg + fr, plus bin n / 2 for threads < 16.
+    // Loads are unconditional (frame index clamped); frames outside [0, T) are zeroed when the values are unpacked.
+    f32x2 xa[NIT], xq[NIT], xm;
+    auto request = [&](int tg) {
+        int t = tg + fr;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k = k0 + 32 * it;
+            xa[it] = X[k * T + t];
+            xq[it] = X[(k == 0 ? n - 1 : n - k) * T + t];             // (k = 0 pairs with the implicit zero Nyquist bin: value unused)
+        }
+        xm = X[NP * T + (tid < 16 ? t : 0)];
+    };
+    auto deposit = [&](int tg, int rel0) {                              // rel0: tg - F0, the group's first ring position
+        const int t = tg + fr;
+        const bool live = t >= 0 && t < T;
+        int slot = rel0 + fr;
+        slot -= slot >= AERO_ISTFT2_SLOTS ? AERO_ISTFT2_SLOTS : 0;
+        slot -= slot >= AERO_ISTFT2_SLOTS ? AERO_ISTFT2_SLOTS : 0;
+        f32x2* row = ring + slot * fs;
+        const f32x2 zero = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k = k0 + 32 * it;
+            f32x2 a = xa[it];
+            if (k == 0) {
+                a[1] = 0.f;                                             // irfft ignores the imaginary part of DC
+                const f32x2 z = unpack(a, zero, 0);
+                row[0] = live ? z : zero;
+            } else {
+                const f32x2 q = xq[it];
+                const f32x2 z0 = unpack(a, (f32x2){q[0], -q[1]}, k);
+                const f32x2 z1 = unpack(q, (f32x2){a[0], -a[1]}, n - k);
+                row[k] = live ? z0 : zero;
+                row[n - k] = live ? z1 : zero;
+            }
+        }
+        if (tid < 16) {
+            const f32x2 z = unpack(xm, (f32x2){xm[0], -xm[1]}, NP);
+            row[NP] = live ? z : zero;
+        }
+    };
+    auto transform = [&](int slot) {
+        slot -= slot >= AERO_ISTFT2_SLOTS ? AERO_ISTFT2_SLOTS : 0;
+        slot -= slot >= AERO_ISTFT2_SLOTS ? AERO_ISTFT2_SLOTS : 0;
+        f32x2* a = ring + slot * fs;
+        f32x2* sb = sbuf0 + wave * n;
+        f32x2* R = aero_fft_wave<LOGN>(a, sb, n, tw);
+        if (R != a) {
+            for (int m = lane; m < n; m += 64) a[m] = R[m];
+            aero_wave_sync();
+        }
+    };
+    request(F0);                                                        // the halo group: frames F0 .. F0 + 7 (lanes fr >= 8 load and drop)
+    __syncthreads();                                                    // twiddles and window are in
+    constexpr int NG = AERO_ISTFT2_SEGF / 16;
+    // group -1 = the halo (8 frames, one per wave), groups 0 .. NG-1 of 16 frames
+    for (int g = -1; g < NG; ++g) {
+        const int rel0 = g < 0 ? 0 : AERO_ISTFT2_HALO + 16 * g;
+        const int tg = F0 + rel0;
+        const int nf = g < 0 ? AERO_ISTFT2_HALO : 16;
+        if (fr < nf) deposit(tg, rel0 % AERO_ISTFT2_SLOTS);
+        __syncthreads();
+        if (g + 1 < NG) request(F0 + AERO_ISTFT2_HALO + 16 * (g + 1));
+        const int rs = rel0 % AERO_ISTFT2_SLOTS;
+        if (g < 0) {
+            transform(rs + wave);
+        } else {
+            transform(rs + 2 * wave);
+            transform(rs + 2 * wave + 1);
+        }
+        __syncthreads();
+        if (g >= 0) {
+            // the samples this group completes: hop index q = tg + (0 .. 15), OLA index i = q * hop + r, kept sample oo = i - n
+            const float* ringf = (const float*)ring;
+            for (int o = tid; o < (16 << hsh); o += 512) {
+                const int qi = o >> hsh, r = o & (hop - 1);
+                const int q = tg + qi;
+                const int oo = (q << hsh) + r - n;
+                if (oo < 0 || oo >= p.Lout) continue;
+                float acc = 0.f;
+                int rel = rel0 + qi - (need - 1);                       // ring position of the oldest frame over this sample
+                int ni = r + ((need - 1) << hsh);
+                for (int j = 0; j < need; ++j, ++rel, ni -= hop) {
+                    if (q - (need - 1) + j < 0 || q - (need - 1) + j >= T) continue;
+                    int slot = rel % AERO_ISTFT2_SLOTS;
+                    const float v = ringf[slot * (2 * fs) + ni];
+                    acc += wl[ni] * ((ni & 1) ? -v : v);
+                }
+                ys[oo] = acc * scale * p.inv_env[oo + n];
+            }
+        }
+        __syncthreads();                                                // the next group's rows overwrite frames this one still read
+    }
+}
+
+static int aero_istft2_ok(int n_fft, int hop, int T) {
+    const int n = n_fft / 2;
+    if (n != 256 && n != 512) return 0;
+    if (hop < 16 || (hop & (hop - 1)) || n % hop || n_fft / hop > AERO_ISTFT2_HALO) return 0;
+    return T >= 1;
+}
+
 static int aero_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 static int aero_stft_launch(const float* x, int nsig, int L, int Lp, int n_fft, int hop, const float* window, int n_bins,
@@ -536,37 +687,54 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
     const int ntile = (p.T + 127) >> 7;
     float s = 0.f, ss = 0.f;
     float* out = p.spec + (int64_t)sig * n_bins * p.T * 2;
+    // the span of the (hop-padded, reflect-padded) signal a tile's 128 frames read, one load batch per tile, REQUESTED a tile ahead (their
+    // latency runs under the MFMAs and stores of the tile before); the barriers between tiles order LDS only (aero_lds_barrier) -- a
+    // __syncthreads() there also waited for the tile's output stores to be acknowledged; only the first one covers the table copies.
+    // (hipcc still waits vmcnt(0) where the prefetched values are first used, behind the stores: the stores sit in branches (t < T), so
+    // it cannot count them.)
+    constexpr int NV = (AERO_DFT_SPAN + 511) / 512;
+    float v[NV];
+    auto span_index = [&](int tl, int u, bool& ok) {
+        const int j = tid + u * 512;
+        int xi = tl * 128 * hop + j + p.win_off - (n_fft >> 1);
+        if (xi < 0) xi = -xi;
+        if (xi >= p.Lp) xi = 2 * (p.Lp - 1) - xi;
+        ok = j < span && xi >= 0 && xi < p.L;
+        return ok ? xi : 0;
+    };
+    auto fetch_span = [&](int tl) {                              // unconditional loads, used raw: the zero padding is applied where the
+#pragma unroll                                                   // values are consumed (a select right behind a load is a wait right behind it)
+        for (int u = 0; u < NV; ++u) {
+            bool ok;
+            v[u] = xs[span_index(tl, u, ok)];
+        }
+    };
+    if ((int)blockIdx.x < ntile) fetch_span((int)blockIdx.x);
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int t0 = tile * 128;
-    // the span of the (hop-padded, reflect-padded) signal the tile's 128 frames read: split into hi + lo fp16.  All loads first.
     {
-        constexpr int NV = (AERO_DFT_SPAN + 511) / 512;
-        float v[NV];
+        if (tile != (int)blockIdx.x) aero_lds_barrier();         // the previous tile's fragment reads of xh / xl are done
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int j = tid + u * 512;
-            int xi = t0 * hop + j + p.win_off - (n_fft >> 1);
-            if (xi < 0) xi = -xi;
-            if (xi >= p.Lp) xi = 2 * (p.Lp - 1) - xi;
-            v[u] = (j < span && xi >= 0 && xi < p.L) ? xs[xi] : 0.f;
-        }
-        if (tile != (int)blockIdx.x) __syncthreads();            // the previous tile's fragment reads of xh / xl are done
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int j = tid + u * 512;
+            bool ok;
+            (void)span_index(tile, u, ok);
+            const float x = ok ? v[u] : 0.f;
             if (j < span) {
-                const h16 hi = (h16)v[u];
+                const h16 hi = (h16)x;
                 xh[j] = hi;
-                xl[j] = (h16)(v[u] - (float)hi);
+                xl[j] = (h16)(x - (float)hi);
             }
         }
+        if (tile + (int)gridDim.x < ntile) fetch_span(tile + (int)gridDim.x);
     }
     f32x4 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();                                             // table slice (vmcnt drained) and span are in
+    if (tile == (int)blockIdx.x) __syncthreads();                // first tile: the table slice's direct copies have landed (vmcnt drained) ...
+    else aero_lds_barrier();                                     // ... later tiles: the span only
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
         h16x8 ah[2], al[2];
@@ -678,6 +846,18 @@ static int aero_istft_launch(const float* spec, int nsig, int F, int T, int n_ff
     AeroIstftK p;
     p.spec = spec; p.window = window; p.inv_env = inv_env; p.y = y;
     p.nsig = nsig; p.F = F; p.T = T; p.n_fft = n_fft; p.hop = hop; p.Lout = Lout;
+    static const int v2 = [] { const char* e = getenv("AERO_ISTFT_V2"); return e ? atoi(e) : 1; }();
+    if (v2 && aero_istft2_ok(n_fft, hop, T)) {
+        p.hsh = aero_ilog2(hop);
+        p.FPB = 0;
+        p.SEG = 0;
+        const int segs = hop * AERO_ISTFT2_SEGF;
+        dim3 grid2((unsigned)((Lout + segs - 1) / segs), (unsigned)nsig);
+        const size_t lds2 = aero_istft2_lds_bytes(n_fft);
+        if (n == 256) AERO_LAUNCH_DYN((aero_istft2_kernel<8>), grid2, dim3(512), lds2, stream, p);
+        else AERO_LAUNCH_DYN((aero_istft2_kernel<9>), grid2, dim3(512), lds2, stream, p);
+        return AERO_OK;
+    }
     const int fpb = aero_istft_fpb(n);
     const int need = (n_fft + hop - 1) / hop;              // frames overlapping one sample
     if (fpb <= need) { *err = "istft: hop too small for the LDS frame ring"; return AERO_ERR_UNSUPPORTED; }

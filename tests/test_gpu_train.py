@@ -168,3 +168,38 @@ def test_captured_training_step_matches_eager(meta):
     assert all(abs(a - b) < 1e-2 * abs(a) for a, b in zip(h0, h1)), (h0, h1)
     assert h0[2] < h0[0] and h1[2] < h1[0]
     assert rel_l2(p1.cpu(), p0.cpu()) < 1e-2        # (5 sign-like Adam updates of 1e-4 on weights of ~0.05: the bound of what can differ)
+
+
+def test_training_tracks_the_reference_loss_trajectory(meta):
+    """30 steps of the reference's own training loop (fp32 CPU: its Aero in train mode, its MultiResolutionSTFTLoss,
+    torch.optim.Adam(lr 3e-4, betas (0.9, 0.999)) as train.py:83 builds it) on one fixed batch are committed as a golden
+    (oracle/make_golden_train.py -> tests/golden/train_small_trajectory.npz).  The HIP loop -- fp16 activation / gradient storage, the
+    loss on the HIP STFT, the fused FlatAdam -- must follow that trajectory: every step's loss within 2 %, the last within 1 %.
+    (The loss falls from 2.07 to 0.70 over these steps: a loop that drifted, stalled or mis-scaled an update would leave that corridor.)"""
+    from aero_amd import Aero, losses
+    from aero_amd.optim import FlatAdam
+    cfgt = meta['train_small_trajectory']
+    gold = load_npz('train_small_trajectory.npz')['loss']                # [steps, {sc, mag}]
+    torch.manual_seed(cfgt['model_seed'])
+    m = Aero(**dict(meta['small_cfg'])).cuda().train()
+    opt = FlatAdam(m.parameters(), lr=cfgt['lr'], betas=tuple(cfgt['betas']), model=m)
+    crit = losses.MultiResolutionSTFTLoss(factor_sc=cfgt['factor_sc'], factor_mag=cfgt['factor_mag'])
+    x = seeded((2, 1, cfgt['L']), cfgt['x_seed']).cuda()
+    hr = (cfgt['hr_scale'] * seeded((2, 1, 4 * cfgt['L']), cfgt['hr_seed'])).cuda()
+    got = []
+    for _ in range(cfgt['steps']):
+        y = m(x)
+        sc, mg = crit(y.squeeze(1), hr.squeeze(1))
+        opt.zero_grad()
+        (sc + mg).backward()
+        opt.step()
+        got.append((float(sc.detach()), float(mg.detach())))
+    got = torch.tensor(got, dtype=torch.float64)
+    ref = torch.from_numpy(gold)
+    tot_g, tot_r = got.sum(1), ref.sum(1)
+    rel = ((tot_g - tot_r).abs() / tot_r)
+    print('trajectory: max relative deviation %.3e (step %d), last step %.3e; first / last loss %.4f / %.4f (reference %.4f / %.4f)' % (
+        float(rel.max()), int(rel.argmax()), float(rel[-1]), float(tot_g[0]), float(tot_g[-1]), float(tot_r[0]), float(tot_r[-1])))
+    assert float(rel.max()) < 2e-2, (rel.tolist(), got.tolist())
+    assert float(rel[-1]) < 1e-2
+    assert float(((got - ref).abs() / ref).max()) < 4e-2                # each term (sc, mag) on its own
