@@ -203,6 +203,11 @@ _PROTOS = {
     'aero_rescale_f16': (i32, [vp, fp, vp, fp, i64, vp, C.c_float, vp, fp, vp]),
     'aero_gconv1d_fwd': (i32, [C.POINTER(GconvDesc), vp]),
     'aero_pw_fwd': (i32, [C.POINTER(PwDesc), vp]),
+    'aero_comm_unique_id': (i32, [vp]),
+    'aero_comm_init': (i32, [i32, i32, vp, C.POINTER(vp)]),
+    'aero_allreduce_f32': (i32, [vp, fp, i64, vp]),
+    'aero_allgather': (i32, [vp, vp, vp, i64, vp]),
+    'aero_comm_destroy': (i32, [vp]),
     'aero_pw_rows': (i32, [i32, i32]),
     'aero_leaky_relu': (i32, [vp, i64, C.c_float, vp]),
     'aero_avgpool1d': (i32, [vp, vp, i32, i32, vp]),

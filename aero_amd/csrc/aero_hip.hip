@@ -78,18 +78,72 @@ static int aero_finish(int rc, const char* err) {
     return AERO_OK;
 }
 
+// RCCL (dlopen()ed on first use) for the aero_comm_* entry points of part 0 -- see the end of this file
+#if AERO_IN(0)
+#ifndef AERO_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct AeroRccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+AeroRccl* aero_rccl() {
+    static AeroRccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        r.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.h) r.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (r.h) {
+            r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+            r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+            r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+            r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+            r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+        }
+    }
+    return (r.h && r.GetUniqueId && r.CommInitRank && r.AllReduce && r.AllGather && r.CommDestroy) ? &r : nullptr;
+}
+int aero_rccl_rc(AeroRccl* r, ncclResult_t rc, const char* what) {
+    if (rc == ncclSuccess) return AERO_OK;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, r->GetErrorString ? r->GetErrorString(rc) : "RCCL error");
+    return AERO_ERR_LAUNCH;
+}
+}  // namespace
+#endif
+#endif
+
 extern "C" {
 
 // ---------------------------------------------------------------------------------------------------------------
 // part 0 -- core: version / errors / kernel names; GroupNorm, Gram statistics, LSTM, LocalState, Adam   (k_norm.h k_gram.h k_lstm.h k_attn.h k_optim.h)
 #if AERO_IN(0)
 
+// Every AERO_* variable present in the environment is a departure from the tested configuration ("all defaults"): the version string
+// names them, so that a stray switch on a user's box shows up in the first line a bug report quotes (hygiene).
+extern char** environ;
 const char* aero_version(void) {
+    static thread_local char ver[768];
 #ifdef AERO_EMU
-    return "aero_hip 0.1 (CPU emulation build -- tests only)";
+    int n = snprintf(ver, sizeof(ver), "aero_hip 0.1 (CPU emulation build -- tests only)");
 #else
-    return "aero_hip 0.1 (gfx950)";
+    int n = snprintf(ver, sizeof(ver), "aero_hip 0.1 (gfx950)");
 #endif
+    bool first = true;
+    for (char** e = environ; e && *e; ++e) {
+        if (strncmp(*e, "AERO_", 5) != 0) continue;
+        if (n >= (int)sizeof(ver) - 8) break;
+        n += snprintf(ver + n, sizeof(ver) - n, "%s%.60s", first ? "; non-default switches: " : " ", *e);
+        first = false;
+    }
+    return ver;
 }
 
 const char* aero_last_error(void) { return g_err; }
@@ -554,5 +608,70 @@ int aero_pw_rows(int32_t C, int32_t M) {
 }
 
 #endif  // part 7
+
+// ---------------------------------------------------------------------------------------------------------------
+// part 0 (cont.) -- RCCL over xGMI behind the same C ABI (aero_comm_*): what a non-Python host needs to shard clips over the
+// GPUs of a node and average gradients -- a communicator per process (one process per GPU), an in-place fp32 sum and an all-gather.
+// librccl.so is opened at the first aero_comm_* call (dlopen): the library has no link-time dependency on it, and a single-GPU user
+// never loads it.  The Python host side does not use these entry points: torch.distributed's "nccl" backend IS RCCL (aero_amd/distrib.py).
+#if AERO_IN(0)
+int aero_comm_unique_id(void* id128) {
+#ifdef AERO_EMU
+    return aero_fail(AERO_ERR_UNSUPPORTED, "comm: not available in the emulation build");
+#else
+    AeroRccl* r = aero_rccl();
+    if (!r) return aero_fail(AERO_ERR_UNSUPPORTED, "comm: librccl.so could not be opened");
+    if (!id128) return aero_fail(AERO_ERR_ARG, "comm_unique_id: null pointer");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    return aero_rccl_rc(r, r->GetUniqueId((ncclUniqueId*)id128), "ncclGetUniqueId");
+#endif
+}
+
+int aero_comm_init(int32_t rank, int32_t world, const void* unique_id_bytes, void** comm) {
+#ifdef AERO_EMU
+    return aero_fail(AERO_ERR_UNSUPPORTED, "comm: not available in the emulation build");
+#else
+    AeroRccl* r = aero_rccl();
+    if (!r) return aero_fail(AERO_ERR_UNSUPPORTED, "comm: librccl.so could not be opened");
+    if (!unique_id_bytes || !comm || world < 1 || rank < 0 || rank >= world) return aero_fail(AERO_ERR_ARG, "comm_init: bad arguments");
+    ncclUniqueId id;
+    memcpy(&id, unique_id_bytes, sizeof(id));
+    ncclComm_t c = nullptr;
+    const int rc = aero_rccl_rc(r, r->CommInitRank(&c, world, id, rank), "ncclCommInitRank");
+    *comm = (void*)c;
+    return rc;
+#endif
+}
+
+int aero_allreduce_f32(void* comm, float* buf, int64_t n, void* stream) {
+#ifdef AERO_EMU
+    return aero_fail(AERO_ERR_UNSUPPORTED, "comm: not available in the emulation build");
+#else
+    AeroRccl* r = aero_rccl();
+    if (!r || !comm || !buf || n < 0) return aero_fail(AERO_ERR_ARG, "allreduce_f32: bad arguments (or no communicator)");
+    return aero_rccl_rc(r, r->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)comm, (hipStream_t)stream), "ncclAllReduce");
+#endif
+}
+
+int aero_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream) {
+#ifdef AERO_EMU
+    return aero_fail(AERO_ERR_UNSUPPORTED, "comm: not available in the emulation build");
+#else
+    AeroRccl* r = aero_rccl();
+    if (!r || !comm || !send || !recv || bytes_per_rank < 0) return aero_fail(AERO_ERR_ARG, "allgather: bad arguments (or no communicator)");
+    return aero_rccl_rc(r, r->AllGather(send, recv, (size_t)bytes_per_rank, ncclInt8, (ncclComm_t)comm, (hipStream_t)stream), "ncclAllGather");
+#endif
+}
+
+int aero_comm_destroy(void* comm) {
+#ifdef AERO_EMU
+    return aero_fail(AERO_ERR_UNSUPPORTED, "comm: not available in the emulation build");
+#else
+    AeroRccl* r = aero_rccl();
+    if (!r || !comm) return aero_fail(AERO_ERR_ARG, "comm_destroy: no communicator");
+    return aero_rccl_rc(r, r->CommDestroy((ncclComm_t)comm), "ncclCommDestroy");
+#endif
+}
+#endif  // part 0 (cont.)
 
 }  // extern "C"

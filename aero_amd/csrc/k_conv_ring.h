@@ -547,15 +547,15 @@ AERO_XPART bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStr
     const int bm = aero_conv_ring_pick_bm(d->M, p.Ktot);
     if (!bm || !d->weight_tiled || d->tiled_bm != bm || ((uintptr_t)d->weight_tiled & 15)) return false;
     if ((long)d->B * d->Fout * ((d->T + 255) / 256) * (d->M / bm) > 0x7fffffffL) return false;
-    // three unit-stride time taps share one activation slab; any other tap grid: one tile per tap (256- and 192-row tiles only:
+    // three unit-stride time taps share one activation slab; any other tap grid: one tile per tap (256-row tile only:
     // the 512-step tiles have no LDS for four full activation tiles)
     const bool slab3 = p.nT == 3 && p.t_step == 1;
     if (bm == 256) {
         if (slab3) aero_conv_ring_go<2, 4, 4, 3>(p, stream, name);
         else aero_conv_ring_go<2, 4, 4, 1>(p, stream, name);
-    } else if (bm == 192 && !slab3) {
-        aero_conv_ring_go<2, 4, 3, 1>(p, stream, name);          // (112 KiB of rings: the encoder's strided [8,1] convs with M = 384)
-    } else if (!slab3) {
+    } else if (!slab3) {                                         // (round 4: the 192-row tile with one slab per tap, <2,4,3,1>, was tried for the
+        // encoder's strided [8,1] conv with M = 384: 173 us against 168 us on the glds8 tile, and the B = 32 forward no longer matched
+        // its two B = 16 halves (2.7e-4) -- the one-phase / one-tap-per-slab combination of the pipeline is unvalidated: not used)
         return false;
     } else if (bm == 192) {
         aero_conv_ring_go<2, 4, 3, 3>(p, stream, name);

@@ -557,6 +557,18 @@ int aero_loss_grad(const void* a, const void* b, int64_t n, float sign, float co
 /* (gl: optional device scalar multiplied into coef for modes 0 / 1 -- the upstream factor of the loss, read on the device) */
 int aero_avgpool1d_bwd(const void* dy, void* dx, int32_t B, int32_t T, void* stream);      /* adjoint of aero_avgpool1d */
 
+/* RCCL over xGMI behind the same ABI (replaces the NCCL process group of the reference's src/ddp/distrib.py:16-34 for a
+ * host that is not PyTorch).  One communicator per process, one process per GPU (hipSetDevice first).  Rank 0 calls aero_comm_unique_id
+ * and hands the 128 bytes to the other ranks by any host channel; every rank then calls aero_comm_init with the same bytes.
+ * aero_allreduce_f32: in-place SUM of n floats (a flat gradient buffer; the mean's 1 / world goes into the optimizer step).
+ * aero_allgather: recv = concatenation over ranks of `bytes_per_rank` bytes (clip results in rank order, distrib.py:100).
+ * librccl.so is dlopen()ed at the first of these calls: no link-time dependency, AERO_ERR_UNSUPPORTED if it is not installed. */
+int aero_comm_unique_id(void* id128);
+int aero_comm_init(int32_t rank, int32_t world, const void* unique_id_bytes, void** comm);
+int aero_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
+int aero_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+int aero_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

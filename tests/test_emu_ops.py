@@ -78,7 +78,6 @@ def test_istft(emu, geom):
     dict(Cin=2, Cout=5, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=7, T=300, act='relu'),
     dict(Cin=12, Cout=96, kF=1, kT=1, stride=1, padF=0, padT=0, Fin=4, T=45),                           # 8-byte aligned rows (h16x4 loads)
     dict(Cin=20, Cout=40, kF=3, kT=3, stride=1, padF=1, padT=1, Fin=3, T=50, split=12),
-    dict(Cin=96, Cout=384, kF=8, kT=1, stride=2, padF=3, padT=0, Fin=6, T=300, B=1),                   # strided taps on the 192-row ring tile (one slab per tap)
 ])
 def test_conv2d(emu, kw):
     oc.case_conv2d(emu, DEV, **kw)

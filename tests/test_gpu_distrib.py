@@ -79,3 +79,27 @@ def test_bench_refuses_more_gpus_than_visible():
                          capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items()
                                                                            if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
     assert out.returncode != 0 and 'visible' in (out.stderr + out.stdout)
+
+
+def test_comm_entry_points_world_size_1():
+    """the RCCL-backed C entry points (include/aero_hip.h: aero_comm_*) with a one-rank communicator on the MI355X: an in-place sum
+    over one rank leaves the buffer as it was, an all-gather of one rank is a copy"""
+    import ctypes as C
+    from aero_amd import _lib
+    lib = _lib.load()
+    uid = (C.c_char * 128)()
+    lib.call('aero_comm_unique_id', C.cast(uid, C.c_void_p))
+    comm = C.c_void_p()
+    torch.cuda.set_device(0)
+    lib.call('aero_comm_init', 0, 1, C.cast(uid, C.c_void_p), C.byref(comm))
+    assert comm.value
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.arange(1000, dtype=torch.float32, device='cuda') * 0.5
+    ref = x.clone()
+    lib.call('aero_allreduce_f32', comm, x.data_ptr(), x.numel(), st)
+    out = torch.zeros(4000, dtype=torch.uint8, device='cuda')
+    lib.call('aero_allgather', comm, ref.data_ptr(), out.data_ptr(), 4000, st)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    assert torch.equal(out.view(torch.float32), ref)
+    lib.call('aero_comm_destroy', comm)
