@@ -31,6 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int WM, int WN, int NRB, int NT>
 struct AeroRingGeom {
     static constexpr int BM = WM * NRB * 32, BN = WN * 64;
+    static constexpr int NW = WM * WN;                                            // waves per block: 8, or 4 for the half-height tile <1,4,3>
     static constexpr int RBP = NRB == 3 ? 3 : 2;                                  // row blocks per phase: 4 MFMAs each
     static constexpr int NPH = NRB / RBP;                                         // phases per K-chunk
     static constexpr int NSA = 4;                                                 // A ring: one [BM][32] tile per slot
@@ -40,8 +41,8 @@ struct AeroRingGeom {
     static constexpr int LB = NT > 1 ? 2 : 3;                                     // groups between a slab copy and its use
     static constexpr int NSB = LB + 1;
     static constexpr int A_SLOT = BM * 32, B_SLOT = SLABR * 32;                   // h16 elements
-    static constexpr int NA = (BM / 16 + 7) / 8;                                  // A copies per wave and chunk
-    static constexpr int NBG = (SLABI + 7) / 8;                                   // slab copies per wave and group
+    static constexpr int NA = (BM / 16 + NW - 1) / NW;                            // A copies per wave and chunk
+    static constexpr int NBG = (SLABI + NW - 1) / NW;                             // slab copies per wave and group
     static constexpr int CS = BM + 8;                                             // epilogue staging row (h16), padded
     static constexpr int EPI = WN * 32 * CS;
     static constexpr int RING = NSA * A_SLOT + NSB * B_SLOT;
@@ -70,7 +71,8 @@ static __device__ __forceinline__ void aero_ring_epilogue(const AeroConvK& p, f3
     constexpr int BMo = GLU ? G::BM / 2 : G::BM;
     constexpr int NVEC = BMo / 8;
     constexpr int NPOS = WN * 32;
-    constexpr int NIT = (NPOS * NVEC + 511) / 512;
+    constexpr int NTH = G::NW * 64;
+    constexpr int NIT = (NPOS * NVEC + NTH - 1) / NTH;
     const aero_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -127,7 +129,7 @@ static __device__ __forceinline__ void aero_ring_epilogue(const AeroConvK& p, f3
         aero_lds_barrier();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 512;
+            const int idx = tid + it * NTH;
             const int pos = idx / NVEC, cv = idx - pos * NVEC;
             const int t = t0 + (pos >> 5) * 64 + cb * 32 + (pos & 31);
             if (idx < NPOS * NVEC && t < T && m0o + cv * 8 < Mout)
@@ -161,7 +163,7 @@ static __device__ __forceinline__ void aero_ring_epilogue(const AeroConvK& p, f3
 // in the loop, 4 no fragment reads in the loop, 8 no interleave hints, 32 no counted vmcnt wait, 64 every copy reads the
 // zero page, 128 no K loop at all (prologue + epilogue only)
 template <int WM, int WN, int NRB, int NT, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void aero_conv_ring_kernel(AeroConvK p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void aero_conv_ring_kernel(AeroConvK p) {
     typedef AeroRingGeom<WM, WN, NRB, NT> G;
     constexpr int BM = G::BM, BN = G::BN, NPH = G::NPH, NA = G::NA, NBG = G::NBG, NSA = G::NSA, NSB = G::NSB, RBP = G::RBP;
     constexpr int KC = 32;
@@ -174,11 +176,18 @@ __global__ __launch_bounds__(512, 2) void aero_conv_ring_kernel(AeroConvK p) {
     // share of the grid and streams activations; with the M-tile fastest the 10-20 MB weight images are re-streamed
     // through every XCD's 4-MB L2 (HBM-side traffic of the first decoder conv: 3.8 GB -> 1.6 GB per launch)
     int id = aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    // (p.tsplit, unused by this kernel otherwise, carries the block order: 2 = the M-tiles of one (row, time tile) are NEIGHBOURS --
+    // for a weight image that stays in L2 anyway it is the activation slab the second M-tile should find there)
+    int mt_f = 0;
+    if (p.tsplit == 2) {
+        mt_f = id % p.nmt;
+        id /= p.nmt;
+    }
     const int tt = id % p.ntt;
     id /= p.ntt;
     const int nrow = d.B * d.Fout;
     const int row = id % nrow;
-    const int mt = id / nrow;
+    const int mt = p.tsplit == 2 ? mt_f : id / nrow;
     const int b = row / d.Fout, fo = row - b * d.Fout;
     const int m0 = mt * BM, t0 = tt * BN;
     const int wset = d.transposed ? (fo % d.fstride) : 0;
@@ -208,14 +217,14 @@ __global__ __launch_bounds__(512, 2) void aero_conv_ring_kernel(AeroConvK p) {
     const h16* base1 = s1 ? s1 + (int64_t)b * d.s1_b - C0 : zp;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        int s = wave + 8 * i;
+        int s = wave + G::NW * i;
         if (s >= BM / 16) s -= BM / 16;                       // uniform copy count per wave: a surplus wave repeats a piece
         a_ptr[i] = Wt + (s * 512 + lane * 8);
         a_slot_off[i] = s * 512;
     }
 #pragma unroll
     for (int i = 0; i < NBG; ++i) {
-        int s = wave + 8 * i;
+        int s = wave + G::NW * i;
         if (s >= G::SLABI) s = G::SLABI - 1;                  // (the halo piece: every wave copies it, identical bytes)
         const int pos = s * 16 + (lane >> 2), q = (lane & 3) ^ aero_tile_swz<KC>(pos);
         b_pos[i] = pos;
@@ -494,6 +503,12 @@ static int aero_conv_ring_pick_bm(int M, int Ktot) {
     if (M % 256 == 0 && Ktot >= 1024) return 256;
     static int no192 = -1;                                       // AERO_RING_TILE192=0: 128 / 64-row x 512-step tiles instead of the 192 x 256 one (A/B)
     if (no192 < 0) { const char* e = getenv("AERO_RING_TILE192"); no192 = (e && e[0] == '0') ? 1 : 0; }
+    // AERO_RING_HALF=1 (round-4 experiment): 96-row x 256-step tiles on FOUR waves, two blocks per CU, for the short contractions of the
+    // last two decoder convs: a 192-row block spends ~40 % of its life in prologue / epilogue / relaunch with the CU to itself; two
+    // independent half-height blocks overlap each other's
+    static int half = -1;
+    if (half < 0) { const char* e = getenv("AERO_RING_HALF"); half = e ? atoi(e) : 0; }
+    if (mode >= 2 && half && M % 96 == 0 && M <= 384 && Ktot >= 768 && Ktot <= 2048) return 96;
     if (mode >= 2 && !no192 && M % 192 == 0 && Ktot >= 768) return 192;
     if (mode >= 2 && M % 128 == 0 && Ktot >= 768) return 128;
     if (mode >= 2 && M % 64 == 0 && Ktot >= 768) return 64;
@@ -511,7 +526,7 @@ static void aero_conv_ring_go(AeroConvK& p, hipStream_t stream, char* name) {
         return;
     }
     const long nwg = (long)d.B * d.Fout * p.ntt * p.nmt;
-    const dim3 grid((unsigned)nwg), block(512);
+    const dim3 grid((unsigned)nwg), block(G::NW * 64);
     const size_t lds = G::SMEM * sizeof(h16);
 #ifdef AERO_RING_ABLATION
     if constexpr (WM == 2 && NT == 3) {
@@ -557,6 +572,10 @@ AERO_XPART bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStr
         // encoder's strided [8,1] conv with M = 384: 173 us against 168 us on the glds8 tile, and the B = 32 forward no longer matched
         // its two B = 16 halves (2.7e-4) -- the one-phase / one-tap-per-slab combination of the pipeline is unvalidated: not used)
         return false;
+    } else if (bm == 96) {
+        p.tsplit = 2;                                            // M-tiles adjacent (see the kernel's block order)
+        aero_conv_ring_go<1, 4, 3, 3>(p, stream, name);
+        p.tsplit = 1;
     } else if (bm == 192) {
         aero_conv_ring_go<2, 4, 3, 3>(p, stream, name);
     } else if (bm == 128) {
