@@ -503,12 +503,14 @@ static int aero_conv_ring_pick_bm(int M, int Ktot) {
     if (M % 256 == 0 && Ktot >= 1024) return 256;
     static int no192 = -1;                                       // AERO_RING_TILE192=0: 128 / 64-row x 512-step tiles instead of the 192 x 256 one (A/B)
     if (no192 < 0) { const char* e = getenv("AERO_RING_TILE192"); no192 = (e && e[0] == '0') ? 1 : 0; }
-    // AERO_RING_HALF=1 (round-4 experiment): 96-row x 256-step tiles on FOUR waves, two blocks per CU, for the short contractions of the
-    // last two decoder convs: a 192-row block spends ~40 % of its life in prologue / epilogue / relaunch with the CU to itself; two
-    // independent half-height blocks overlap each other's
+    // 96-row x 256-step tiles on FOUR waves (two 77-KiB blocks per CU) for contractions with exactly 96 rows (the dilated Conv1d of the
+    // deepest DConv: K = 3 x 384): 66 -> 44 us against the 4-wave glds tile.  AERO_RING_HALF=2 also gives the 192 / 384-row decoder convs
+    // this tile (round-4 experiment: 694 -> 666 us and 821 -> 831 us -- neutral: those loops are bound by LDS operand bandwidth, ~107 of
+    // 128 B/clk per CU for a 96 x 64 wave tile, not by the per-block prologue / epilogue a second resident block would hide); 0 = off
     static int half = -1;
-    if (half < 0) { const char* e = getenv("AERO_RING_HALF"); half = e ? atoi(e) : 0; }
-    if (mode >= 2 && half && M % 96 == 0 && M <= 384 && Ktot >= 768 && Ktot <= 2048) return 96;
+    if (half < 0) { const char* e = getenv("AERO_RING_HALF"); half = e ? atoi(e) : 1; }
+    if (mode >= 2 && half && M == 96 && Ktot >= 768) return 96;
+    if (mode >= 2 && half >= 2 && M % 96 == 0 && M <= 384 && Ktot >= 768 && Ktot <= 2048) return 96;
     if (mode >= 2 && !no192 && M % 192 == 0 && Ktot >= 768) return 192;
     if (mode >= 2 && M % 128 == 0 && Ktot >= 768) return 128;
     if (mode >= 2 && M % 64 == 0 && Ktot >= 768) return 64;
