@@ -424,6 +424,10 @@ class _ShapeCache(dict):
 
 
 class HipEngine:
+    use_pw = os.environ.get('AERO_PW', '1') != '0'              # (class default: tests build bare engines with __new__)
+    stagger = 0
+    prof_streams = False
+
     def __init__(self, model, lib=None):
         self.model = model
         self.lib = lib if lib is not None else _lib.load()
@@ -603,13 +607,16 @@ class HipEngine:
                 L['lstm'] = [pack.pack_lstm_layer(self.lib, sd, f'{q}.lstm.lstm', l, H, device) for l in range(2)]
                 w = sd[f'{q}.lstm.linear.weight']
                 L['lstm_lin'] = mk(w[None, :, None, :], sd[f'{q}.lstm.linear.bias'], w.shape[1], 0, [0], [0], device)
+                L['lstm_lin_pw'] = pack.make_pw_spec(w, sd[f'{q}.lstm.linear.bias'], ACT_NONE, self.lib, device)
             if dc.time_attn:
                 a = f'{q}.time_attn'
                 w = torch.cat([sd[f'{a}.{n}.weight'][:, :, 0] for n in ('query', 'key', 'content', 'query_decay')], 0)
                 b = torch.cat([sd[f'{a}.{n}.bias'] for n in ('query', 'key', 'content', 'query_decay')], 0)
                 L['attn_qkvd'] = mk(w[None, :, None, :], b, w.shape[1], 0, [0], [0], device)
+                L['attn_qkvd_pw'] = pack.make_pw_spec(w, b, ACT_NONE, self.lib, device)
                 w = sd[f'{a}.proj.weight'][:, :, 0]
                 L['attn_proj'] = mk(w[None, :, None, :], sd[f'{a}.proj.bias'], w.shape[1], 0, [0], [0], device)
+                L['attn_proj_pw'] = pack.make_pw_spec(w, sd[f'{a}.proj.bias'], ACT_NONE, self.lib, device)
                 mod = dc.layers[d]['time_attn']
                 L['attn_geom'] = (mod.heads, mod.ndecay)
             w, df, dt = pack.conv1d_taps(sd[f'{q}.conv2.0.weight'], 1, 0)
@@ -1010,9 +1017,13 @@ class HipEngine:
                 h = self._blstm(dc, L, h, B, Fo, T)
             if 'attn_qkvd' in L:
                 heads, ndecay = L['attn_geom']
-                qkvd = ops.conv(L['attn_qkvd'], h, None, B, Fo, Fo, T)
+                pwq, pwp = (L.get('attn_qkvd_pw'), L.get('attn_proj_pw')) if (self.use_pw and h.is_contiguous()) else (None, None)
+                qkvd = ops.pw(pwq, h, B, Fo, T) if pwq is not None else ops.conv(L['attn_qkvd'], h, None, B, Fo, Fo, T)
                 att = ops.localstate(qkvd, B * Fo, T, dc.hidden, heads, ndecay)
-                h = ops.conv(L['attn_proj'], att.view(B, Fo, T, dc.hidden), None, B, Fo, Fo, T, res=h)
+                if pwp is not None:
+                    h = ops.pw(pwp, att.view(B, Fo, T, dc.hidden), B, Fo, T, res=h)
+                else:
+                    h = ops.conv(L['attn_proj'], att.view(B, Fo, T, dc.hidden), None, B, Fo, Fo, T, res=h)
             if g2 is not None and self.fuse_dconv_tail and L['conv2_glu'].M % 16 == 0 and L['conv2_glu'].C0 % 8 == 0:
                 # pass 0: statistics of conv2(h) only (nothing stored); pass 1: recompute, normalise, GLU, scale, + skip
                 st2 = ops.new_stats(B, Fo, 1, True, x.device)
@@ -1089,6 +1100,8 @@ class HipEngine:
         else:
             xp1 = ops.conv(pj1, out0.view(nseq, 1, W, 2 * H), None, nseq, 1, 1, W)  # [nseq,1,W,8H]
             ops.lstm(xp1, xb1, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1)
+        if self.use_pw and L.get('lstm_lin_pw') is not None:
+            return ops.pw(L['lstm_lin_pw'], out1.view(B, Fo, T, 2 * H), B, Fo, T, res=h)
         return ops.conv(L['lstm_lin'], out1.view(B, Fo, T, 2 * H), None, B, Fo, Fo, T, res=h)
 
     def _decode(self, j, dec, L, x, skip, B, Fq, T, mean, std):

@@ -32,7 +32,7 @@ PEAK_HBM_GBS = 8000.0              # HBM3E spec peak, same table
 
 
 INFERENCE_KERNEL_SOURCES = ('aero_common.h', 'k_attn.h', 'k_conv.h', 'k_conv_ring.h', 'k_dconv.h', 'k_enc0.h', 'k_ftb.h', 'k_gram.h', 'k_lstm.h',
-                            'k_norm.h', 'k_stft.h')
+                            'k_norm.h', 'k_pw.h', 'k_stft.h')
 
 
 def kernels_sha():
@@ -348,7 +348,7 @@ def main():
                 stamp = table.get('_meta', {})
                 if stamp.get('kernels_sha') != kernels_sha():
                     traffic_note = (f"PMC visit {stamp.get('kernels_sha', '(unstamped)')} predates the current kernel sources {kernels_sha()}: "
-                                    'omitted rather than reported stale (re-run tools/gpu/r3_evidence.sh)')
+                                    'omitted rather than reported stale (re-run tools/gpu/r4_evidence.sh)')
                 else:
                     ent = table.get(dom.replace('void ', '').split('(')[0])
                     traffic = ent['bytes'] if ent else None   # HBM-side bytes per launch (rocprofv3 --pmc, see tools/pmc_traffic.py)
