@@ -287,6 +287,146 @@ __global__ __launch_bounds__(256) void aero_norm_apply_kernel(aero_norm_desc d, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// aero_norm_apply, fast form (round 4) for 8-channel vectors.  Same arithmetic as aero_norm_apply_kernel<8>; what changes is what the
+// streaming pointwise kernel (k_pw.h) taught about hipcc and memory latency:
+//   * the activation and the residual are TEMPLATE parameters: nothing is decided per element;
+//   * the per-channel coefficients (statistics -> rstd, gamma, beta, LayerScale, the GLU gate's -log2 e) are computed ONCE PER BLOCK into
+//     LDS by the first threads instead of by every thread for its own channels (fp64 moments per thread were the whole cost of a block
+//     that then streams six time steps);
+//   * loads are UNCONDITIONAL (time index clamped into the chunk) and used raw; a predicated load is a branch, and with branches between
+//     a prefetch and its use the compiler waits vmcnt(0) -- for the loads it has just issued;
+//   * the next trip's loads are issued before the current trip's arithmetic; the loop is entered with nothing in flight.
+// grid (t-chunks, F, B) and thread -> (channel vector, time lane) as the general kernel: results are bit-identical to it.
+template <int ACT, bool RES>
+__global__ __launch_bounds__(256) void aero_norm_apply_fast_kernel(aero_norm_desc d, int tchunk) {
+    constexpr int VEC = 8, UNR = 4;
+    constexpr bool GLU = ACT == AERO_ACT_GLU;
+    float* cA = (float*)AERO_DYN_SMEM;                           // [Cout] x {A, B, A2, B2}
+    const int Cout = GLU ? d.C / 2 : d.C;
+    float* cB = cA + Cout;
+    float* cA2 = cB + Cout;
+    float* cB2 = cA2 + Cout;
+    const int vpp = Cout / VEC;
+    const int TY = 256 / vpp;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, f = blockIdx.y;
+    const int item = d.per_row == 1 ? b * d.F + f : (d.per_row == 2 ? 0 : b);
+    const int gs = d.C / d.G;
+    const double inv_count = d.stats ? 1.0 / d.stat_count : 0.0;
+    for (int cc = tid; cc < d.C; cc += 256) {                    // conv channel cc: value half (cc < Cout) or gate half
+        float a = 1.f, bb = 0.f;
+        if (d.stats) {
+            const double* st = d.stats + ((int64_t)item * d.G + cc / gs) * 2;
+            const double mean = st[0] * inv_count;
+            double var = st[1] * inv_count - mean * mean;
+            if (var < 0) var = 0;
+            const float vf = (float)var + d.eps;
+            float r = aero_rsqrt(vf);
+            r = r * (1.5f - 0.5f * vf * r * r);
+            a = r;
+            bb = -(float)mean * r;
+        }
+        if (d.gamma) {
+            const float gm = d.gamma[cc], bt = d.beta[cc];
+            a *= gm;
+            bb = bb * gm + bt;
+        }
+        if (cc < Cout) {
+            const float ls = (GLU && d.layer_scale) ? d.layer_scale[cc] : 1.f;
+            cA[cc] = GLU ? a * ls : a;
+            cB[cc] = GLU ? bb * ls : bb;
+        } else {
+            cA2[cc - Cout] = a * -1.4426950408889634f;
+            cB2[cc - Cout] = bb * -1.4426950408889634f;
+        }
+    }
+    __syncthreads();
+    const int v = tid % vpp, ty = tid / vpp;
+    if (ty >= TY) return;
+    const int c0 = v * VEC;
+    float A[VEC], Bc[VEC], A2[VEC], B2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        A[i] = cA[c0 + i];
+        Bc[i] = cB[c0 + i];
+        A2[i] = GLU ? cA2[c0 + i] : 0.f;
+        B2[i] = GLU ? cB2[c0 + i] : 0.f;
+    }
+    float snake_a = 0.f, snake_ia = 0.f;
+    if constexpr (ACT == AERO_ACT_SNAKE) { snake_a = d.snake_a[f]; snake_ia = 1.0f / snake_a; }
+    const h16* src = (const h16*)d.src + (int64_t)b * d.s_b + (int64_t)f * d.s_f + c0;
+    const h16* res = RES ? (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)f * d.r_f + c0 : nullptr;
+    h16* dst = (h16*)d.dst + (int64_t)b * d.d_b + (int64_t)f * d.d_f + c0;
+    const int t0 = blockIdx.x * tchunk;
+    const int t1 = (t0 + tchunk < d.T) ? t0 + tchunk : d.T;
+    const int tl = t1 - 1;
+    h16x8 cx[UNR], cz[UNR], cr[UNR], nx[UNR], nz[UNR], nr[UNR];
+    auto fetch = [&](h16x8 (&rx)[UNR], h16x8 (&rz)[UNR], h16x8 (&rr)[UNR], int t) {
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            int tk = t + k * TY;
+            tk = tk < tl ? tk : tl;                                // (clamped: the store is what is masked)
+            rx[k] = *(const h16x8*)(src + (int64_t)tk * d.s_t);
+            if constexpr (GLU) rz[k] = *(const h16x8*)(src + (int64_t)tk * d.s_t + Cout);
+            if constexpr (RES) rr[k] = *(const h16x8*)(res + (int64_t)tk * d.r_t);
+        }
+    };
+    int t = t0 + ty;
+    if (t < t1) fetch(cx, cz, cr, t);
+#ifndef AERO_EMU
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): clean scoreboard at the loop header (see k_pw.h)
+#endif
+#pragma unroll 1
+    for (; t < t1; t += UNR * TY) {
+        const int tn = t + UNR * TY;
+        fetch(nx, nz, nr, tn < t1 ? tn : t);
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int tk = t + k * TY;
+            h16x8 o;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float y = (float)cx[k][i] * A[i] + Bc[i];
+                float qv;
+                if constexpr (GLU) {
+                    const float g = (float)cz[k][i] * A2[i] + B2[i];
+                    qv = y * aero_rcp(aero_exp2(g) + 1.0f);
+                } else if constexpr (ACT == AERO_ACT_GELU) {
+                    qv = y;                                        // (pairs below: aero_gelu2 as the general kernel)
+                } else if constexpr (ACT == AERO_ACT_RELU) {
+                    qv = fmaxf(y, 0.f);
+                } else if constexpr (ACT == AERO_ACT_SNAKE) {
+                    const float sn = aero_fast_sin(y * snake_a);
+                    qv = y + (sn * sn) * snake_ia;
+                } else {
+                    qv = y;
+                }
+                if constexpr (ACT != AERO_ACT_GELU) {
+                    if constexpr (RES) qv += (float)cr[k][i];
+                    o[i] = (h16)qv;
+                } else {
+                    o[i] = (h16)0.f;
+                    if (i & 1) {
+                        const float y0 = (float)cx[k][i - 1] * A[i - 1] + Bc[i - 1];
+                        f32x2 gg = aero_gelu2((f32x2){y0, y});
+                        if constexpr (RES) gg += (f32x2){(float)cr[k][i - 1], (float)cr[k][i]};
+                        o[i - 1] = (h16)gg[0];
+                        o[i] = (h16)gg[1];
+                    }
+                }
+            }
+            if (tk < t1) *(h16x8*)(dst + (int64_t)tk * d.d_t) = o;
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            cx[k] = nx[k];
+            if constexpr (GLU) cz[k] = nz[k];
+            if constexpr (RES) cr[k] = nr[k];
+        }
+    }
+}
+
 static int aero_norm_pick_vec(int n, const void* p0, const void* p1, const void* p2, int64_t s0, int64_t s1, int64_t s2,
                               int64_t s3, int64_t s4, int64_t s5, int64_t s6, int64_t s7, int64_t s8) {
     const int64_t strides[9] = {s0, s1, s2, s3, s4, s5, s6, s7, s8};
@@ -365,6 +505,26 @@ static int aero_norm_apply_launch(const aero_norm_desc* d, hipStream_t stream, c
     const int TY = 256 / vpp;
     const int tchunk = aero_norm_tchunk(d->T, TY, (int64_t)64 * d->F, d->C * 2);
     dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)d->F, (unsigned)d->B), block(256);
+    static int fast = -1;
+    if (fast < 0) { const char* e = getenv("AERO_NORM_FAST"); fast = e ? atoi(e) : 1; }
+    if (fast && vec == 8 && (int64_t)d->T * d->s_t < (1ll << 31)) {
+        const size_t lds = (size_t)4 * Cout * sizeof(float);
+        const bool res = d->res != nullptr;
+#define AERO_NORM_FAST_GO(ACT_)                                                                                             \
+        do {                                                                                                                \
+            if (res) AERO_LAUNCH_DYN((aero_norm_apply_fast_kernel<ACT_, true>), grid, block, lds, stream, *d, tchunk);      \
+            else AERO_LAUNCH_DYN((aero_norm_apply_fast_kernel<ACT_, false>), grid, block, lds, stream, *d, tchunk);         \
+        } while (0)
+        switch (d->act) {
+            case AERO_ACT_GLU: AERO_NORM_FAST_GO(AERO_ACT_GLU); break;
+            case AERO_ACT_GELU: AERO_NORM_FAST_GO(AERO_ACT_GELU); break;
+            case AERO_ACT_RELU: AERO_NORM_FAST_GO(AERO_ACT_RELU); break;
+            case AERO_ACT_SNAKE: AERO_NORM_FAST_GO(AERO_ACT_SNAKE); break;
+            default: AERO_NORM_FAST_GO(AERO_ACT_NONE); break;
+        }
+#undef AERO_NORM_FAST_GO
+        return AERO_OK;
+    }
     if (vec == 8) AERO_LAUNCH((aero_norm_apply_kernel<8>), grid, block, stream, *d, tchunk);
     else if (vec == 4) AERO_LAUNCH((aero_norm_apply_kernel<4>), grid, block, stream, *d, tchunk);
     else AERO_LAUNCH((aero_norm_apply_kernel<1>), grid, block, stream, *d, tchunk);

@@ -2,8 +2,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 700 python -m pytest tests -m gpu -q -p no:cacheprovider --maxfail=20 2>&1 | grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL version" | tail -6 > gpurun_out/r4n_pytest.txt
-B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra-configs --no-kernel-events"
-for i in 1 2 3; do timeout 120 $B 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['ms_per_step'])"; done > gpurun_out/r4n_bench.txt
-timeout 200 python tools/launch_table.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4n_table.txt
-cat gpurun_out/r4n_pytest.txt gpurun_out/r4n_bench.txt; tail -1 gpurun_out/r4n_table.txt
+timeout 400 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_determinism.py -m gpu -q -p no:cacheprovider 2>&1 | grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL version" | tail -4 > gpurun_out/r4o_pytest.txt
+AERO_NORM_FAST=0 timeout 200 python tools/launch_table.py 2>&1 | grep "norm_apply\|sum of" > gpurun_out/r4o_norm_old.txt
+timeout 200 python tools/launch_table.py 2>&1 | grep "norm_apply\|sum of" > gpurun_out/r4o_norm_fast.txt
+cat gpurun_out/r4o_pytest.txt; paste -d'|' <(cut -c1-60 gpurun_out/r4o_norm_old.txt) <(cut -c1-90 gpurun_out/r4o_norm_fast.txt)
