@@ -602,6 +602,13 @@ int aero_pw_fwd(const aero_pw_desc* d, void* stream) {
     return aero_finish(rc, err);
 }
 
+int aero_squeeze_fwd(const void* x, int64_t x_b, int64_t x_f, int64_t x_t, const void* wimg, const float* bias, void* dst, int32_t B, int32_t F,
+                     int32_t T, int32_t C, int32_t M, int32_t rp, int32_t act, void* stream) {
+    const char* err = "";
+    int rc = aero_squeeze_launch(x, x_b, x_f, x_t, wimg, bias, dst, B, F, T, C, M, rp, act, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 int aero_pw_rows(int32_t C, int32_t M) {
     if (C < 8 || C % 8 || C > 96 || M < 16 || M % 16) return 0;
     return 128 * aero_pw_gw(C, M);

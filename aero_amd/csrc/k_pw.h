@@ -294,3 +294,111 @@ static int aero_pw_launch(const aero_pw_desc* d, hipStream_t stream, const char*
     else { if (gw == 1) aero_pw_go<3, 1>(p, grid, stream); else aero_pw_go<3, 2>(p, grid, stream); }
     return AERO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The FTB's channel squeeze (modules.py:284-288 + 307-309: Conv2d(C, r = 5, 1x1) -> BatchNorm -> ReLU, reshaped to [B, r*F, T] for the Conv1d
+// over time) as one streaming pass.  dst is the "image" the Conv1d reads: fp16 [B][T][F * rp], element (b, f, t, m) at (b*T + t) * F*rp +
+// f*rp + m -- for one (b, f) row that is five halves every 640 bytes, which is what bound the general skinny kernel (137 us for 197 MB).
+// Here a block owns 64 time steps x FG = 16 frequency rows: a wave walks the rows for its 16 steps (B fragments straight from global
+// memory, the 16 x C weight tile resident in registers, next row's loads in flight), parks its r values per step in an LDS tile
+// [64][FG * rp] and the block writes the tile as 16-byte runs of FG * rp halves per time step.
+struct AeroSqueezeK {
+    const h16* x; int64_t x_b, x_f, x_t;
+    const h16* wimg; const float* bias;
+    h16* dst;
+    int B, F, T, C, M, rp, act;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void aero_squeeze_kernel(AeroSqueezeK p) {
+    constexpr int FG = 16, TT = 64;
+    __shared__ AERO_LDS_ALIGN h16 Ys[TT * FG * 8];                 // [TT][FG * rp], rp <= 8
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int t0 = blockIdx.x * TT, f0 = blockIdx.y * FG, b = blockIdx.z;
+    const int rowlen = FG * p.rp;                                  // halves per time step in the tile
+    if (p.rp > p.M) {                                              // pad channels of a slot are written as zeros (the caller's image has them zero)
+        for (int i = tid; i < TT * rowlen; i += 256) Ys[i] = (h16)0;
+        __syncthreads();
+    }
+    h16x8 A[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) A[ks] = *(const h16x8*)(p.wimg + ks * 512 + lane * 8);       // [ks][lane][8]: row = lane & 15, k-octet = lane >> 4
+    float bias[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias[i] = (p.bias && 4 * q + i < p.M) ? p.bias[4 * q + i] : 0.f;
+    int t = t0 + wave * 16 + n;
+    const bool tin = t < p.T;
+    t = tin ? t : p.T - 1;
+    const h16* px = p.x + (int64_t)b * p.x_b + (int64_t)t * p.x_t;
+    const int kq = 8 * q;
+    const int nf = p.F - f0 < FG ? p.F - f0 : FG;
+    auto fetch = [&](h16x8 (&Bf)[KS], int f) {
+        const h16* pr = px + (int64_t)(f0 + f) * p.x_f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = 32 * ks + kq;
+            Bf[ks] = *(const h16x8*)(pr + (k0 < p.C ? k0 : 0));   // (padding lanes: valid data against zero weight columns)
+        }
+    };
+    h16x8 Bc[KS], Bn[KS];
+    fetch(Bc, 0);
+#ifndef AERO_EMU
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+#pragma unroll 1
+    for (int f = 0; f < nf; ++f) {
+        fetch(Bn, f + 1 < nf ? f + 1 : f);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks], Bc[ks], acc, 0, 0, 0);
+        h16* yr = Ys + (wave * 16 + n) * rowlen + f * p.rp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = 4 * q + i;
+            float v = acc[i] + bias[i];
+            if (p.act == AERO_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == AERO_ACT_GELU) v = aero_gelu(v);
+            if (m < p.M) yr[m] = (h16)v;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) Bc[ks] = Bn[ks];
+    }
+    __syncthreads();
+    // tile -> image: time step tt holds nf * rp valid halves at Ys[tt * rowlen ..], destined for dst[(b*T + t0 + tt) * F*rp + f0*rp ..]
+    const int vl = nf * p.rp;                                       // valid halves per step
+    const int64_t Frp = (int64_t)p.F * p.rp;
+    if ((vl & 7) == 0 && ((f0 * p.rp) & 7) == 0 && (Frp & 7) == 0 && (rowlen & 7) == 0) {
+        const int nv = vl >> 3;
+        for (int idx = tid; idx < TT * nv; idx += 256) {
+            const int tt = idx / nv, v = idx - tt * nv;
+            if (t0 + tt < p.T) *(h16x8*)(p.dst + ((int64_t)b * p.T + t0 + tt) * Frp + f0 * p.rp + v * 8) = *(const h16x8*)&Ys[tt * rowlen + v * 8];
+        }
+    } else {
+        for (int idx = tid; idx < TT * vl; idx += 256) {
+            const int tt = idx / vl, e = idx - tt * vl;
+            if (t0 + tt < p.T) p.dst[((int64_t)b * p.T + t0 + tt) * Frp + f0 * p.rp + e] = Ys[tt * rowlen + e];
+        }
+    }
+}
+
+static int aero_squeeze_launch(const void* x, int64_t x_b, int64_t x_f, int64_t x_t, const void* wimg, const float* bias, void* dst, int B, int F, int T,
+                               int C, int M, int rp, int act, hipStream_t stream, const char** err) {
+    if (!x || !wimg || !dst) { *err = "squeeze: null pointer"; return AERO_ERR_ARG; }
+    if (B < 1 || F < 1 || T < 1 || M < 1 || M > 16 || rp < M || rp > 8 || C < 8 || C % 8 || C > 192) { *err = "squeeze: 1 <= M <= rp <= 8, C <= 192 in steps of 8"; return AERO_ERR_UNSUPPORTED; }
+    if ((x_b % 8) || (x_f % 8) || (x_t % 8) || ((uintptr_t)x & 15) || ((uintptr_t)wimg & 15) || (int64_t)T * x_t >= (1ll << 31)) { *err = "squeeze: 16-byte aligned channels-last rows required"; return AERO_ERR_UNSUPPORTED; }
+    if (act != AERO_ACT_NONE && act != AERO_ACT_RELU && act != AERO_ACT_GELU) { *err = "squeeze: activation"; return AERO_ERR_UNSUPPORTED; }
+    AeroSqueezeK p;
+    p.x = (const h16*)x; p.x_b = x_b; p.x_f = x_f; p.x_t = x_t; p.wimg = (const h16*)wimg; p.bias = bias; p.dst = (h16*)dst;
+    p.B = B; p.F = F; p.T = T; p.C = C; p.M = M; p.rp = rp; p.act = act;
+    const dim3 grid((unsigned)((T + 63) / 64), (unsigned)((F + 15) / 16), (unsigned)B), block(256);
+    switch ((C + 31) / 32) {
+        case 1: AERO_LAUNCH(aero_squeeze_kernel<1>, grid, block, stream, p); break;
+        case 2: AERO_LAUNCH(aero_squeeze_kernel<2>, grid, block, stream, p); break;
+        case 3: AERO_LAUNCH(aero_squeeze_kernel<3>, grid, block, stream, p); break;
+        case 4: AERO_LAUNCH(aero_squeeze_kernel<4>, grid, block, stream, p); break;
+        case 5: AERO_LAUNCH(aero_squeeze_kernel<5>, grid, block, stream, p); break;
+        default: AERO_LAUNCH(aero_squeeze_kernel<6>, grid, block, stream, p); break;
+    }
+    return AERO_OK;
+}

@@ -205,6 +205,14 @@ class Ops:
         self._call('aero_pw_fwd', tag, 2.0 * B * F * T * spec.M * spec.C, nb, C.byref(d), self.stream(x))
         return dst
 
+    def squeeze(self, spec, x, B, F, T, dst, rp):
+        """the FTB's channel squeeze into the Conv1d image dst [B, T, F*rp] (aero_squeeze_fwd, k_pw.h)"""
+        sb, sf, st = _strides4(x)
+        self._shape_note = f'squeeze M={spec.M} C={spec.C} F={F}'
+        self._call('aero_squeeze_fwd', 'aero_squeeze_kernel', 2.0 * B * F * T * spec.M * spec.C, B * F * T * 2 * (spec.C + spec.M),
+                   _ptr(x), sb, sf, st, _ptr(spec.wimg), _ptr(spec.bias), _ptr(dst), B, F, T, spec.C, spec.M, rp, spec.act, self.stream(x))
+        return dst
+
     def begin_step(self, device):
         """Zero the statistics arena of the current stream once: the ~25 GroupNorm accumulators of a forward pass are
         slices of it instead of 25 separate torch.zeros fill launches."""
@@ -505,6 +513,7 @@ class HipEngine:
                                     sd[f'{q}.conv1.1.bias'], sd[f'{q}.conv1.1.running_mean'], sd[f'{q}.conv1.1.running_var'])
                 w, df, dt = pack.conv2d_taps(w, 0, 0)
                 L['ftb_c1'] = mk(w, b, Cc, 0, df, dt, device, act=ACT_RELU)
+                L['ftb_c1_sq'] = pack.make_squeeze_spec(w[0, :, 0, :], b, ACT_RELU, device) if rp <= 8 else None
                 w, b = pack.bn_fold(sd[f'{q}.conv1d.0.weight'], sd[f'{q}.conv1d.0.bias'], sd[f'{q}.conv1d.1.weight'],
                                     sd[f'{q}.conv1d.1.bias'], sd[f'{q}.conv1d.1.running_mean'], sd[f'{q}.conv1d.1.running_var'])
                 k9 = w.shape[-1]
@@ -871,7 +880,10 @@ class HipEngine:
         if 'ftb_c1' in L:
             Cc, rp = L['ftb_c2'].M, L['ftb_rp']
             c1 = (torch.empty if rp == L['ftb_c1'].M else torch.zeros)(B, T, Fq * rp, dtype=torch.float16, device=x.device)
-            ops.conv(L['ftb_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
+            if self.use_pw and L.get('ftb_c1_sq') is not None and x.is_contiguous():
+                ops.squeeze(L['ftb_c1_sq'], x, B, Fq, T, c1, rp)
+            else:
+                ops.conv(L['ftb_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
             gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T, tap_split=self._tap_split(L['ftb_c1d'], B, T))      # [B,1,T,Cc]
             fc = ops.freqfc(x, L['ftb_fc'], gate.view(B, T, Cc))
             x = ops.conv(L['ftb_c2'], fc, x, B, Fq, Fq, T)

@@ -97,6 +97,25 @@ def pw_image(w, rows):
     return img.to(torch.float16).contiguous()
 
 
+class SqueezeSpec:
+    def __init__(self, wimg, bias, M, C, act):
+        self.wimg, self.bias, self.M, self.C, self.act = wimg, bias, M, C, act
+
+
+def make_squeeze_spec(w, bias, act, device):
+    """w [M <= 8, C] (BatchNorm already folded) -> the fragment image of aero_squeeze_fwd: [KS][64 lanes][8]; None if not served"""
+    M, C = w.shape
+    if M > 8 or C % 8 or C < 8 or C > 192:
+        return None
+    ks = (C + 31) // 32
+    wp = torch.zeros(16, ks * 32, dtype=torch.float32)
+    wp[:M, :C] = w.detach().float().cpu()
+    lane = torch.arange(64)
+    kk = torch.arange(ks)[:, None, None] * 32 + ((lane >> 4) * 8)[None, :, None] + torch.arange(8)[None, None, :]
+    img = wp[(lane & 15)[None, :, None], kk]                       # [KS, 64, 8]
+    return SqueezeSpec(img.to(device=device, dtype=torch.float16).contiguous(), None if bias is None else bias.detach().float().to(device).contiguous(), M, C, act)
+
+
 def make_pw_spec(w, bias, act, lib, device):
     """w [M, C] fp32 in the reference's row order; GLU: rows / bias interleaved (value, gate) as make_conv_spec does.  None if the
     geometry is not served by the streaming pointwise kernel."""

@@ -221,6 +221,11 @@ typedef struct aero_pw_desc {
     int32_t B, F, T, M, act;
 } aero_pw_desc;
 int aero_pw_fwd(const aero_pw_desc* d, void* stream);
+/* the FTB's channel squeeze (modules.py:284-288, 307-309): y[m] = act(W[m,:] . x[b,f,t,:] + bias[m]) for M <= rp <= 8 output channels, written as the
+ * image the FTB's Conv1d over time reads: dst fp16 [B][T][F*rp], element (b, f, t, m) at (b*T + t)*F*rp + f*rp + m (channels m >= M of a slot
+ * are not written).  wimg: fp16 [KS = ceil(C/32)][64 lanes][8]: lane l holds W[l & 15][32*ks + 8*(l >> 4) ..] (rows >= M and columns >= C zero). */
+int aero_squeeze_fwd(const void* x, int64_t x_b, int64_t x_f, int64_t x_t, const void* wimg, const float* bias, void* dst, int32_t B, int32_t F,
+                     int32_t T, int32_t C, int32_t M, int32_t rp, int32_t act, void* stream);
 /* conv rows one block covers (128 * GW) for a C -> M pointwise conv, 0 if the geometry is not served (C > 96, C % 8, M % 16) */
 int aero_pw_rows(int32_t C, int32_t M);
 

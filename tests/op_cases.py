@@ -164,6 +164,25 @@ def case_pw(lib, dev, Cin, Cout, Fq, T, B=2, act='glu', norm=False, residual=Fal
     assert e < TOL16, e
 
 
+def case_squeeze(lib, dev, Cin, Fq, T, M=5, B=2, seed=18):
+    """aero_squeeze_fwd: Conv2d(C, M, 1x1) + bias + ReLU written as the [B, T, F*rp] image of the FTB's Conv1d (k_pw.h)"""
+    ops = Ops(lib)
+    g = _g(seed)
+    w = torch.randn(M, Cin, generator=g) / math.sqrt(Cin)
+    b = torch.randn(M, generator=g)
+    x = torch.randn(B, Cin, Fq, T, generator=g)
+    rp = M if (Fq * M) % 8 == 0 else 8
+    spec = pack.make_squeeze_spec(q16(w), b, _lib.ACT_RELU, dev)
+    assert spec is not None
+    dst = torch.zeros(B, T, Fq * rp, dtype=torch.float16, device=dev)
+    ops.squeeze(spec, cl(x).to(dev), B, Fq, T, dst, rp)
+    ref = F.relu(torch.einsum('mc,bcft->bmft', q16(w), q16(x)) + b.view(1, -1, 1, 1))          # [B, M, F, T]
+    got = dst.cpu().float().view(B, T, Fq, rp)[..., :M].permute(0, 3, 2, 1)
+    assert rel_l2(got, ref) < TOL16
+    if rp > M:
+        assert float(dst.cpu().float().view(B, T, Fq, rp)[..., M:].abs().max()) == 0.0
+
+
 def case_conv_tiny(lib, dev, Cin, Cout, Fq, T, B=2, act='relu', seed=15):
     """Pointwise conv with few channels written into a frequency-major [B, T, F*M] destination (the first FTB's squeeze,
     engine._encode): exercises aero_conv_tiny_kernel."""

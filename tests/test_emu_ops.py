@@ -83,6 +83,11 @@ def test_conv2d(emu, kw):
     oc.case_conv2d(emu, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Cin=48, Fq=64, T=70), dict(Cin=96, Fq=16, T=130, B=1), dict(Cin=192, Fq=8, T=37), dict(Cin=24, Fq=3, T=20)])
+def test_squeeze(emu, kw):
+    oc.case_squeeze(emu, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', oc.PW_CASES)
 def test_pw(emu, kw):
     oc.case_pw(emu, DEV, **kw)

@@ -53,6 +53,11 @@ def test_conv2d(lib, kw):
     oc.case_conv2d(lib, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Cin=48, Fq=64, T=70), dict(Cin=96, Fq=16, T=130, B=1), dict(Cin=192, Fq=8, T=37), dict(Cin=24, Fq=3, T=20)])
+def test_squeeze(lib, kw):
+    oc.case_squeeze(lib, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', oc.PW_CASES)
 def test_pw(lib, kw):
     oc.case_pw(lib, DEV, **kw)
