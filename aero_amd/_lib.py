@@ -69,7 +69,8 @@ class PwDesc(C.Structure):
                 ('gamma', fp), ('beta', fp), ('layer_scale', fp), ('post_add', fp),
                 ('res', vp), ('r_b', i64), ('r_f', i64), ('r_t', i64),
                 ('dst', vp), ('d_b', i64), ('d_f', i64), ('d_t', i64),
-                ('B', i32), ('F', i32), ('T', i32), ('M', i32), ('act', i32)]
+                ('B', i32), ('F', i32), ('T', i32), ('M', i32), ('act', i32),
+                ('x1', vp), ('x1_b', i64), ('x1_f', i64), ('x1_t', i64), ('C0', i32)]
 
 
 class GramDesc(C.Structure):

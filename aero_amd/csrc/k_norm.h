@@ -93,23 +93,44 @@ __global__ __launch_bounds__(256) void aero_norm_stats_kernel(aero_norm_desc d, 
     float s = 0.f, ss = 0.f;
     if (ty < TY) {
         if (!wide) {
-            // four time steps per trip, all loads issued before the first use: one wave keeps 4 KiB in flight instead of 1
+            // four time steps per trip.  Loads are UNCONDITIONAL (time index clamped into the chunk; a step past the end contributes
+            // zeros through a select) and the next trip's are issued before this trip's sums: with `if (t < t1) load` every load sat in
+            // a branch and hipcc waited vmcnt(0) in front of the first use (round 4: same finding as k_pw.h / aero_norm_apply_fast).
+            // The order of the fp32 additions is unchanged: results are bit-identical to the predicated form.
             const h16* colp = base + v * VEC;
-            // (the last trip is predicated per step rather than finished by a one-load-at-a-time remainder loop)
-            for (int t = t0 + ty; t < t1; t += 4 * TY) {
-                typename AeroVecT<VEC>::type r[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (t + k * TY < t1) r[k] = aero_load_raw<VEC>(colp + (int64_t)(t + k * TY) * d.s_t);
+            const int tl = t1 - 1;
+            typename AeroVecT<VEC>::type r[4], rn[4];
+            auto fetch = [&](typename AeroVecT<VEC>::type (&q)[4], int t) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (t + k * TY < t1) {
-                        float x[VEC];
-                        aero_cvt_vec<VEC>(r[k], x);
+                    int tk = t + k * TY;
+                    tk = tk < tl ? tk : tl;
+                    q[k] = aero_load_raw<VEC>(colp + (int64_t)tk * d.s_t);
+                }
+            };
+            int t = t0 + ty;
+            if (t < t1) fetch(r, t);
+#ifndef AERO_EMU
+            __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): the loop is entered with nothing in flight
+#endif
+#pragma unroll 1
+            for (; t < t1; t += 4 * TY) {
+                const int tn = t + 4 * TY;
+                fetch(rn, tn < t1 ? tn : t);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) { s += x[i]; ss += x[i] * x[i]; }
+                for (int k = 0; k < 4; ++k) {
+                    const bool in = t + k * TY < t1;
+                    float x[VEC];
+                    aero_cvt_vec<VEC>(r[k], x);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float xv = in ? x[i] : 0.f;
+                        s += xv;
+                        ss += xv * xv;
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = rn[k];
             }
         } else {
             for (int t = t0 + ty; t < t1; t += TY) {

@@ -92,6 +92,10 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
     __syncthreads();
 
     const h16* xr = (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)f * d.x_f;
+    // second source (torch.cat([x, x1], 1) in front of the conv: the FTB's conv2, modules.py:322-323): channels C0 .. C-1 come from x1
+    const int C0 = d.x1 ? d.C0 : d.C;
+    const h16* x1r = d.x1 ? (const h16*)d.x1 + (int64_t)b * d.x1_b + (int64_t)f * d.x1_f - C0 : xr;
+    const int x1t = d.x1 ? (int)d.x1_t : (int)d.x_t;
     const h16* rr = d.res ? (const h16*)d.res + (int64_t)b * d.r_b + (int64_t)f * d.r_f : nullptr;
     h16* dr = (h16*)d.dst + (int64_t)b * d.d_b + (int64_t)f * d.d_f;
     const int xt = (int)d.x_t, rt = (int)d.r_t, dt = (int)d.d_t;
@@ -113,10 +117,11 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
         int t = u * 16 + n;
         t = t < T ? t : T - 1;                                    // (masked at the store: the load stays in range)
         const h16* px = xr + t * xt;
+        const h16* px1 = x1r + t * x1t;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k0 = 32 * ks + kq;
-            Bf[ks] = *(const h16x8*)(px + (k0 < d.C ? k0 : 0));
+            Bf[ks] = *(const h16x8*)(k0 < C0 ? px + k0 : (k0 < d.C ? px1 + k0 : px));
         }
     };
     auto load_r = [&](h16x8 (&R)[GW][NV], int u) {
@@ -244,6 +249,8 @@ static int aero_pw_ok(const aero_pw_desc* d) {
     if (!al(d->x_b) || !al(d->x_f) || !al(d->x_t) || !al(d->d_b) || !al(d->d_f) || !al(d->d_t)) return 0;
     if (((uintptr_t)d->x & 15) || ((uintptr_t)d->dst & 15) || ((uintptr_t)d->wimg & 15)) return 0;
     if (d->res && (!al(d->r_b) || !al(d->r_f) || !al(d->r_t) || ((uintptr_t)d->res & 15))) return 0;
+    if (d->x1 && (!al(d->x1_b) || !al(d->x1_f) || !al(d->x1_t) || ((uintptr_t)d->x1 & 15) || d->C0 < 8 || d->C0 % 8 || d->C0 >= d->C ||
+                  (int64_t)d->T * d->x1_t >= (1ll << 31))) return 0;
     if ((int64_t)d->T * d->x_t >= (1ll << 31) || (int64_t)d->T * d->d_t >= (1ll << 31) || (d->res && (int64_t)d->T * d->r_t >= (1ll << 31))) return 0;
     if (d->stats && !(d->stat_count > 0)) return 0;
     return aero_pw_gw(d->C, d->M) > 0;

@@ -180,7 +180,7 @@ class Ops:
         return dst
 
     def pw(self, spec, x, B, F, T, res=None, post_add=None, stats=None, count=None, gamma=None, beta=None, layer_scale=None,
-           eps=1e-5, tag='aero_pw_kernel'):
+           eps=1e-5, tag='aero_pw_kernel', x1=None):
         """streaming pointwise conv (aero_pw_fwd, k_pw.h): x fp16 [B,F,T,C] (channels-last view) -> [B,F,T,Mout]; optional GroupNorm
         from per-row sums `stats` [(B*F), 2] (count = elements per row), activation of the spec, LayerScale, residual, frequency-embedding row"""
         Mout = spec.M // 2 if spec.act == ACT_GLU else spec.M
@@ -200,8 +200,12 @@ class Ops:
         d.dst = _ptr(dst)
         d.d_b, d.d_f, d.d_t = _strides4(dst)
         d.B, d.F, d.T, d.M, d.act = B, F, T, spec.M, spec.act
+        if x1 is not None:                                        # cat([x, x1], channel) in front of the conv
+            d.x1 = _ptr(x1)
+            d.x1_b, d.x1_f, d.x1_t = _strides4(x1)
+            d.C0 = x.shape[-1]
         self._shape_note = f'pw M={spec.M} C={spec.C} F={F} act={spec.act} res={int(res is not None)} norm={int(stats is not None)}'
-        nb = x.numel() // x.shape[-1] * (2 * spec.C + 2 * Mout * (2 if res is not None else 1))
+        nb = x.numel() // x.shape[-1] * (2 * spec.C + 2 * Mout * (2 if res is not None else 1))          # (spec.C counts both sources)
         self._call('aero_pw_fwd', tag, 2.0 * B * F * T * spec.M * spec.C, nb, C.byref(d), self.stream(x))
         return dst
 
@@ -532,6 +536,7 @@ class HipEngine:
                                     sd[f'{q}.conv2.1.bias'], sd[f'{q}.conv2.1.running_mean'], sd[f'{q}.conv2.1.running_var'])
                 w, df, dt = pack.conv2d_taps(w, 0, 0)
                 L['ftb_c2'] = mk(w, b, Cc, Cc, df, dt, device, act=ACT_RELU)
+                L['ftb_c2_pw'] = pack.make_pw_spec(w[0, :, 0, :], b, ACT_RELU, self.lib, device) if 2 * Cc <= 96 else None
                 if enc.is_first and Cc % 8 == 0 and Cc <= 64:
                     # encoder 0: pre_conv feeds the FTB linearly -> collapse onto the 2 input channels (k_ftb.h)
                     Wp = sd[f'{p}.pre_conv.weight'][:, :, 0, 0]                    # [C, 2]
@@ -886,7 +891,10 @@ class HipEngine:
                 ops.conv(L['ftb_c1'], x, None, B, Fq, Fq, T, dst=c1, dst_strides=(T * Fq * rp, rp, Fq * rp))
             gate = ops.conv(L['ftb_c1d'], c1.view(B, 1, T, Fq * rp), None, B, 1, 1, T, tap_split=self._tap_split(L['ftb_c1d'], B, T))      # [B,1,T,Cc]
             fc = ops.freqfc(x, L['ftb_fc'], gate.view(B, T, Cc))
-            x = ops.conv(L['ftb_c2'], fc, x, B, Fq, Fq, T)
+            if self.use_pw and L.get('ftb_c2_pw') is not None and x.is_contiguous() and fc.is_contiguous():
+                x = ops.pw(L['ftb_c2_pw'], fc, B, Fq, T, x1=x)
+            else:
+                x = ops.conv(L['ftb_c2'], fc, x, B, Fq, Fq, T)
         return x
 
     def _encode_head_train(self, i, enc, L, x, B, Fq, T):

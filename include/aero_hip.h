@@ -219,6 +219,7 @@ typedef struct aero_pw_desc {
     const void* res; int64_t r_b, r_f, r_t;
     void* dst; int64_t d_b, d_f, d_t;
     int32_t B, F, T, M, act;
+    const void* x1; int64_t x1_b, x1_f, x1_t; int32_t C0;     /* optional second source: input channels C0 .. C-1 are x1's 0 .. C-C0-1 (cat([x, x1], 1)) */
 } aero_pw_desc;
 int aero_pw_fwd(const aero_pw_desc* d, void* stream);
 /* the FTB's channel squeeze (modules.py:284-288, 307-309): y[m] = act(W[m,:] . x[b,f,t,:] + bias[m]) for M <= rp <= 8 output channels, written as the

@@ -23,7 +23,9 @@ PW_CASES = [dict(Cin=48, Cout=384, Fq=3, T=70, norm=True, residual=True, scale=T
             dict(Cin=48, Cout=96, Fq=5, T=50, post=True),                                        # encoder-0 rewrite + GLU + frequency embedding (M padded to a group)
             dict(Cin=96, Cout=192, Fq=2, T=33),                                                  # encoder-1 rewrite + GLU
             dict(Cin=24, Cout=64, Fq=2, T=17, act='gelu', residual=True),                        # non-GLU store path, one k-step
-            dict(Cin=16, Cout=32, Fq=1, T=5, act='none', B=1)]
+            dict(Cin=16, Cout=32, Fq=1, T=5, act='none', B=1),
+            dict(Cin=96, Cout=48, Fq=4, T=70, act='relu', split=48),                            # FTB conv2 over cat([att, x]): a k-step spans both sources
+            dict(Cin=48, Cout=32, Fq=2, T=21, act='relu', split=24)]
 TOL32 = 2e-6
 BLSTM_TOL = 1e-3      # whole BLSTM block / LocalState block (output incl. the skip path) against the oracle: the north-star bar itself
 ATTN_TOL = 1e-3
@@ -123,7 +125,7 @@ def case_conv2d(lib, dev, Cin, Cout, kF, kT, stride, padF, padT, Fin, T, act='no
     assert rel_l2(uncl(y.cpu()), ref) < TOL16
 
 
-def case_pw(lib, dev, Cin, Cout, Fq, T, B=2, act='glu', norm=False, residual=False, post=False, scale=False, seed=16):
+def case_pw(lib, dev, Cin, Cout, Fq, T, B=2, act='glu', norm=False, residual=False, post=False, scale=False, seed=16, split=None):
     """aero_pw_fwd (k_pw.h): 1x1 conv [-> GroupNorm(1 group per (b, f) row) from given sums] -> act [* LayerScale] [+ res] [+ frequency
     embedding row] against fp32 torch on the fp16-rounded operands"""
     ops = Ops(lib)
@@ -158,7 +160,11 @@ def case_pw(lib, dev, Cin, Cout, Fq, T, B=2, act='glu', norm=False, residual=Fal
         pe = torch.randn(Fq, Mout, generator=g)
         ref = ref + pe.t().reshape(1, Mout, Fq, 1)
         kw['post_add'] = pe.to(dev).contiguous()
-    y = ops.pw(spec, cl(x).to(dev), B, Fq, T, **kw)
+    xc = cl(x).to(dev)
+    if split:                                                     # two sources: cat([x[:split], x[split:]], channel)
+        y = ops.pw(spec, xc[..., :split].contiguous(), B, Fq, T, x1=xc[..., split:].contiguous(), **kw)
+    else:
+        y = ops.pw(spec, xc, B, Fq, T, **kw)
     assert y.shape == (B, Fq, T, Mout)
     e = rel_l2(uncl(y.cpu()), ref)
     assert e < TOL16, e
