@@ -309,6 +309,72 @@ __global__ __launch_bounds__(256) void aero_norm_apply_kernel(aero_norm_desc d, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// aero_norm_stats for NARROW groups (round 4): with 48-channel groups a block of the kernel above reads a 96-byte piece of every 384-byte
+// position -- four blocks (one per group) each pull the same lines (the second decoder's GroupNorm: 74 us at 1.8 TB/s).  Here a block
+// reads whole positions (all C channels); a thread's 8-channel vector lies in one group (gs % 8 == 0), its fp32 partial sums are added
+// to the block's per-group fp64 pair in LDS and the block adds G pairs to the global sums.  Same per-thread summation order as the
+// kernel above (thread = (channel vector, time phase)); the cross-thread order differs only at fp64 rounding level.
+__global__ __launch_bounds__(256) void aero_norm_stats_rows_kernel(aero_norm_desc d, int tchunk) {
+    __shared__ double red[2][64];
+    const int gs = d.C / d.G;
+    const int item = blockIdx.z;
+    const int b = d.per_row == 1 ? item / d.F : item;
+    const int f = d.per_row == 1 ? item % d.F : blockIdx.y;
+    const int vpp = d.C / 8;
+    const int TY = 256 / vpp;
+    const int tid = threadIdx.x;
+    const int v = tid % vpp, ty = tid / vpp;
+    for (int i = tid; i < 2 * 64; i += 256) (&red[0][0])[i] = 0.0;
+    __syncthreads();
+    const h16* colp = (const h16*)d.src + (int64_t)b * d.s_b + (int64_t)f * d.s_f + v * 8;
+    const int t0 = blockIdx.x * tchunk;
+    const int t1 = (t0 + tchunk < d.T) ? t0 + tchunk : d.T;
+    float s = 0.f, ss = 0.f;
+    if (ty < TY) {
+        const int tl = t1 - 1;
+        h16x8 r[4], rn[4];
+        auto fetch = [&](h16x8 (&q)[4], int t) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int tk = t + k * TY;
+                tk = tk < tl ? tk : tl;
+                q[k] = *(const h16x8*)(colp + (int64_t)tk * d.s_t);
+            }
+        };
+        int t = t0 + ty;
+        if (t < t1) fetch(r, t);
+#ifndef AERO_EMU
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+#pragma unroll 1
+        for (; t < t1; t += 4 * TY) {
+            const int tn = t + 4 * TY;
+            fetch(rn, tn < t1 ? tn : t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = t + k * TY < t1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xv = in ? (float)r[k][i] : 0.f;
+                    s += xv;
+                    ss += xv * xv;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = rn[k];
+        }
+        const int g = (v * 8) / gs;
+        atomicAdd(&red[0][g], (double)s);
+        atomicAdd(&red[1][g], (double)ss);
+    }
+    __syncthreads();
+    if (tid < d.G) {
+        atomicAdd(d.stats + ((int64_t)item * d.G + tid) * 2 + 0, red[0][tid]);
+        atomicAdd(d.stats + ((int64_t)item * d.G + tid) * 2 + 1, red[1][tid]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // aero_norm_apply, fast form (round 4) for 8-channel vectors.  Same arithmetic as aero_norm_apply_kernel<8>; what changes is what the
 // streaming pointwise kernel (k_pw.h) taught about hipcc and memory latency:
 //   * the activation and the residual are TEMPLATE parameters: nothing is decided per element;
@@ -502,6 +568,15 @@ static int aero_norm_stats_launch(const aero_norm_desc* d, hipStream_t stream, c
     const int TY = vpp > 256 ? 1 : 256 / vpp;
     // (chunking from the rows of ONE item x 64, not from the batch: a clip's partial sums -- fp32 per thread over a chunk --
     // must not depend on how many other clips share the launch (x 64: the batch the chunk sizes were tuned on), or its output would differ between batch sizes / ranks)
+    static int rows_on = -1;
+    if (rows_on < 0) { const char* e = getenv("AERO_NORM_STATS_ROWS"); rows_on = e ? atoi(e) : 1; }
+    if (rows_on && vec == 8 && d->per_row != 2 && d->G > 1 && d->G <= 64 && gs % 8 == 0 && gs * 2 < 256 && d->C / 8 <= 256) {
+        const int TYr = 256 / (d->C / 8);
+        const int tchunk_r = aero_norm_tchunk(d->T, TYr, (items / d->B) * 64 * nf, d->C * 2);
+        dim3 gridr((unsigned)((d->T + tchunk_r - 1) / tchunk_r), (unsigned)nf, (unsigned)items);
+        AERO_LAUNCH(aero_norm_stats_rows_kernel, gridr, dim3(256), stream, *d, tchunk_r);
+        return AERO_OK;
+    }
     const int tchunk = aero_norm_tchunk(d->T, TY, (items / d->B) * 64 * d->G * nf, gs * 2);
     dim3 grid((unsigned)((d->T + tchunk - 1) / tchunk), (unsigned)nf, (unsigned)(items * d->G)), block(256);
     if (vec == 8) AERO_LAUNCH((aero_norm_stats_kernel<8>), grid, block, stream, *d, tchunk);

@@ -142,7 +142,8 @@ def test_freq_emb_epilogue(emu):
                                 dict(Cc=12, G=1, Fq=4, T=33, act='snake', per_row=True),
                                 dict(Cc=24, G=1, Fq=3, T=40, act='glu_ls_res', per_row=True),
                                 dict(Cc=8, G=4, Fq=10, T=21, act='gelu', trim=2), dict(Cc=2, G=1, Fq=3, T=20, act='snake', per_row=True),
-                                dict(Cc=8, G=4, Fq=6, T=17, act='none', trim=1)])
+                                dict(Cc=8, G=4, Fq=6, T=17, act='none', trim=1),
+                                dict(Cc=192, G=4, Fq=3, T=70, act='gelu'), dict(Cc=64, G=4, Fq=2, T=130, act='glu')])      # narrow groups: statistics from whole positions
 def test_groupnorm(emu, kw):
     oc.case_groupnorm(emu, DEV, **kw)
 
