@@ -210,6 +210,7 @@ _PROTOS = {
     'aero_allgather': (i32, [vp, vp, vp, i64, vp]),
     'aero_comm_destroy': (i32, [vp]),
     'aero_pw_rows': (i32, [i32, i32]),
+    'aero_pw_ksteps': (i32, [i32]),
     'aero_squeeze_fwd': (i32, [vp, i64, i64, i64, vp, fp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'aero_leaky_relu': (i32, [vp, i64, C.c_float, vp]),
     'aero_avgpool1d': (i32, [vp, vp, i32, i32, vp]),

@@ -25,7 +25,10 @@ struct AeroPwK {
     int Mout;                        // stored channels: M / 2 with GLU
 };
 
-template <int KS, int GW, int ACT, bool NORM>
+// WLDS: the weight fragments live in LDS instead of registers (contractions of 128 .. 384 channels: KS = 4 .. 12 k-steps of one 64-row group
+// per wave are 64-192 registers); every MFMA's A operand is then one ds_read_b128 of the image in fragment order, everything else is
+// unchanged.  8 KS KiB of LDS per block (three / one block per CU at KS 6 / 12).
+template <int KS, int GW, int ACT, bool NORM, bool WLDS = false>
 __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
     constexpr bool GLU = ACT == AERO_ACT_GLU;
     constexpr int MC = 128 * GW;                                  // conv rows per chunk (block)
@@ -79,8 +82,15 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
         }
     }
     // ---- the wave's weight fragments: image [chunk][wm][g][j][ks][lane][8]
-    h16x8 A[GW][4][KS];
-    {
+    h16x8 A[WLDS ? 1 : GW][WLDS ? 1 : 4][WLDS ? 1 : KS];
+    const h16* Wl = nullptr;                                      // WLDS: this wave's fragments in LDS, fragment (g, j, ks) at ((g*4 + j)*KS + ks)*512 + lane*8
+    if constexpr (WLDS) {
+        h16* Ws = (h16*)AERO_DYN_SMEM;
+        const h16* w = (const h16*)d.wimg + ((int64_t)chunk * 2 * GW * 4 * KS) * 512;
+        constexpr int NV = 2 * GW * 4 * KS * 64;                  // 16-byte vectors of the chunk's image (both row halves)
+        for (int i = tid; i < NV; i += 256) *(h16x8*)(Ws + i * 8) = *(const h16x8*)(w + i * 8);
+        Wl = Ws + (wm * GW * 4 * KS) * 512 + lane * 8;
+    } else {
         const h16* w = (const h16*)d.wimg + ((int64_t)(chunk * 2 + wm) * GW * 4 * KS) * 512 + lane * 8;
 #pragma unroll
         for (int g = 0; g < GW; ++g)
@@ -171,7 +181,10 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[g][j][ks], Bc[ks], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (WLDS) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const h16x8*)(Wl + ((g * 4 + j) * KS + ks) * 512), Bc[ks], acc[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[g][j][ks], Bc[ks], acc[j], 0, 0, 0);
+                }
             // rows 16 q + 4 j + i of the group: coefficients are 4 + 4 consecutive float4 of the block's tables, applied tile by tile IN the
             // accumulator registers (a group's live set stays small: with everything fetched up front the three groups of a unit
             // spilled 63 registers and every spill reload drained the next unit's prefetch: 1.5 TB/s)
@@ -229,11 +242,18 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
     }
 }
 
+// k-steps of the weight image for C input channels: ceil(C / 32) up to 6, then the 8- and 12-step instantiations (zero columns)
+static int aero_pw_ks(int C) {
+    const int ks = (C + 31) / 32;
+    return ks <= 6 ? ks : (ks <= 8 ? 8 : 12);
+}
+
 // rows per chunk (= per block) for a contraction of C channels: the register budget of the resident weight fragments
 static int aero_pw_gw(int C, int M) {
-    const int ks = (C + 31) / 32;
+    const int ks = aero_pw_ks(C);
     const int groups = (M + 63) / 64;
-    if (ks > 3 || ks < 1) return 0;
+    if (ks > 12 || ks < 1) return 0;
+    if (ks > 3) return 1;                                         // weights in LDS (WLDS): one 64-row group per wave
     int gw = ks == 3 ? 2 : 3;                                     // 96 fragment registers per wave
     while (gw > 1 && 2 * (gw - 1) >= groups) --gw;                // no larger than the layer needs
     return gw;
@@ -241,7 +261,7 @@ static int aero_pw_gw(int C, int M) {
 
 static int aero_pw_ok(const aero_pw_desc* d) {
     if (!d || !d->x || !d->wimg || !d->dst) return 0;
-    if (d->C < 8 || d->C % 8 || d->C > 96 || d->M < 16 || d->M % 16) return 0;
+    if (d->C < 8 || d->C % 8 || d->C > 384 || d->M < 16 || d->M % 16) return 0;
     if (d->act != AERO_ACT_NONE && d->act != AERO_ACT_RELU && d->act != AERO_ACT_GELU && d->act != AERO_ACT_GLU) return 0;
     const int Mout = d->act == AERO_ACT_GLU ? d->M / 2 : d->M;
     if (Mout % 8) return 0;
@@ -260,10 +280,12 @@ template <int KS, int GW>
 static void aero_pw_go(const AeroPwK& p, dim3 grid, hipStream_t stream) {
     const bool norm = p.d.stats != nullptr;
     const dim3 block(256);
-#define AERO_PW_CASE(ACT_)                                                                              \
-    do {                                                                                                \
-        if (norm) AERO_LAUNCH((aero_pw_kernel<KS, GW, ACT_, true>), grid, block, stream, p);            \
-        else AERO_LAUNCH((aero_pw_kernel<KS, GW, ACT_, false>), grid, block, stream, p);                \
+    constexpr bool WL = KS > 3;
+    constexpr size_t lds = WL ? (size_t)2 * GW * 4 * KS * 1024 : 0;
+#define AERO_PW_CASE(ACT_)                                                                                            \
+    do {                                                                                                              \
+        if (norm) AERO_LAUNCH_DYN((aero_pw_kernel<KS, GW, ACT_, true, WL>), grid, block, lds, stream, p);             \
+        else AERO_LAUNCH_DYN((aero_pw_kernel<KS, GW, ACT_, false, WL>), grid, block, lds, stream, p);                 \
     } while (0)
     switch (p.d.act) {
         case AERO_ACT_GLU: AERO_PW_CASE(AERO_ACT_GLU); break;
@@ -275,12 +297,12 @@ static void aero_pw_go(const AeroPwK& p, dim3 grid, hipStream_t stream) {
 }
 
 static int aero_pw_launch(const aero_pw_desc* d, hipStream_t stream, const char** err) {
-    if (!aero_pw_ok(d)) { *err = "pw: unsupported geometry (C <= 96 in steps of 8, 16-byte aligned channels-last rows, M % 16 == 0)"; return AERO_ERR_UNSUPPORTED; }
+    if (!aero_pw_ok(d)) { *err = "pw: unsupported geometry (C <= 384 in steps of 8, 16-byte aligned channels-last rows, M % 16 == 0)"; return AERO_ERR_UNSUPPORTED; }
     if (d->B < 1 || d->F < 1 || d->T < 1) { *err = "pw: empty tensor"; return AERO_ERR_ARG; }
     AeroPwK p;
     p.d = *d;
     p.Mout = d->act == AERO_ACT_GLU ? d->M / 2 : d->M;
-    const int ks = (d->C + 31) / 32, gw = aero_pw_gw(d->C, d->M);
+    const int ks = aero_pw_ks(d->C), gw = aero_pw_gw(d->C, d->M);
     const int nchunk = (d->M + 128 * gw - 1) / (128 * gw);
     const long rows = (long)d->B * d->F;
     const int nunit = (d->T + 15) / 16;
@@ -298,7 +320,12 @@ static int aero_pw_launch(const aero_pw_desc* d, hipStream_t stream, const char*
     const dim3 grid((unsigned)(rows * nsplit * nchunk));
     if (ks == 1) { if (gw == 1) aero_pw_go<1, 1>(p, grid, stream); else if (gw == 2) aero_pw_go<1, 2>(p, grid, stream); else aero_pw_go<1, 3>(p, grid, stream); }
     else if (ks == 2) { if (gw == 1) aero_pw_go<2, 1>(p, grid, stream); else if (gw == 2) aero_pw_go<2, 2>(p, grid, stream); else aero_pw_go<2, 3>(p, grid, stream); }
-    else { if (gw == 1) aero_pw_go<3, 1>(p, grid, stream); else aero_pw_go<3, 2>(p, grid, stream); }
+    else if (ks == 3) { if (gw == 1) aero_pw_go<3, 1>(p, grid, stream); else aero_pw_go<3, 2>(p, grid, stream); }
+    else if (ks == 4) aero_pw_go<4, 1>(p, grid, stream);
+    else if (ks == 5) aero_pw_go<5, 1>(p, grid, stream);
+    else if (ks == 6) aero_pw_go<6, 1>(p, grid, stream);
+    else if (ks <= 8) aero_pw_go<8, 1>(p, grid, stream);
+    else aero_pw_go<12, 1>(p, grid, stream);
     return AERO_OK;
 }
 

@@ -572,6 +572,8 @@ class HipEngine:
                                   act=ACT_NONE if enc.norm else ACT_GLU)
                 if enc.norm:
                     L['norm2'] = (sd[f'{p}.norm2.weight'].to(device), sd[f'{p}.norm2.bias'].to(device))
+                    if len(df) == 1 and w.shape[-1] <= 384:      # pointwise rewrite, GroupNorm + GLU behind it: the conv alone on the streaming kernel
+                        L['rewrite_pw'] = pack.make_pw_spec(w[0, :, 0, :], sd[f'{p}.rewrite.bias'], ACT_NONE, self.lib, device)
                 elif len(df) == 1:                                 # pointwise rewrite + GLU with no norm between: the streaming kernel (k_pw.h)
                     L['rewrite_pw'] = pack.make_pw_spec(w[0, :, 0, :], sd[f'{p}.rewrite.bias'], ACT_GLU, self.lib, device)
             P[p] = L
@@ -983,7 +985,10 @@ class HipEngine:
                     raise NotImplementedError('GroupNorm on encoder 0 together with the frequency embedding')
                 st = self._stats_for(L['rewrite'].M, enc.norm_groups, B, Fo, y.device, spec=L['rewrite'])
                 ops.tag = 'stack'
-                r = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, stat=self._acc(st, enc.norm_groups))
+                if st is None and self.use_pw and L.get('rewrite_pw') is not None and y.is_contiguous():
+                    r = ops.pw(L['rewrite_pw'], y, B, Fo, T)
+                else:
+                    r = ops.conv(L['rewrite'], y, None, B, Fo, Fo, T, stat=self._acc(st, enc.norm_groups))
                 ops.tag = ''
                 y = ops.norm_act(r, enc.norm_groups, False, L['norm2'][0], L['norm2'][1], ACT_GLU, stats=st)
             else:

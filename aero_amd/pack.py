@@ -74,13 +74,13 @@ class PwSpec:
         self.wimg, self.bias, self.M, self.C, self.act = wimg, bias, M, C, act
 
 
-def pw_image(w, rows):
+def pw_image(w, rows, ks=None):
     """w fp32/fp16 [M, C] (rows already GLU-interleaved where GLU follows) -> the fp16 image aero_pw_fwd reads (include/aero_hip.h):
     [chunk][2][GW][4][KS][64 lanes][8], rows = 128 * GW rows per chunk; lane l of tile j holds logical row 16 * ((l & 15) >> 2) + 4 j +
     (l & 3) of its 64-row group and the k-octet l >> 4: the permutation that leaves a lane's accumulators consecutive rows."""
     M, C = w.shape
     gw = rows // 128
-    ks = (C + 31) // 32
+    ks = (C + 31) // 32 if ks is None else ks
     nchunk = (M + rows - 1) // rows
     wp = torch.zeros(nchunk * rows, ks * 32, dtype=torch.float32, device=w.device)
     wp[:M, :C] = w.float()
@@ -116,17 +116,19 @@ def make_squeeze_spec(w, bias, act, device):
     return SqueezeSpec(img.to(device=device, dtype=torch.float16).contiguous(), None if bias is None else bias.detach().float().to(device).contiguous(), M, C, act)
 
 
-def make_pw_spec(w, bias, act, lib, device):
+def make_pw_spec(w, bias, act, lib, device, max_c=96):
     """w [M, C] fp32 in the reference's row order; GLU: rows / bias interleaved (value, gate) as make_conv_spec does.  None if the
-    geometry is not served by the streaming pointwise kernel."""
+    geometry is not served by the streaming pointwise kernel.  max_c: the kernel also takes 96 < C <= 384 (weights in LDS), but on the
+    MI355X that form is 15-80% SLOWER than the LDS-tiled conv at the model's widths (profiles/r04_pw_wlds_ab.txt), so the engine keeps
+    the default and only the op tests ask for more."""
     M, C = w.shape
-    rows = int(lib.cdll.aero_pw_rows(C, M))
+    rows = int(lib.cdll.aero_pw_rows(C, M)) if C <= max_c else 0
     if not rows:
         return None
     if act == _lib.ACT_GLU:
         w = glu_interleave(w)
         bias = None if bias is None else glu_interleave(bias)
-    return PwSpec(pw_image(w.to(device), rows), None if bias is None else bias.detach().float().to(device).contiguous(), M, C, act)
+    return PwSpec(pw_image(w.to(device), rows, int(lib.cdll.aero_pw_ksteps(C))), None if bias is None else bias.detach().float().to(device).contiguous(), M, C, act)
 
 
 def ring_bm(M, Ktot):

@@ -199,14 +199,14 @@ typedef struct aero_gram_desc {
 } aero_gram_desc;
 int aero_gram_stats(const aero_gram_desc* d, void* stream);
 
-/* K9' -- a pointwise (1x1) convolution with a SHORT contraction (C <= 96) and a wide output, as ONE streaming pass (k_pw.h): the tail of a
+/* K9' -- a pointwise (1x1) convolution with a SHORT contraction (C <= 384) and a wide output, as ONE streaming pass (k_pw.h): the tail of a
  * DConv layer behind a BLSTM / LocalState (modules.py:240-247: Conv1d(hidden, 2C, 1) -> GroupNorm(1, 2C) -> GLU -> LayerScale, + x) and the
  * encoder's rewrite conv + GLU (+ frequency embedding) where no GroupNorm sits between them (aero.py:133, 475-480).
  *   x fp16 [B][F][T][C] channels-last; dst fp16 [B][F][T][Mout], Mout = M/2 with AERO_ACT_GLU (rows 2u, 2u+1 = value, gate) else M.
  *   v[m] = W[m,:] . x + bias[m];  if stats: v = (v - mean) * rstd * gamma[m] + beta[m] with {sum, sum of squares} of ROW b*F + f at
  *   stats[2*(b*F+f)], mean = sum / stat_count (the sums aero_gram_stats / aero_conv_fwd stat_mode 2 leave);  y = act(v) * layer_scale[c]
  *   + res[b,f,t,c] + post_add[f][c]  (each optional).
- *   wimg: fp16 image of W packed by the host (aero_amd/pack.py: pw_image): [chunk][2][GW][4][KS][64 lanes][8], KS = ceil(C/32),
+ *   wimg: fp16 image of W packed by the host (aero_amd/pack.py: pw_image): [chunk][2][GW][4][KS][64 lanes][8], KS = aero_pw_ksteps(C),
  *   GW = aero_pw_rows(C, M) / 128 rows-per-wave groups; element (chunk, wm, g, j, ks, lane, e) = W[r][k],
  *   r = 128*GW*chunk + 64*(GW*wm + g) + 16*((lane & 15) >> 2) + 4*j + (lane & 3),  k = 32*ks + 8*(lane >> 4) + e  (zero outside M x C):
  *   the row permutation that makes a lane's accumulators 16 consecutive rows of one time step (no transpose before the store). */
@@ -229,6 +229,9 @@ int aero_squeeze_fwd(const void* x, int64_t x_b, int64_t x_f, int64_t x_t, const
                      int32_t T, int32_t C, int32_t M, int32_t rp, int32_t act, void* stream);
 /* conv rows one block covers (128 * GW) for a C -> M pointwise conv, 0 if the geometry is not served (C > 96, C % 8, M % 16) */
 int aero_pw_rows(int32_t C, int32_t M);
+/* k-steps KS of the weight image for C input channels (ceil(C/32) up to 6, then 8 or 12: the image is zero padded to 32*KS columns).
+ * C <= 96: the fragments stay in registers; 96 < C <= 384: in LDS (one ds_read_b128 per MFMA), rows per block = 128 */
+int aero_pw_ksteps(int32_t C);
 
 /* K10 -- the recurrent part of nn.LSTM(bidirectional) inside BLSTM (modules.py:28,46), both
  * directions of ONE layer per call; the input projection is an aero_conv_fwd 1x1.

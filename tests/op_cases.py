@@ -25,7 +25,10 @@ PW_CASES = [dict(Cin=48, Cout=384, Fq=3, T=70, norm=True, residual=True, scale=T
             dict(Cin=24, Cout=64, Fq=2, T=17, act='gelu', residual=True),                        # non-GLU store path, one k-step
             dict(Cin=16, Cout=32, Fq=1, T=5, act='none', B=1),
             dict(Cin=96, Cout=48, Fq=4, T=70, act='relu', split=48),                            # FTB conv2 over cat([att, x]): a k-step spans both sources
-            dict(Cin=48, Cout=32, Fq=2, T=21, act='relu', split=24)]
+            dict(Cin=48, Cout=32, Fq=2, T=21, act='relu', split=24),
+            dict(Cin=192, Cout=384, Fq=2, T=70, act='none', B=1),                               # weights in LDS (KS 6): encoder-2 rewrite
+            dict(Cin=384, Cout=192, Fq=2, T=37, act='relu', split=192, B=1),                    # KS 12, two sources: FTB conv2 of the deepest encoder
+            dict(Cin=224, Cout=64, Fq=1, T=20, act='gelu', residual=True, B=1)]                # KS 7 -> the 8-step image
 TOL32 = 2e-6
 BLSTM_TOL = 1e-3      # whole BLSTM block / LocalState block (output incl. the skip path) against the oracle: the north-star bar itself
 ATTN_TOL = 1e-3
@@ -134,7 +137,7 @@ def case_pw(lib, dev, Cin, Cout, Fq, T, B=2, act='glu', norm=False, residual=Fal
     b = torch.randn(Cout, generator=g)
     x = torch.randn(B, Cin, Fq, T, generator=g)
     actc = {'none': _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'gelu': _lib.ACT_GELU, 'glu': _lib.ACT_GLU}[act]
-    spec = pack.make_pw_spec(q16(w), b, actc, lib, dev)
+    spec = pack.make_pw_spec(q16(w), b, actc, lib, dev, max_c=384)
     assert spec is not None
     v = torch.einsum('mc,bcft->bmft', q16(w), q16(x)) + b.view(1, -1, 1, 1)
     kw = {}
