@@ -113,6 +113,61 @@ static __device__ __forceinline__ f32x2* aero_fft_wave(f32x2* a, f32x2* b, int n
     return src;
 }
 
+// 256 points with the pass twiddles in REGISTERS (round 4, the ring-resident iSTFT).  Measured there (tools/dbg/istft_ablation.py): the
+// transforms are bound by VALU issue and LDS stores together, not by latency -- two interleaved frames per wave changed nothing -- so
+// what is taken out is work: a lane's twiddles depend on (pass, lane) only, so the nine of passes 1-3 are loaded once per kernel
+// (aero_fft256_twiddles) instead of three LDS reads and their address arithmetic per butterfly, and pass 0 (all twiddles = 1) has no
+// complex products at all.  Same butterflies and the same twiddle values as aero_fft_wave<8>: results are bit-identical.
+struct AeroFft256Tw { f32x2 w[3][3]; };                        // [pass - 1][w2, w1, w3]
+static __device__ __forceinline__ AeroFft256Tw aero_fft256_twiddles(const f32x2* tw) {
+    AeroFft256Tw t;
+    const int i = aero_lane();
+#pragma unroll
+    for (int s4 = 1; s4 < 4; ++s4) {
+        const int p = 1 << (2 * s4), k = i & (p - 1);
+        t.w[s4 - 1][0] = tw[k * (512 / (2 * p))];
+        t.w[s4 - 1][1] = tw[k * (512 / (4 * p))];
+        t.w[s4 - 1][2] = tw[(k + p) * (512 / (4 * p))];
+    }
+    return t;
+}
+static __device__ __forceinline__ void aero_fft256_regtw(f32x2* a, f32x2* b, const AeroFft256Tw& t) {   // in place: four passes a -> b -> a -> b -> a
+    constexpr int half = 128, quarter = 64;
+    const int i = aero_lane();
+    f32x2* src = a;
+    f32x2* dst = b;
+    {                                                            // pass 0: p = 1, k = 0, linear input
+        const f32x2 A = src[i], B = src[i + quarter], Cc = src[i + half], D = src[i + half + quarter];
+        const f32x2 m0 = A + Cc, m1 = A - Cc, m2 = B + D, m3 = B - D;
+        const f32x2 f = (f32x2){m3[1], -m3[0]};                 // w3 = tw[n_fft / 4] = -i   (cmul(-i, m3); the table holds exactly (0, -1))
+        const int jj = i << 2;
+        dst[aero_fft_swz(jj, 1)] = m0 + m2;
+        dst[aero_fft_swz(jj + 1, 1)] = m1 + f;
+        dst[aero_fft_swz(jj + 2, 1)] = m0 - m2;
+        dst[aero_fft_swz(jj + 3, 1)] = m1 - f;
+        aero_wave_sync();
+        f32x2* tmp = src; src = dst; dst = tmp;
+    }
+#pragma unroll
+    for (int s4 = 1; s4 < 4; ++s4) {
+        const int p = 1 << (2 * s4), pr = p >> 2;
+        const int k = i & (p - 1);
+        const f32x2 w2 = t.w[s4 - 1][0], w1 = t.w[s4 - 1][1], w3 = t.w[s4 - 1][2];
+        const f32x2 A = src[aero_fft_swz(i, pr)], B = src[aero_fft_swz(i + quarter, pr)];
+        const f32x2 Cc = src[aero_fft_swz(i + half, pr)], D = src[aero_fft_swz(i + half + quarter, pr)];
+        const f32x2 c2 = aero_cmul(w2, Cc), d2 = aero_cmul(w2, D);
+        const f32x2 m0 = A + c2, m1 = A - c2, m2 = B + d2, m3 = B - d2;
+        const f32x2 e = aero_cmul(w1, m2), f = aero_cmul(w3, m3);
+        const int jj = ((i - k) << 2) + k;
+        dst[aero_fft_swz(jj, p)] = m0 + e;
+        dst[aero_fft_swz(jj + p, p)] = m1 + f;
+        dst[aero_fft_swz(jj + 2 * p, p)] = m0 - e;
+        dst[aero_fft_swz(jj + 3 * p, p)] = m1 - f;
+        aero_wave_sync();
+        f32x2* tmp = src; src = dst; dst = tmp;
+    }
+}
+
 struct AeroStftK {
     const float* x; const float* window; float* spec; double* stats;
     int nsig, L, Lp, n_fft, hop, n_bins, T, sig_per_item, FPB;
@@ -448,26 +503,25 @@ __global__ __launch_bounds__(NW * 64) void aero_istft_kernel(AeroIstftK p) {
 
 static inline size_t aero_istft2_lds_bytes(int n_fft) {
     const size_t n = (size_t)n_fft / 2;
-    return (n + AERO_ISTFT2_SLOTS * (n + 1) + 8 * n) * sizeof(f32x2) + (size_t)n_fft * sizeof(float);
+    return (n + AERO_ISTFT2_SLOTS * (n + 1) + 8 * n) * sizeof(f32x2);
 }
 
-template <int LOGN>
+template <int LOGN, int NEED>
 __global__ __launch_bounds__(512) void aero_istft2_kernel(AeroIstftK p) {
     constexpr int n = 1 << LOGN, n_fft = 2 * n, fs = n + 1, NP = n / 2;          // NP (k, n - k) pairs with k < n / 2; bin n / 2 pairs with itself
     constexpr int NIT = NP * 16 / 512;                                             // pair items per thread and 16-frame group
     f32x2* tw = (f32x2*)AERO_DYN_SMEM;
     f32x2* ring = tw + n;                                                          // [SLOTS][n + 1]
     f32x2* sbuf0 = ring + AERO_ISTFT2_SLOTS * fs;                                  // [8][n]
-    float* wl = (float*)(sbuf0 + 8 * n);
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int nseg = (int)gridDim.x;
     const int lin = aero_xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
     const int sig = lin / nseg, seg = lin - sig * nseg;
     const int hop = p.hop, hsh = p.hsh, T = p.T;
-    const int need = n_fft >> hsh, h2 = n >> hsh;                                  // frames over a sample; frames before the first kept sample
+    constexpr int need = NEED;                                                     // frames over a sample = n_fft / hop
+    const int h2 = n >> hsh;                                                       // frames before the first kept sample
     const int F0 = seg * AERO_ISTFT2_SEGF + h2 - AERO_ISTFT2_HALO;                 // first frame this block transforms (may be < 0: zeros)
     aero_fft_init_twiddles(tw, n_fft);
-    for (int i = tid; i < n_fft; i += 512) wl[i] = p.window[i];
     const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * T;
     float* ys = p.y + (int64_t)sig * p.Lout;
     const float scale = sqrtf((float)n_fft) / (float)n;
@@ -481,6 +535,7 @@ __global__ __launch_bounds__(512) void aero_istft2_kernel(AeroIstftK p) {
     // ---- spectrum values of one group: per thread NIT pairs (k, n - k) of frame tg + fr, plus bin n / 2 for threads < 16.
     // Loads are unconditional (frame index clamped); frames outside [0, T) are zeroed when the values are unpacked.
     f32x2 xa[NIT], xq[NIT], xm;
+    f32x2 twh[NIT];                                                     // tw[k] / 2 of this thread's pairs (filled once the twiddle table is in)
     auto request = [&](int tg) {
         int t = tg + fr;
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);
@@ -509,9 +564,15 @@ __global__ __launch_bounds__(512) void aero_istft2_kernel(AeroIstftK p) {
                 const f32x2 z = unpack(a, zero, 0);
                 row[0] = live ? z : zero;
             } else {
+                // bins k and n - k together: with S = a + conj(q), D = a - conj(q) and O = (D / 2) * conj(tw[k]) the two unpacked values are
+                // (S / 2 -+ ...) of the SAME S, D, O  (tw[n - k] = -conj(tw[k]) makes the second O the conjugate of the first): 16 VALU a pair
+                // against 36 for two independent unpacks; the halves are folded into the twiddle register (exact) and the closing fmas
                 const f32x2 q = xq[it];
-                const f32x2 z0 = unpack(a, (f32x2){q[0], -q[1]}, k);
-                const f32x2 z1 = unpack(q, (f32x2){a[0], -a[1]}, n - k);
+                const f32x2 w = twh[it];
+                const float s0 = a[0] + q[0], s1 = a[1] - q[1], d0 = a[0] - q[0], d1 = a[1] + q[1];
+                const float o0 = d0 * w[0] + d1 * w[1], o1 = d1 * w[0] - d0 * w[1];
+                const f32x2 z0 = (f32x2){s0 * 0.5f - o1, -(s1 * 0.5f) - o0};
+                const f32x2 z1 = (f32x2){s0 * 0.5f + o1, s1 * 0.5f - o0};
                 row[k] = live ? z0 : zero;
                 row[n - k] = live ? z1 : zero;
             }
@@ -521,54 +582,99 @@ __global__ __launch_bounds__(512) void aero_istft2_kernel(AeroIstftK p) {
             row[NP] = live ? z : zero;
         }
     };
+    AeroFft256Tw rtw;                                                   // (LOGN == 8: filled once the twiddle table is in)
     auto transform = [&](int slot) {
         slot -= slot >= AERO_ISTFT2_SLOTS ? AERO_ISTFT2_SLOTS : 0;
         slot -= slot >= AERO_ISTFT2_SLOTS ? AERO_ISTFT2_SLOTS : 0;
         f32x2* a = ring + slot * fs;
         f32x2* sb = sbuf0 + wave * n;
-        f32x2* R = aero_fft_wave<LOGN>(a, sb, n, tw);
-        if (R != a) {
-            for (int m = lane; m < n; m += 64) a[m] = R[m];
-            aero_wave_sync();
+        if constexpr (LOGN == 8) {
+            aero_fft256_regtw(a, sb, rtw);
+        } else {
+            f32x2* R = aero_fft_wave<LOGN>(a, sb, n, tw);
+            if (R != a) {
+                for (int m = lane; m < n; m += 64) a[m] = R[m];
+                aero_wave_sync();
+            }
         }
     };
+#ifdef AERO_ISTFT_ABLATION
+    const int abl = p.FPB;                                              // (tools/dbg/istft_ablation.py; p.FPB is unused by this form)
+#else
+    constexpr int abl = 0;
+#endif
     request(F0);                                                        // the halo group: frames F0 .. F0 + 7 (lanes fr >= 8 load and drop)
-    __syncthreads();                                                    // twiddles and window are in
+    // overlap-add constants of this thread: its samples are o = tid + 512 * it of a group's 16 * hop, so r = o mod hop is FIXED (hop
+    // divides 512) and with it the NEED window values r + j * hop and the sign of the conjugate ((ni & 1) = (r & 1): hop is even)
+    const int r_o = tid & (hop - 1);
+    float wreg[NEED];
+#pragma unroll
+    for (int j = 0; j < NEED; ++j) {
+        const float w = p.window[r_o + ((NEED - 1 - j) << hsh)];
+        wreg[j] = (r_o & 1) ? -w : w;
+    }
+    __syncthreads();                                                    // twiddles are in
+    if constexpr (LOGN == 8) rtw = aero_fft256_twiddles(tw);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) twh[it] = tw[k0 + 32 * it] * 0.5f;
     constexpr int NG = AERO_ISTFT2_SEGF / 16;
     // group -1 = the halo (8 frames, one per wave), groups 0 .. NG-1 of 16 frames
     for (int g = -1; g < NG; ++g) {
         const int rel0 = g < 0 ? 0 : AERO_ISTFT2_HALO + 16 * g;
         const int tg = F0 + rel0;
         const int nf = g < 0 ? AERO_ISTFT2_HALO : 16;
-        if (fr < nf) deposit(tg, rel0 % AERO_ISTFT2_SLOTS);
+        if (fr < nf && !(abl & 8)) deposit(tg, rel0 % AERO_ISTFT2_SLOTS);
         __syncthreads();
-        if (g + 1 < NG) request(F0 + AERO_ISTFT2_HALO + 16 * (g + 1));
+        if (g + 1 < NG && !(abl & 1)) request(F0 + AERO_ISTFT2_HALO + 16 * (g + 1));
         const int rs = rel0 % AERO_ISTFT2_SLOTS;
-        if (g < 0) {
+        if (abl & 2) {
+        } else if (g < 0) {
             transform(rs + wave);
         } else {
             transform(rs + 2 * wave);
             transform(rs + 2 * wave + 1);
         }
         __syncthreads();
-        if (g >= 0) {
-            // the samples this group completes: hop index q = tg + (0 .. 15), OLA index i = q * hop + r, kept sample oo = i - n
+        if (g >= 0 && !(abl & 4)) {
+            // the samples this group completes: hop index q = tg + (0 .. 15), OLA index i = q * hop + r, kept sample oo = i - n.
+            // Frames outside [0, T) are zero rows (deposit), so the NEED terms are added without a range test; the row walk is a
+            // running slot with one conditional wrap.  (First form: per term a division by 24, two range tests and a window read
+            // from LDS -- ~25 VALU per term, 10 of the kernel's 39 us.)
             const float* ringf = (const float*)ring;
-            for (int o = tid; o < (16 << hsh); o += 512) {
-                const int qi = o >> hsh, r = o & (hop - 1);
-                const int q = tg + qi;
-                const int oo = (q << hsh) + r - n;
-                if (oo < 0 || oo >= p.Lout) continue;
-                float acc = 0.f;
-                int rel = rel0 + qi - (need - 1);                       // ring position of the oldest frame over this sample
-                int ni = r + ((need - 1) << hsh);
-                for (int j = 0; j < need; ++j, ++rel, ni -= hop) {
-                    if (q - (need - 1) + j < 0 || q - (need - 1) + j >= T) continue;
-                    int slot = rel % AERO_ISTFT2_SLOTS;
-                    const float v = ringf[slot * (2 * fs) + ni];
-                    acc += wl[ni] * ((ni & 1) ? -v : v);
+            if (hsh >= 6) {
+                // hop >= 64: the 64 samples of a wave share their hop index, so the frame rows are WAVE-UNIFORM -- the slot walk runs on the
+                // scalar unit and a term is one address add, one LDS read and one fma
+                for (int ob = wave * 64; ob < (16 << hsh); ob += 512) {
+                    const int qi = ob >> hsh;
+                    const int oo = ((tg + qi) << hsh) + r_o - n;
+                    const bool ok = oo >= 0 && oo < p.Lout;
+                    const float ie = p.inv_env[ok ? oo + n : n];        // (issued before the LDS reads: its latency hides under them)
+                    int slot = (rel0 + qi - (NEED - 1)) % AERO_ISTFT2_SLOTS;   // ring position of the oldest frame over these samples
+                    const float* col = ringf + r_o;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NEED; ++j) {
+                        acc += wreg[j] * col[slot * (2 * fs) + ((NEED - 1 - j) << hsh)];
+                        slot = slot + 1 == AERO_ISTFT2_SLOTS ? 0 : slot + 1;
+                    }
+                    if (ok) ys[oo] = acc * scale * ie;
                 }
-                ys[oo] = acc * scale * p.inv_env[oo + n];
+            } else {
+                for (int o = tid; o < (16 << hsh); o += 512) {
+                    const int qi = o >> hsh;
+                    const int oo = ((tg + qi) << hsh) + r_o - n;
+                    int slot = (rel0 + qi - (NEED - 1)) % AERO_ISTFT2_SLOTS;
+                    int idx = slot * (2 * fs) + r_o + ((NEED - 1) << hsh);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NEED; ++j) {
+                        acc += wreg[j] * ringf[idx];
+                        ++slot;
+                        idx += 2 * fs - hop;
+                        if (slot == AERO_ISTFT2_SLOTS) { slot = 0; idx -= AERO_ISTFT2_SLOTS * 2 * fs; }
+                    }
+                    if (oo >= 0 && oo < p.Lout) ys[oo] = acc * scale * p.inv_env[oo + n];
+                }
             }
         }
         __syncthreads();                                                // the next group's rows overwrite frames this one still read
@@ -850,12 +956,18 @@ static int aero_istft_launch(const float* spec, int nsig, int F, int T, int n_ff
     if (v2 && aero_istft2_ok(n_fft, hop, T)) {
         p.hsh = aero_ilog2(hop);
         p.FPB = 0;
+#ifdef AERO_ISTFT_ABLATION
+        { const char* e = getenv("AERO_ISTFT_ABL"); p.FPB = e ? atoi(e) : 0; }
+#endif
         p.SEG = 0;
         const int segs = hop * AERO_ISTFT2_SEGF;
         dim3 grid2((unsigned)((Lout + segs - 1) / segs), (unsigned)nsig);
         const size_t lds2 = aero_istft2_lds_bytes(n_fft);
-        if (n == 256) AERO_LAUNCH_DYN((aero_istft2_kernel<8>), grid2, dim3(512), lds2, stream, p);
-        else AERO_LAUNCH_DYN((aero_istft2_kernel<9>), grid2, dim3(512), lds2, stream, p);
+        const int need2 = n_fft / hop;
+#define AERO_ISTFT2_GO(LOGN_, NEED_) AERO_LAUNCH_DYN((aero_istft2_kernel<LOGN_, NEED_>), grid2, dim3(512), lds2, stream, p)
+        if (n == 256) { if (need2 == 8) AERO_ISTFT2_GO(8, 8); else if (need2 == 4) AERO_ISTFT2_GO(8, 4); else AERO_ISTFT2_GO(8, 2); }
+        else { if (need2 == 8) AERO_ISTFT2_GO(9, 8); else if (need2 == 4) AERO_ISTFT2_GO(9, 4); else AERO_ISTFT2_GO(9, 2); }
+#undef AERO_ISTFT2_GO
         return AERO_OK;
     }
     const int fpb = aero_istft_fpb(n);
