@@ -29,6 +29,22 @@ def _strides4(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
+_SIDE_STREAMS = {}
+
+
+def side_streams(device, n):
+    """The first n of ONE per-device list of HIP streams shared by everything in the package that runs work next to the caller's stream
+    (the engine's half-batch streams, BatchPipeline's ring).  The ROCm runtime multiplexes streams onto a few hardware queues (4 by
+    default, GPU_MAX_HW_QUEUES): every extra stream object created -- even an idle one -- shifts which streams share a queue, and two
+    busy streams on one queue run one after the other.  Measured on the MI355X: three batches in flight 9.3 ms per batch with only
+    these streams alive, 9.6-9.9 ms once two more (idle) streams had been created before them."""
+    dev = torch.device(device)
+    lst = _SIDE_STREAMS.setdefault(dev, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst[:n]
+
+
 class Ops:
     """Tensor-level wrappers over the C ABI (used by the engine and by the op-level tests)."""
 
@@ -738,7 +754,7 @@ class HipEngine:
         cur = torch.cuda.current_stream(mix.device)
         key = ('streams', ns, str(mix.device))
         if key not in self._tables:
-            self._tables[key] = [torch.cuda.Stream(device=mix.device) for _ in range(ns)]
+            self._tables[key] = side_streams(mix.device, ns)
         outs = []
         self._prepare(mix.device)                       # weights packed once, on the caller's stream
         # STAGGER: sub-batch k + 1 starts when sub-batch k has finished stage `stagger` (1..4: encoder layers, 5..8: decoder layers).

@@ -25,16 +25,22 @@ def get_estimate(model, lr_sig):
 MAX_CLIPS_PER_FORWARD = 64         # bound on chunk-channels per forward: activation memory stays constant for any file length
 
 
+PIPELINE_DEPTH = 3                 # forwards in flight on separate HIP streams (aero_amd/pipeline.py)
+
+
 def _forward_groups(model, groups, device):
     """Run the [n_i, 1, L] host batches of `groups` through the model, one forward each.  On the GPU the uploads and
-    downloads run on their own HIP streams through pinned buffers, so group g+1's H2D copy and group g-1's D2H copy
-    overlap with group g's kernels (predict.py:76-80 moves one chunk at a time, synchronously)."""
+    downloads run on their own HIP streams through pinned buffers and up to PIPELINE_DEPTH forwards are in flight on a ring of
+    compute streams (BatchPipeline), so group g+1's H2D copy, group g-1's D2H copy and the latency-bound launches of neighbouring
+    forwards overlap with group g's kernels (predict.py:76-80 moves one chunk at a time, synchronously)."""
     dev = torch.device(device)
     if dev.type != 'cuda' or len(groups) == 0:
         return [model(g.to(dev)).cpu() for g in groups]
+    from .pipeline import BatchPipeline
+    pipe = BatchPipeline(model, depth=int(os.environ.get('AERO_PIPELINE', PIPELINE_DEPTH)))
     main = torch.cuda.current_stream(dev)
     s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    outs, pending = [], None
+    outs = []
     with torch.cuda.stream(s_in):
         nxt = groups[0].pin_memory().to(dev, non_blocking=True)
         ev = torch.cuda.Event()
@@ -48,11 +54,11 @@ def _forward_groups(model, groups, device):
                 ev.record(s_in)
         main.wait_event(ev_x)
         x.record_stream(main)
-        y = model(x)
-        done = torch.cuda.Event()
-        done.record(main)
+        ticket = pipe.submit(x)                              # (ordered behind `main`, i.e. behind this group's upload only)
+        y = ticket.out
         with torch.cuda.stream(s_out):
-            s_out.wait_event(done)
+            if ticket.event is not None:
+                s_out.wait_event(ticket.event)
             y.record_stream(s_out)
             host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
             host.copy_(y, non_blocking=True)

@@ -1,0 +1,113 @@
+"""Several batches in flight: the serving loop of the drop-in (the reference's predict.py:76-80 / enhance.py:11-15 run one forward at a
+time and wait for it).
+
+One forward of the model is a chain of ~90 launches of which a fifth (by time) are latency-bound -- the recurrent LSTM kernels keep a
+quarter of the CUs busy for 200 dependent steps, the attention and the 1-D FTB convs not many more.  `HipEngine.forward` already cuts ONE
+batch into two halves on two HIP streams, but the halves run the same kernel sequence from the same start, so mostly the same kernel meets
+itself.  Batches that do not depend on each other can do better: `BatchPipeline` enqueues batch i on stream i mod depth without waiting
+for batch i - 1, the streams drift apart, and the recurrent phase of one batch runs under the MFMA / bandwidth-bound phases of the
+others.  Measured on the MI355X at the bench workload (64 clips per batch, tools/bench_pipelined.py): 10.30 ms per batch one at a time on
+one stream, 10.00 ms with the two half-batch streams, 9.2 ms with three batches in flight; results are bit-identical to the single-stream
+forward of each batch (every batch runs the single-stream kernel sequence, only on its own stream).
+
+Stream semantics are PyTorch's: `submit` orders the batch behind everything the caller's current stream has issued so far (its input is
+ready), `result` makes the caller's current stream wait for that batch.  Collect results a few submissions late (or call `drain`), not
+right after each `submit` -- a `result` immediately behind its `submit` serialises the batches again.
+"""
+import torch
+
+
+class _Ticket:
+    __slots__ = ('out', 'event', 'stream')
+
+    def __init__(self, out, event, stream):
+        self.out, self.event, self.stream = out, event, stream
+
+
+def _tensors(out):
+    if torch.is_tensor(out):
+        yield out
+    elif isinstance(out, (tuple, list)):
+        for o in out:
+            yield from _tensors(o)
+
+
+class BatchPipeline:
+    """pipe = BatchPipeline(model, depth=3);  t = pipe.submit(x);  ...;  y = pipe.result(t)   (inference, model.eval())."""
+
+    def __init__(self, model, depth=3):
+        self.model = model
+        self.depth = max(1, int(depth))
+        self._streams = {}
+        self._n = 0
+        self._seen = set()
+        self._open = []
+
+    def _ring(self, dev):
+        if dev not in self._streams:
+            from .engine import side_streams
+            self._streams[dev] = side_streams(dev, self.depth)     # (shared with the engine's half-batch streams: see there)
+        return self._streams[dev]
+
+    def submit(self, mix, **kw):
+        """enqueue model(mix, **kw) (Aero.forward's keywords) and return a ticket for `result`"""
+        if self.model.training:
+            raise RuntimeError('BatchPipeline is the inference loop: call model.eval() first')
+        if not mix.is_cuda or self.depth == 1:
+            with torch.no_grad():
+                return _Ticket(self.model(mix, **kw), None, None)
+        dev = mix.device
+        cur = torch.cuda.current_stream(dev)
+        eng = self.model._get_engine()
+        eng._prepare(dev)                                   # weights are (re-)packed on the caller's stream, which the batch stream waits for
+        ring = self._ring(dev)
+        st = ring[self._n % self.depth]
+        self._n += 1
+        st.wait_stream(cur)
+        mix.record_stream(st)
+        saved = eng.streams
+        eng.streams = 1                                     # the whole batch on this stream (no half-batch split inside a pipelined batch)
+        try:
+            with torch.cuda.stream(st), torch.no_grad():
+                out = self.model(mix, **kw)
+        finally:
+            eng.streams = saved
+        key = (str(dev), tuple(mix.shape), tuple(sorted(kw.items())))
+        if key not in self._seen:
+            # the first batch of a shape builds the engine's lazily created device tables (window, envelope, DFT table, constant
+            # buffers) on ITS stream: the other streams must not run ahead of that
+            self._seen.add(key)
+            for s in ring:
+                s.wait_stream(st)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        t = _Ticket(out, ev, st)
+        self._open.append(t)
+        return t
+
+    def result(self, ticket):
+        """the output of a submitted batch, ordered into the caller's current stream"""
+        if ticket.event is not None:
+            cur = torch.cuda.current_stream(ticket.stream.device)
+            cur.wait_event(ticket.event)
+            for t in _tensors(ticket.out):
+                t.record_stream(cur)
+            ticket.event = None
+            if ticket in self._open:
+                self._open.remove(ticket)
+        return ticket.out
+
+    def drain(self):
+        """make the caller's current stream wait for every batch submitted so far"""
+        for t in list(self._open):
+            self.result(t)
+
+    def run(self, batches, **kw):
+        """all of `batches` (an iterable of inputs), results in order; at most `depth` outputs are held un-collected"""
+        outs, tickets = [], []
+        for x in batches:
+            tickets.append(self.submit(x, **kw))
+            if len(tickets) > self.depth:
+                outs.append(self.result(tickets.pop(0)))
+        outs.extend(self.result(t) for t in tickets)
+        return outs

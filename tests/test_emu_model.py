@@ -162,3 +162,21 @@ def test_data_writes_need_repack_and_shape_cache_is_bounded(emu, meta):
         if isinstance(k, tuple):
             kinds[k[0]] = kinds.get(k[0], 0) + 1
     assert all(n <= 8 for kind, n in kinds.items() if kind in ('hidpad', 'ones', 'env', 'graph')), kinds
+
+
+def test_batch_pipeline_on_cpu_is_the_plain_forward(emu, meta):
+    """aero_amd/pipeline.py off the GPU: submit / result / run degrade to one forward at a time with the same results (the stream ring
+    itself is covered on the MI355X: tests/test_gpu_model.py::test_batch_pipeline_matches_one_at_a_time)."""
+    from aero_amd.pipeline import BatchPipeline
+    m = _with_engine(build_model(meta, 'tiny'), emu).eval()
+    io = load_npz('tiny_io.npz')
+    xs = [torch.from_numpy(io['x_400']), torch.from_numpy(io['x_1000'])]
+    pipe = BatchPipeline(m, depth=3)
+    outs = pipe.run(xs, return_spec=True)
+    with torch.no_grad():
+        for x, (y, s) in zip(xs, outs):
+            y0, s0 = m(x, return_spec=True)
+            assert torch.equal(y, y0) and torch.equal(s, s0)
+    m.train()
+    with pytest.raises(RuntimeError):
+        pipe.submit(xs[0])

@@ -230,3 +230,27 @@ def test_two_stream_forward_equals_one_stream(meta):
     finally:
         eng.streams = 0
     assert rel_l2(s2, s1) < 1e-5 and rel_l2(y2, y1) < 1e-5
+
+
+def test_batch_pipeline_matches_one_at_a_time(meta):
+    """aero_amd/pipeline.py: batches enqueued on a ring of HIP streams without waiting for each other (the bench's timed region, the
+    enhance loop) give, batch for batch, the BIT-identical output of the single-stream forward -- 30 batches of 3 different inputs and two
+    shapes, 3 in flight."""
+    from aero_amd.pipeline import BatchPipeline
+    m = build_model(meta, 'full').cuda().eval()
+    eng = m._get_engine()
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(16, 1, 8000, generator=g).cuda(), torch.randn(16, 1, 8000, generator=g).cuda(), torch.randn(8, 1, 6000, generator=g).cuda()]
+    try:
+        eng.streams = 1
+        with torch.no_grad():
+            refs = [m(x, return_spec=True) for x in xs]
+    finally:
+        eng.streams = 0
+    pipe = BatchPipeline(m, depth=3)
+    order = [i % 3 for i in range(30)]
+    outs = pipe.run([xs[i] for i in order], return_spec=True)
+    torch.cuda.synchronize()
+    assert eng.streams == 0
+    for i, (y, s) in zip(order, outs):
+        assert torch.equal(y, refs[i][0]) and torch.equal(s, refs[i][1])
