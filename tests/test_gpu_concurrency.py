@@ -67,6 +67,37 @@ def test_two_stream_forward_equals_one_stream_100_times(rig):
     assert not bad, (len(bad), bad[:4])
 
 
+def test_pipelined_batches_300_times_bit_equal(rig):
+    """the serving loop (aero_amd/pipeline.py: three whole batches in flight on three streams -- every kernel of one batch, its STFT and
+    iSTFT included, next to the kernels of two others; the bench's timed region): 300 batches of two alternating inputs, every output
+    bit-equal to the one-stream forward of its input"""
+    from aero_amd.pipeline import BatchPipeline
+    m, _ = rig
+    m.eval()
+    eng = m._get_engine()
+    xs = [seeded((32, 1, 8000), 5).cuda(), seeded((32, 1, 8000), 6).cuda()]
+    with torch.no_grad():
+        eng.streams = 1
+        refs = [tuple(t.clone() for t in m(x, return_spec=True)) for x in xs]
+        eng.streams = 0
+    pipe = BatchPipeline(m, depth=3)
+    bad = []
+    tickets = []
+    for it in range(300):
+        tickets.append((it, pipe.submit(xs[it % 2], return_spec=True)))
+        if len(tickets) > 6:
+            i, t = tickets.pop(0)
+            y, s = pipe.result(t)
+            if not (torch.equal(y, refs[i % 2][0]) and torch.equal(s, refs[i % 2][1])):
+                bad.append((i, float((y - refs[i % 2][0]).abs().max())))
+    for i, t in tickets:
+        y, s = pipe.result(t)
+        if not (torch.equal(y, refs[i % 2][0]) and torch.equal(s, refs[i % 2][1])):
+            bad.append((i, float((y - refs[i % 2][0]).abs().max())))
+    torch.cuda.synchronize()
+    assert not bad, (len(bad), bad[:4])
+
+
 def test_training_step_gradients_do_not_depend_on_the_second_stream(meta):
     """the training backward issues its weight-gradient GEMMs on a second stream beside the main stream's ring / norm / recurrent
     kernels (train.py: on_param_stream).  The backward is not bit-reproducible from run to run even on ONE stream (its loss-scale
