@@ -31,6 +31,7 @@ struct AeroPwK {
 template <int KS, int GW, int ACT, bool NORM, bool WLDS = false>
 __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
     constexpr bool GLU = ACT == AERO_ACT_GLU;
+    constexpr int DEPTH = (!WLDS && GW * KS >= 6) ? 1 : 2;        // units requested ahead (96 weight-fragment registers leave room for one)
     constexpr int MC = 128 * GW;                                  // conv rows per chunk (block)
     constexpr int OC = GLU ? MC / 2 : MC;                         // stored channels per chunk
     constexpr int NV = GLU ? 1 : 2;                               // 16-byte vectors a lane stores per group
@@ -148,15 +149,24 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
             }
     };
 
-    h16x8 Bc[KS], Bn[KS], Rc[GW][NV], Rn[GW][NV];
+    // DEPTH + 1 fragment buffers, used in rotation by an unrolled loop: the unit computed in a trip was requested DEPTH trips (of this
+    // wave) earlier.  (First form: two buffers and `Bc = Bn` at the end of the trip -- the copy needs the prefetched registers, so the
+    // compiler waited vmcnt(0) there, for the loads AND the trip's store: a prefetch lived for one epilogue, ~0.3 us against ~2 us of
+    // memory latency, and with 8-12 waves per CU the kernel ran at 3.0-3.3 TB/s where its epilogue is long (GLU).)
+    h16x8 B[DEPTH + 1][KS], R[DEPTH + 1][GW][NV];
 #pragma unroll
-    for (int g = 0; g < GW; ++g)
+    for (int s_ = 0; s_ <= DEPTH; ++s_)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) Rc[g][v] = Rn[g][v] = zero8;
+        for (int g = 0; g < GW; ++g)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) R[s_][g][v] = zero8;
     int u = u_lo + wt;
-    if (u < u_hi) {
-        load_b(Bc, u);
-        load_r(Rc, u);
+    if (u >= u_hi) return;                                           // (no barrier below)
+#pragma unroll
+    for (int s_ = 0; s_ < DEPTH; ++s_) {
+        const int ul = u + 2 * s_ < u_hi ? u + 2 * s_ : u;
+        load_b(B[s_], ul);
+        load_r(R[s_], ul);
     }
 #ifndef AERO_EMU
     // the loop is ENTERED with nothing in flight: otherwise hipcc merges the preheader's pending first loads into the loop header's state
@@ -164,12 +174,11 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
     // is invisible to its scoreboard)
     __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
 #endif
-#pragma unroll 1
-    for (; u < u_hi; u += 2) {
+    auto trip = [&](h16x8 (&Bc)[KS], h16x8 (&Rc)[GW][NV], h16x8 (&Bl)[KS], h16x8 (&Rl)[GW][NV], int u) {
         {
-            const int un = u + 2 < u_hi ? u + 2 : u;              // (the last trip re-reads its own unit: no branch around the prefetch)
-            load_b(Bn, un);
-            load_r(Rn, un);
+            const int un = u + 2 * DEPTH < u_hi ? u + 2 * DEPTH : u;   // (past the end: re-read this unit, no branch around the prefetch)
+            load_b(Bl, un);
+            load_r(Rl, un);
         }
         const int t = u * 16 + n;
         const bool tin = t < T;
@@ -233,12 +242,22 @@ __global__ __launch_bounds__(256, 2) void aero_pw_kernel(AeroPwK p) {
             }
             aero_sched_fence();                                                   // the next group's MFMAs and reads start after this one's store
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) Bc[ks] = Bn[ks];
-#pragma unroll
-        for (int g = 0; g < GW; ++g)
-#pragma unroll
-            for (int vv = 0; vv < NV; ++vv) Rc[g][vv] = Rn[g][vv];
+    };
+#pragma unroll 1
+    for (;;) {
+        if constexpr (DEPTH == 1) {
+            trip(B[0], R[0], B[1], R[1], u);
+            if ((u += 2) >= u_hi) break;
+            trip(B[1], R[1], B[0], R[0], u);
+            if ((u += 2) >= u_hi) break;
+        } else {
+            trip(B[0], R[0], B[2], R[2], u);
+            if ((u += 2) >= u_hi) break;
+            trip(B[1], R[1], B[0], R[0], u);
+            if ((u += 2) >= u_hi) break;
+            trip(B[2], R[2], B[1], R[1], u);
+            if ((u += 2) >= u_hi) break;
+        }
     }
 }
 
