@@ -562,7 +562,8 @@ class TrainEngine:
         if self._side_streams is None:
             self._side_streams = {}
         if dev not in self._side_streams:
-            self._side_streams[dev] = torch.cuda.Stream(device=dev)
+            from .engine import side_streams
+            self._side_streams[dev] = side_streams(dev, 1)[0]   # (the package's shared side streams: engine.side_streams on hardware queues)
         return self._side_streams[dev]
 
     @contextlib.contextmanager
@@ -996,7 +997,8 @@ class CapturedStep:
         for o in self.optimizers:
             o.prepare_capture()
         self.static_in = [t.clone() for t in example_inputs]
-        side = torch.cuda.Stream(device=example_inputs[0].device)
+        from .engine import side_streams
+        side = side_streams(example_inputs[0].device, 2)[1]       # (not the parameter-gradient stream, which forks from this one inside the capture)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                            # (capture must not run on the legacy default stream)
             for _ in range(warmup):
