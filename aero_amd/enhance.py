@@ -29,42 +29,15 @@ PIPELINE_DEPTH = 3                 # forwards in flight on separate HIP streams 
 
 
 def _forward_groups(model, groups, device):
-    """Run the [n_i, 1, L] host batches of `groups` through the model, one forward each.  On the GPU the uploads and
-    downloads run on their own HIP streams through pinned buffers and up to PIPELINE_DEPTH forwards are in flight on a ring of
-    compute streams (BatchPipeline), so group g+1's H2D copy, group g-1's D2H copy and the latency-bound launches of neighbouring
-    forwards overlap with group g's kernels (predict.py:76-80 moves one chunk at a time, synchronously)."""
+    """Run the [n_i, 1, L] host batches of `groups` through the model, one forward each.  On the GPU up to PIPELINE_DEPTH groups are in
+    flight, each on its own HIP stream (BatchPipeline): a group's pinned upload, its kernels and its pinned download are ordered on that
+    stream and run next to the kernels and copies of the neighbouring groups (predict.py:76-80 moves one chunk at a time, synchronously)."""
     dev = torch.device(device)
     if dev.type != 'cuda' or len(groups) == 0:
         return [model(g.to(dev)).cpu() for g in groups]
     from .pipeline import BatchPipeline
     pipe = BatchPipeline(model, depth=int(os.environ.get('AERO_PIPELINE', PIPELINE_DEPTH)))
-    main = torch.cuda.current_stream(dev)
-    s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    outs = []
-    with torch.cuda.stream(s_in):
-        nxt = groups[0].pin_memory().to(dev, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(s_in)
-    for i in range(len(groups)):
-        x, ev_x = nxt, ev
-        if i + 1 < len(groups):
-            with torch.cuda.stream(s_in):
-                nxt = groups[i + 1].pin_memory().to(dev, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(s_in)
-        main.wait_event(ev_x)
-        x.record_stream(main)
-        ticket = pipe.submit(x)                              # (ordered behind `main`, i.e. behind this group's upload only)
-        y = ticket.out
-        with torch.cuda.stream(s_out):
-            if ticket.event is not None:
-                s_out.wait_event(ticket.event)
-            y.record_stream(s_out)
-            host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
-            host.copy_(y, non_blocking=True)
-        outs.append(host)
-    s_out.synchronize()
-    return outs
+    return pipe.run(groups, to_host=True)
 
 
 def predict_signal(model, lr_sig, sr, device=None, batch_chunks=True, max_clips=MAX_CLIPS_PER_FORWARD):

@@ -18,10 +18,10 @@ import torch
 
 
 class _Ticket:
-    __slots__ = ('out', 'event', 'stream')
+    __slots__ = ('out', 'event', 'stream', 'host', 'keep')
 
-    def __init__(self, out, event, stream):
-        self.out, self.event, self.stream = out, event, stream
+    def __init__(self, out, event, stream, host=False, keep=None):
+        self.out, self.event, self.stream, self.host, self.keep = out, event, stream, host, keep
 
 
 def _tensors(out):
@@ -49,14 +49,24 @@ class BatchPipeline:
             self._streams[dev] = side_streams(dev, self.depth)     # (shared with the engine's half-batch streams: see there)
         return self._streams[dev]
 
-    def submit(self, mix, **kw):
-        """enqueue model(mix, **kw) (Aero.forward's keywords) and return a ticket for `result`"""
+    def submit(self, mix, to_host=False, **kw):
+        """enqueue model(mix, **kw) (Aero.forward's keywords) and return a ticket for `result`.
+        A HOST tensor `mix` is uploaded on the batch's own stream (pinned, asynchronous) and with `to_host` the outputs are downloaded on
+        it into pinned host tensors: the copies of one batch then run next to the kernels of the others without any further stream object
+        (the hardware queues are few: engine.side_streams); `result` of such a ticket waits for the batch on the host."""
         if self.model.training:
             raise RuntimeError('BatchPipeline is the inference loop: call model.eval() first')
-        if not mix.is_cuda or self.depth == 1:
+        mdev = next(self.model.parameters()).device
+        if mdev.type != 'cuda':
             with torch.no_grad():
                 return _Ticket(self.model(mix, **kw), None, None)
-        dev = mix.device
+        if mix.is_cuda and self.depth == 1 and not to_host:
+            with torch.no_grad():
+                return _Ticket(self.model(mix, **kw), None, None)
+        host_in = None
+        if not mix.is_cuda:
+            host_in = mix if mix.is_pinned() else mix.pin_memory()
+        dev = mdev
         cur = torch.cuda.current_stream(dev)
         eng = self.model._get_engine()
         eng._prepare(dev)                                   # weights are (re-)packed on the caller's stream, which the batch stream waits for
@@ -64,12 +74,23 @@ class BatchPipeline:
         st = ring[self._n % self.depth]
         self._n += 1
         st.wait_stream(cur)
-        mix.record_stream(st)
+        if host_in is None:
+            mix.record_stream(st)
         saved = eng.streams
         eng.streams = 1                                     # the whole batch on this stream (no half-batch split inside a pipelined batch)
         try:
             with torch.cuda.stream(st), torch.no_grad():
+                if host_in is not None:
+                    mix = host_in.to(dev, non_blocking=True)
                 out = self.model(mix, **kw)
+                if to_host:
+                    def down(t):
+                        if not torch.is_tensor(t):
+                            return t
+                        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                        h.copy_(t, non_blocking=True)
+                        return h
+                    out = tuple(down(t) for t in out) if isinstance(out, (tuple, list)) else down(out)
         finally:
             eng.streams = saved
         key = (str(dev), tuple(mix.shape), tuple(sorted(kw.items())))
@@ -81,18 +102,22 @@ class BatchPipeline:
                 s.wait_stream(st)
         ev = torch.cuda.Event()
         ev.record(st)
-        t = _Ticket(out, ev, st)
+        t = _Ticket(out, ev, st, host=to_host, keep=host_in)
         self._open.append(t)
         return t
 
     def result(self, ticket):
-        """the output of a submitted batch, ordered into the caller's current stream"""
+        """the output of a submitted batch, ordered into the caller's current stream (`to_host` tickets: complete on the host)"""
         if ticket.event is not None:
-            cur = torch.cuda.current_stream(ticket.stream.device)
-            cur.wait_event(ticket.event)
-            for t in _tensors(ticket.out):
-                t.record_stream(cur)
+            if ticket.host:
+                ticket.event.synchronize()
+            else:
+                cur = torch.cuda.current_stream(ticket.stream.device)
+                cur.wait_event(ticket.event)
+                for t in _tensors(ticket.out):
+                    t.record_stream(cur)
             ticket.event = None
+            ticket.keep = None
             if ticket in self._open:
                 self._open.remove(ticket)
         return ticket.out
@@ -102,11 +127,11 @@ class BatchPipeline:
         for t in list(self._open):
             self.result(t)
 
-    def run(self, batches, **kw):
+    def run(self, batches, to_host=False, **kw):
         """all of `batches` (an iterable of inputs), results in order; at most `depth` outputs are held un-collected"""
         outs, tickets = [], []
         for x in batches:
-            tickets.append(self.submit(x, **kw))
+            tickets.append(self.submit(x, to_host=to_host, **kw))
             if len(tickets) > self.depth:
                 outs.append(self.result(tickets.pop(0)))
         outs.extend(self.result(t) for t in tickets)

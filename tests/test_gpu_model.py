@@ -254,3 +254,7 @@ def test_batch_pipeline_matches_one_at_a_time(meta):
     assert eng.streams == 0
     for i, (y, s) in zip(order, outs):
         assert torch.equal(y, refs[i][0]) and torch.equal(s, refs[i][1])
+    # host tensors in, pinned host tensors out: upload and download ride on each batch's own stream (the enhance.py loop)
+    outs_h = pipe.run([xs[i].cpu() for i in order[:9]], to_host=True, return_spec=True)
+    for i, (y, s) in zip(order[:9], outs_h):
+        assert not y.is_cuda and y.is_pinned() and torch.equal(y, refs[i][0].cpu()) and torch.equal(s, refs[i][1].cpu())
