@@ -69,8 +69,13 @@ class BatchPipeline:
         dev = mdev
         cur = torch.cuda.current_stream(dev)
         eng = self.model._get_engine()
-        eng._prepare(dev)                                   # weights are (re-)packed on the caller's stream, which the batch stream waits for
         ring = self._ring(dev)
+        if eng._weights_key(dev) != eng._key:
+            # the weights changed since the last pack: the packed images are about to be replaced (and their memory recycled on the caller's
+            # stream) while batches in flight may still read them -- let the caller's stream wait for those batches first
+            for s in ring:
+                cur.wait_stream(s)
+        eng._prepare(dev)                                   # weights are (re-)packed on the caller's stream, which the batch stream waits for
         st = ring[self._n % self.depth]
         self._n += 1
         st.wait_stream(cur)

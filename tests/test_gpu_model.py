@@ -258,3 +258,35 @@ def test_batch_pipeline_matches_one_at_a_time(meta):
     outs_h = pipe.run([xs[i].cpu() for i in order[:9]], to_host=True, return_spec=True)
     for i, (y, s) in zip(order[:9], outs_h):
         assert not y.is_cuda and y.is_pinned() and torch.equal(y, refs[i][0].cpu()) and torch.equal(s, refs[i][1].cpu())
+
+
+def test_batch_pipeline_repacks_between_batches(meta):
+    """weights edited while batches are in flight: the batches submitted before the edit come out with the old weights, the ones after it
+    with the new (the re-pack waits for the batches in flight: their packed images must not be recycled under them)"""
+    from aero_amd.pipeline import BatchPipeline
+    m = build_model(meta, 'full').cuda().eval()
+    eng = m._get_engine()
+    x = torch.randn(16, 1, 8000, generator=torch.Generator().manual_seed(12)).cuda()
+    w = m.decoder[-1].conv_tr.weight
+    try:
+        eng.streams = 1
+        with torch.no_grad():
+            y_old = m(x).clone()
+            w.mul_(1.5)
+            y_new = m(x).clone()
+            w.div_(1.5)
+            assert torch.equal(m(x), y_old)
+    finally:
+        eng.streams = 0
+    assert not torch.equal(y_old, y_new)
+    pipe = BatchPipeline(m, depth=3)
+    with torch.no_grad():
+        before = [pipe.submit(x) for _ in range(4)]
+        w.mul_(1.5)
+        after = [pipe.submit(x) for _ in range(4)]
+        outs_b = [pipe.result(t) for t in before]
+        outs_a = [pipe.result(t) for t in after]
+        torch.cuda.synchronize()
+        w.div_(1.5)
+    assert all(torch.equal(y, y_old) for y in outs_b)
+    assert all(torch.equal(y, y_new) for y in outs_a)
