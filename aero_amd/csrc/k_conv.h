@@ -1235,12 +1235,36 @@ __global__ __launch_bounds__(256) void aero_conv_tiny_kernel(AeroConvK p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) w[m][c] = Wt[m * 8 + c];
     }
+    // two-channel source with a pitch of two (the normalised spectrogram's (re, im) pairs: the first FTB): a step is ONE dword; all eight
+    // are requested up front, unconditionally (row / step clamped, zeroed below) -- the general form loads 16 halves one by one, each under
+    // its own predicate, i.e. each behind its own wait (70 us for 115 MB)
+    const bool pair = C == 2 && d.s0_t == 2 && ((((uintptr_t)d.src0) | (uintptr_t)(d.s0_b * 2) | (uintptr_t)(d.s0_f * 2)) & 3) == 0;
+    uint32_t xp[8];
+    if (pair) {
+        const int fc = f < F ? f : F - 1;
+        const uint32_t* s32 = (const uint32_t*)((const h16*)d.src0 + (int64_t)b * d.s0_b + (int64_t)fc * d.s0_f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + tl0 + k;
+            xp[k] = s32[t < T ? t : T - 1];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int tl = tl0 + k, t = t0 + tl;
         float x[8];
+        if (pair) {
+            union { uint32_t u; h16x2 h; } cv;
+            cv.u = xp[k];
+            const bool live = f < F && t < T;
+            x[0] = live ? (float)cv.h[0] : 0.f;
+            x[1] = live ? (float)cv.h[1] : 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = (f < F && t < T && c < C) ? (float)src[(int64_t)t * d.s0_t + c] : 0.f;
+            for (int c = 2; c < 8; ++c) x[c] = 0.f;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] = (f < F && t < T && c < C) ? (float)src[(int64_t)t * d.s0_t + c] : 0.f;
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             if (m >= M) continue;
@@ -1259,6 +1283,15 @@ __global__ __launch_bounds__(256) void aero_conv_tiny_kernel(AeroConvK p) {
     const int ndw = (run + 1) >> 1;
     h16* dbase = (h16*)d.dst + (int64_t)b * d.d_b + (int64_t)f0 * d.d_f;
     const bool al = ((((uintptr_t)dbase) | (uintptr_t)(d.d_t * 2)) & 3) == 0 && (run & 1) == 0;
+    if (al && (run & 7) == 0 && ((M * AERO_TINY_TF) & 7) == 0 && ((((uintptr_t)dbase) | (uintptr_t)(d.d_t * 2)) & 15) == 0) {
+        const int nv = run >> 3;                                  // 16-byte pieces of a step's run (full tiles of the first FTB: 20)
+        for (int idx = tid; idx < AERO_TINY_TT * nv; idx += 256) {
+            const int tl = idx / nv, v = idx - tl * nv;
+            const int t = t0 + tl;
+            if (t < T) *(h16x8*)(dbase + (int64_t)t * d.d_t + v * 8) = *(const h16x8*)(Os + tl * AERO_TINY_TF * M + v * 8);
+        }
+        return;
+    }
     for (int idx = tid; idx < AERO_TINY_TT * ndw; idx += 256) {
         const int tl = idx / ndw, wd = idx - tl * ndw;
         const int t = t0 + tl;

@@ -160,7 +160,8 @@ def test_localstate(emu, kw):
     oc.case_localstate(emu, DEV, **kw)
 
 
-@pytest.mark.parametrize('kw', [dict(Fq=16, Cc=8, T=20), dict(Fq=70, Cc=12, T=11), dict(Fq=4, Cc=4, T=9, B=1), dict(Fq=8, Cc=16, T=33), dict(Fq=13, Cc=8, T=7)])
+@pytest.mark.parametrize('kw', [dict(Fq=16, Cc=8, T=20), dict(Fq=70, Cc=12, T=11), dict(Fq=4, Cc=4, T=9, B=1), dict(Fq=8, Cc=16, T=33), dict(Fq=13, Cc=8, T=7),
+                                dict(Fq=40, Cc=2, T=75), dict(Fq=33, Cc=3, T=21)])    # rows 4-byte aligned only (N = 2 T) / odd N
 def test_freqfc(emu, kw):
     oc.case_freqfc(emu, DEV, **kw)
 
