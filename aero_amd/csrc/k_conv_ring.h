@@ -566,7 +566,7 @@ AERO_XPART bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStr
     if ((long)d->B * d->Fout * ((d->T + 255) / 256) * (d->M / bm) > 0x7fffffffL) return false;
     // three unit-stride time taps share one activation slab; any other tap grid: one tile per tap (256-row tile only:
     // the 512-step tiles have no LDS for four full activation tiles)
-    const bool slab3 = p.nT == 3 && p.t_step == 1;
+    const bool slab3 = p.nT == 3 && (p.t_step == 1 || p.t_step == 2);   // (dilation 2: the taps read rows 0 / 2 / 4 of the slab's 16 spare rows)
     if (bm == 256) {
         if (slab3) aero_conv_ring_go<2, 4, 4, 3>(p, stream, name);
         else aero_conv_ring_go<2, 4, 4, 1>(p, stream, name);

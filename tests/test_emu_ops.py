@@ -112,7 +112,8 @@ def test_gram_stats(emu, kw):
 
 @pytest.mark.parametrize('kw', [dict(Cin=48, Cout=12, k=3, dil=1, R=6, T=131), dict(Cin=16, Cout=4, k=3, dil=2, R=3, T=60),
                                 dict(Cin=40, Cout=16, k=9, dil=1, R=2, T=50),
-                                dict(Cin=256, Cout=48, k=9, dil=1, R=2, T=150)])     # long K on a small grid: 16-row tiles
+                                dict(Cin=256, Cout=48, k=9, dil=1, R=2, T=150),      # long K on a small grid: 16-row tiles
+                                dict(Cin=384, Cout=96, k=3, dil=2, R=2, T=300), dict(Cin=384, Cout=96, k=3, dil=1, R=1, T=130)])   # 96-row ring tile, dilated / plain
 def test_conv1d(emu, kw):
     oc.case_conv1d(emu, DEV, **kw)
 
