@@ -500,7 +500,11 @@ static int aero_conv_ring_mode() {
 static int aero_conv_ring_pick_bm(int M, int Ktot) {
     const int mode = aero_conv_ring_mode();
     if (!mode || M <= 0 || Ktot % 32) return 0;
-    if (M % 256 == 0 && Ktot >= 1024) return 256;
+    // shortest contraction the 256-row tile takes (AERO_RING_KMIN256, A/B; 1024 until round 4): the deepest encoder's 1x1 rewrite conv
+    // (M 768, K 384: twelve chunks) runs 160 us here WITH its GroupNorm sums against 147 + 35 us (LDS-tiled conv + statistics pass)
+    static int kmin256 = -1;
+    if (kmin256 < 0) { const char* e = getenv("AERO_RING_KMIN256"); kmin256 = e ? atoi(e) : 384; }
+    if (M % 256 == 0 && Ktot >= kmin256) return 256;
     static int no192 = -1;                                       // AERO_RING_TILE192=0: 128 / 64-row x 512-step tiles instead of the 192 x 256 one (A/B)
     if (no192 < 0) { const char* e = getenv("AERO_RING_TILE192"); no192 = (e && e[0] == '0') ? 1 : 0; }
     // 96-row x 256-step tiles on FOUR waves (two 77-KiB blocks per CU) for contractions with exactly 96 rows (the dilated Conv1d of the

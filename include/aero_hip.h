@@ -26,7 +26,8 @@
  *                                                                                iSTFT waves per block)
  *       AERO_WGRAD_ABL                                                          (weight-gradient ablations; AERO_WGRAD_256 -- the tile
  *                                                                                choice -- is the one switch read at every call)
- *       AERO_ATTN_BWD_VALU, AERO_RING_TILE192                                   (LocalState backward form; ring-tile A/B)
+ *       AERO_ATTN_BWD_VALU, AERO_RING_TILE192, AERO_RING_HALF, AERO_RING_KMIN256 (LocalState backward form; ring-tile A/B)
+ *       AERO_ISTFT_V2, AERO_NORM_FAST, AERO_NORM_STATS_ROWS                     (round-4 kernel forms: off = the earlier form)
  *     The Python host side has its own AERO_* switches (aero_amd/engine.py); they never reach the library.
  */
 #ifndef AERO_HIP_H
