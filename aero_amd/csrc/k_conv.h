@@ -1750,8 +1750,12 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         if (p.tsplit == 1 && aero_conv_ring_try(d, p, stream, name)) return AERO_OK;
         static int wide = -1;
         if (wide < 0) { const char* e = getenv("AERO_CONV_BM256"); wide = e ? atoi(e) : 2; }
+        // shortest contraction the 8-wave 192-row tile takes (AERO_CONV_KMIN192, A/B; 768 until round 4): the two-source 1x1 conv of the
+        // third encoder's FTB (K = 384) 89 -> 78 us, the second decoder's transposed conv (K = 384) unchanged
+        static int kmin192 = -1;
+        if (kmin192 < 0) { const char* e = getenv("AERO_CONV_KMIN192"); kmin192 = e ? atoi(e) : 384; }
         const int wbm = p.tsplit > 1 ? 0 : (wide >= 1 && d->M % 256 == 0 && p.Ktot >= 1024) ? 256
-                        : (wide >= 2 && d->M % 192 == 0 && p.Ktot >= 768) ? 192 : 0;
+                        : (wide >= 2 && d->M % 192 == 0 && p.Ktot >= kmin192) ? 192 : 0;
         if (wbm) {
             p.nmt = d->M / wbm;
             grid = dim3((unsigned)((long)d->B * d->Fout * p.ntt * p.nmt));

@@ -18,7 +18,7 @@
  *     first launch of the kernel family concerned (A/B and profiling switches; the defaults are what is tested and benchmarked, and
  *     a value must be set before the first call -- later changes are ignored):
  *       AERO_CONV_RING, AERO_CONV_GLDS, AERO_CONV_MODE, AERO_CONV_BM256, AERO_CONV_SKINNY, AERO_CONV_STREAM, AERO_CONV_TINY_OFF,
- *       AERO_CONVTR_CARRY, AERO_CARRY_QC, AERO_CONV_DEBUG, AERO_RING_ABL        (convolution family: kernel selection / ablations)
+ *       AERO_CONVTR_CARRY, AERO_CARRY_QC, AERO_CONV_DEBUG, AERO_RING_ABL, AERO_CONV_KMIN192   (convolution family: kernel selection / ablations)
  *       AERO_LSTM_RING, AERO_LSTM_WIDE                                          (recurrent kernel form)
  *       AERO_ATTN_FOLD                                                          (LocalState: folded vs streaming kernel)
  *       AERO_NORM_CHUNK_KB                                                      (GroupNorm work-item size)
