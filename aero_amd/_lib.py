@@ -59,7 +59,7 @@ class NormBwdDesc(C.Structure):
                 ('B', i32), ('F', i32), ('T', i32), ('C', i32), ('G', i32), ('per_row', i32),
                 ('eps', C.c_float), ('stats', dp), ('stat_count', C.c_double),
                 ('gamma', fp), ('beta', fp), ('layer_scale', fp), ('act', i32),
-                ('sums', dp), ('dgamma', fp), ('dbeta', fp), ('dlayer_scale', fp), ('snake_a', fp), ('dsnake_a', fp)]
+                ('sums', dp), ('dgamma', fp), ('dbeta', fp), ('dlayer_scale', fp), ('snake_a', fp), ('dsnake_a', fp), ('psums', dp)]
 
 
 class PwDesc(C.Structure):

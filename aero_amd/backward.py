@@ -151,6 +151,10 @@ def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, 
     want = {'sums': (0 if (stats is None or per_row == 2) else stats.numel() * 2), 'dgamma': (Cc if gamma is not None else 0),
             'dbeta': (Cc if beta is not None else 0), 'dsn': (F if snake_a is not None else 0),
             'dls': (Cc // 2 if (layer_scale is not None and act == _lib.ACT_GLU) else 0)}        # fp32 words (the sums are fp64 pairs)
+    # fp64 staging of the parameter-gradient sums (dgamma | dbeta | dlayer_scale | dsnake_a): order-independent (aero_norm_bwd_desc.psums)
+    npar = 3 * Cc + F if any(want[k] for k in ('dgamma', 'dbeta', 'dsn', 'dls')) else 0
+    want = dict(psums=2 * npar, **want)                                                          # (first: 8-byte aligned in the scratch)
+    out = dict(out, psums=None)
     offs, n = {}, 0
     for k, sz in want.items():
         if sz and out.get(k) is None:
@@ -170,6 +174,7 @@ def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, 
     dgamma, dbeta, dsn, dls = res['dgamma'], res['dbeta'], res['dsn'], res['dls']
     d.snake_a, d.dsnake_a = _ptr(snake_a), _ptr(dsn)
     d.sums, d.dgamma, d.dbeta, d.dlayer_scale = _ptr(sums), _ptr(dgamma), _ptr(dbeta), _ptr(dls)
+    d.psums = _ptr(None if res['psums'] is None else res['psums'].view(torch.float64))
     ops.lib.call('aero_norm_bwd_reduce', C.byref(d), ops.stream(x))
     ops.lib.call('aero_norm_bwd_apply', C.byref(d), ops.stream(x))
     if snake_a is not None:

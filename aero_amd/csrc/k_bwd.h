@@ -478,9 +478,12 @@ struct AeroNormBwdK {
 
 template <bool APPLY, int ACT>
 __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
-    __shared__ float red_c[3][2048];                           // dgamma, dbeta (all C channels), dlayer_scale (C/2)
-    __shared__ float red_g[2][256];                            // S1, S2 per group
-    __shared__ float red_a;                                    // d snake_a[f] of the current item
+    // block-level sums in fp64: the order in which waves (LDS atomics) and blocks (global atomics) arrive changes an fp64 sum of fp32
+    // partials by ~1e-16 relative -- invisible once it is rounded to fp32 -- where fp32 atomics made the parameter gradients and, through
+    // the group sums, dx differ from run to run by ~1e-7, which 30 Adam steps amplify to percents of the loss (tests/test_gpu_train.py)
+    __shared__ double red_c[3][2048];                          // dgamma, dbeta (all C channels), dlayer_scale (C/2)
+    __shared__ double red_g[2][256];                           // S1, S2 per group
+    __shared__ double red_a;                                   // d snake_a[f] of the current item
     const aero_norm_bwd_desc& d = p.d;
     constexpr bool glu = ACT == AERO_ACT_GLU;                 // (one instantiation per activation: the unused halves and paths cost registers)
     const int Cout = glu ? d.C / 2 : d.C;
@@ -491,8 +494,8 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     const int gs = d.C / d.G;
     const int nh = glu ? 2 : 1;
     if (!APPLY) {
-        for (int i = tid; i < d.C; i += 256) { red_c[0][i] = 0.f; red_c[1][i] = 0.f; }
-        for (int i = tid; i < Cout; i += 256) red_c[2][i] = 0.f;
+        for (int i = tid; i < d.C; i += 256) { red_c[0][i] = 0.0; red_c[1][i] = 0.0; }
+        for (int i = tid; i < Cout; i += 256) red_c[2][i] = 0.0;
     }
     float dgam[2][8], dbet[2][8], dls[8];
 #pragma unroll
@@ -501,6 +504,18 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
         for (int i = 0; i < 8; ++i) dgam[h][i] = dbet[h][i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) dls[i] = 0.f;
+    if (APPLY && d.psums && blockIdx.x == 0) {
+        // the reduce pass (finished: same stream) left the parameter-gradient sums in fp64: add them, rounded once, to the caller's fp32
+        // destinations (one thread per element: nothing else writes these ranges while this kernel runs)
+        for (int c = tid; c < d.C; c += 256) {
+            if (d.dgamma) d.dgamma[c] += (float)d.psums[c];
+            if (d.dbeta) d.dbeta[c] += (float)d.psums[d.C + c];
+        }
+        if (glu && d.dlayer_scale)
+            for (int c = tid; c < Cout; c += 256) d.dlayer_scale[c] += (float)d.psums[2 * (int64_t)d.C + c];
+        if (ACT == AERO_ACT_SNAKE && d.dsnake_a)
+            for (int f = tid; f < d.F; f += 256) d.dsnake_a[f] += (float)d.psums[3 * (int64_t)d.C + f];
+    }
     // work items (b, f, time chunk), grid-strided: the parameter gradients stay in registers across a block's items and reach
     // memory once per block (one block per item made 8192 blocks x 2C same-line atomics: 12 ms for the last decoder's norm)
     const int ntch = (d.T + p.tchunk - 1) / p.tchunk;
@@ -513,8 +528,8 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     const bool bn = d.per_row == 2;                            // BatchNorm on batch statistics: group = channel over the whole batch
     if (!APPLY) {
         __syncthreads();                                       // the previous item's group sums have been flushed
-        for (int i = tid; i < (bn ? 0 : d.G); i += 256) { red_g[0][i] = 0.f; red_g[1][i] = 0.f; }
-        if (tid == 0) red_a = 0.f;
+        for (int i = tid; i < (bn ? 0 : d.G); i += 256) { red_g[0][i] = 0.0; red_g[1][i] = 0.0; }
+        if (tid == 0) red_a = 0.0;
         __syncthreads();
     }
     const float inv_count = (float)(1.0 / d.stat_count);
@@ -552,8 +567,10 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
                         g_k2 = (float)sm[1] * inv_count;
                     } else if (APPLY) {
                         // per-channel groups: S1 = gamma * dbeta, S2 = gamma * dgamma -- the reduce pass's parameter gradients ARE the sums
-                        g_k1 = d.gamma[c] * d.dbeta[c] * inv_count;
-                        g_k2 = d.gamma[c] * d.dgamma[c] * inv_count;
+                        const float sb = d.psums ? (float)d.psums[d.C + c] : d.dbeta[c];
+                        const float sg = d.psums ? (float)d.psums[c] : d.dgamma[c];
+                        g_k1 = d.gamma[c] * sb * inv_count;
+                        g_k2 = d.gamma[c] * sg * inv_count;
                     }
                 }
                 rs[h][i] = g_r;
@@ -661,8 +678,8 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
                 a1 += s1[h][i];
                 a2 += s2[h][i];
                 if (!bn && (i == 7 || grp[h][i + 1 < 8 ? i + 1 : 7] != grp[h][i])) {
-                    atomicAdd(&red_g[0][grp[h][i]], a1);
-                    atomicAdd(&red_g[1][grp[h][i]], a2);
+                    atomicAdd(&red_g[0][grp[h][i]], (double)a1);
+                    atomicAdd(&red_g[1][grp[h][i]], (double)a2);
                     a1 = a2 = 0.f;
                 }
             }
@@ -671,16 +688,19 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
     if (ACT == AERO_ACT_SNAKE && d.dsnake_a) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dsn += __shfl_xor(dsn, o);
-        if ((tid & 63) == 0) atomicAdd(&red_a, dsn);
+        if ((tid & 63) == 0) atomicAdd(&red_a, (double)dsn);
     }
     __syncthreads();
     if (d.stats && !bn)
         for (int g = tid; g < d.G; g += 256) {
             double* sm = d.sums + ((int64_t)item * d.G + g) * 2;
-            atomicAdd(sm, (double)red_g[0][g]);
-            atomicAdd(sm + 1, (double)red_g[1][g]);
+            atomicAdd(sm, red_g[0][g]);
+            atomicAdd(sm + 1, red_g[1][g]);
         }
-    if (tid == 0 && ACT == AERO_ACT_SNAKE && d.dsnake_a) atomicAdd(d.dsnake_a + f, red_a);
+    if (tid == 0 && ACT == AERO_ACT_SNAKE && d.dsnake_a) {
+        if (d.psums) atomicAdd(d.psums + 3 * (int64_t)d.C + f, red_a);
+        else atomicAdd(d.dsnake_a + f, (float)red_a);
+    }
     }   // work items
     if (APPLY) return;
     __syncthreads();
@@ -691,22 +711,31 @@ __global__ __launch_bounds__(256) void aero_norm_bwd_kernel(AeroNormBwdK p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = h * Cout + v * 8 + i;
-                atomicAdd(&red_c[0][c], dgam[h][i]);
-                atomicAdd(&red_c[1][c], dbet[h][i]);
+                atomicAdd(&red_c[0][c], (double)dgam[h][i]);
+                atomicAdd(&red_c[1][c], (double)dbet[h][i]);
             }
         }
         if (glu && d.dlayer_scale) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) atomicAdd(&red_c[2][v * 8 + i], dls[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(&red_c[2][v * 8 + i], (double)dls[i]);
         }
     }
     __syncthreads();
+    if (d.psums) {                                             // fp64 staging [dgamma C | dbeta C | dlayer_scale C | dsnake_a F]: the apply pass rounds once
+        for (int c = tid; c < d.C; c += 256) {
+            if (d.dgamma) atomicAdd(d.psums + c, red_c[0][c]);
+            if (d.dbeta) atomicAdd(d.psums + d.C + c, red_c[1][c]);
+        }
+        if (glu && d.dlayer_scale)
+            for (int c = tid; c < Cout; c += 256) atomicAdd(d.psums + 2 * (int64_t)d.C + c, red_c[2][c]);
+        return;
+    }
     for (int c = tid; c < d.C; c += 256) {
-        if (d.dgamma) atomicAdd(d.dgamma + c, red_c[0][c]);
-        if (d.dbeta) atomicAdd(d.dbeta + c, red_c[1][c]);
+        if (d.dgamma) atomicAdd(d.dgamma + c, (float)red_c[0][c]);
+        if (d.dbeta) atomicAdd(d.dbeta + c, (float)red_c[1][c]);
     }
     if (glu && d.dlayer_scale)
-        for (int c = tid; c < Cout; c += 256) atomicAdd(d.dlayer_scale + c, red_c[2][c]);
+        for (int c = tid; c < Cout; c += 256) atomicAdd(d.dlayer_scale + c, (float)red_c[2][c]);
 }
 
 static int aero_norm_bwd_launch(const aero_norm_bwd_desc* d, int apply, hipStream_t stream, const char** err) {

@@ -405,6 +405,10 @@ typedef struct {
     double* sums;
     float* dgamma; float* dbeta; float* dlayer_scale;
     const float* snake_a; float* dsnake_a;      /* Snake (act 4): a per frequency row [F], its gradient (accumulated, may be NULL) */
+    double* psums;                               /* fp64 [3*C + F], zero-filled by the caller, or NULL.  Given: the reduce pass adds its
+                                                  * parameter-gradient sums HERE (dgamma | dbeta | dlayer_scale | dsnake_a) and the apply pass
+                                                  * adds them, rounded once, to dgamma / dbeta / dlayer_scale / dsnake_a -- results do not
+                                                  * depend on the order in which blocks finish.  NULL: fp32 atomics straight into those. */
 } aero_norm_bwd_desc;
 int aero_norm_bwd_reduce(const aero_norm_bwd_desc* d, void* stream);
 int aero_norm_bwd_apply(const aero_norm_bwd_desc* d, void* stream);
