@@ -18,13 +18,14 @@
 //     rows an MFMA covers are a STRIDED set of channels -- any row permutation is as good as any other for a GEMM -- so the
 //     64 (j, j') products tile a 128 x 128 block of dw with no further data movement;
 //   * fragments are exchanged between the four waves through LDS in fragment order (16-byte conflict-free writes / reads).
-// Block: 256 threads, a 128 (m) x 128 (c) tile of one tap, 64 positions per step (threads 0-127 stage dy, 128-255 stage x),
+// Block: 256 threads, a 128 (m) x 128 ((tap, c) columns) tile, 64 positions per step (threads 0-127 stage dy, 128-255 stage x),
 // wave w owns channels j = 2w, 2w+1 of the m side against all eight j'.  Partial sums of a block's row chunk are added to dw
 // with fp32 atomics (the sum order across chunks is not fixed: results differ in the last bits from run to run, as
 // torch's own weight gradients do).
 struct AeroWgradK {
     aero_wgrad_desc d;
     int nmt, nct, SC, nchunk, noswz; int64_t w_n, sl_stride;                 // SC = 64-position steps per chunk; w_n = ntaps * M * C
+    int dt_min, dt_max, ncol;                                                  // range of the time shifts; ncol = ntaps * C (the column index is (tap, c))
 };
 
 static __device__ __forceinline__ void aero_transpose8x8(const h16x8* r, h16x8* c) {
@@ -61,19 +62,23 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
     // consecutive tiles of a row chunk share dy / x slices: give each XCD (private L2) a contiguous run of them
     int id = (p.noswz & 1) ? (int)blockIdx.x : aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const int mt = id % p.nmt; id /= p.nmt;
-    const int ct = id % p.nct; id /= p.nct;
-    const int tap = id % d.ntaps;
-    const int chunk = id / d.ntaps;
+    const int ct = id % p.nct;
+    const int chunk = id / p.nct;
+    // The COLUMN index of the tile is (tap, c) flattened, ncol = ntaps * C (round 4; before: one tile column set per tap, so a 48-channel
+    // x side filled 48 of a tile's 128 columns, nine times over): an octet of columns lies inside one tap (C % 8 == 0), so a thread of
+    // the x side has ITS tap -- time shift and frequency offset are per lane, everything else is unchanged.
     const int m0 = mt * 128, c0 = ct * 128;
     const int opnd = tid >> 7, o = tid & 15, g8 = (tid >> 4) & 7;
-    const int dtj = d.dt[tap], dfj = d.df[tap];
+    const int col0 = c0 + 8 * o;                              // (x side) first of this thread's 8 columns
+    const int tap_l = opnd ? (col0 < p.ncol ? col0 / d.C : 0) : 0;
+    const int dtj = opnd ? d.dt[tap_l] : 0, dfj = opnd ? d.df[tap_l] : 0;
     const int nrows = d.B * d.Fout;
     const int nT = (d.T + 63) >> 6;
     const int it_lo = chunk * p.SC;                           // chunks are runs of the linear step index (row, 64-step segment): a tensor
     const int it_hi = it_lo + p.SC < nrows * nT ? it_lo + p.SC : nrows * nT;   // of few long rows still fills the chip
     const h16* zpv = aero_zero_page;
-    const int ch = (opnd ? c0 : m0) + 8 * o;                  // first of this thread's 8 channels
-    const bool ch_ok = ch < (opnd ? d.C : d.M);
+    const int ch = opnd ? col0 - tap_l * d.C : m0 + 8 * o;    // first of this thread's 8 channels
+    const bool ch_ok = opnd ? col0 < p.ncol : ch < d.M;
     f32x4 acc[2][8];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
     float bsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-    const bool do_bias = d.db != nullptr && ct == 0 && tap == 0 && opnd == 0;
+    const bool do_bias = d.db != nullptr && ct == 0 && opnd == 0;
     h16x8 r[8];
     // per-lane element offsets inside a 64-step segment, fixed for the whole kernel: an interior step (all 64 positions and the
     // shifted ones inside [0, T)) then costs no vector address arithmetic at all -- block-uniform row pointer + 32-bit lane offset.
@@ -97,11 +102,12 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
         const int fi = fo * d.fstride + dfj;
         const bool row_ok = fi >= 0 && fi < d.Fin;
         const int sh = opu ? dtj : 0;
-        if (t0 + 64 <= d.T && t0 + sh >= 0 && t0 + 64 + sh <= d.T && (!opu || row_ok)) {
-            const h16* rowp = (opu ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f
+        if (t0 + 64 <= d.T && (!opu || (t0 + p.dt_min >= 0 && t0 + 64 + p.dt_max <= d.T))) {     // (block-uniform: every tap's shift stays inside the row)
+            const bool live = ch_ok && (!opu || row_ok);        // a frequency offset outside the input: this lane's operand is zero
+            const h16* rowp = (opu ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)(row_ok ? fi : 0) * d.x_f
                                    : (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)fo * d.dy_f) + (int64_t)(t0 + sh) * st_e;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = ch_ok ? *(const h16x8*)(rowp + (int64_t)i * st_e + coff) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 8; ++i) r[i] = live ? *(const h16x8*)(rowp + (int64_t)i * st_e + coff) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
             return;
         }
         const h16* base = opnd ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f + ch
@@ -144,23 +150,24 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
         }
     }
     // accumulator (a, j')[i] of lane l: m = m0 + 8 * ((l >> 4) * 4 + i) + 2 * wave + a,  c = c0 + 8 * (l & 15) + j'
+    const int colb = c0 + 8 * (lane & 15);                    // this lane's eight columns: one tap, eight consecutive c
+    const int tap_o = colb < p.ncol ? colb / d.C : 0, ccb = colb - tap_o * d.C;
     if (d.slabs) {
         // this chunk's partial tile -> its own slab with plain 16-byte stores (a lane's eight j' are eight consecutive c);
         // aero_wgrad_finish_kernel adds the slabs in chunk order: deterministic, and no scattered 4-byte atomics
-        float* sl = d.slabs + (int64_t)chunk * p.sl_stride + (int64_t)tap * d.M * d.C;
+        float* sl = d.slabs + (int64_t)chunk * p.sl_stride + (int64_t)tap_o * d.M * d.C;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + 8 * ((lane >> 4) * 4 + i) + 2 * wave + a;
-                const int cc = c0 + 8 * (lane & 15);
-                if (m < d.M && cc < d.C) {
-                    *(f32x4*)(sl + (int64_t)m * d.C + cc) = (f32x4){acc[a][0][i], acc[a][1][i], acc[a][2][i], acc[a][3][i]};
-                    *(f32x4*)(sl + (int64_t)m * d.C + cc + 4) = (f32x4){acc[a][4][i], acc[a][5][i], acc[a][6][i], acc[a][7][i]};
+                if (m < d.M && colb < p.ncol) {
+                    *(f32x4*)(sl + (int64_t)m * d.C + ccb) = (f32x4){acc[a][0][i], acc[a][1][i], acc[a][2][i], acc[a][3][i]};
+                    *(f32x4*)(sl + (int64_t)m * d.C + ccb + 4) = (f32x4){acc[a][4][i], acc[a][5][i], acc[a][6][i], acc[a][7][i]};
                 }
             }
     } else {
-    float* dw = d.dw + (int64_t)tap * d.M * d.C;
+    float* dw = d.dw + (int64_t)tap_o * d.M * d.C;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -168,11 +175,10 @@ __global__ __launch_bounds__(256, 2) void aero_conv_wgrad_kernel(AeroWgradK p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + 8 * ((lane >> 4) * 4 + i) + 2 * wave + a;
-                const int cc = c0 + 8 * (lane & 15) + j;
-                if (m < d.M && cc < d.C && !(p.noswz & 2)) atomicAdd(dw + (int64_t)m * d.C + cc, acc[a][j][i]);
+                if (m < d.M && colb < p.ncol && !(p.noswz & 2)) atomicAdd(dw + (int64_t)m * d.C + ccb + j, acc[a][j][i]);
             }
     }
-    if (d.db != nullptr && ct == 0 && tap == 0) {            // (block-uniform) the eight position octets of a channel: summed in fixed order
+    if (d.db != nullptr && ct == 0) {                        // (block-uniform) the eight position octets of a channel: summed in fixed order
         __syncthreads();
         float* bs = (float*)&FR2[0][0][0][0][0];               // [8][128]
         if (opnd == 0) {
@@ -201,20 +207,21 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
     // consecutive tiles of a row chunk share dy / x slices: give each XCD (private L2) a contiguous run of them
     int id = (p.noswz & 1) ? (int)blockIdx.x : aero_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const int mt = id % p.nmt; id /= p.nmt;
-    const int ct = id % p.nct; id /= p.nct;
-    const int tap = id % d.ntaps;
-    const int chunk = id / d.ntaps;
-    const int m0 = mt * 256, c0 = ct * 256;
+    const int ct = id % p.nct;
+    const int chunk = id / p.nct;
+    const int m0 = mt * 256, c0 = ct * 256;                   // (columns = (tap, c) flattened: see the 128 x 128 kernel)
     const int opnd = tid >> 8, o32 = tid & 31, g8 = (tid >> 5) & 7;
     const int half = o32 >> 4, o = o32 & 15;
-    const int dtj = d.dt[tap], dfj = d.df[tap];
+    const int col0 = c0 + 128 * half + 8 * o;                 // (x side) first of this thread's 8 columns
+    const int tap_l = opnd ? (col0 < p.ncol ? col0 / d.C : 0) : 0;
+    const int dtj = opnd ? d.dt[tap_l] : 0, dfj = opnd ? d.df[tap_l] : 0;
     const int nrows = d.B * d.Fout;
     const int nT = (d.T + 63) >> 6;
     const int it_lo = chunk * p.SC;                           // chunks are runs of the linear step index (row, 64-step segment): a tensor
     const int it_hi = it_lo + p.SC < nrows * nT ? it_lo + p.SC : nrows * nT;   // of few long rows still fills the chip
     const h16* zpv = aero_zero_page;
-    const int ch = (opnd ? c0 : m0) + 128 * half + 8 * o;
-    const bool ch_ok = ch < (opnd ? d.C : d.M);
+    const int ch = opnd ? col0 - tap_l * d.C : m0 + 128 * half + 8 * o;
+    const bool ch_ok = opnd ? col0 < p.ncol : ch < d.M;
     const int mh = wave >> 2, chh = (wave >> 1) & 1, jq = wave & 1;
     f32x4 acc[4][8];
 #pragma unroll
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
     float bsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-    const bool do_bias = d.db != nullptr && ct == 0 && tap == 0 && opnd == 0;
+    const bool do_bias = d.db != nullptr && ct == 0 && opnd == 0;
     h16x8 r[8];
     // per-lane element offsets inside a 64-step segment, fixed for the whole kernel: an interior step (all 64 positions and the
     // shifted ones inside [0, T)) then costs no vector address arithmetic at all -- block-uniform row pointer + 32-bit lane offset.
@@ -239,11 +246,12 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
         const int fi = fo * d.fstride + dfj;
         const bool row_ok = fi >= 0 && fi < d.Fin;
         const int sh = opu ? dtj : 0;
-        if (t0 + 64 <= d.T && t0 + sh >= 0 && t0 + 64 + sh <= d.T && (!opu || row_ok)) {
-            const h16* rowp = (opu ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f
+        if (t0 + 64 <= d.T && (!opu || (t0 + p.dt_min >= 0 && t0 + 64 + p.dt_max <= d.T))) {     // (block-uniform: every tap's shift stays inside the row)
+            const bool live = ch_ok && (!opu || row_ok);        // a frequency offset outside the input: this lane's operand is zero
+            const h16* rowp = (opu ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)(row_ok ? fi : 0) * d.x_f
                                    : (const h16*)d.dy + (int64_t)b * d.dy_b + (int64_t)fo * d.dy_f) + (int64_t)(t0 + sh) * st_e;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = ch_ok ? *(const h16x8*)(rowp + (int64_t)i * st_e + coff) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 8; ++i) r[i] = live ? *(const h16x8*)(rowp + (int64_t)i * st_e + coff) : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
             return;
         }
         const h16* base = opnd ? (const h16*)d.x + (int64_t)b * d.x_b + (int64_t)fi * d.x_f + ch
@@ -290,21 +298,22 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
             }
         }
     }
+    const int colb = c0 + 128 * chh + 8 * (lane & 15);
+    const int tap_o = colb < p.ncol ? colb / d.C : 0, ccb = colb - tap_o * d.C;
     if (d.slabs) {
-        float* sl = d.slabs + (int64_t)chunk * p.sl_stride + (int64_t)tap * d.M * d.C;
+        float* sl = d.slabs + (int64_t)chunk * p.sl_stride + (int64_t)tap_o * d.M * d.C;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + 128 * mh + 8 * ((lane >> 4) * 4 + i) + 4 * jq + a;
-                const int cc = c0 + 128 * chh + 8 * (lane & 15);
-                if (m < d.M && cc < d.C) {
-                    *(f32x4*)(sl + (int64_t)m * d.C + cc) = (f32x4){acc[a][0][i], acc[a][1][i], acc[a][2][i], acc[a][3][i]};
-                    *(f32x4*)(sl + (int64_t)m * d.C + cc + 4) = (f32x4){acc[a][4][i], acc[a][5][i], acc[a][6][i], acc[a][7][i]};
+                if (m < d.M && colb < p.ncol) {
+                    *(f32x4*)(sl + (int64_t)m * d.C + ccb) = (f32x4){acc[a][0][i], acc[a][1][i], acc[a][2][i], acc[a][3][i]};
+                    *(f32x4*)(sl + (int64_t)m * d.C + ccb + 4) = (f32x4){acc[a][4][i], acc[a][5][i], acc[a][6][i], acc[a][7][i]};
                 }
             }
     } else {
-    float* dw = d.dw + (int64_t)tap * d.M * d.C;
+    float* dw = d.dw + (int64_t)tap_o * d.M * d.C;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -312,11 +321,10 @@ __global__ __launch_bounds__(512, 2) void aero_conv_wgrad256_kernel(AeroWgradK p
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + 128 * mh + 8 * ((lane >> 4) * 4 + i) + 4 * jq + a;
-                const int cc = c0 + 128 * chh + 8 * (lane & 15) + j;
-                if (m < d.M && cc < d.C && !(p.noswz & 2)) atomicAdd(dw + (int64_t)m * d.C + cc, acc[a][j][i]);
+                if (m < d.M && colb < p.ncol && !(p.noswz & 2)) atomicAdd(dw + (int64_t)m * d.C + ccb + j, acc[a][j][i]);
             }
     }
-    if (d.db != nullptr && ct == 0 && tap == 0) {
+    if (d.db != nullptr && ct == 0) {
         __syncthreads();
         float* bs = (float*)FR;                                // [8][256]
         if (opnd == 0) {
@@ -392,11 +400,12 @@ static void aero_wgrad_plan(int M, int C, int ntaps, int nrows, int T, bool* big
     const int mode = e256 ? atoi(e256) : 1;
     // AERO_WGRAD_256: 0 never, 2 whenever both sides are >= 192 channels (tests), default: only the widest layers -- measured
     // D0 (1536 x 768) 427 -> 510 TF/s, D1 (768 x 384) 380 -> 366: with one 8-wave block per CU the smaller problem has too few tiles
-    const bool big = mode && M >= 192 && C >= 192 && (mode == 2 || (long)M * C >= 768L * 1024);
+    const bool big = mode && M >= 192 && C >= 192 && (mode == 2 || (long)M * C >= 768L * 1024);   // (on C, not ntaps * C: the measured crossover)
     const int TS = big ? 256 : 128;
-    const long tiles = (long)((M + TS - 1) / TS) * ((C + TS - 1) / TS) * ntaps;
+    const long ncol = (long)ntaps * C;                       // the column index of a tile is (tap, c)
+    const long tiles = (long)((M + TS - 1) / TS) * ((ncol + TS - 1) / TS);
     const long nsteps = (long)nrows * ((T + 63) / 64);
-    const long Mc = M < TS ? M : TS, Cc = C < TS ? C : TS;
+    const long Mc = M < TS ? M : TS, Cc = ncol < TS ? ncol : TS;
     long min_steps = (Mc * Cc + 4 * (Mc + Cc) - 1) / (4 * (Mc + Cc));
     if (min_steps < 4) min_steps = 4;
     long nchunk = ((big ? 1024 : 2048) + tiles - 1) / tiles;
@@ -422,7 +431,7 @@ static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, 
         *err = "wgrad: channel counts and strides must be multiples of 8 (16-byte aligned channel vectors)"; return AERO_ERR_UNSUPPORTED;
     }
     if ((int64_t)(d->T + 64) * d->dy_t + d->M + 256 > 0x7fffffffLL || (int64_t)(d->T + 64) * d->x_t + d->C + 256 > 0x7fffffffLL) { *err = "wgrad: rows too long for 32-bit in-row offsets"; return AERO_ERR_UNSUPPORTED; }
-    if ((int64_t)d->B * d->Fout * ((d->T + 63) / 64) > 0x3fffffffLL) { *err = "wgrad: too many positions"; return AERO_ERR_UNSUPPORTED; }
+    if ((int64_t)d->B * d->Fout * ((d->T + 63) / 64) > 0x3fffffffLL || (int64_t)d->ntaps * d->C > 0x3fffffffLL) { *err = "wgrad: too many positions"; return AERO_ERR_UNSUPPORTED; }
     if (!d->slabs && (d->store || d->dw_layout)) { *err = "wgrad: store / dw_layout need the slab workspace"; return AERO_ERR_ARG; }
     if (d->dw_layout < 0 || d->dw_layout > 1 || d->dw_rowlen < 0 || d->dw_coff < 0 || (d->dw_rowlen && d->dw_coff + d->C > d->dw_rowlen) ||
         (!d->dw_rowlen && d->dw_coff) || (int64_t)d->M * d->C > 0x7fffffffLL) { *err = "wgrad: bad destination layout"; return AERO_ERR_ARG; }
@@ -440,13 +449,19 @@ static int aero_conv_wgrad_launch(const aero_wgrad_desc* d, hipStream_t stream, 
         nchunk = (int)((nsteps + SC - 1) / SC);
     }
     const int TS = big ? 256 : 128;
+    p.ncol = d->ntaps * d->C;
     p.nmt = (d->M + TS - 1) / TS;
-    p.nct = (d->C + TS - 1) / TS;
+    p.nct = (p.ncol + TS - 1) / TS;
+    p.dt_min = p.dt_max = d->dt[0];
+    for (int j = 1; j < d->ntaps; ++j) {
+        if (d->dt[j] < p.dt_min) p.dt_min = d->dt[j];
+        if (d->dt[j] > p.dt_max) p.dt_max = d->dt[j];
+    }
     p.SC = SC;
     p.nchunk = nchunk;
     p.w_n = (int64_t)d->ntaps * d->M * d->C;
     p.sl_stride = p.w_n + (d->db ? d->M : 0);
-    const long nb = (long)p.nmt * p.nct * d->ntaps * p.nchunk;
+    const long nb = (long)p.nmt * p.nct * p.nchunk;
     if (nb > 0x7fffffffL) { *err = "wgrad: grid too large"; return AERO_ERR_ARG; }
     if (big) AERO_LAUNCH_DYN(aero_conv_wgrad256_kernel, dim3((unsigned)nb), dim3(512), (size_t)128 * 1024, stream, p);
     else AERO_LAUNCH(aero_conv_wgrad_kernel, dim3((unsigned)nb), dim3(256), stream, p);
