@@ -246,6 +246,12 @@ class Lib:
             fn.argtypes = args
         self.version = self.cdll.aero_version().decode()
         self.is_emulator = 'emulation' in self.version
+        # a device library compiled with packed-fp32 instructions returns wrong FFT results next to other streams' MFMA waves:
+        # the build reports `no-packed-fp32` in its version; anything else (an out-of-tree build, AERO_HIP_LIB pointing at an experiment
+        # build) is refused unless the experiment says so explicitly
+        if not self.is_emulator and 'no-packed-fp32' not in self.version and os.environ.get('AERO_ALLOW_PACKED_FP32') != '1':
+            raise ImportError(f'{path} was not built with -packed-fp32-ops off / -DAERO_NO_PACKED_FP32 ({self.version}): rebuild it with '
+                              f'__graft_entry__.build() (set AERO_ALLOW_PACKED_FP32=1 only for tools/dbg experiment builds)')
 
     def check(self, rc, what):
         if rc != 0:

@@ -57,3 +57,42 @@ def save(path, wav, sr):
     hdr = b'RIFF' + struct.pack('<I', 36 + len(pcm)) + b'WAVE' + b'fmt ' + struct.pack('<IHHIIHH', 16, 3, nch, sr, sr * nch * 4, nch * 4, 32)
     with open(path, 'wb') as f:
         f.write(hdr + b'data' + struct.pack('<I', len(pcm)) + pcm)
+
+
+def resample(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """`torchaudio.functional.resample(waveform, orig_freq, new_freq)` with its defaults (Hann-windowed sinc interpolation), which the
+    reference calls before the model when `experiment.upsample` is set (predict.py:55-57, datasets.py:144).  Host plumbing outside the hot
+    path: torchaudio is used when importable; otherwise its published algorithm is restated here (polyphase sinc kernel of
+    `new_freq / gcd` phases, width ceil(lowpass_filter_width * orig / (rolloff * min(orig, new))), a strided conv1d, output cropped to
+    ceil(new * length / orig) samples).  PARITY UNPINNED: torchaudio is absent from this image, so the restatement is checked only
+    against its defining properties (tests/test_callers.py: identity at equal rates, length rule, a band-limited tone is reproduced)."""
+    try:
+        from torchaudio.functional import resample as ta_resample
+        return ta_resample(waveform, orig_freq, new_freq)
+    except ImportError:
+        pass
+    import math
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq <= 0 or new_freq <= 0:
+        raise ValueError('resample: frequencies must be positive integers')
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // g, new_freq // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig)
+    kernels = kernels.to(torch.float32)
+    shape = waveform.shape
+    w = waveform.reshape(-1, shape[-1]).to(torch.float32)
+    length = w.shape[-1]
+    w = torch.nn.functional.pad(w, (width, width + orig))
+    out = torch.nn.functional.conv1d(w[:, None], kernels, stride=orig)
+    out = out.transpose(1, 2).reshape(w.shape[0], -1)
+    target = int(math.ceil(new * length / orig))
+    return out[..., :target].reshape(shape[:-1] + (target,))

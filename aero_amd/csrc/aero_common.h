@@ -26,6 +26,14 @@
 #define aero_rsqrt(x) __builtin_amdgcn_rsqf(x)
 #define aero_med3(x, lo, hi) __builtin_amdgcn_fmed3f((x), (lo), (hi))   /* one-instruction clamp */
 #include <hip/hip_runtime.h>
+// The library must be compiled WITHOUT packed-fp32 instructions (with them the FFT kernels return wrong values next to
+// another stream's MFMA waves).  The build passes `-Xclang -target-feature -Xclang -packed-fp32-ops` TOGETHER with -DAERO_NO_PACKED_FP32
+// (__graft_entry__.HIPCC_FLAGS); a compile line that lost the pair stops here instead of producing a library that is silently wrong
+// under concurrency.  aero_version() reports the define, aero_amd/_lib.py refuses a library that does not, tools/isa_lint.py fails the
+// build if a v_pk_{fma,mul,add}_f32 is found in the code object.  tools/dbg experiment builds opt out with -DAERO_ALLOW_PACKED_FP32.
+#if !defined(AERO_NO_PACKED_FP32) && !defined(AERO_ALLOW_PACKED_FP32)
+#error "aero_hip: compile with -Xclang -target-feature -Xclang -packed-fp32-ops -DAERO_NO_PACKED_FP32 (see __graft_entry__.HIPCC_FLAGS, DESIGN.md 5b)"
+#endif
 // every launch records which instantiation it was: aero_last_kernel_name() (profiling labels that match rocprofv3)
 #ifdef AERO_PART
 extern thread_local const void* aero_last_kernel_ptr_;      /* the library is built in parts (aero_hip.hip): defined in part 0 */
@@ -91,6 +99,9 @@ static __device__ h16 aero_zero_page[64];
 static __device__ __forceinline__ void aero_glds16(const h16* gsrc, h16* lds_wave_base) {
 #ifdef AERO_EMU
     memcpy(lds_wave_base + (threadIdx.x & 63) * 8, gsrc, 16);
+#elif defined(AERO_DBG_NO_GLDS)                                 /* tools/dbg experiment builds only: the same copy through a VGPR */
+    const h16x8 v = *(const h16x8*)gsrc;
+    *(h16x8*)(lds_wave_base + (threadIdx.x & 63) * 8) = v;
 #else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

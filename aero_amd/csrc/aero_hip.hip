@@ -6,8 +6,9 @@
 // Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DAERO_PART=k  for k = 0..7 (no 5), IN PARALLEL,
 // then one link into aero_amd/libaero_hip.so.  The library is ONE source file cut into six independently compiled parts (each
 // kernel header belongs to exactly one part; a part holds the entry points over its kernels): as a single translation unit it took
-// four minutes to compile; now a change to one header rebuilds one part.  Without -DAERO_PART (the emulator's build, or a plain
-// `hipcc -c aero_hip.hip`) the file is the whole library in one unit, as before.
+// four minutes to compile; now a change to one header rebuilds one part.  Without -DAERO_PART (the emulator's build) the file is the
+// whole library in one unit, as before.  EVERY device build carries `-Xclang -target-feature -Xclang -packed-fp32-ops
+// -DAERO_NO_PACKED_FP32` (aero_common.h refuses to compile without the define: DESIGN.md 5b).
 #include "aero_common.h"
 #ifdef AERO_PART
 #define AERO_IN(p) (AERO_PART == (p))
@@ -134,7 +135,11 @@ const char* aero_version(void) {
 #ifdef AERO_EMU
     int n = snprintf(ver, sizeof(ver), "aero_hip 0.1 (CPU emulation build -- tests only)");
 #else
-    int n = snprintf(ver, sizeof(ver), "aero_hip 0.1 (gfx950)");
+#ifdef AERO_NO_PACKED_FP32
+    int n = snprintf(ver, sizeof(ver), "aero_hip 0.1 (gfx950; no-packed-fp32)");
+#else
+    int n = snprintf(ver, sizeof(ver), "aero_hip 0.1 (gfx950; PACKED-FP32 EXPERIMENT BUILD)");
+#endif
 #endif
     bool first = true;
     for (char** e = environ; e && *e; ++e) {

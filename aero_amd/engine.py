@@ -39,7 +39,9 @@ def side_streams(device, n):
     busy streams on one queue run one after the other.  Measured on the MI355X: three batches in flight 9.3 ms per batch with only
     these streams alive, 9.6-9.9 ms once two more (idle) streams had been created before them."""
     dev = torch.device(device)
-    lst = _SIDE_STREAMS.setdefault(dev, [])
+    if dev.type == 'cuda' and dev.index is None:             # 'cuda', 'cuda:0', torch.device('cuda', 0): ONE key, hence one list, per device
+        dev = torch.device('cuda', torch.cuda.current_device())
+    lst = _SIDE_STREAMS.setdefault((dev.type, dev.index), [])
     while len(lst) < n:
         lst.append(torch.cuda.Stream(device=dev))
     return lst[:n]

@@ -33,10 +33,17 @@ def _forward_groups(model, groups, device):
     flight, each on its own HIP stream (BatchPipeline): a group's pinned upload, its kernels and its pinned download are ordered on that
     stream and run next to the kernels and copies of the neighbouring groups (predict.py:76-80 moves one chunk at a time, synchronously)."""
     dev = torch.device(device)
-    if dev.type != 'cuda' or len(groups) == 0:
+    # the pipelined loop needs the generator itself (its engine, eval mode); anything else that is callable -- a distrib.wrap()'ed model, a
+    # model left in training mode, a reference-style nn.Module -- takes the plain loop the reference runs (predict.py:76-80)
+    core = getattr(model, 'module', model)
+    if dev.type != 'cuda' or len(groups) == 0 or not hasattr(core, '_get_engine') or getattr(core, 'training', False):
         return [model(g.to(dev)).cpu() for g in groups]
+    try:
+        depth = max(1, int(os.environ.get('AERO_PIPELINE', PIPELINE_DEPTH)))
+    except ValueError:                                   # (a malformed AERO_PIPELINE must not take the serving path down)
+        depth = PIPELINE_DEPTH
     from .pipeline import BatchPipeline
-    pipe = BatchPipeline(model, depth=int(os.environ.get('AERO_PIPELINE', PIPELINE_DEPTH)))
+    pipe = BatchPipeline(core, depth=depth)
     return pipe.run(groups, to_host=True)
 
 

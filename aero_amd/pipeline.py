@@ -14,11 +14,13 @@ Stream semantics are PyTorch's: `submit` orders the batch behind everything the 
 ready), `result` makes the caller's current stream wait for that batch.  Collect results a few submissions late (or call `drain`), not
 right after each `submit` -- a `result` immediately behind its `submit` serialises the batches again.
 """
+import weakref
+
 import torch
 
 
 class _Ticket:
-    __slots__ = ('out', 'event', 'stream', 'host', 'keep')
+    __slots__ = ('out', 'event', 'stream', 'host', 'keep', '__weakref__')
 
     def __init__(self, out, event, stream, host=False, keep=None):
         self.out, self.event, self.stream, self.host, self.keep = out, event, stream, host, keep
@@ -81,8 +83,11 @@ class BatchPipeline:
         st.wait_stream(cur)
         if host_in is None:
             mix.record_stream(st)
-        saved = eng.streams
-        eng.streams = 1                                     # the whole batch on this stream (no half-batch split inside a pipelined batch)
+        # the whole batch on this stream as the plain eager kernel sequence: no half-batch split inside a pipelined batch, and NOT the
+        # AERO_GRAPH replay path -- HipEngine._forward_graph keeps one (graph, static input, static output) per shape whatever the stream, so
+        # two batches in flight would share the graph's static buffers
+        saved = eng.streams, eng.use_graph
+        eng.streams, eng.use_graph = 1, False
         try:
             with torch.cuda.stream(st), torch.no_grad():
                 if host_in is not None:
@@ -97,7 +102,7 @@ class BatchPipeline:
                         return h
                     out = tuple(down(t) for t in out) if isinstance(out, (tuple, list)) else down(out)
         finally:
-            eng.streams = saved
+            eng.streams, eng.use_graph = saved
         key = (str(dev), tuple(mix.shape), tuple(sorted(kw.items())))
         if key not in self._seen:
             # the first batch of a shape builds the engine's lazily created device tables (window, envelope, DFT table, constant
@@ -105,10 +110,14 @@ class BatchPipeline:
             self._seen.add(key)
             for s in ring:
                 s.wait_stream(st)
+            cur.wait_stream(st)                             # ... nor a direct model(x) on the caller's stream right behind this submit
         ev = torch.cuda.Event()
         ev.record(st)
         t = _Ticket(out, ev, st, host=to_host, keep=host_in)
-        self._open.append(t)
+        # tickets are held WEAKLY: a caller that drops a ticket (or dies between submit and result) frees its outputs, pinned buffers and
+        # event with it instead of leaving them in this list for the life of the pipeline
+        self._open = [r for r in self._open if r() is not None]
+        self._open.append(weakref.ref(t))
         return t
 
     def result(self, ticket):
@@ -123,14 +132,20 @@ class BatchPipeline:
                     t.record_stream(cur)
             ticket.event = None
             ticket.keep = None
-            if ticket in self._open:
-                self._open.remove(ticket)
+            self._open = [r for r in self._open if r() is not None and r() is not ticket]
         return ticket.out
 
     def drain(self):
         """make the caller's current stream wait for every batch submitted so far"""
-        for t in list(self._open):
-            self.result(t)
+        for r in list(self._open):
+            t = r()
+            if t is not None:
+                self.result(t)
+        self._open = []
+        for dev, ring in self._streams.items():             # (batches whose tickets were dropped: their streams are waited for all the same)
+            cur = torch.cuda.current_stream(dev)
+            for s in ring:
+                cur.wait_stream(s)
 
     def run(self, batches, to_host=False, **kw):
         """all of `batches` (an iterable of inputs), results in order; at most `depth` outputs are held un-collected"""

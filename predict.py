@@ -25,8 +25,9 @@ def main(argv=None):
     args = load_config(os.path.join(ROOT, 'conf'), argv if argv is not None else sys.argv[1:])
     model = enhance.load_generator(args, device='cuda')
     lr_sig, sr = audio_io.load(args.filename)
-    if args.experiment.upsample:
-        raise NotImplementedError('experiment.upsample=true (sinc pre-upsampling) is not used by the aero configs')
+    if args.experiment.upsample:                                   # predict.py:55-57 (no aero config sets it; host-side sinc resampling)
+        lr_sig = audio_io.resample(lr_sig, sr, args.experiment.hr_sr)
+        sr = args.experiment.hr_sr
     logger.info(f'lr wav shape: {tuple(lr_sig.shape)}')
     t0 = time.time()
     pr = enhance.predict_signal(model, lr_sig, sr)

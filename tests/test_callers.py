@@ -247,3 +247,23 @@ def test_test_py_pair_listing(tmp_path):
     json.dump([[str(tmp_path / 'hr' / 'a.wav'), 40], [str(tmp_path / 'hr' / 'b.wav'), 40]], open(tmp_path / 'hr.json', 'w'))
     pairs = mod._listing(A(dset=A(test=str(tmp_path))))
     assert len(pairs) == 1 and pairs[0][1].endswith('hr/a.wav')
+
+
+def test_resample_restatement_properties():
+    """`experiment.upsample` (predict.py:55-57): torchaudio.functional.resample restated in aero_amd.audio_io (torchaudio is absent from the
+    image, so the restatement is pinned by its defining properties only): identity at equal rates, torchaudio's length rule
+    ceil(new * n / orig), a band-limited tone reproduced on the new grid, linearity"""
+    import math
+    from aero_amd import audio_io
+    x = torch.randn(2, 4001, generator=torch.Generator().manual_seed(3))
+    assert audio_io.resample(x, 4000, 4000) is x
+    for new in (16000, 11025, 3000):
+        y = audio_io.resample(x, 4000, new)
+        assert y.shape == (2, math.ceil(new * 4001 / 4000)) and y.dtype == torch.float32
+    t = torch.arange(4000) / 4000.0
+    tone = torch.sin(2 * math.pi * 440 * t)[None]
+    up = audio_io.resample(tone, 4000, 16000)
+    t2 = torch.arange(up.shape[-1]) / 16000.0
+    assert float((up - torch.sin(2 * math.pi * 440 * t2)[None])[:, 200:-200].abs().max()) < 2e-3
+    a, b = x[:1], x[1:]
+    assert torch.allclose(audio_io.resample(a + 2 * b, 4000, 16000), audio_io.resample(a, 4000, 16000) + 2 * audio_io.resample(b, 4000, 16000), atol=1e-5)

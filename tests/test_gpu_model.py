@@ -20,6 +20,17 @@ def test_native_library_is_the_gfx950_build():
     from aero_amd import _lib
     lib = _lib.load()
     assert 'gfx950' in lib.version and not lib.is_emulator
+    assert 'no-packed-fp32' in lib.version, lib.version           # (the build flag the concurrency fence rests on)
+
+
+def test_no_aero_switch_is_set_on_the_test_box():
+    """the -m gpu suite is evidence for the DEFAULT configuration: aero_version() names every AERO_* variable present in the environment
+    (each one is a departure from what is tested), and on the box that runs this suite there must be none (VERDICT r4 hygiene)"""
+    import os
+    from aero_amd import _lib
+    ver = _lib.load().cdll.aero_version().decode()                # (read now: the switches are looked up at call time)
+    stray = sorted(k for k in os.environ if k.startswith('AERO_'))
+    assert 'non-default switches' not in ver and not stray, (ver, stray)
 
 
 @pytest.mark.parametrize('L', [400, 1000, 999])

@@ -10,7 +10,9 @@ Per kernel it reports: barriers, direct-to-LDS copies, MFMAs, and
   W2  direct-to-LDS copies issued after LDS reads with NO `s_barrier` between the last `ds_read` and the copy (same basic block).
 Neither is an error by itself (W1 is harmless when the MFMA's operands were read before the wait; W2 when the slot is not the one being
 read): the report is for review whenever a kernel with rings of LDS slots changes, and `--strict K1,K2` fails if a named kernel's counts grow
-over the committed baseline (profiles/isa_lint_baseline.json).   usage: isa_lint.py [--write-baseline] [--strict]"""
+over the committed baseline (profiles/isa_lint_baseline.json).  It also counts the packed-fp32 VALU instructions of the whole code
+object and exits with code 3 if there is one (the build fails on that: DESIGN.md 5b).
+usage: isa_lint.py [lib.so] [--write-baseline] [--strict] [--allow-packed]"""
 import json
 import os
 import re
@@ -86,9 +88,19 @@ def demangle(names):
         return {n: n for n in names}
 
 
+PACKED_FP32 = re.compile(r'^\s*(v_pk_fma_f32|v_pk_mul_f32|v_pk_add_f32)\b', re.M)
+
+
 def main():
     lib = os.path.join(ROOT, 'aero_amd', 'libaero_hip.so')
-    rep = lint(disassemble(lib))
+    for a in sys.argv[1:]:
+        if a.endswith('.so'):
+            lib = a
+    text = disassemble(lib)
+    # packed-fp32 VALU instructions anywhere in the code object: with them the FFT-family kernels return wrong values next to another
+    # stream's MFMA waves; the library is built without them, and this count FAILS the build (exit code 3) if it is not 0
+    npk = len(PACKED_FP32.findall(text))
+    rep = lint(text)
     dm = demangle(list(rep))
     rep = {dm[k].split('(')[0].replace('void ', ''): v for k, v in rep.items()}
     base_path = os.path.join(ROOT, 'profiles', 'isa_lint_baseline.json')
@@ -106,10 +118,13 @@ def main():
     print(f'{"kernel":70s} {"bar":>4s} {"glds":>5s} {"mfma":>5s} {"W1":>4s} {"W2":>4s}')
     for k, v in sorted(rep.items(), key=lambda kv: -(kv[1]['W1_mfma_in_wait_barrier_window'] + kv[1]['W2_lds_copy_after_reads_without_barrier'])):
         print(f'{k[:70]:70s} {v["barriers"]:4d} {v["lds_copies"]:5d} {v["mfma"]:5d} {v["W1_mfma_in_wait_barrier_window"]:4d} {v["W2_lds_copy_after_reads_without_barrier"]:4d}')
+    print(f'PACKED_FP32 {npk} v_pk_{{fma,mul,add}}_f32 instructions in the code object (must be 0)')
     if bad:
         print('GREW over the baseline:', [b[0] for b in bad])
-        if '--strict' in sys.argv:
-            sys.exit(1)
+    if npk and '--allow-packed' not in sys.argv:
+        sys.exit(3)
+    if bad and '--strict' in sys.argv:
+        sys.exit(1)
 
 
 if __name__ == '__main__':
