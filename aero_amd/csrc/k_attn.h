@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) void aero_attn_kernel(aero_attn_desc d) {
 //     in the two score loops).
 #define AERO_ATTN_FOLD_T 512
 template <int DT>
-__global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d, int skip) {
+__global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d) {
     constexpr int KC = AERO_ATTN_FOLD_T;
     constexpr int VS = KC + 4;
     __shared__ AERO_LDS_ALIGN h16 Ks[KC * 32];
@@ -433,40 +433,30 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d, i
     // fragments, the diagonal block takes the general path, blocks after it the "after" fragments -- three straight loops.
     const int tdiag = sw_lo;
 
-    // ---- pass 1: the maximum of every query's scores -- and WHICH key blocks can matter at all.  The probabilities enter the PV MFMA
-    // as fp16: exp2(x) with x < -26 converts to +0 (half of the smallest subnormal is 2^-25), so a key block whose every score lies
-    // more than 26 below its query's maximum contributes exactly nothing, numerator and denominator alike, and pass 2 may skip it
-    // without changing a bit of the result.  With the decay slopes LocalState learns (modules.py:88-90 starts them at 0.3 per step of
-    // distance: e^-17 after ~60 steps) that is most of the row.  The diagonal block goes first and the walk proceeds outwards, so the
-    // running maximum a block is compared with is already close to the final one; it can only grow, hence a block found negligible
-    // against the running maximum is negligible against the final one (`live` is a superset of the blocks that matter: exact).
+    // ---- pass 1: the maximum of every query's scores
     float m[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) m[j] = -1e30f;
-    unsigned live = 0;                                            // bit tb / 32 (T <= 512: 16 blocks); wave-uniform
-    constexpr float NEGL = -26.f;
     {
         h16x8 qbv[NQ], qav[NQ];
 #pragma unroll
         for (int j = 0; j < NQ; ++j) { qbv[j] = with_bias(j, 1.f, -Dq[j] * (float)sq[j]); qav[j] = with_bias(j, -1.f, Dq[j] * (float)sq[j]); }
-        auto visit = [&](int tb, const h16x8 (&q)[NQ], bool general) {
-            float sc[NQ][8];
-            block(tb, q, general, sc);
-            bool mine = false;
+        auto run = [&](int lo, int hi, const h16x8 (&q)[NQ]) {
+            for (int tb = lo; tb < hi; tb += 32) {
+                float sc[NQ][8];
+                block(tb, q, false, sc);
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const float bm = max8(sc[j]);
-                m[j] = fmaxf(m[j], bm);
-                mine = mine || (bm >= m[j] + NEGL);
+                for (int j = 0; j < NQ; ++j) m[j] = fmaxf(m[j], max8(sc[j]));
             }
-            if (skip && !aero_wave_any(mine)) return;
-            live |= 1u << (tb >> 5);
         };
+        run(0, tdiag < kn32 ? tdiag : kn32, qbv);
         if (tdiag < kn32) {
-            visit(tdiag, qf, true);
-            for (int tb = tdiag + 32; tb < kn32; tb += 32) visit(tb, qav, false);
+            float sc[NQ][8];
+            block(tdiag, qf, true, sc);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) m[j] = fmaxf(m[j], max8(sc[j]));
+            run(tdiag + 32, kn32, qav);
         }
-        for (int tb = (tdiag < kn32 ? tdiag : kn32) - 32; tb >= 0; tb -= 32) visit(tb, qbv, false);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             m[j] = fmaxf(m[j], __shfl_xor(m[j], 16));
@@ -504,18 +494,14 @@ __global__ __launch_bounds__(512) void aero_attn_fold_kernel(aero_attn_desc d, i
                 for (int j = 0; j < NQ; ++j) O[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[j], O[j][i], 0, 0, 0);
             }
         };
-        // (the key blocks in ascending order as before -- the accumulation order of the blocks that are not skipped is unchanged)
         if (fold_ok) {
-            for (int tb = 0; tb < (tdiag < kn32 ? tdiag : kn32); tb += 32)
-                if ((live >> (tb >> 5)) & 1u) step(tb, qbv, false);
+            for (int tb = 0; tb < (tdiag < kn32 ? tdiag : kn32); tb += 32) step(tb, qbv, false);
             if (tdiag < kn32) {
                 step(tdiag, qf, true);
-                for (int tb = tdiag + 32; tb < kn32; tb += 32)
-                    if ((live >> (tb >> 5)) & 1u) step(tb, qav, false);
+                for (int tb = tdiag + 32; tb < kn32; tb += 32) step(tb, qav, false);
             }
         } else {
-            for (int tb = 0; tb < kn32; tb += 32)
-                if ((live >> (tb >> 5)) & 1u) step(tb, qf, true);
+            for (int tb = 0; tb < kn32; tb += 32) step(tb, qf, true);
         }
     }
     // the denominator: row dh of O, held by lane group (dh % 16) / 4 in register dh % 4 of tile dh / 16
@@ -561,11 +547,8 @@ static int aero_attn_launch(const aero_attn_desc* d, hipStream_t stream, const c
     if (fold < 0) { const char* e = getenv("AERO_ATTN_FOLD"); fold = (e && e[0] == '0') ? 0 : 1; }
     if (fold && d->T <= AERO_ATTN_FOLD_T && ((dh + 3) & ~3) + 5 <= 32 && dh + 1 <= 32) {
         dim3 grid(1, (unsigned)d->heads, (unsigned)d->R);
-        // AERO_ATTN_SKIP=0: visit every key block in pass 2 (A/B; the results are bit-identical either way, tests/op_cases.py)
-        static int skip = -1;
-        if (skip < 0) { const char* e = getenv("AERO_ATTN_SKIP"); skip = (e && e[0] == '0') ? 0 : 1; }
-        if (dh + 1 <= 16) AERO_LAUNCH((aero_attn_fold_kernel<1>), grid, block, stream, *d, skip);
-        else AERO_LAUNCH((aero_attn_fold_kernel<2>), grid, block, stream, *d, skip);
+        if (dh + 1 <= 16) AERO_LAUNCH((aero_attn_fold_kernel<1>), grid, block, stream, *d);
+        else AERO_LAUNCH((aero_attn_fold_kernel<2>), grid, block, stream, *d);
         return AERO_OK;
     }
     dim3 grid((unsigned)((d->T + 127) / 128), (unsigned)d->heads, (unsigned)d->R);

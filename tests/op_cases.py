@@ -426,45 +426,6 @@ def case_localstate(lib, dev, Cc, heads, R, T, seed=70):
     return err
 
 
-def localstate_raw(lib, dev, Cc, heads, R, T, decay_bias, seed=75):
-    """the LocalState core alone on a seeded q|k|v|decay tensor whose decay logits are shifted by `decay_bias` (large: steep decay, most
-    key blocks negligible; very negative: no decay, every block matters); returns the [R, T, C] output"""
-    ops = Ops(lib)
-    nd = 4
-    ld = 3 * Cc + heads * nd
-    g = torch.Generator().manual_seed(seed)
-    qkvd = torch.randn(1, R, T, ld, generator=g)
-    qkvd[..., 3 * Cc:] = 0.5 * qkvd[..., 3 * Cc:] + decay_bias
-    return ops.localstate(qkvd.half().to(dev).contiguous(), R, T, Cc, heads, nd).float().cpu()
-
-
-def case_localstate_skip_is_exact(emulator, **kw):
-    """k_attn.h: pass 2 of the folded kernel skips the key blocks whose probabilities all round to +0 in fp16 -- the result must not change
-    in a single bit against the kernel that visits every block (AERO_ATTN_SKIP=0), with steep, mild and no decay.  The switch is read
-    once per process, so each setting runs in its own interpreter."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    with tempfile.TemporaryDirectory() as td:
-        for skip in ('1', '0'):
-            path = os.path.join(td, f'att{skip}.pt')
-            load = "from emu.build_emu import build\nlib = _lib.load(build())\ndev = 'cpu'" if emulator else "lib = _lib.load()\ndev = 'cuda'"
-            code = (f"import sys; sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
-                    f"import torch\nimport op_cases as oc\nfrom aero_amd import _lib\n{load}\n"
-                    f"res = [oc.localstate_raw(lib, dev, decay_bias=b, **{kw!r}) for b in (3.0, 0.0, -2.0, -30.0)]\n"
-                    f"torch.save(res, {path!r})\nprint('ok')\n")
-            out = subprocess.run([sys.executable, '-c', code], env={**os.environ, 'AERO_ATTN_SKIP': skip}, capture_output=True, text=True, timeout=900)
-            assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-1500:]
-            outs.append(torch.load(path))
-    for a, b in zip(*outs):
-        assert torch.isfinite(a).all() and torch.equal(a, b), float((a - b).abs().max())
-    # (and the cases are not degenerate: steep and flat decay give different outputs)
-    assert not torch.equal(outs[0][0], outs[0][3])
-
-
 def case_freqfc(lib, dev, Fq, Cc, T, B=2, seed=80):
     ops = Ops(lib)
     w = q16(_rand((Fq, Fq), seed, 1.0 / math.sqrt(Fq)))

@@ -167,10 +167,6 @@ def test_freqfc(emu, kw):
     oc.case_freqfc(emu, DEV, **kw)
 
 
-def test_localstate_block_skip_is_exact():
-    oc.case_localstate_skip_is_exact(True, Cc=48, heads=4, R=1, T=300)
-
-
 def test_localstate_streaming_form_for_short_rows():
     """AERO_ATTN_FOLD=0: rows with T <= 512 on the streaming kernel (the default for them is the folded two-pass kernel)."""
     import os

@@ -124,11 +124,6 @@ def test_localstate(lib, kw):
     oc.case_localstate(lib, DEV, **kw)
 
 
-@pytest.mark.parametrize('kw', [dict(Cc=48, heads=4, R=16, T=501), dict(Cc=96, heads=4, R=8, T=376)])
-def test_localstate_block_skip_is_exact(kw):
-    oc.case_localstate_skip_is_exact(False, **kw)
-
-
 @pytest.mark.parametrize('kw', [dict(Fq=256, Cc=48, T=501, B=1), dict(Fq=64, Cc=48, T=501), dict(Fq=8, Cc=192, T=501), dict(Fq=16, Cc=96, T=501), dict(Fq=4, Cc=4, T=9, B=1),
                                 dict(Fq=256, Cc=2, T=501), dict(Fq=33, Cc=3, T=21)])    # encoder 0's (re, im) rows: 4-byte aligned only
 def test_freqfc(lib, kw):

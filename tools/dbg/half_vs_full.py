@@ -3,7 +3,7 @@ B = 32?  Runs the SAME clips as one batch of `k` and as a batch of `k // 2` (bot
 returns, and reports launch by launch where the slice of the first k // 2 clips starts to differ; then repeats each run to tell a
 batch-size dependent code path (same differences every time) from an order-of-atomics effect (differences come and go).
 usage: half_vs_full.py [full|small] [L] [k]"""
-import json, os, sys
+import inspect, json, os, sys, types
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -19,7 +19,8 @@ eng = m._get_engine()
 eng.streams = 1
 x = torch.randn(k, 1, L, generator=torch.Generator().manual_seed(5)).cuda()
 log, cur = [], {'B': k}
-names = [n for n in dir(Ops) if not n.startswith('_') and callable(getattr(Ops, n)) and n not in ('stream', 'begin_step', 'new_stats')]
+names = [n for n in dir(Ops) if not n.startswith('_') and isinstance(inspect.getattr_static(Ops, n), types.FunctionType)
+         and n not in ('stream', 'begin_step', 'new_stats')]
 
 
 def wrap(n, fn):
