@@ -240,6 +240,41 @@ def test_training_is_reproducible_run_to_run(meta):
     assert torch.equal(p1, p2)
 
 
+def test_adversarial_training_tracks_the_reference_trajectory(meta):
+    """the recipe BASELINE config 5's experiment file trains with (`adversarial: true`, msd_melgan).  The reference's
+    own loop -- its generator, its MelGAN critic, its MultiResolutionSTFTLoss, hinge and feature-matching losses of solver.py:475-520, two
+    torch.optim.Adam, generator step then critic step (solver.py:602-612), fp32 CPU -- over 12 steps on one fixed batch is committed as a
+    golden (oracle/make_golden_train_gan.py -> tests/golden/train_gan_trajectory.npz: per step stft, adversarial, features, discriminator
+    loss).  `aero_amd.trainer.TrainStep` (HIP generator + critic, fp16 activation storage, both FlatAdam) must follow it term by term."""
+    from aero_amd import trainer
+    from aero_amd.config import _wrap
+    cfgt = meta['train_gan_trajectory']
+    gold = torch.from_numpy(load_npz('train_gan_trajectory.npz')['loss'])              # [steps, {stft, adv, feat, disc}]
+    args = _wrap(dict(optim='adam', lr=cfgt['lr'], beta2=cfgt['betas'][1], losses=['stft'], stft_sc_factor=0.5, stft_mag_factor=0.5,
+                      experiment=dict(model='aero', aero=cfgt['gen_cfg'], adversarial=True, features_loss_lambda=cfgt['features_loss_lambda'],
+                                      only_features_loss=False, only_adversarial_loss=False, discriminator_models=['msd_melgan'],
+                                      melgan_discriminator=cfgt['disc_cfg'])))
+    torch.manual_seed(cfgt['seed'])
+    models = {k: m.cuda().train() for k, m in trainer.build_models(args).items()}
+    opts = trainer.build_optimizers(models, args)
+    step = trainer.TrainStep(models, opts, args)
+    x = seeded((2, 1, cfgt['L']), cfgt['x_seed']).cuda()
+    hr = (cfgt['hr_scale'] * seeded((2, 1, 4 * cfgt['L']), cfgt['hr_seed'])).cuda()
+    got = []
+    for _ in range(cfgt['steps']):
+        rec = step(x, hr)
+        got.append([float(rec[k]) for k in ('generator_stft', 'generator_adversarial_melgan', 'generator_features_melgan', 'discriminator_msd_melgan')])
+    got = torch.tensor(got, dtype=torch.float64)
+    rel = (got - gold).abs() / gold
+    print('adversarial trajectory: worst relative deviation per term (stft, adv, feat, disc) %s, at the last step %s' % (
+        [f'{float(v):.2e}' for v in rel.max(0).values], [f'{float(v):.2e}' for v in rel[-1]]))
+    # the first step is a pure forward comparison (same weights on both sides): tight; later steps carry twelve Adam updates of two models
+    assert float(rel[0].max()) < 5e-3, rel[0].tolist()
+    assert float(rel[:, 0].max()) < 3e-2 and float(rel[:, 1].max()) < 1e-2 and float(rel[:, 2].max()) < 3e-2 and float(rel[:, 3].max()) < 1e-2, rel.max(0).values.tolist()
+    tot_g, tot_r = got[:, :3].sum(1), gold[:, :3].sum(1)
+    assert float(((tot_g - tot_r).abs() / tot_r).max()) < 2e-2
+
+
 def test_adversarial_training_is_reproducible_run_to_run():
     """the step the experiment files train with (generator step with MR-STFT + adversarial + feature-matching losses, then the msd_melgan
     critic's step: aero_amd/trainer.py) twice from the same seed: bit-identical generator AND critic parameters after four steps"""

@@ -25,12 +25,23 @@ LLVM = '/opt/rocm/lib/llvm/bin'
 
 
 def disassemble(lib):
+    """the gfx950 code objects of EVERY fat-binary bundle in `lib` (the library is linked from seven separately compiled parts, each with
+    its own bundle in .hip_fatbin: unbundling the section as a whole yields only the first one), disassembled and concatenated"""
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    out = []
     with tempfile.TemporaryDirectory() as td:
-        fat, co = os.path.join(td, 'fat.bin'), os.path.join(td, 'gfx950.co')
+        fat = os.path.join(td, 'fat.bin')
         subprocess.run([f'{LLVM}/llvm-objcopy', '-O', 'binary', '--only-section=.hip_fatbin', lib, fat], check=True)
-        subprocess.run([f'{LLVM}/clang-offload-bundler', '--type=o', f'--input={fat}', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
-                        f'--output={co}', '--unbundle'], check=True)
-        return subprocess.run([f'{LLVM}/llvm-objdump', '-d', co], check=True, capture_output=True, text=True).stdout
+        blob = open(fat, 'rb').read()
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        assert starts, f'{lib}: no offload bundle in .hip_fatbin'
+        for i, a in enumerate(starts):
+            part, co = os.path.join(td, f'bundle{i}.bin'), os.path.join(td, f'gfx950_{i}.co')
+            open(part, 'wb').write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            subprocess.run([f'{LLVM}/clang-offload-bundler', '--type=o', f'--input={part}', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
+                            f'--output={co}', '--unbundle'], check=True)
+            out.append(subprocess.run([f'{LLVM}/llvm-objdump', '-d', co], check=True, capture_output=True, text=True).stdout)
+    return '\n'.join(out)
 
 
 def lint(text):
@@ -82,7 +93,7 @@ def lint(text):
 
 def demangle(names):
     try:
-        p = subprocess.run([f'{LLVM}/llvm-cxxfilt'], input='\n'.join(names), capture_output=True, text=True, check=True)
+        p = subprocess.run(['c++filt'], input='\n'.join(names), capture_output=True, text=True, check=True)
         return dict(zip(names, p.stdout.splitlines()))
     except Exception:
         return {n: n for n in names}
