@@ -800,7 +800,12 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
     }
     const int span = 127 * hop + AERO_DFT_K;
     const int ntile = (p.T + 127) >> 7;
+    // Per-item statistics (sum, sum of squares of the spectrogram: aero.py:462-464).  A thread's fp32 partial covers ONE tile and is
+    // folded into an fp64 per-thread sum at the end of the tile: the number of tiles a block walks depends on the batch size (gridDim.x
+    // below), and a partial that ran over two tiles in fp32 made mean / std of an item -- hence the whole output of that clip -- differ in
+    // the last bit between a batch of 64 and the same clips in two batches of 32 (tools/dbg/half_vs_full.py, round 5).
     float s = 0.f, ss = 0.f;
+    double ds_acc = 0.0, dss_acc = 0.0;
     float* out = p.spec + (int64_t)sig * n_bins * p.T * 2;
     // the span of the (hop-padded, reflect-padded) signal a tile's 128 frames read, one load batch per tile, REQUESTED a tile ahead (their
     // latency runs under the MFMAs and stores of the tile before); the barriers between tiles order LDS only (aero_lds_barrier) -- a
@@ -887,9 +892,12 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
             ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
     }
+    ds_acc += (double)s;
+    dss_acc += (double)ss;
+    s = ss = 0.f;
     }
     if (p.stats) {
-        const double ds = aero_wave_sum((double)s), dss = aero_wave_sum((double)ss);
+        const double ds = aero_wave_sum(ds_acc), dss = aero_wave_sum(dss_acc);
         if (lane == 0) { red[0][wave] = ds; red[1][wave] = dss; }
         __syncthreads();
         if (tid == 0) {
