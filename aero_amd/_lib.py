@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ('stat_mode', i32), ('stat_G', i32), ('stat_per_row', i32), ('stat_eps', C.c_float),
                 ('gamma', fp), ('beta', fp), ('layer_scale', fp),
                 ('scatter_M', i32), ('scatter_stride', i32), ('scatter_off', i32), ('scatter_F', i32),
-                ('weight_tiled', vp), ('tiled_bm', i32), ('tap_split', i32), ('split_acc', fp)]
+                ('weight_tiled', vp), ('tiled_bm', i32), ('tap_split', i32), ('split_acc', fp),
+                ('tail_w', vp), ('tail_lo', fp), ('tail_hi', fp), ('tail_cp', i32)]
 
 
 class NormDesc(C.Structure):
@@ -167,6 +168,7 @@ _PROTOS = {
     'aero_istft_bwd_pack': (i32, [fp, fp, i32, i32, i32, i32, i32, vp]),
     'aero_conv_tile_m': (i32, [i32]),
     'aero_conv_ring_bm': (i32, [i32, i32]),
+    'aero_convtr_tail_finish': (i32, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, vp]),
     'aero_conv_kernel_name': (i32, [C.POINTER(ConvDesc), C.c_char_p, i32]),
     'aero_norm_stats': (i32, [C.POINTER(NormDesc), vp]),
     'aero_norm_apply': (i32, [C.POINTER(NormDesc), vp]),

@@ -594,6 +594,13 @@ int aero_avgpool1d_bwd(const void* dy, void* dx, int32_t B, int32_t T, void* str
 
 int aero_conv_ring_bm(int32_t M, int32_t Ktot) { return aero_conv_ring_pick_bm(M, Ktot); }
 
+int aero_convtr_tail_finish(const float* lo, const float* hi, const float* bias, const float* scale, const float* shift, float* dst,
+                            int32_t B, int32_t Fin, int32_t T, int32_t dst_F, int32_t pad, void* stream) {
+    const char* err = "";
+    int rc = aero_convtr_tail_finish_launch(lo, hi, bias, scale, shift, dst, B, Fin, T, dst_F, pad, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
 #endif  // part 6
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1574,7 +1574,12 @@ static int aero_split_finish_launch(const float* acc, int nsplit, const float* b
 AERO_XPART bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStream_t stream, char* name);
 
 static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const char** err, char* name = nullptr) {
-    if (!d || !d->weight || (!d->dst && d->stat_mode != 2 && d->tap_split <= 1)) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
+    if (!d || !d->weight || (!d->dst && d->stat_mode != 2 && d->tap_split <= 1 && !d->tail_w)) { *err = "conv: null weight/dst"; return AERO_ERR_ARG; }
+    if (d->tail_w) {                                            // fused transposed-conv tail (aero_hip.h): only the 192-row ring tile carries it
+        if (!d->tail_lo || !d->tail_hi || ((uintptr_t)d->tail_w & 15) || ((uintptr_t)d->tail_lo & 15) || ((uintptr_t)d->tail_hi & 15)) { *err = "conv: fused tail needs 16-byte aligned tail_w / tail_lo / tail_hi"; return AERO_ERR_ARG; }
+        if (d->act != AERO_ACT_GLU || d->M != 192 || d->tail_cp != 96 || d->stat_mode || d->res || d->post_add || d->batch_scale || d->scatter_M ||
+            d->tap_split > 1 || d->transposed || d->dst_f_off != 0 || d->dst_F != d->Fout) { *err = "conv: fused tail needs a plain GLU conv with M = 192 (tail_cp 96)"; return AERO_ERR_UNSUPPORTED; }
+    }
     if (d->tap_split > 1 && (!d->split_acc || d->M <= 16 || d->stat_mode || d->scatter_M || d->res || d->post_add || d->batch_scale)) {
         *err = "conv: tap split needs split_acc, M > 16 and a plain epilogue";
         return AERO_ERR_UNSUPPORTED;
@@ -1748,6 +1753,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
             grid = dim3(grid.x * (unsigned)p.tsplit);
         }
         if (p.tsplit == 1 && aero_conv_ring_try(d, p, stream, name)) return AERO_OK;
+        if (d->tail_w) { *err = "conv: fused tail needs the 192-row software-pipelined tile (3x3 taps, tiled weight image, K >= 768)"; return AERO_ERR_UNSUPPORTED; }
         static int wide = -1;
         if (wide < 0) { const char* e = getenv("AERO_CONV_BM256"); wide = e ? atoi(e) : 2; }
         // shortest contraction the 8-wave 192-row tile takes (AERO_CONV_KMIN192, A/B; 768 until round 4): the two-source 1x1 conv of the
@@ -1796,6 +1802,7 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
     }
     if (d->scatter_M) { *err = "conv: row scatter needs a regular tap grid"; return AERO_ERR_UNSUPPORTED; }
     if (d->tap_split > 1) { *err = "conv: tap split needs aligned fp16 operands on a regular tap grid"; return AERO_ERR_UNSUPPORTED; }
+    if (d->tail_w) { *err = "conv: fused tail needs aligned fp16 operands on a regular tap grid"; return AERO_ERR_UNSUPPORTED; }
     switch (bm) {
         case 128: AERO_CONV_GO2(aero_conv_kernel, 4, 2); break;
         case 96: AERO_CONV_GO2(aero_conv_kernel, 3, 2); break;

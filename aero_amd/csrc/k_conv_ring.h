@@ -159,6 +159,105 @@ static __device__ __forceinline__ void aero_ring_epilogue(const AeroConvK& p, f3
     }
 }
 
+// Fused transposed-conv tail (aero_conv_desc.tail_w, round 5): the last decoder layer's ConvTranspose2d(C -> 2, [8,1] / [4,1]) applied to the
+// GLU'd tile while it sits in the staging area.  The 16 x C tail matrix (rows 2 * tap + out channel) is the A operand of
+// v_mfma_f32_16x16x32_f16 (three k-steps for C = 96, fragments fetched once per block), the B operand "8 consecutive channels of one time
+// step" is one ds_read_b128 of the staging row the epilogue has just written -- the row stride of 200 halves puts the 16 lanes of a read
+// group on 16 different bank quadruples --, and a lane ends up with four consecutive tail rows of one time step: one 16-byte store into
+// tail_lo (rows 0..7: taps 0..3) or tail_hi (rows 8..15).  The [B][F][T][C] activation (394 MB at the bench size) is never written or read
+// back, and the stand-alone transposed conv over it (aero_convtr_carry_kernel: 102 us) is replaced by aero_convtr_tail_finish_kernel
+// (two 32-byte reads and four 8-byte writes per (row, time step)).
+template <int WM, int WN, int NRB>
+static __device__ __forceinline__ void aero_ring_tail_epilogue(const AeroConvK& p, f32x16 (&acc)[NRB][2], h16* Cs, int b, int fo, int m0, int t0) {
+    typedef AeroRingGeom<WM, WN, NRB, 1> G;
+    constexpr int BMo = G::BM / 2;                                // channels after GLU: the whole layer (one M-tile)
+    constexpr int KS = BMo / 32;
+    static_assert(BMo % 32 == 0 && G::NW * 16 == WN * 32, "eight waves x 16 time steps cover one half of the tile's columns");
+    const aero_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int T = d.T;
+    const int kq = lane >> 4, col = lane & 15;
+    h16x8 wa[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wa[ks] = *(const h16x8*)((const h16*)d.tail_w + col * d.tail_cp + ks * 32 + kq * 8);
+    const int hi4 = (lane >> 5) * 4;
+    float* tdst = (kq < 2 ? d.tail_lo : d.tail_hi) + ((int64_t)b * d.Fout + fo) * (int64_t)T * 8 + (kq & 1) * 4;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int pc = wn * 32 + (lane & 31);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ml = (wm * NRB + rb) * 32 + 8 * j + hi4;
+                float o[4];
+                if (d.bias) {
+                    const f32x4 bv = *(const f32x4*)(d.bias + m0 + ml);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = acc[rb][cb][4 * j + r] + bv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = acc[rb][cb][4 * j + r];
+                }
+                const float g0 = o[0] * aero_sigmoid(o[1]);
+                const float g1 = o[2] * aero_sigmoid(o[3]);
+                *(h16x2*)&Cs[pc * G::CS + (ml >> 1)] = (h16x2){(h16)g0, (h16)g1};
+            }
+        }
+        aero_lds_barrier();
+        {
+            const int pp = wave * 16 + col;                        // staging row = time step (pp >> 5) * 64 + cb * 32 + (pp & 31) of the tile
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const h16x8 bf = *(const h16x8*)&Cs[pp * G::CS + ks * 32 + kq * 8];
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks], bf, o, 0, 0, 0);
+            }
+            const int t = t0 + (pp >> 5) * 64 + cb * 32 + (pp & 31);
+            if (t < T) *(f32x4*)(tdst + (int64_t)t * 8) = o;
+        }
+        aero_lds_barrier();
+    }
+}
+
+// out[b][fo][t][co] = (lo[b][q][t][2k + co] + hi[b][q - 1][t][2k + co] + bias[co]) * scale[b] + shift[b],  q = (fo + pad) / 4, k = (fo + pad) % 4
+__global__ __launch_bounds__(256) void aero_convtr_tail_finish_kernel(const float* lo, const float* hi, const float* bias, const float* scale,
+                                                                      const float* shift, float* dst, int Fin, int T, int dstF, int pad) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int q = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0, h0 = a0, h1 = a0;
+    if (q < Fin) {
+        const float* pl = lo + (((int64_t)b * Fin + q) * T + t) * 8;
+        a0 = *(const f32x4*)pl;
+        a1 = *(const f32x4*)(pl + 4);
+    }
+    if (q >= 1) {
+        const float* ph = hi + (((int64_t)b * Fin + (q - 1)) * T + t) * 8;
+        h0 = *(const f32x4*)ph;
+        h1 = *(const f32x4*)(ph + 4);
+    }
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
+    const float sc = scale ? scale[b] : 1.f, sh = shift ? shift[b] : 0.f;
+    const float v[8] = {a0[0] + h0[0], a0[1] + h0[1], a0[2] + h0[2], a0[3] + h0[3], a1[0] + h1[0], a1[1] + h1[1], a1[2] + h1[2], a1[3] + h1[3]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int fo = 4 * q + k - pad;
+        if (fo < 0 || fo >= dstF) continue;
+        *(f32x2*)(dst + (((int64_t)b * dstF + fo) * T + t) * 2) = (f32x2){fmaf(v[2 * k] + b0, sc, sh), fmaf(v[2 * k + 1] + b1, sc, sh)};
+    }
+}
+
+static int aero_convtr_tail_finish_launch(const float* lo, const float* hi, const float* bias, const float* scale, const float* shift, float* dst,
+                                          int B, int Fin, int T, int dstF, int pad, hipStream_t stream, const char** err) {
+    if (!lo || !hi || !dst || B < 1 || Fin < 1 || T < 1 || dstF < 1 || pad < 0 || pad > 3) { *err = "convtr_tail_finish: bad arguments"; return AERO_ERR_ARG; }
+    if (((uintptr_t)lo & 15) || ((uintptr_t)hi & 15) || ((uintptr_t)dst & 7) || B > 65535 || Fin + 1 > 65535) { *err = "convtr_tail_finish: alignment / size"; return AERO_ERR_ARG; }
+    AERO_LAUNCH(aero_convtr_tail_finish_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)(Fin + 1), (unsigned)B), dim3(256), stream, lo, hi, bias, scale, shift,
+                dst, Fin, T, dstF, pad);
+    return AERO_OK;
+}
+
 // ABL: ablation bits for profiling builds (results are WRONG with any bit set): 1 no barriers in the K loop, 2 no copies
 // in the loop, 4 no fragment reads in the loop, 8 no interleave hints, 32 no counted vmcnt wait, 64 every copy reads the
 // zero page, 128 no K loop at all (prologue + epilogue only)
@@ -474,6 +573,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void aero_conv_ring_kernel(AeroCon
     }
     aero_wait_vm<0>();
     aero_phase_barrier();                  // every wave is done with the rings: they become the output staging tile
+    if constexpr (WM == 2 && WN == 4 && NRB == 3 && ABL == 0) {
+        if (d.tail_w) {                                    // (block-uniform: the fused transposed-conv tail instead of the activation's store)
+            aero_ring_tail_epilogue<WM, WN, NRB>(p, acc, smem, b, fo, m0, t0);
+            return;
+        }
+    }
     if (d.stat_mode == 1) {
         aero_ring_epilogue<WM, WN, NRB, AERO_ACT_NONE, 1>(p, acc, smem, b, fo, m0, t0);
         return;
@@ -567,6 +672,8 @@ AERO_XPART bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStr
         return false;
     const int bm = aero_conv_ring_pick_bm(d->M, p.Ktot);
     if (!bm || !d->weight_tiled || d->tiled_bm != bm || ((uintptr_t)d->weight_tiled & 15)) return false;
+    // fused transposed-conv tail: only the 192-row tile with the shared three-tap slab carries it, and the block must hold every channel
+    if (d->tail_w && !(bm == 192 && d->M == 192 && d->act == AERO_ACT_GLU && p.nT == 3 && (p.t_step == 1 || p.t_step == 2))) return false;
     if ((long)d->B * d->Fout * ((d->T + 255) / 256) * (d->M / bm) > 0x7fffffffL) return false;
     // three unit-stride time taps share one activation slab; any other tap grid: one tile per tap (256-row tile only:
     // the 512-step tiles have no LDS for four full activation tiles)

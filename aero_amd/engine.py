@@ -128,9 +128,11 @@ class Ops:
     # -- convolution family --------------------------------------------------------------------
     def conv(self, spec, src0, src1, B, Fin, Fout, T, dst=None, dst_f32=False, dst_f_off=0, dst_F=None, res=None,
              post_add=None, batch_scale=None, batch_shift=None, act=None, dst_strides=None, src0_strides=None,
-             stat=None, scatter=None, tap_split=1):
+             stat=None, scatter=None, tap_split=1, tail=None):
         """src0/src1: channels-last [B,Fin,T,C] tensors (src0 may be None = zeros).  Returns dst.
-        tap_split = S > 1 (aero_hip.h "tap split"): S x the blocks, partial sums into an fp32 accumulator, then aero_split_finish."""
+        tap_split = S > 1 (aero_hip.h "tap split"): S x the blocks, partial sums into an fp32 accumulator, then aero_split_finish.
+        tail = fp16 [16][C] image (pack.convtr_tail_image): the fused transposed-conv tail of aero_hip.h -- the activation is not stored,
+        the call returns the two fp32 tap-product tensors (lo, hi) [B, Fout, T, 8] for convtr_tail_finish."""
         dev = spec.weight.device
         act = spec.act if act is None else act
         split_acc = None
@@ -139,7 +141,12 @@ class Ops:
             split_acc = torch.empty(tap_split, B, Fout, T, spec.M, dtype=torch.float32, device=dev)
         Mout = spec.M // 2 if act == ACT_GLU else spec.M
         dst_F = Fout if dst_F is None else dst_F
-        no_store = stat is not None and stat['mode'] == 2
+        no_store = (stat is not None and stat['mode'] == 2) or tail is not None
+        tail_lo = tail_hi = None
+        if tail is not None:
+            assert dst is None and stat is None and res is None and act == ACT_GLU and tap_split == 1
+            tail_lo = torch.empty(B, Fout, T, 8, dtype=torch.float32, device=dev)
+            tail_hi = torch.empty(B, Fout, T, 8, dtype=torch.float32, device=dev)
         if dst is None and not no_store:
             dst = torch.empty(B, dst_F, T, Mout, dtype=torch.float32 if dst_f32 else torch.float16, device=dev)
         d = _lib.ConvDesc()
@@ -178,6 +185,8 @@ class Ops:
         d.batch_scale, d.batch_shift = _ptr(batch_scale), _ptr(batch_shift)
         if split_acc is not None:
             d.tap_split, d.split_acc = tap_split, _ptr(split_acc)
+        if tail is not None:
+            d.tail_w, d.tail_lo, d.tail_hi, d.tail_cp = _ptr(tail), _ptr(tail_lo), _ptr(tail_hi), tail.shape[1]
         ref_t = dst if dst is not None else spec.weight
         if self.prof is None:
             self.lib.call('aero_conv_fwd', C.byref(d), self.stream(ref_t))
@@ -190,11 +199,22 @@ class Ops:
             pos = B * dst_F * T
             cin_exec = spec.C1 + (spec.C0 if src0 is not None else 0)
             flops = 2.0 * pos * spec.M * len(spec.df) * cin_exec       # executed (NULL source skipped)
-            nbytes = pos * (Mout * (dst.element_size() if dst is not None else 0)) + B * Fin * T * cin_exec * 2
+            nbytes = pos * (Mout * (dst.element_size() if dst is not None else 0)) + B * Fin * T * cin_exec * 2 + (pos * 64 if tail is not None else 0)
             self._call('aero_conv_fwd', kname, flops, nbytes, C.byref(d), self.stream(ref_t))
         if split_acc is not None:
             self._call('aero_split_finish', 'aero_split_finish_kernel', 0.0, split_acc.numel() * 4 + dst.numel() * 2, _ptr(split_acc), tap_split,
                        _ptr(spec.bias), act, _ptr(dst), B * Fout * T, spec.M, self.stream(dst))
+        if tail is not None:
+            return tail_lo, tail_hi
+        return dst
+
+    def convtr_tail_finish(self, lo, hi, bias, scale, shift, dst_F, pad, cin):
+        """second half of the fused last layer (aero_convtr_tail_finish): (lo, hi) [B, Fin, T, 8] -> fp32 [B, dst_F, T, 2]"""
+        B, Fin, T, _ = lo.shape
+        dst = torch.empty(B, dst_F, T, 2, dtype=torch.float32, device=lo.device)
+        self._shape_note = f'convtr tail finish F={Fin}->{dst_F}'
+        self._call('aero_convtr_tail_finish', 'aero_convtr_tail_finish_kernel', 2.0 * B * Fin * T * 16 * cin, lo.numel() * 8 + dst.numel() * 4,
+                   _ptr(lo), _ptr(hi), _ptr(bias), _ptr(scale), _ptr(shift), _ptr(dst), B, Fin, T, dst_F, pad, self.stream(lo))
         return dst
 
     def pw(self, spec, x, B, F, T, res=None, post_add=None, stats=None, count=None, gamma=None, beta=None, layer_scale=None,
@@ -490,6 +510,7 @@ class HipEngine:
         self.use_pw = os.environ.get('AERO_PW', '1') != '0'                   # streaming pointwise kernel (k_pw.h) for the DConv tails / rewrite + GLU convs
         self.fuse_dconv_row = os.environ.get('AERO_DCONV_ROW', '1') != '0'    # DConv branches without LSTM / attention: one launch, the row stays in LDS (k_dconv.h)
         self.fuse_enc0 = os.environ.get('AERO_FUSE_ENC0', '1') != '0'     # ... and fused with the layer's strided conv (k_enc0.h)
+        self.fuse_tail = os.environ.get('AERO_FUSE_TAIL', '1') != '0'     # last decoder layer: the transposed conv inside the rewrite conv's epilogue (k_conv_ring.h)
 
     # ------------------------------------------------------------------ weights
     def _weights_key(self, device):
@@ -609,6 +630,13 @@ class HipEngine:
             act = ACT_NONE if (dec.norm or dec.last) else ACT_GELU
             L['conv_tr'] = mk(w, sd[f'{p}.conv_tr.bias'], w.shape[-1], 0, df, dt, device, transposed=1,
                               fstride=dec.stride, act=act)
+            if dec.last and not dec.norm and dec.rewrite is not None:
+                # fused tail (aero_hip.h): when the rewrite conv runs on the 192-row ring tile and the transposed conv is C -> 2, [8,1] / [4,1]
+                timg = pack.convtr_tail_image(sd[f'{p}.conv_tr.weight'], dec.stride, device)
+                rw = L['rewrite']
+                if (timg is not None and rw.M == 192 and rw.tiled_bm == 192 and len(rw.df) == 9 and timg.shape[1] == 96 and dec.pad == 2
+                        and dec.kernel_size == 8):
+                    L['tail'] = (timg, sd[f'{p}.conv_tr.bias'].detach().float().to(device).contiguous())
             if not dec.last and os.environ.get('AERO_CONVTR_STACK', '1') != '0':
                 # input-side form (all `stride` residue classes from one pass over the source rows), when Cout % 8 == 0
                 st = pack.convtr_stacked_spec(sd[f'{p}.conv_tr.weight'], sd[f'{p}.conv_tr.bias'], dec.stride, device, act=act)
@@ -744,7 +772,8 @@ class HipEngine:
         Clips are independent units: with `self.streams` > 1 the batch is cut into that many sub-batches whose
         kernel sequences are enqueued on separate HIP streams, so latency-bound launches of one sub-batch (the
         recurrent LSTM kernel: one block per CU, 200 dependent steps) overlap with bandwidth/MFMA-bound launches of
-        the others.  Results are identical to the single-stream order (per-clip arithmetic does not change)."""
+        the others.  Results are BIT-identical to the single-stream order (per-clip arithmetic does not depend on the batch a clip sits
+        in: tests/test_gpu_model.py::test_two_stream_forward_equals_one_stream)."""
         if train:
             return self._forward_one(mix, want_spec, want_lr_spec, train=True)
         want = self.streams if self.streams > 0 else (2 if mix.shape[0] >= 32 else 1)
@@ -779,11 +808,11 @@ class HipEngine:
             prev_events = events
         for st in self._tables[key]:
             cur.wait_stream(st)
-        # The iSTFT runs AFTER the join, on the caller's stream, never next to another stream's kernels: measured on the MI355X, an
-        # iSTFT launch that shares the chip with the convolution kernels of the other half-batch now and then (2-14 % of forwards,
-        # box dependent) returns 512-sample segments in which ONE frequency bin of the block's frames was read wrong (a constant
-        # offset or a clean sinusoid of 2e-3 relative; the spectrogram itself is exact; iSTFT next to iSTFT never fails; no
-        # uninitialised or out-of-range LDS access found by poisoning: DESIGN.md 5b).  Until that is understood it gets the chip alone.
+        # The iSTFT of the halves runs AFTER the join, on the caller's stream.  History: in round 3 an iSTFT that shared the chip with the
+        # other half's convolutions now and then returned wrong 512-sample segments; round 4 traced that class to packed-fp32 VALU code and
+        # round 5 to the neighbour's LDS-DMA copies as the second ingredient -- the library is built without packed fp32, and
+        # BatchPipeline runs every batch's iSTFT beside other batches' kernels by design (tests/test_gpu_concurrency.py fences both).  The
+        # join stays here because it costs nothing measurable and keeps one iSTFT launch order for the two halves.
         ys = []
         for o in outs:
             spec_out, hop, win, T, Lout = o[0]
@@ -1157,6 +1186,12 @@ class HipEngine:
     def _decode_tagged(self, j, dec, L, x, skip, B, Fq, T, mean, std):
         ops = self.ops
         if 'rewrite' in L:
+            if dec.last and 'tail' in L and self.fuse_tail:
+                # the whole last layer in two launches: rewrite 3x3 + GLU + the transposed conv's 16 tap products per time step (the 96-channel
+                # activation never reaches memory), then the row combination + bias + x*std + mean (aero.py:189-215, 497-498)
+                timg, tbias = L['tail']
+                lo, hi = ops.conv(L['rewrite'], x, skip, B, Fq, Fq, T, tail=timg)
+                return ops.convtr_tail_finish(lo, hi, tbias, std, mean, (Fq - 1) * dec.stride + dec.kernel_size - 2 * dec.pad, dec.pad, timg.shape[1])
             if dec.norm:
                 st = self._stats_for(L['rewrite'].M, dec.norm_groups, B, Fq, skip.device, spec=L['rewrite'])
                 r = ops.conv(L['rewrite'], x, skip, B, Fq, Fq, T, stat=self._acc(st, dec.norm_groups))

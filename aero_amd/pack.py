@@ -189,6 +189,18 @@ def convtr_taps(w, stride):
     return taps, [-j for j in range(nt)], [0] * nt
 
 
+def convtr_tail_image(w, stride, device):
+    """the last decoder layer's nn.ConvTranspose2d weight [Cin, 2, 8, 1] (stride 4) as the 16 x Cin matrix of the fused tail
+    (include/aero_hip.h, aero_conv_desc.tail_w): row 2 k + co holds W[:, co, k, 0]; fp16 [16][roundup(Cin, 32)].  None for any other shape."""
+    Cin, Cout, K, kT = w.shape
+    if kT != 1 or Cout != 2 or K != 8 or stride != 4:
+        return None
+    cp = _round_up(Cin, 32)
+    img = torch.zeros(16, cp, dtype=torch.float32, device=w.device)
+    img[:, :Cin] = w[:, :, :, 0].permute(2, 1, 0).reshape(16, Cin)           # [k][co][c] -> row 2 k + co
+    return img.to(device=device, dtype=torch.float16).contiguous()
+
+
 def convtr_stacked_spec(w, bias, stride, device, act=_lib.ACT_NONE):
     """nn.ConvTranspose2d [Cin, Cout, K, 1] computed from the input side (aero_hip.h, row scatter): the `stride` residue
     classes are stacked into M = stride*Cout rows (row r*Cout + m), taps df = 0, -1, ...; output channel block r of the

@@ -144,12 +144,28 @@ typedef struct {
      * result does not depend on block order); dst / bias / act are ignored.  nT % tap_split == 0; no statistics / scatter /
      * residual.  aero_split_finish() adds the slabs in order and produces the fp16 activation. */
     int32_t tap_split; float* split_acc;
+    /* Fused transposed-conv tail (NULL = off; round 5).  The LAST decoder layer of the U-Net (aero.py:172,189-215: GLU(rewrite 3x3) ->
+     * ConvTranspose2d(C -> 2, kernel [8,1], stride [4,1]) -> trim) never needs its C-channel activation in memory: the block that has
+     * finished row fi of the rewrite conv applies the 16 x C tail matrix (rows r = 2 * tap + out_channel, tail_w fp16 [16][tail_cp],
+     * tail_w[2k + co][c] = W_tr[c][co][k]) to its activated tile while that is still in LDS and stores the 16 tap products of
+     * every time step: taps 0..3 -> tail_lo, taps 4..7 -> tail_hi, both fp32 contiguous [B][Fout][T][8].  Output row fo = 4 fi + k - 2
+     * of the transposed conv is tail_lo[fi = (fo + 2) / 4] + tail_hi[fi - 1]: aero_convtr_tail_finish() adds the two (fixed order, no
+     * atomics), the bias and the per-item affine.  dst is ignored (may be NULL).  Needs act = GLU, M = 192 on the 192-row software-
+     * pipelined tile (one M-tile: the block holds every channel), tail_cp = M / 2 rounded to 32, no statistics / residual / embedding /
+     * affine / scatter; AERO_ERR_UNSUPPORTED otherwise. */
+    const void* tail_w; float* tail_lo; float* tail_hi; int32_t tail_cp;
 } aero_conv_desc;
 int aero_conv_fwd(const aero_conv_desc* d, void* stream);
 /* dst fp16 [npos][M] (contiguous) = act(sum_s acc[s][npos][M] + bias[M]), s = 0..nsplit-1 in that order; act NONE / RELU / GELU;
  * bias may be NULL */
 int aero_split_finish(const float* acc, int32_t nsplit, const float* bias, int32_t act, void* dst, int64_t npos, int32_t M, void* stream);
 /* rows per block (16/32/48/64/128) of the kernel instantiation aero_conv_fwd picks for M output channels */
+/* second half of the fused transposed-conv tail (aero_conv_desc.tail_w): dst fp32 [B][dst_F][T][2] (= complex64 [B][dst_F][T]),
+ * dst[b][fo][t][co] = (lo[b][(fo + pad) / 4][t][2 k + co] + hi[b][(fo + pad) / 4 - 1][t][2 k + co] + bias[co]) * scale[b] + shift[b]
+ * with k = (fo + pad) % 4, terms whose source row lies outside [0, Fin) dropped (aero.py:207-214 with pad = 2, dst_F = 4 Fin; the
+ * per-item affine is the de-normalisation of aero.py:497-498); bias / scale / shift may be NULL */
+int aero_convtr_tail_finish(const float* lo, const float* hi, const float* bias, const float* scale, const float* shift, float* dst,
+                            int32_t B, int32_t Fin, int32_t T, int32_t dst_F, int32_t pad, void* stream);
 int aero_conv_tile_m(int32_t M);
 /* rows per block (256/128/64) of the software-pipelined kernel for a contraction with M rows and Ktot = ntaps * Cp
  * columns, or 0 if that kernel does not take the shape: the tile height `weight_tiled` must be prepared for */

@@ -291,6 +291,53 @@ def case_convtr(lib, dev, Cin, Cout, K, stride, Fin, T, trim=True, f32_affine=Fa
     assert rel_l2(uncl(y.cpu()), ref) < TOL16
 
 
+def case_conv_tail(lib, dev, Fin, T, B=2, seed=36):
+    """the fused last decoder layer (aero_hip.h, aero_conv_desc.tail_w; aero.py:189-215, 497-498): 3x3 rewrite conv over two 48-channel
+    sources -> GLU -> ConvTranspose2d(96 -> 2, [8,1] / [4,1]) -> trim -> x * std + mean, as ONE conv launch (the 96-channel activation is
+    never stored) + aero_convtr_tail_finish, against (i) torch on fp16-rounded operands with the activation rounded to fp16 where the
+    unfused path stores it and (ii) the unfused pair of launches."""
+    ops = Ops(lib)
+    C, M, K, stride, pad = 48, 192, 8, 4, 2
+    w = _rand((M, 2 * C, 3, 3), seed, 1.0 / math.sqrt(2 * C * 9))
+    b = _rand((M,), seed + 1)
+    wt = _rand((M // 2, 2, K, 1), seed + 2, 1.0 / math.sqrt(M // 2 * K / stride))
+    bt = _rand((2,), seed + 3)
+    x = _rand((B, 2 * C, Fin, T), seed + 4)
+    sc, sh = _rand((B,), seed + 5).abs() + 0.5, _rand((B,), seed + 6)
+    taps, df, dt = pack.conv2d_taps(q16(w), 1, 1)
+    spec = pack.make_conv_spec(taps, b, C, C, df, dt, dev, act=_lib.ACT_GLU)
+    assert spec.tiled_bm == 192, spec.tiled_bm
+    timg = pack.convtr_tail_image(q16(wt), stride, dev)
+    xc = cl(x).to(dev)
+    s0, s1 = xc[..., :C].contiguous(), xc[..., C:].contiguous()
+    lo, hi = ops.conv(spec, s0, s1, B, Fin, Fin, T, tail=timg)
+    kname = ops.lib.cdll.aero_last_kernel_name().decode()
+    assert 'aero_conv_ring_kernel' in kname and ('<2, 4, 3, 3' in kname or lib.is_emulator), kname
+    y = ops.convtr_tail_finish(lo, hi, bt.to(dev), sc.to(dev), sh.to(dev), 4 * Fin, pad, M // 2)
+    assert y.shape == (B, 4 * Fin, T, 2)
+    # reference
+    r = F.glu(F.conv2d(q16(x), q16(w), b, padding=1), dim=1)
+    ref = F.conv_transpose2d(q16(r), q16(wt), bt, stride=(stride, 1))[:, :, pad:-pad] * sc.view(B, 1, 1, 1) + sh.view(B, 1, 1, 1)
+    assert rel_l2(uncl(y.cpu()), ref) < TOL16
+    # the unfused pair: same arithmetic up to the summation order of the two taps of an output row
+    yy = ops.conv(spec, s0, s1, B, Fin, Fin, T)
+    tt, dft, dtt = pack.convtr_taps(q16(wt), stride)
+    tspec = pack.make_conv_spec(tt, bt, M // 2, 0, dft, dtt, dev, transposed=1, fstride=stride)
+    Fu = (Fin - 1) * stride + K
+    y2 = ops.conv(tspec, yy, None, B, Fin, Fu, T, dst_f_off=pad, dst_F=Fu - 2 * pad, dst_f32=True, batch_scale=sc.to(dev), batch_shift=sh.to(dev))
+    assert rel_l2(y.cpu(), y2.cpu()) < 2e-6, rel_l2(y.cpu(), y2.cpu())
+    # (a descriptor the fused form cannot take fails loudly instead of dropping the tail: 128 rows are not the 192-row tile)
+    from aero_amd._lib import AeroHipError
+    taps2, df2, dt2 = pack.conv2d_taps(q16(w[:128]), 1, 1)
+    bad = pack.make_conv_spec(taps2, b[:128], C, C, df2, dt2, dev, act=_lib.ACT_GLU)
+    try:
+        ops.conv(bad, s0, s1, B, Fin, Fin, T, tail=timg)
+    except AeroHipError as e:
+        assert 'fused tail' in str(e)
+    else:
+        raise AssertionError('a 128-row conv accepted a fused tail')
+
+
 def case_convtr_stacked(lib, dev, Cin, Cout, K, stride, Fin, T, trim=True, act='none', B=2, seed=33):
     """ConvTranspose2d computed from the input side (stacked residue classes + row scatter, aero_hip.h) against
     F.conv_transpose2d, with and without the frequency trim."""

@@ -135,6 +135,11 @@ def test_convtr_stacked(emu, kw):
     oc.case_convtr_stacked(emu, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Fin=3, T=70), dict(Fin=1, T=260, B=1)])
+def test_conv_tail_fused_last_layer(emu, kw):
+    oc.case_conv_tail(emu, DEV, **kw)
+
+
 def test_freq_emb_epilogue(emu):
     oc.case_freq_emb_epilogue(emu, DEV)
 

@@ -49,10 +49,11 @@ def test_istft_and_stft_next_to_the_ring_kernel(rig):
 
 
 def test_two_stream_forward_equals_one_stream_100_times(rig):
-    """the product's own schedule (two half-batches on two streams from 32 clips up, engine.py) against the one-stream order, bit for bit"""
+    """the product's own schedule (two half-batches on two streams from 32 clips up, engine.py) against the one-stream order, bit for bit,
+    at the bench size (64 clips: two halves of 32)"""
     m, _ = rig
     eng = m._get_engine()
-    x = seeded((32, 1, 8000), 5).cuda()
+    x = seeded((64, 1, 8000), 5).cuda()
     with torch.no_grad():
         eng.streams = 1
         y1, s1 = m(x, return_spec=True)

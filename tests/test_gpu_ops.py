@@ -100,6 +100,11 @@ def test_convtr_stacked(lib, kw):
     oc.case_convtr_stacked(lib, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(Fin=64, T=501), dict(Fin=128, T=376, B=1), dict(Fin=3, T=70)])
+def test_conv_tail_fused_last_layer(lib, kw):
+    oc.case_conv_tail(lib, DEV, **kw)
+
+
 def test_freq_emb_epilogue(lib):
     oc.case_freq_emb_epilogue(lib, DEV)
 
