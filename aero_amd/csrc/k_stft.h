@@ -800,12 +800,9 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
     }
     const int span = 127 * hop + AERO_DFT_K;
     const int ntile = (p.T + 127) >> 7;
-    // Per-item statistics (sum, sum of squares of the spectrogram: aero.py:462-464).  A thread's fp32 partial covers ONE tile and is
-    // folded into an fp64 per-thread sum at the end of the tile: the number of tiles a block walks depends on the batch size (gridDim.x
-    // below), and a partial that ran over two tiles in fp32 made mean / std of an item -- hence the whole output of that clip -- differ in
-    // the last bit between a batch of 64 and the same clips in two batches of 32 (tools/dbg/half_vs_full.py, round 5).
+    // Per-item statistics (sum, sum of squares of the spectrogram: aero.py:462-464): fp32 per thread over the tiles its block walks.  WHICH
+    // tiles a block walks must therefore not depend on the batch size -- see the launcher: gridDim.x is a function of T only.
     float s = 0.f, ss = 0.f;
-    double ds_acc = 0.0, dss_acc = 0.0;
     float* out = p.spec + (int64_t)sig * n_bins * p.T * 2;
     // the span of the (hop-padded, reflect-padded) signal a tile's 128 frames read, one load batch per tile, REQUESTED a tile ahead (their
     // latency runs under the MFMAs and stores of the tile before); the barriers between tiles order LDS only (aero_lds_barrier) -- a
@@ -892,12 +889,9 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
             ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
     }
-    ds_acc += (double)s;
-    dss_acc += (double)ss;
-    s = ss = 0.f;
     }
     if (p.stats) {
-        const double ds = aero_wave_sum(ds_acc), dss = aero_wave_sum(dss_acc);
+        const double ds = aero_wave_sum((double)s), dss = aero_wave_sum((double)ss);
         if (lane == 0) { red[0][wave] = ds; red[1][wave] = dss; }
         __syncthreads();
         if (tid == 0) {
@@ -935,13 +929,16 @@ static int aero_stft_dft_launch(const float* x, int nsig, int L, int Lp, int n_f
     p.x = x; p.table = (const h16*)table; p.spec = spec; p.stats = stats;
     p.nsig = nsig; p.L = L; p.Lp = Lp; p.n_fft = n_fft; p.hop = hop; p.win_off = win_off; p.T = T;
     p.sig_per_item = sig_per_item > 0 ? sig_per_item : 1;
-    // blocks walk the time tiles of their (signal, table quarter) with the table slice resident; enough blocks to fill the chip
-    // twice over (two 74-KiB blocks fit a CU), never more than one per tile
+    // blocks walk the time tiles of their (signal, table quarter) with the table slice resident: TWO blocks per (signal, quarter), each
+    // walking every second tile (B = 64: 512 blocks = the chip twice over, two 74-KiB blocks fit a CU; measured 26.0 / 23.3 / 28.4 / 26.5 us
+    // with 1 / 2 / 3 / 4).  The count must NOT follow the batch size (until round 5 it was "enough blocks for 512": 2 at B = 64, 4 at
+    // B = 32): a thread's fp32 partial sums of the per-item statistics run over the tiles its block walks, so mean / std of a clip -- hence
+    // its whole output -- differed in the last bit between a batch of 64 and the same clips in two batches of 32 (tools/dbg/half_vs_full.py,
+    // profiles/r05_half_vs_full*.txt).
     const int ntile = (T + 127) / 128;
     static int tpb_env = -1;
     if (tpb_env < 0) { const char* e = getenv("AERO_STFT_DFT_BLOCKS"); tpb_env = e ? atoi(e) : 0; }
-    int gx = tpb_env > 0 ? tpb_env : (int)((512 + (long)nsig * (n_fft / 128) - 1) / ((long)nsig * (n_fft / 128)));
-    if (gx < 1) gx = 1;
+    int gx = tpb_env > 0 ? tpb_env : 2;
     if (gx > ntile) gx = ntile;
     dim3 grid((unsigned)gx, (unsigned)nsig, (unsigned)(n_fft / 128)), block(512);
     AERO_LAUNCH(aero_stft_dft_kernel, grid, block, stream, p);
