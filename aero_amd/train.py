@@ -999,6 +999,9 @@ class CapturedStep:
         self.static_in = [t.clone() for t in example_inputs]
         from .engine import side_streams
         side = side_streams(example_inputs[0].device, 2)[1]       # (not the parameter-gradient stream, which forks from this one inside the capture)
+        # the package's side streams are SHARED (engine.side_streams: BatchPipeline's ring, the half-batch streams): whatever they still carry
+        # -- pipelined inference batches of the same process -- must be done before warm-up and capture run on them
+        torch.cuda.synchronize(example_inputs[0].device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                            # (capture must not run on the legacy default stream)
             for _ in range(warmup):

@@ -107,8 +107,8 @@ def test_kernels_we_do_not_compile_next_to_the_ring_kernel(rig):
     a training step also runs kernels the repo does NOT compile beside its ring / MFMA tiles: torch's fp32 element-wise glue on the main
     stream while `aero_conv_wgrad` runs on the side stream, and RCCL's reduction kernels during the overlapped gradient all-reduce
     (reference distrib.py:58-69: DDP reduces beside the backward).  Each as a victim next to the 192-row ring tile, 300 launches, bit-equal
-    to its solo run: (i) an add / mul / addcmul / sub chain over a gradient-sized fp32 buffer (hipcc-built torch kernels DO contain
-    v_pk_*_f32), (ii) the fused Adam step of aero_amd.optim.FlatAdam over the same size, (iii) the C ABI's RCCL all-reduce
+    to its solo run: (i) an add / mul / addcmul / sub chain over a gradient-sized fp32 buffer (torch's kernels are built by hipcc with its
+    default features, packed fp32 among them), (ii) the fused Adam step of aero_amd.optim.FlatAdam over the same size, (iii) the C ABI's RCCL all-reduce
     (aero_allreduce_f32, one-rank communicator: the in-place sum must leave the buffer as it was) and all-gather."""
     import ctypes as C
     from aero_amd import _lib
