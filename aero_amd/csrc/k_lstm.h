@@ -12,6 +12,14 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+#ifndef AERO_LSTM_PRESCALE
+#define AERO_LSTM_PRESCALE 1                 /* tools/dbg A/B: 0 = gate constants applied per step */
+#endif
+#ifndef AERO_LSTM_IMM
+#define AERO_LSTM_IMM 1                      /* tools/dbg A/B: 0 = ring slots addressed from the run-time step index */
+#endif
+
 #include "aero_common.h"
 
 struct AeroLstmK {
@@ -284,8 +292,9 @@ struct AeroLstmRingGeom {
 // tanh(g) and sigmoid(o) fall out of the shared reciprocals of the gate math), and the step barrier becomes LDS-only (lgkmcnt + s_barrier)
 // so that the stores stay in flight: with `__syncthreads()` every step waited for their acknowledgement (the step-wise kernel's 2.5 us
 // per step).
+// (twelve one-tile waves -- the H = 48 launches, 384 blocks on 256 CUs -- must fit TWICE on a CU: six waves per SIMD, at most 80 registers per wave; the second launch-bound argument is waves per SIMD)
 template <int NW, int TPW, int KT, int KTI, int G, bool SAVE = false>
-__global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
+__global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) void aero_lstm_ring_kernel(AeroLstmK p) {
     constexpr int R = 2 * G;
     constexpr int KP = KT * 32, HS = KP + 8, KPI = KTI * 32, XS = KPI + 8, SPR = KTI * 4, NT = NW * 64;
     constexpr int NXV = (G * 16 * SPR + NT - 1) / NT;              // x vectors per thread per group
@@ -302,18 +311,38 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
     const h16* xin = (const h16*)d.x;
     h16* out = (h16*)d.out;
 
+    // Round 5: the gate pre-activations come out of the MFMAs ALREADY multiplied by the constant their exponential wants (-log2 e for the
+    // sigmoids of i, f, o; +2 log2 e for tanh(g)): the weight fragments and the bias are scaled once per block while they are loaded (row
+    // 4j + gate of the image is gate `row & 3`: a per-lane constant for an A fragment, a per-register one for the bias), which removes
+    // four multiplies per (unit, sequence) from every one of the W steps -- the step is VALU-bound on the CUs that host two blocks.
+    // The scaled weights are rounded to fp16 a second time (<= 1 ulp on top of the pack's rounding; whole-block error vs the oracle
+    // unchanged at 3-5e-4, tests/op_cases.py BLSTM_TOL 1e-3).
+    constexpr float L2E = 1.4426950408889634f;
+#if AERO_LSTM_PRESCALE
+    const float wsc = ((col & 3) == 2) ? 2.f * L2E : -L2E;          // A-fragment lane `col` holds image row 16 * tile + col
+    constexpr float GS = 1.f, GG = 1.f, BS = -L2E, BG = 2.f * L2E;  // (gate-math factors left over; bias factors)
+#else
+    const float wsc = 1.f;
+    constexpr float GS = -L2E, GG = 2.f * L2E, BS = 1.f, BG = 1.f;
+#endif
+    auto scaled = [&](h16x8 v) {
+        h16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (h16)((float)v[e] * wsc);
+        return o;
+    };
     h16x8 wf[TPW][KT], wi[TPW][KTI];
     f32x4 bias4[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int wrow = (wave * TPW + i) * 16 + col;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) wf[i][kt] = *(const h16x8*)(whh + (int64_t)wrow * KP + kt * 32 + q * 8);
+        for (int kt = 0; kt < KT; ++kt) wf[i][kt] = scaled(*(const h16x8*)(whh + (int64_t)wrow * KP + kt * 32 + q * 8));
 #pragma unroll
-        for (int kt = 0; kt < KTI; ++kt) wi[i][kt] = *(const h16x8*)(wih + (int64_t)wrow * KPI + kt * 32 + q * 8);
+        for (int kt = 0; kt < KTI; ++kt) wi[i][kt] = scaled(*(const h16x8*)(wih + (int64_t)wrow * KPI + kt * 32 + q * 8));
         const int rr = (wave * TPW + i) * 16 + q * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias4[i][r] = (rr + r < H4) ? d.bias[dir * H4 + rr + r] : 0.f;
+        for (int r = 0; r < 4; ++r) bias4[i][r] = (rr + r < H4) ? d.bias[dir * H4 + rr + r] * (r == 2 ? BG : BS) : 0.f;
     }
     for (int idx = tid; idx < R * 16 * HS / 8; idx += NT) ((h16x8*)hring)[idx] = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -444,6 +473,139 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
 #pragma unroll
     for (int i = 0; i < TPW; ++i) c[i] = 0.f;
     f32x4 accx[TPW];                    // bias + W_ih x for the step about to run
+#if AERO_LSTM_IMM
+    const int ngroups = (W + G - 1) / G;
+    load_x(0);
+    park_x(0);
+    __syncthreads();
+    // Round 5: the ring-slot addressing as IMMEDIATES.  Step s = g G + i uses h-ring slot s mod 2G = (g & 1) G + i and reads slot s - 1; the
+    // x ring likewise.  The step loop over i is unrolled (i a compile-time constant), so a slot is the group's parity offset (one scalar per
+    // group) plus a constant that goes into the DS instruction's offset field.  Before, every step rebuilt three LDS addresses from the
+    // run-time step index: 7 of the 34 vector instructions of a step on a kernel that is VALU-bound where two blocks share a CU.
+    // The unrolled body is STRAIGHT-LINE code: no run-time condition around the next step's projection.  A first version kept
+    // `if (i + 1 < nst) project(...)`: hipcc then carried accx through phi copies behind a `s_cbranch_execnz`, and on the taken path a
+    // `v_mov_b64` read the projection MFMA's destination with ZERO wait states (the hazard recogniser had padded only the fall-through
+    // path) -- wrong and run-to-run different results on the MI355X, correct on the emulator (tools/dbg/lstm_check.py).  A ragged last
+    // group (W % G != 0: no reference config) takes the run-time loop.
+    const int hrd0 = col * HS + q * 8;                             // this lane's B-fragment row inside a slot (h16 elements from hring)
+    const int xrd0 = col * XS + q * 8;
+    int hwr0[TPW];                                                 // ... its h_t element(s): + unit index
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) hwr0[t] = col * HS + (wave * TPW + t) * 4 + q;
+    bool jok[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) jok[t] = (wave * TPW + t) * 4 + q < H;
+    auto project_at = [&](const h16* xs) {                         // xs: lane base incl. q * 8; constant offsets fold into the reads
+        h16x8 xf[KTI];
+#pragma unroll
+        for (int kt = 0; kt < KTI; ++kt) xf[kt] = *(const h16x8*)(xs + kt * 32);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) accx[t] = bias4[t];
+#pragma unroll
+        for (int kt = 0; kt < KTI; ++kt)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wi[t][kt], xf[kt], accx[t], 0, 0, 0);
+    };
+    // one step: h_{s-1} from `hprev` (lane base incl. q * 8), h_s to wdst[t][0]
+    auto step_core = [&](const h16* hprev, h16* (&wdst)[TPW], int wofs, int s) {
+        h16x8 bf[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) bf[kt] = *(const h16x8*)(hprev + kt * 32);
+        f32x4 accs[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) accs[t] = accx[t];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][kt], bf[kt], accs[t], 0, 0, 0);
+        // gate math of all the wave's tiles first, the h stores after it: with the store's `if (j < H)` inside the tile loop the
+        // compiler sank half of each tile's math into that branch and ran the tiles strictly one after the other -- two
+        // dependent exp -> rcp -> exp -> rcp chains back to back instead of interleaved
+        float hq[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const f32x4 a = accs[t];                                            // (pre-scaled with AERO_LSTM_PRESCALE: see the weight load)
+            constexpr float LIM = 60.f, NOLIM = -3.0e38f;
+            const float ei = aero_exp2(a[0] * GS), ef = aero_exp2(a[1] * GS);
+            const float eg = aero_exp2(aero_med3(a[2] * GG, NOLIM, LIM));
+            const float eo = aero_exp2(a[3] * GS);
+            const float r1 = aero_rcp((1.f + ei) * (eg + 1.f));
+            const float igg = fmaf(eg, r1, -r1);                                        // sigmoid(i) * tanh(g)
+            c[t] = fmaf(aero_rcp(1.f + ef), c[t], igg);
+            const float ec = aero_exp2(aero_med3(c[t] * (2.f * L2E), NOLIM, LIM));
+            const float r2 = aero_rcp((1.f + eo) * (ec + 1.f));
+            hq[t] = fmaf(ec, r2, -r2);                                                  // sigmoid(o) * tanh(c)
+            if constexpr (SAVE) {
+                const int j = (wave * TPW + t) * 4 + q;
+                if (j < H) {
+                    const int tau_s = dir ? W - 1 - s : s;
+                    const int64_t sb = ((int64_t)blockIdx.x * 2 + dir) * W + tau_s;
+                    const float sig_i = r1 * (eg + 1.f), tanh_g = (eg - 1.f) * r1 * (1.f + ei);
+                    const float sig_f = aero_rcp(1.f + ef), sig_o = r2 * (ec + 1.f);
+                    *(h16x4*)((h16*)d.save_gates + sb * H * 64 + ((int64_t)j * 16 + col) * 4) = (h16x4){(h16)sig_i, (h16)sig_f, (h16)tanh_g, (h16)sig_o};
+                    d.save_c[sb * H * 16 + j * 16 + col] = c[t];
+                }
+            }
+        }
+#ifndef AERO_EMU
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) asm volatile("" : "+v"(hq[t]));                   // (keeps the math above out of the store's branch)
+#endif
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+            if (jok[t]) wdst[t][wofs] = (h16)hq[t];
+    };
+    auto step_barrier = [&]() {
+        if constexpr (SAVE) aero_phase_barrier();
+        else __syncthreads();
+    };
+    const h16* hbase = hring + hrd0;                                // ONE lane base per ring: every slot offset below is a compile-time constant
+    const h16* xbase = xring + xrd0;
+    h16* wbase[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) wbase[t] = hring + hwr0[t];
+    // a FULL group of G steps whose parity (g & 1) is the compile-time constant PAR
+    auto group_full = [&](auto parc, int g) {
+        constexpr int PAR = decltype(parc)::value;
+        constexpr int HC = PAR * G * 16 * HS, HO = (1 - PAR) * G * 16 * HS, XC = PAR * G * 16 * XS;
+        if (g + 1 < ngroups) load_x(g + 1);
+        if (g > 0) store_group(g - 1);
+        project_at(xbase + XC);                                         // first step of a group: x just parked
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            step_core(hbase + (i == 0 ? HO + (G - 1) * 16 * HS : HC + (i - 1) * 16 * HS), wbase, HC + i * 16 * HS, g * G + i);
+            // input projection of the NEXT step (independent of h): issued before the barrier so its LDS reads and MFMAs fill the pipes
+            // while the other waves finish their gate math; at the end of the group the next group's x goes to its ring buffer
+            if (i + 1 < G) project_at(xbase + XC + (i + 1) * 16 * XS);
+            else if (g + 1 < ngroups) park_x((g + 1) & 1);              // loads issued G steps ago
+            step_barrier();
+        }
+    };
+    const int nfull = W / G;
+    int g = 0;
+    for (; g + 2 <= nfull; g += 2) {
+        group_full(std::integral_constant<int, 0>{}, g);
+        group_full(std::integral_constant<int, 1>{}, g + 1);
+    }
+    if (g < nfull) {
+        group_full(std::integral_constant<int, 0>{}, g);
+        ++g;
+    }
+    if (g < ngroups) {                                                  // ragged last group (W % G steps): run-time slots
+        if (g > 0) store_group(g - 1);
+        const int nst = W - g * G;
+        const int pofs = (g & 1) * (G * 16);
+        const h16* hcur = hbase + pofs * HS;
+        const h16* hoth = hbase + (G * 16 - pofs) * HS;
+        const h16* xcur = xbase + pofs * XS;
+        project_at(xcur);
+        for (int i = 0; i < nst; ++i) {
+            step_core(i == 0 ? hoth + (G - 1) * 16 * HS : hcur + (i - 1) * 16 * HS, wbase, (pofs + i * 16) * HS, g * G + i);
+            project_at(xcur + (i + 1 < G ? i + 1 : 0) * 16 * XS);       // (the projection behind the last step is computed and never used)
+            step_barrier();
+        }
+    }
+#else
     auto project = [&](const h16* xs) {
         h16x8 xf[KTI];
 #pragma unroll
@@ -485,11 +647,10 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const f32x4 a = accs[t];
-                constexpr float L2E = 1.4426950408889634f, LIM = 60.f, NOLIM = -3.0e38f;
-                const float ei = aero_exp2(a[0] * -L2E);
-                const float ef = aero_exp2(a[1] * -L2E);
-                const float eg = aero_exp2(aero_med3(a[2] * (2.f * L2E), NOLIM, LIM));
-                const float eo = aero_exp2(a[3] * -L2E);
+                constexpr float LIM = 60.f, NOLIM = -3.0e38f;
+                const float ei = aero_exp2(a[0] * GS), ef = aero_exp2(a[1] * GS);
+                const float eg = aero_exp2(aero_med3(a[2] * GG, NOLIM, LIM));
+                const float eo = aero_exp2(a[3] * GS);
                 const float r1 = aero_rcp((1.f + ei) * (eg + 1.f));
                 const float igg = fmaf(eg, r1, -r1);                                    // sigmoid(i) * tanh(g)
                 c[t] = fmaf(aero_rcp(1.f + ef), c[t], igg);
@@ -525,6 +686,7 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_ring_kernel(AeroLstmK p) {
             else __syncthreads();
         }
     }
+#endif
     store_group(ngroups - 1);
 }
 

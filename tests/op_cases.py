@@ -450,6 +450,46 @@ def case_blstm(lib, dev, H, R, T, seed=60, fuse=True):
     return err
 
 
+def case_lstm_bitwise(lib, dev, H, R, T=501, seed=55):
+    """the recurrent kernel alone (two stacked bidirectional layers with framing, as BLSTM runs them): the same launch twice gives the same
+    bits, and a permutation of the rows gives the permuted result bit for bit -- a sequence's arithmetic must not depend on the lane or
+    block it lands in.  (Round 5: an unrolled step loop that hipcc compiled with an MFMA -> VALU read hazard on one branch path returned
+    run-to-run different hidden states; every tolerance-based model test still passed because LayerScale (1e-3) hides the branch.)"""
+    ops = Ops(lib)
+    W, S = 200, 100
+    nframes = max(1, -(-T // S)) if T > W else 1
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / math.sqrt(H)
+    sd = {}
+    for l in range(2):
+        for sfx in ('', '_reverse'):
+            inp = H if l == 0 else 2 * H
+            sd[f'l.weight_ih_l{l}{sfx}'] = (torch.rand(4 * H, inp, generator=g) * 2 - 1) * k
+            sd[f'l.weight_hh_l{l}{sfx}'] = (torch.rand(4 * H, H, generator=g) * 2 - 1) * k
+            sd[f'l.bias_ih_l{l}{sfx}'] = (torch.rand(4 * H, generator=g) * 2 - 1) * k
+            sd[f'l.bias_hh_l{l}{sfx}'] = (torch.rand(4 * H, generator=g) * 2 - 1) * k
+    packs = [pack.pack_lstm_layer(lib, sd, 'l', l, H, dev) for l in range(2)]
+    framed = T > W
+    Wk = W if framed else T
+    nseq = R * nframes
+
+    def run(x):
+        out0 = torch.zeros(nseq, Wk, 2 * H, device=dev, dtype=torch.float16)
+        out1 = torch.zeros(R, T, 2 * H, device=dev, dtype=torch.float16)
+        ops.lstm(None, None, packs[0][2], H, nseq, Wk, int(framed), 0, nframes, S, T, out0, x=x, fused=packs[0][3])
+        ops.lstm(None, None, packs[1][2], H, nseq, Wk, 0, int(framed), nframes, S, T, out1, x=out0, fused=packs[1][3])
+        return out0.clone(), out1.clone()
+    x = torch.randn(R, T, H, generator=g).half().to(dev)
+    a0, a1 = run(x)
+    b0, b1 = run(x)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1), 'the LSTM kernel is not reproducible run to run'
+    perm = torch.randperm(R, generator=g).to(dev)
+    p0, p1 = run(x[perm].contiguous())
+    assert torch.equal(p1, a1[perm]), float((p1.float() - a1[perm].float()).abs().max())
+    assert torch.equal(p0.view(R, nframes, Wk, 2 * H), a0.view(R, nframes, Wk, 2 * H)[perm])
+    assert float(a1.float().abs().max()) > 1e-2 and torch.isfinite(a1.float()).all()
+
+
 def case_localstate(lib, dev, Cc, heads, R, T, seed=70):
     ops = Ops(lib)
     nd = 4

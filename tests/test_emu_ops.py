@@ -172,6 +172,11 @@ def test_freqfc(emu, kw):
     oc.case_freqfc(emu, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(H=48, R=3, T=251), dict(H=8, R=5, T=150)])
+def test_lstm_bitwise_reproducible_and_row_permutation_invariant(emu, kw):
+    oc.case_lstm_bitwise(emu, DEV, **kw)
+
+
 def test_localstate_streaming_form_for_short_rows():
     """AERO_ATTN_FOLD=0: rows with T <= 512 on the streaming kernel (the default for them is the folded two-pass kernel)."""
     import os

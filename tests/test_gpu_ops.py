@@ -123,6 +123,11 @@ def test_blstm(lib, kw):
     oc.case_blstm(lib, DEV, **kw)
 
 
+@pytest.mark.parametrize('kw', [dict(H=48, R=512), dict(H=96, R=256), dict(H=48, R=37), dict(H=96, R=5, T=150), dict(H=8, R=7, T=251)])
+def test_lstm_bitwise_reproducible_and_row_permutation_invariant(lib, kw):
+    oc.case_lstm_bitwise(lib, DEV, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(Cc=48, heads=4, R=16, T=501), dict(Cc=96, heads=4, R=8, T=501), dict(Cc=4, heads=4, R=3, T=33),
                                 dict(Cc=48, heads=4, R=4, T=1724), dict(Cc=96, heads=4, R=2, T=376)])   # streaming form (10-s segments), config 4's T
 def test_localstate(lib, kw):
