@@ -91,6 +91,82 @@ def lint(text):
     return out
 
 
+def _regs(tok):
+    """VGPR indices named by an operand token: v12, v[12:15]"""
+    m = re.match(r'^v\[(\d+):(\d+)\]$', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'^v(\d+)$', tok)
+    return {int(m.group(1))} if m else set()
+
+
+def mfma_branch_hazards(text, min_wait=2):
+    """W3 (round 5): a VALU instruction at a BRANCH TARGET that reads the destination of a matrix instruction issued right in front of the
+    branch, with fewer than `min_wait` wait states in between (2: the rule looks for paths
+    the recogniser did not pad at all, not for the exact count a given matrix shape needs).  hipcc's hazard recogniser pads the fall-through path of such a diamond and
+    has been seen to leave the taken path bare (`v_mfma ... ; s_cbranch_execnz L ; ... L: v_mov_b64 <mfma dst>`): the first unrolled LSTM
+    step of round 5 returned run-to-run different results on the MI355X because of exactly that.  Returns
+    {kernel: count}; any hit FAILS the lint."""
+    out = {}
+    for blk in re.split(r'\n(?=[0-9a-f]{16} <)', text):
+        m = re.match(r'[0-9a-f]{16} <(\S+)>:', blk)
+        if not m:
+            continue
+        ins = []
+        for line in blk.splitlines()[1:]:
+            mm = re.match(r'\s+(\S+)\s*(.*?)\s*//\s*([0-9A-F]+):', line)
+            if mm:
+                ins.append((int(mm.group(3), 16), mm.group(1), [t.strip() for t in mm.group(2).split(',') if t.strip()]))
+        at = {a: i for i, (a, _, _) in enumerate(ins)}
+        hits = 0
+        for i, (a, op, args) in enumerate(ins):
+            if not (op.startswith('s_cbranch') or op == 's_branch') or not args:
+                continue
+            try:
+                off = int(args[0].split()[0])
+            except ValueError:
+                continue
+            if off >= 32768:
+                off -= 65536
+            j = at.get(a + 4 + off * 4)
+            if j is None:
+                continue
+            # matrix results still in flight at the branch: MFMAs among the last three instructions in front of it
+            dst, waited = set(), 0
+            for k in range(i - 1, max(-1, i - 4), -1):
+                o, ar = ins[k][1], ins[k][2]
+                if o.startswith('v_mfma') and ar:
+                    dst |= _regs(ar[0])
+                    break
+                if o == 's_nop' and ar:
+                    waited += int(ar[0]) + 1
+                elif not o.startswith('s_'):
+                    waited += 1
+            if not dst:
+                continue
+            w = waited
+            for k in range(j, min(len(ins), j + 6)):
+                o, ar = ins[k][1], ins[k][2]
+                if o == 's_nop' and ar:
+                    w += int(ar[0]) + 1
+                    continue
+                if o.startswith('v_') and not o.startswith('v_mfma'):
+                    if any(_regs(t) & dst for t in ar[1:]):
+                        if w < min_wait:
+                            hits += 1
+                        break
+                    if ar:
+                        dst -= _regs(ar[0])                       # overwritten by this VALU: later readers see ITS value
+                        if not dst:
+                            break
+                if o.startswith(('s_cbranch', 's_branch', 's_barrier', 's_waitcnt')):
+                    break
+                w += 1
+        if hits:
+            out[m.group(1)] = hits
+    return out
+
+
 def demangle(names):
     try:
         p = subprocess.run(['c++filt'], input='\n'.join(names), capture_output=True, text=True, check=True)
@@ -111,6 +187,7 @@ def main():
     # packed-fp32 VALU instructions anywhere in the code object: with them the FFT-family kernels return wrong values next to another
     # stream's MFMA waves; the library is built without them, and this count FAILS the build (exit code 3) if it is not 0
     npk = len(PACKED_FP32.findall(text))
+    w3 = mfma_branch_hazards(text)
     rep = lint(text)
     dm = demangle(list(rep))
     rep = {dm[k].split('(')[0].replace('void ', ''): v for k, v in rep.items()}
@@ -130,10 +207,15 @@ def main():
     for k, v in sorted(rep.items(), key=lambda kv: -(kv[1]['W1_mfma_in_wait_barrier_window'] + kv[1]['W2_lds_copy_after_reads_without_barrier'])):
         print(f'{k[:70]:70s} {v["barriers"]:4d} {v["lds_copies"]:5d} {v["mfma"]:5d} {v["W1_mfma_in_wait_barrier_window"]:4d} {v["W2_lds_copy_after_reads_without_barrier"]:4d}')
     print(f'PACKED_FP32 {npk} v_pk_{{fma,mul,add}}_f32 instructions in the code object (must be 0)')
+    w3d = demangle(list(w3))
+    print(f'MFMA_BRANCH_HAZARD {sum(w3.values())} VALU reads of a matrix result at a branch target without wait states (must be 0)'
+          + (': ' + ', '.join(f'{w3d[k].split("(")[0]} x{v}' for k, v in w3.items()) if w3 else ''))
     if bad:
         print('GREW over the baseline:', [b[0] for b in bad])
     if npk and '--allow-packed' not in sys.argv:
         sys.exit(3)
+    if w3:
+        sys.exit(4)
     if bad and '--strict' in sys.argv:
         sys.exit(1)
 
