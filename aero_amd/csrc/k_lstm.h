@@ -576,6 +576,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
             step_core(hbase + (i == 0 ? HO + (G - 1) * 16 * HS : HC + (i - 1) * 16 * HS), wbase, HC + i * 16 * HS, g * G + i);
             // input projection of the NEXT step (independent of h): issued before the barrier so its LDS reads and MFMAs fill the pipes
             // while the other waves finish their gate math; at the end of the group the next group's x goes to its ring buffer
+            // (pinning the projection's MFMAs in front of the barrier -- hipcc floats them behind it, to the head of the next step's chain -- was
+            // measured neutral: 141 / 164 / 166 / 197 us against 141 / 164 / 159 / 199, profiles/r05_lstm_pin_ab.txt)
             if (i + 1 < G) project_at(xbase + XC + (i + 1) * 16 * XS);
             else if (g + 1 < ngroups) park_x((g + 1) & 1);              // loads issued G steps ago
             step_barrier();
