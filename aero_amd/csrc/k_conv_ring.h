@@ -16,7 +16,8 @@
 //     instruction reads 1 KiB of consecutive bytes), and (ii) with NT = 3 unit-stride time taps the activation SLAB
 //     [t0-1, t0+BN+1) x 32 channels is copied ONCE per (frequency tap, channel chunk) and read at row offsets 0/1/2 by
 //     the three taps: a third of the activation requests.
-// Tiles <WM,WN,NRB>: <2,4,4> 256 rows x 256 steps; <2,4,3> 192 x 256 (one 12-MFMA phase per chunk); <1,8,4> 128 rows x
+// Tiles <WM,WN,NRB>: <2,4,4> 256 rows x 256 steps; <2,2,3> 192 x 128 on four waves (two blocks per CU; round 5) and <2,4,3> 192 x 256
+// (one 12-MFMA phase per chunk); <1,8,4> 128 rows x
 // 512 steps (a whole T = 501 row per block); <1,8,2> 64 rows x 512 steps.
 // Ordering rules the schedule relies on (LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt followed by a
 // barrier the reader has passed): the wait for chunk j sits before the barrier that ENDS the phase preceding the phase in
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void aero_conv_ring_kernel(AeroCon
     }
     aero_wait_vm<0>();
     aero_phase_barrier();                  // every wave is done with the rings: they become the output staging tile
-    if constexpr (WM == 2 && WN == 4 && NRB == 3 && ABL == 0) {
+    if constexpr (WM == 2 && (WN == 4 || WN == 2) && NRB == 3 && ABL == 0) {
         if (d.tail_w) {                                    // (block-uniform: the fused transposed-conv tail instead of the activation's store)
             aero_ring_tail_epilogue<WM, WN, NRB>(p, acc, smem, b, fo, m0, t0);
             return;
@@ -690,7 +691,14 @@ AERO_XPART bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStr
         aero_conv_ring_go<1, 4, 3, 3>(p, stream, name);
         p.tsplit = 1;
     } else if (bm == 192) {
-        aero_conv_ring_go<2, 4, 3, 3>(p, stream, name);
+        // Round 5: the 192-row tile on FOUR waves over 128 time steps, two 77-KiB blocks per CU at FULL height -- one
+        // block's prologue / epilogue (22 % of a 27-chunk tile's life) runs under the other block's K loop, at twice the weight-tile
+        // traffic per FLOP.  Measured against the 8-wave 192 x 256 tile: D2 701 -> 672-699 us, D3 843 -> 807-822 us, bench 8.90 -> 8.81 ms
+        // (profiles/r05_ring_narrow_ab.txt).  AERO_RING_192X128=0 restores the 8-wave tile.
+        static int narrow = -1;
+        if (narrow < 0) { const char* e = getenv("AERO_RING_192X128"); narrow = e ? atoi(e) : 1; }
+        if (narrow) aero_conv_ring_go<2, 2, 3, 3>(p, stream, name);
+        else aero_conv_ring_go<2, 4, 3, 3>(p, stream, name);
     } else if (bm == 128) {
         aero_conv_ring_go<1, 8, 4, 3>(p, stream, name);
     } else {

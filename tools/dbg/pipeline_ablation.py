@@ -58,7 +58,7 @@ def timed(depth=3):
 cases = [('nothing skipped', set(), None), ('LSTM', {'aero_lstm_fwd'}, None), ('LocalState core', {'aero_localstate_fwd'}, None),
          ('LSTM + LocalState', {'aero_lstm_fwd', 'aero_localstate_fwd'}, None), ('GroupNorm apply / stats', {'aero_norm_apply', 'aero_norm_stats'}, None),
          ('pointwise kernel (k_pw.h)', {'aero_pw_fwd'}, None), ('ring conv 256-row <2, 4, 4, 3', set(), 'ring_kernel<2, 4, 4, 3'),
-         ('ring conv 192-row <2, 4, 3, 3', set(), 'ring_kernel<2, 4, 3, 3'), ('8-wave LDS-tiled convs (glds8)', set(), 'glds8'),
+         ('ring conv 192-row <2, 2|4, 3, 3', set(), ', 3, 3, 0>'), ('8-wave LDS-tiled convs (glds8)', set(), 'glds8'),
          ('4-wave LDS-tiled convs (glds_kernel)', set(), 'glds_kernel'), ('enc0 + dconv rows', {'aero_enc0_fwd', 'aero_dconv_row_fwd'}, None),
          ('freq_fc + squeeze + gram', {'aero_freqfc_fwd', 'aero_squeeze_fwd', 'aero_gram_stats'}, None),
          ('STFT + normalise + iSTFT + tail finish', {'aero_stft_dft_fwd', 'aero_spec_normalize', 'aero_istft_fwd', 'aero_convtr_tail_finish'}, None),
