@@ -490,10 +490,32 @@ __global__ __launch_bounds__(512) void aero_lstm_bwd_ring_kernel(AeroLstmBwdK p)
         }
     };
     const int j0 = wave * 16 + q * 4;                          // this lane's 4 hidden units
-    const bool seq_ok = seq0 + col < d.nseq;
     float dc[4] = {0.f, 0.f, 0.f, 0.f};
     const int vec = 8, per = H4 / vec;
     const int ngroups = (W + G - 1) / G;
+    // Round 5: the step's addressing hoisted.  Everything lane-dependent about a step's LDS reads / writes and its two global stores is a
+    // per-thread constant (computed once, here); what changes from step to step is block-uniform (step-in-group i, double-buffer side, tau)
+    // and is added as ONE scalar per array.  The ISA of the round-4 step rebuilt (i * H + j) * stride per unit and a 64-bit store address
+    // with an integer division per piece: 35 of its 163 vector instructions.
+    const int gl = j0 * GS + col * 4;                          // gates ring:  + i * H * GS + r * GS
+    const int cl = j0 * CS + col;                              // cell ring:   + i * H * CS + r * CS  (next step's row: + H * CS)
+    const int dl = col * DYS + j0;                             // dout ring:   + i * 16 * DYS
+    const int bl = col * LD + q * 8;                           // da buffer read:  + side * 16 * LD + kt * 32
+    const int wl = col * LD + j0 * 4;                          // da buffer write: + side * 16 * LD + r * 4
+    // the block's da rows of a step go out as 16-byte pieces, piece = tid + k * NT: with NT = 4 H threads exactly two per thread
+    constexpr int NPC = 2;
+    int st_src[NPC];
+    int64_t st_dst[NPC];                                       // element offset of tau = 0 (< 0: nothing to store)
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+        const int idx = tid + k * NT;
+        const int sl = idx / per, e = idx - sl * per;
+        const int s2 = seq0 + sl;
+        st_src[k] = sl * LD + e * 8;
+        st_dst[k] = (idx < 16 * per && s2 < d.nseq) ? ((int64_t)s2 * W * 2 + dir) * H4 + e * vec : -1;
+    }
+    const int64_t st_tau = (int64_t)2 * H4;                    // elements per step of one sequence's [W][2][4H] block
+    const bool two_pieces = 16 * per <= NPC * NT;              // (always with NT = 4 H; a launch with fewer threads takes the generic loop)
     load_group(0);
     park_group();
     __syncthreads();
@@ -504,25 +526,29 @@ __global__ __launch_bounds__(512) void aero_lstm_bwd_ring_kernel(AeroLstmBwdK p)
         for (int i = 0; i < nst; ++i) {
             const int step = g * G + i;
             const int tau = tau_of(step);
+            const int iH = i * H;                               // (block-uniform: scalar unit)
+            const h16* gp = gring + (gl + iH * GS);
+            const float* cq = cring + (cl + iH * CS);
+            const h16* rb = dabuf + (bl + cur * 16 * LD);
+            h16* wb = dabuf + (wl + (cur ^ 1) * 16 * LD);
             // every LDS read of the step first (one latency, not one per MFMA pair / per hidden unit), then the two MFMA chains, then the
             // four units' cell algebra as straight-line code: H is a multiple of 16 here, so every lane's four units exist, and a lane of
             // a sequence past nseq computes on whatever its rows hold -- its column of the MFMA never meets another column and the store
-            // loop below skips it.  (With `if (j < H && seq_ok)` around each unit the compiler emitted four separate blocks, each
+            // below skips it.  (With `if (j < H && seq_ok)` around each unit the compiler emitted four separate blocks, each
             // waiting for its own LDS reads and its own exp -> rcp chain: 1.7 us per step.)
             h16x8 bf[KT4];
 #pragma unroll
-            for (int kt = 0; kt < KT4; ++kt) bf[kt] = *(const h16x8*)&dabuf[cur * 16 * LD + col * LD + kt * 32 + q * 8];
+            for (int kt = 0; kt < KT4; ++kt) bf[kt] = *(const h16x8*)(rb + kt * 32);
             h16x4 g4[4];
             float ct[4], cp[4], dyv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = j0 + r;
-                g4[r] = *(const h16x4*)(gring + (i * H + j) * GS + col * 4);
-                ct[r] = cring[(i * H + j) * CS + col];
-                cp[r] = cring[((i + 1) * H + j) * CS + col];
+                g4[r] = *(const h16x4*)(gp + r * GS);
+                ct[r] = cq[r * CS];
+                cp[r] = cq[H * CS + r * CS];
             }
             {
-                const h16x4 d4 = *(const h16x4*)(dyring + (i * 16 + col) * DYS + j0);
+                const h16x4 d4 = *(const h16x4*)(dyring + (dl + i * 16 * DYS));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dyv[r] = (float)d4[r];
             }
@@ -543,15 +569,22 @@ __global__ __launch_bounds__(512) void aero_lstm_bwd_ring_kernel(AeroLstmBwdK p)
                 const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cp[r];
                 dc[r] = dct * fg;
                 const h16x4 dav = (h16x4){(h16)(d_i * ig * (1.f - ig)), (h16)(d_f * fg * (1.f - fg)), (h16)(d_g * (1.f - gg * gg)), (h16)(d_o * og * (1.f - og))};
-                *(h16x4*)&dabuf[(cur ^ 1) * 16 * LD + col * LD + (j0 + r) * 4] = dav;
+                *(h16x4*)(wb + r * 4) = dav;
             }
             aero_phase_barrier();                               // LDS only: the da stores below (and the group loads) stay in flight
-            for (int idx = tid; idx < 16 * per; idx += NT) {
-                const int sl = idx / per, e = idx - sl * per;
-                const int s2 = seq0 + sl;
-                if (s2 >= d.nseq) continue;
-                h16* dst = da_out + (((int64_t)s2 * W + tau) * 2 + dir) * H4 + e * vec;
-                *(h16x8*)dst = *(const h16x8*)&dabuf[(cur ^ 1) * 16 * LD + sl * LD + e * 8];
+            if (two_pieces) {
+                const h16* sb = dabuf + (cur ^ 1) * 16 * LD;
+#pragma unroll
+                for (int k = 0; k < NPC; ++k)
+                    if (st_dst[k] >= 0) *(h16x8*)(da_out + st_dst[k] + tau * st_tau) = *(const h16x8*)(sb + st_src[k]);
+            } else {
+                for (int idx = tid; idx < 16 * per; idx += NT) {
+                    const int sl = idx / per, e = idx - sl * per;
+                    const int s2 = seq0 + sl;
+                    if (s2 >= d.nseq) continue;
+                    h16* dst = da_out + (((int64_t)s2 * W + tau) * 2 + dir) * H4 + e * vec;
+                    *(h16x8*)dst = *(const h16x8*)&dabuf[(cur ^ 1) * 16 * LD + sl * LD + e * 8];
+                }
             }
             cur ^= 1;
         }
