@@ -167,6 +167,10 @@ static __device__ __forceinline__ void aero_conv_epilogue_fast(const AeroConvK& 
                     }
                     *(h16x4*)&Cs[pc * CS + cl] = (h16x4){(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
                 }
+                // 8-wave tiles live at 128 registers: hipcc otherwise SINKS the statistics FMAs of a pass below the copy-out (they are not
+                // needed before the end), keeps every `o` alive in between and spills three of them -- a private segment, and a
+                // launch of a kernel that has one was measured ~40 us slower whenever the stream's scratch had to grow
+                if constexpr ((SM == 1 || SM == 2) && NWV == 8) aero_pin(st1[i], st2[i]);
             }
         }
         if constexpr (SM == 2) continue;
@@ -576,12 +580,25 @@ __global__ __launch_bounds__(256) void aero_conv_kernel(AeroConvK p) {
 // PMC on the first version showed the loop was ISSUE-bound by integer overhead (~200 scalar/vector instructions per
 // 16 MFMAs), not by LDS or HBM: everything lane-dependent is therefore hoisted out of the loop (per-lane pointers and
 // 32-bit offsets), the per-chunk part is a handful of block-uniform scalars, and KC = 64 halves what is left.
+// Round 5: NST LDS stages instead of two.  With two stages a chunk's copies have ONE chunk of MFMAs (0.1-0.3 us at 8-16 waves per CU)
+// to land before the block-wide wait.  With NST > 2 the copies of chunk i + NST - 1 are issued while chunk i feeds the MFMAs, the wait in
+// front of the barrier is a COUNTED `s_waitcnt vmcnt((NST - 2) * copies per wave and chunk)` and the barrier waits for LDS only (the
+// k_conv_ring.h rules: a wave's vmcnt wait followed by a barrier every reader has passed orders the LDS-DMA writes; a stage is refilled
+// after the barrier that follows its last read).  Measured per instantiation on the B = 64 forward (profiles/r05_glds_stages_ab.txt;
+// 2 -> 3 stages): the 8-wave tile 164 -> 116, 166 -> 158, 405 -> 388, 234 -> 219, 207 -> 192 us (strided / transposed convs of the
+// U-Net), the 48-row 4-wave tile 62 -> 56 us; but the 96-row 4-wave tile (three blocks per CU, 7.8 TB/s of L2 -> LDS traffic on the second
+// encoder's strided conv) 120 -> 160 us and the 64-channel-chunk tiles 80 -> 87 us: those keep two stages.  Four stages of the 8-wave
+// tile (80 KiB: one block per CU) lose what three gained.
+#ifndef AERO_GLDS_NST
+#define AERO_GLDS_NST 3
+#endif
 template <int MF, int WM, int KC, int NWV>
 struct AeroGldsGeom {
     static constexpr int BM = 16 * MF * WM;
+    static constexpr int NST = (NWV == 8 || (KC == 32 && WM == 1)) ? AERO_GLDS_NST : 2;
     static constexpr int STAGE = (BM + 128) * KC;
     static constexpr int CS = BM + 8;
-    static constexpr int SMEM = 2 * STAGE > 64 * CS ? 2 * STAGE : 64 * CS;    // h16 elements
+    static constexpr int SMEM = NST * STAGE > 64 * CS ? NST * STAGE : 64 * CS;    // h16 elements
 };
 
 template <int MF, int WM, int KC, bool STATS, int NWV>
@@ -743,7 +760,8 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
                 for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[n], acc[i][n], 0, 0, 0);
         }
     };
-    {
+    constexpr int NST = AeroGldsGeom<MF, WM, KC, NWV>::NST;
+    if constexpr (NST == 2) {
         bool have = next_chunk();
         if (have) issue(0);
         int buf = 0;
@@ -754,6 +772,37 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
             compute(buf);
             buf ^= 1;
         }
+    } else {
+        // copies THIS wave issues per chunk: NIB activation pieces + NIA or NIA - 1 weight pieces (they are dealt out to the waves in
+        // rounds; wave-uniform) -- the loop is instantiated for both counts so that the wait's immediate is a compile-time constant
+        auto pipeline = [&](auto keep_c) {
+            constexpr int KEEP = decltype(keep_c)::value;        // copies of the NST - 2 younger chunks may stay in flight
+            bool have = next_chunk();
+            int wr = 0, rd = 0, fl = 0;                          // fl: chunks issued and not yet consumed
+            for (; fl < NST - 1 && have; ++fl) {
+                issue(wr);
+                wr = wr + 1 == NST ? 0 : wr + 1;
+                have = next_chunk();
+            }
+            while (have) {                                       // steady state: NST - 1 chunks in flight
+                aero_wait_vm<KEEP>();                            // the oldest of them has landed (this wave's part of it)
+                aero_phase_barrier();                            // ... every wave's part; and the stage read last iteration is free
+                issue(wr);
+                wr = wr + 1 == NST ? 0 : wr + 1;
+                have = next_chunk();
+                compute(rd);
+                rd = rd + 1 == NST ? 0 : rd + 1;
+            }
+            for (; fl; --fl) {                                   // tail (or a contraction shorter than the pipeline)
+                aero_wait_vm<0>();
+                aero_phase_barrier();
+                compute(rd);
+                rd = rd + 1 == NST ? 0 : rd + 1;
+            }
+        };
+        constexpr int TOTA = BM * SLOTS / 64;
+        if (TOTA % NWV == 0 || wave + NWV * (NIA - 1) < TOTA) pipeline(std::integral_constant<int, (NST - 2) * (NIB + NIA)>());
+        else pipeline(std::integral_constant<int, (NST - 2) * (NIB + NIA - 1)>());
     }
     if (p.tsplit > 1) {                        // partial sums of this tap group -> fp32 accumulator (finished by aero_split_finish)
         float* ws = d.split_acc + ((int64_t)((sp * d.B + b) * d.Fout + fo) * T) * d.M;
@@ -778,8 +827,7 @@ static __device__ __forceinline__ void aero_conv_glds_body(const AeroConvK& p, h
 // (KC 32, 128-row tile: ask for 3 blocks per CU -- 168 registers -- instead of the 204 the allocator takes by default)
 template <int MF, int WM, int KC, bool STATS>
 __global__ __launch_bounds__(256, (KC == 32 && MF * WM >= 6) ? 3 : 1) void aero_conv_glds_kernel(AeroConvK p) {
-    __shared__ AERO_LDS_ALIGN h16 smem[AeroGldsGeom<MF, WM, KC, 4>::SMEM];
-    aero_conv_glds_body<MF, WM, KC, STATS, 4>(p, smem);
+    aero_conv_glds_body<MF, WM, KC, STATS, 4>(p, (h16*)AERO_DYN_SMEM);      // (dynamic: three 64-channel stages exceed the static 64 KiB)
 }
 
 // 256 output channels x 128 steps with EIGHT waves (4 x 2, each 64 x 64 as above): the activation tile is shared by
@@ -1537,11 +1585,12 @@ static int aero_conv_pick_bm(int M, int Mpad) {
 }
 
 // `name` != NULL: dry run -- only report which kernel instantiation would run (profiling labels that match rocprofv3)
-#define AERO_CONV_GO(K, A, B, C_)                                                                              \
-    do {                                                                                                       \
-        if (name) snprintf(name, 96, #K "<" #A ", " #B ", " #C_ ", %s>", d->stat_mode ? "true" : "false");    \
-        else if (d->stat_mode) AERO_LAUNCH((K<A, B, C_, true>), grid, block, stream, p);                       \
-        else AERO_LAUNCH((K<A, B, C_, false>), grid, block, stream, p);                                        \
+#define AERO_CONV_GO_GLDS(A, B, C_)                                                                                             \
+    do {                                                                                                                        \
+        const size_t dyn = AeroGldsGeom<A, B, C_, 4>::SMEM * sizeof(h16);                                                       \
+        if (name) snprintf(name, 96, "aero_conv_glds_kernel<" #A ", " #B ", " #C_ ", %s>", d->stat_mode ? "true" : "false");    \
+        else if (d->stat_mode) AERO_LAUNCH_DYN((aero_conv_glds_kernel<A, B, C_, true>), grid, block, dyn, stream, p);           \
+        else AERO_LAUNCH_DYN((aero_conv_glds_kernel<A, B, C_, false>), grid, block, dyn, stream, p);                            \
     } while (0)
 #define AERO_CONV_GO2(K, A, B)                                                                                 \
     do {                                                                                                       \
@@ -1781,21 +1830,21 @@ static int aero_conv_launch(const aero_conv_desc* d, hipStream_t stream, const c
         }
         if (k64) {
             switch (bm) {
-                case 128: AERO_CONV_GO(aero_conv_glds_kernel, 4, 2, 64); break;
-                case 96: AERO_CONV_GO(aero_conv_glds_kernel, 3, 2, 64); break;
-                case 64: AERO_CONV_GO(aero_conv_glds_kernel, 4, 1, 64); break;
-                case 48: AERO_CONV_GO(aero_conv_glds_kernel, 3, 1, 64); break;
-                case 32: AERO_CONV_GO(aero_conv_glds_kernel, 2, 1, 64); break;
-                default: AERO_CONV_GO(aero_conv_glds_kernel, 1, 1, 64); break;
+                case 128: AERO_CONV_GO_GLDS(4, 2, 64); break;
+                case 96: AERO_CONV_GO_GLDS(3, 2, 64); break;
+                case 64: AERO_CONV_GO_GLDS(4, 1, 64); break;
+                case 48: AERO_CONV_GO_GLDS(3, 1, 64); break;
+                case 32: AERO_CONV_GO_GLDS(2, 1, 64); break;
+                default: AERO_CONV_GO_GLDS(1, 1, 64); break;
             }
         } else {
             switch (bm) {
-                case 128: AERO_CONV_GO(aero_conv_glds_kernel, 4, 2, 32); break;
-                case 96: AERO_CONV_GO(aero_conv_glds_kernel, 3, 2, 32); break;
-                case 64: AERO_CONV_GO(aero_conv_glds_kernel, 4, 1, 32); break;
-                case 48: AERO_CONV_GO(aero_conv_glds_kernel, 3, 1, 32); break;
-                case 32: AERO_CONV_GO(aero_conv_glds_kernel, 2, 1, 32); break;
-                default: AERO_CONV_GO(aero_conv_glds_kernel, 1, 1, 32); break;
+                case 128: AERO_CONV_GO_GLDS(4, 2, 32); break;
+                case 96: AERO_CONV_GO_GLDS(3, 2, 32); break;
+                case 64: AERO_CONV_GO_GLDS(4, 1, 32); break;
+                case 48: AERO_CONV_GO_GLDS(3, 1, 32); break;
+                case 32: AERO_CONV_GO_GLDS(2, 1, 32); break;
+                default: AERO_CONV_GO_GLDS(1, 1, 32); break;
             }
         }
         return AERO_OK;

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
     const bool xvec = (d.in_ch % 8 == 0) && (d.x_pitch % 8 == 0) && (((uintptr_t)xin & 15) == 0);
     h16x8 xr[NXV];
     int lx_i[NXV], lx_tmax[NXV], lx_c[NXV], lx_dst[NXV];          // tmax: tau must stay below it (-1: this thread copies nothing)
-    int64_t lx_base[NXV];
+    int lx_base[NXV];                                             // (row indices: 32 bits, checked on the host -- a 64-bit pair per entry spilled to scratch)
 #pragma unroll
     for (int v = 0; v < NXV; ++v) {
         const int L = tid + v * NT;
@@ -370,10 +370,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
         if (d.in_mode == 1) {
             const int r = seq / d.nframes, k = seq - r * d.nframes;
             lx_tmax[v] = ok ? d.T - k * d.S : -1;
-            lx_base[v] = (int64_t)r * d.T + k * d.S;
+            lx_base[v] = r * d.T + k * d.S;
         } else {
             lx_tmax[v] = ok ? W : -1;
-            lx_base[v] = (int64_t)seq * W;
+            lx_base[v] = seq * W;
         }
     }
     auto load_x = [&](int g) {          // global -> VGPR for group g (steps beyond W, padded frames, bad rows: zeros)
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
             const bool ok = step < W && tau < lx_tmax[v];
             h16x8 z = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
             if (ok) {
-                const h16* sp = xin + (lx_base[v] + tau) * d.x_pitch + lx_c[v];
+                const h16* sp = xin + (int64_t)(lx_base[v] + tau) * d.x_pitch + lx_c[v];
                 if (xvec) {
                     z = *(const h16x8*)sp;
                 } else {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
     constexpr int NSV = (G * 16 * KT * 4 + NT - 1) / NT;           // precomputed 16-byte pieces per thread (vecs <= KT * 4)
     const bool sg_fast = vecs != 0;
     int sg_pk[NSV], sg_tlo[NSV], sg_thi[NSV];                      // (step-in-group << 20 | LDS offset), valid range of tau (empty: thi = -1)
-    int64_t sg_base[NSV];
+    int sg_base[NSV];                                             // (element offsets < 2^31: checked on the host)
 #pragma unroll
     for (int k2 = 0; k2 < NSV; ++k2) {
         const int idx = tid + k2 * NT;
@@ -425,9 +425,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
             const int tl = d.T - kf * d.S;                          // t = kf*S + tau must stay below T
             sg_tlo[k2] = (kf == 0) ? 0 : lim;
             sg_thi[k2] = ok ? (hi < tl ? hi : tl) : -1;
-            sg_base[k2] = ((int64_t)r * d.T + kf * d.S) * H2 + dir * H + e * 8;
+            sg_base[k2] = (r * d.T + kf * d.S) * H2 + dir * H + e * 8;
         } else {
-            sg_base[k2] = ((int64_t)s2 * W) * H2 + dir * H + e * 8;
+            sg_base[k2] = (s2 * W) * H2 + dir * H + e * 8;
         }
     }
     auto store_group = [&](int g) {
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
                 const int step = s_base + i;
                 const int tau = dir ? W - 1 - step : step;
                 if (i >= nst || tau < sg_tlo[k2] || tau >= sg_thi[k2]) continue;
-                *(h16x8*)(out + sg_base[k2] + (int64_t)tau * H2) = *(const h16x8*)(hring + (step & (R - 1)) * 16 * HS + (sg_pk[k2] & 0xFFFFF));
+                *(h16x8*)(out + (sg_base[k2] + tau * H2)) = *(const h16x8*)(hring + (step & (R - 1)) * 16 * HS + (sg_pk[k2] & 0xFFFFF));
             }
             return;
         }
@@ -705,6 +705,11 @@ static int aero_lstm_launch(const aero_lstm_desc* d, hipStream_t stream, const c
     if ((d->in_mode == 1 || d->out_mode == 1) && (d->nframes < 1 || d->S < 1 || d->T < 1 || d->nseq % d->nframes)) {
         *err = "lstm: bad framing";
         return AERO_ERR_ARG;
+    }
+    {   // the ring kernel keeps per-thread row indices / output element offsets in 32 bits
+        const int64_t rows_in = d->in_mode == 1 ? (int64_t)(d->nseq / d->nframes) * d->T : (int64_t)d->nseq * d->W;
+        const int64_t rows_out = d->out_mode == 1 ? (int64_t)(d->nseq / d->nframes) * d->T : (int64_t)d->nseq * d->W;
+        if (rows_in + d->W >= (1ll << 31) || (rows_out + d->W) * 2 * d->H >= (1ll << 31)) { *err = "lstm: tensor too large for 32-bit offsets"; return AERO_ERR_UNSUPPORTED; }
     }
     int nw, tpw, kt;
     if (aero_lstm_pick(d->H, &nw, &tpw, &kt)) { *err = "lstm: hidden size > 128 unsupported"; return AERO_ERR_UNSUPPORTED; }

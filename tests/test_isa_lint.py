@@ -54,3 +54,23 @@ def test_padded_target_and_overwrites_are_not_flagged():
 def test_packed_fp32_counter():
     txt = _asm(['v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7]', 'v_pk_mul_f32 v[0:1], v[2:3], v[4:5]', 'v_pk_fma_f16 v0, v1, v2, v3', 's_endpgm'])
     assert len(isa_lint.PACKED_FP32.findall(txt)) == 2
+
+
+def test_private_segment_rule():
+    # kernel metadata as `llvm-readelf --notes` prints it: one kernel with a private segment, one without
+    notes = ['''amdhsa.kernels:
+  - .agpr_count:     0
+    .name:           _Z1av
+    .private_segment_fixed_size: 16
+    .vgpr_count:     128
+  - .agpr_count:     0
+    .name:           _Z1bv
+    .private_segment_fixed_size: 0
+    .vgpr_count:     64
+''']
+    assert isa_lint.private_segments(notes) == {'_Z1av': 16}
+    import re
+    assert any(re.match(a, 'aero_conv_skinny_kernel<8>') for a in isa_lint.SCRATCH_ALLOWED)
+    # the kernels of the measured paths are NOT on the allowed list
+    for k in ('aero_conv_glds8_kernel<3, 32, true>', 'aero_lstm_ring_kernel<12, 1, 2, 3, 4, false>', 'aero_conv_ring_kernel<2, 4, 4, 3, 0>'):
+        assert not any(re.match(a, k) for a in isa_lint.SCRATCH_ALLOWED)

@@ -12,6 +12,7 @@ Neither is an error by itself (W1 is harmless when the MFMA's operands were read
 read): the report is for review whenever a kernel with rings of LDS slots changes, and `--strict K1,K2` fails if a named kernel's counts grow
 over the committed baseline (profiles/isa_lint_baseline.json).  It also counts the packed-fp32 VALU instructions of the whole code
 object and exits with code 3 if there is one (the build fails on that: DESIGN.md 5b).
+W4: kernels with a private segment outside SCRATCH_ALLOWED (exit code 5; see the comment there).
 usage: isa_lint.py [lib.so] [--write-baseline] [--strict] [--allow-packed]"""
 import json
 import os
@@ -24,9 +25,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = '/opt/rocm/lib/llvm/bin'
 
 
-def disassemble(lib):
+def disassemble(lib, notes=None):
     """the gfx950 code objects of EVERY fat-binary bundle in `lib` (the library is linked from seven separately compiled parts, each with
-    its own bundle in .hip_fatbin: unbundling the section as a whole yields only the first one), disassembled and concatenated"""
+    its own bundle in .hip_fatbin: unbundling the section as a whole yields only the first one), disassembled and concatenated;
+    notes: a list that receives each code object's `llvm-readelf --notes` text (kernel metadata)"""
     magic = b'__CLANG_OFFLOAD_BUNDLE__'
     out = []
     with tempfile.TemporaryDirectory() as td:
@@ -41,7 +43,29 @@ def disassemble(lib):
             subprocess.run([f'{LLVM}/clang-offload-bundler', '--type=o', f'--input={part}', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
                             f'--output={co}', '--unbundle'], check=True)
             out.append(subprocess.run([f'{LLVM}/llvm-objdump', '-d', co], check=True, capture_output=True, text=True).stdout)
+            if notes is not None:
+                notes.append(subprocess.run([f'{LLVM}/llvm-readelf', '--notes', co], check=True, capture_output=True, text=True).stdout)
     return '\n'.join(out)
+
+
+# Kernels with a PRIVATE SEGMENT (spilled registers, indexed local arrays).  Measured in round 5 (profiles/r05_noscratch.txt): a launch of
+# such a kernel is ~40 us slower whenever it needs more scratch than the stream's queue holds at that moment -- the first one of every
+# forward, and every later one that needs more than its predecessors (an 8-wave conv tile with 3 spilled registers 160 -> 115 us, the LSTM
+# with 8 spilled dwords 193 -> 148 us; the same kernel 40 launches later, with the scratch already there: no difference).  No kernel of the
+# measured paths may have one; these are the instantiations outside them that still do (rule W4, exit code 5 for anything else):
+SCRATCH_ALLOWED = (r'^aero_pw_kernel<2, 3, [012], (true|false), false>$', r'^aero_lstm_kernel<8, 3, 3, 6>$', r'^aero_conv_glds_kernel<4, 2, 32, true>$',
+                   r'^aero_conv_glds8_kernel<4, 32, true>$', r'^aero_conv_skinny_kernel<[1248]>$')
+
+
+def private_segments(notes):
+    """{mangled kernel name: private_segment_fixed_size} for every kernel of the code objects' metadata that has one"""
+    out = {}
+    for txt in notes:
+        for blk in re.split(r'\n\s*- \.agpr_count', txt)[1:]:
+            nm, ps = re.search(r'\.name:\s+(\S+)', blk), re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk)
+            if nm and ps and int(ps.group(1)):
+                out[nm.group(1)] = int(ps.group(1))
+    return out
 
 
 def lint(text):
@@ -75,6 +99,8 @@ def lint(text):
                     w2 += 1
             elif i.startswith(('s_cbranch', 's_branch', 's_endpgm')):
                 in_window = False
+                if not i.startswith('s_cbranch'):               # no fall-through: what follows in the text is another path (e.g. the prologue of a
+                    reads_since_barrier = 0                     # second instantiation of a pipelined loop), not the continuation of these reads
         if nbar and (nglds or nmfma):
             out[name] = {'barriers': nbar, 'lds_copies': nglds, 'mfma': nmfma, 'W1_mfma_in_wait_barrier_window': w1,
                          'W2_lds_copy_after_reads_without_barrier': w2}
@@ -183,7 +209,12 @@ def main():
     for a in sys.argv[1:]:
         if a.endswith('.so'):
             lib = a
-    text = disassemble(lib)
+    notes = []
+    text = disassemble(lib, notes)
+    priv = private_segments(notes)
+    pdm = demangle(list(priv))
+    priv = {pdm[k].split('(')[0].replace('void ', ''): v for k, v in priv.items()}
+    priv_bad = sorted(k for k in priv if not any(re.match(a, k) for a in SCRATCH_ALLOWED))
     # packed-fp32 VALU instructions anywhere in the code object: with them the FFT-family kernels return wrong values next to another
     # stream's MFMA waves; the library is built without them, and this count FAILS the build (exit code 3) if it is not 0
     npk = len(PACKED_FP32.findall(text))
@@ -210,12 +241,16 @@ def main():
     w3d = demangle(list(w3))
     print(f'MFMA_BRANCH_HAZARD {sum(w3.values())} VALU reads of a matrix result at a branch target without wait states (must be 0)'
           + (': ' + ', '.join(f'{w3d[k].split("(")[0]} x{v}' for k, v in w3.items()) if w3 else ''))
+    print(f'PRIVATE_SEGMENT {len(priv)} kernels use scratch memory, {len(priv_bad)} of them outside the allowed list (must be 0)'
+          + (': ' + ', '.join(f'{k} ({priv[k]} B)' for k in priv_bad) if priv_bad else ''))
     if bad:
         print('GREW over the baseline:', [b[0] for b in bad])
     if npk and '--allow-packed' not in sys.argv:
         sys.exit(3)
     if w3:
         sys.exit(4)
+    if priv_bad:
+        sys.exit(5)
     if bad and '--strict' in sys.argv:
         sys.exit(1)
 
