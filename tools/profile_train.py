@@ -43,7 +43,11 @@ def main():
         e0.record()
         orig_call(name, *a)
         e1.record()
-        rec.append((name, note[0], e0, e1))
+        nt = note[0]
+        if name.startswith('aero_norm_bwd'):                     # descriptor fields: the shape of this GroupNorm's backward
+            d = a[0]._obj
+            nt = f'B{d.B} F{d.F} T{d.T} C{d.C} G{d.G} per_row{d.per_row} act{d.act}'
+        rec.append((name, nt, e0, e1))
     lib.call = timed
     orig_wgrad = bw.conv_wgrad
 
@@ -89,6 +93,19 @@ def main():
         ideal_tot += floor * v[0]
         print(f'{v[1]:8.3f} ms {v[0]:3d} calls  {k}   per call {v[1] / v[0] * 1e3:7.1f} us, floor {floor * 1e3:6.1f} us')
     print(f'   (sum of floors of the rows shown: {ideal_tot:.2f} ms)')
+    print('-- GroupNorm backward by shape (reduce | apply; floor: x, dy read twice + dx written once at 5 TB/s)')
+    nb = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for name, nt, e0, e1 in rec:
+        if name.startswith('aero_norm_bwd'):
+            ms = e0.elapsed_time(e1)
+            nb[nt][0] += name.endswith('reduce')
+            nb[nt][1 if name.endswith('reduce') else 2] += ms
+    for k, v in sorted(nb.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+        dims = [int(t) for t in re.findall(r'\d+', k)]
+        n = dims[0] * dims[1] * dims[2] * dims[3]
+        glu = dims[6] == 3
+        floor = (2 * n * 2 + 2 * (n // 2 if glu else n) * 2 + 2 * n) / 5e12 * 1e6
+        print(f'{v[1] + v[2]:8.3f} ms {v[0]:3d} norms  {k:46s} per norm: reduce {v[1] / v[0] * 1e3:6.1f} us, apply {v[2] / v[0] * 1e3:6.1f} us, floor {floor:5.1f} us')
 
 
 if __name__ == '__main__':
