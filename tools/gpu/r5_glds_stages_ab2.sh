@@ -1,5 +1,8 @@
 #!/bin/bash
 # second visit: stage count chosen per instantiation (release) vs two stages everywhere (nst2); AERO_CONV_KMIN192=192 on top
+# the variant libraries are experiment builds of part 2 (not tracked): python -c "import __graft_entry__ as g; g.build_library(out='tools/dbg/libaero_glds_nst2.so',
+#   defines=['AERO_GLDS_NST=2'], objdir='aero_amd/csrc/build/nst2', only_parts=[2], force=True)"  (nst4: AERO_GLDS_NST=4; at the time of the first visit a second
+#   macro, AERO_GLDS_NST64, set the stage count of the 64-channel-chunk tiles separately: nst3_64x2 = 3 / 2)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 for rep in 1 2; do
