@@ -274,6 +274,8 @@ typedef struct {
      * [H][16] at save_c + (((ib*2 + dir)*W + tau)*H*16): what aero_lstm_bwd reads.  Runs the step-wise kernel. */
     void* save_gates; float* save_c;
 } aero_lstm_desc;
+/* AERO_ERR_UNSUPPORTED ("tensor too large for 32-bit offsets") when the input holds 2^31 rows of W steps or the output 2^31 elements or
+ * more: the kernel keeps per-thread row indices / element offsets in 32 bits (a 64-bit pair per entry spilled registers). */
 int aero_lstm_fwd(const aero_lstm_desc* d, void* stream);
 /* padded W_hh geometry the kernel instantiation for hidden size H expects: MP rows, KP columns */
 int aero_lstm_geometry(int32_t H, int32_t* MP, int32_t* KP);

@@ -38,3 +38,9 @@ def test_argument_errors_are_reported_not_thrown():
     mp, kp = C.c_int32(), C.c_int32()
     assert lib.cdll.aero_lstm_geometry(96, C.byref(mp), C.byref(kp)) == 0 and (mp.value, kp.value) == (384, 96)
     assert lib.cdll.aero_lstm_geometry(200, C.byref(mp), C.byref(kp)) == -3
+    # the LSTM kernel keeps per-thread offsets in 32 bits: a tensor beyond 2^31 output elements is refused up front (no launch, fake pointers)
+    ld = _lib.LstmDesc()
+    ld.xproj = ld.xbias = ld.whh = ld.out = 16
+    ld.H, ld.nseq, ld.W = 48, 1 << 20, 400                       # 2^20 x 400 rows x 96 = 4e10 elements
+    rc = lib.cdll.aero_lstm_fwd(C.byref(ld), None)
+    assert rc == -3 and b'32-bit' in lib.cdll.aero_last_error()
