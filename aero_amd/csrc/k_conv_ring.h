@@ -16,7 +16,7 @@
 //     instruction reads 1 KiB of consecutive bytes), and (ii) with NT = 3 unit-stride time taps the activation SLAB
 //     [t0-1, t0+BN+1) x 32 channels is copied ONCE per (frequency tap, channel chunk) and read at row offsets 0/1/2 by
 //     the three taps: a third of the activation requests.
-// Tiles <WM,WN,NRB>: <2,4,4> 256 rows x 256 steps; <2,2,3> 192 x 128 on four waves (two blocks per CU; round 5) and <2,4,3> 192 x 256
+// Tiles <WM,WN,NRB>: <2,4,4> 256 rows x 256 steps (<2,2,4> 256 x 128 on four waves when T leaves the last 256-step tile half empty); <2,2,3> 192 x 128 on four waves (two blocks per CU; round 5) and <2,4,3> 192 x 256
 // (one 12-MFMA phase per chunk); <1,8,4> 128 rows x
 // 512 steps (a whole T = 501 row per block); <1,8,2> 64 rows x 512 steps.
 // Ordering rules the schedule relies on (LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt followed by a
@@ -35,8 +35,10 @@ struct AeroRingGeom {
     static constexpr int NW = WM * WN;                                            // waves per block: 8, or 4 for the half-height tile <1,4,3>
     static constexpr int RBP = NRB == 3 ? 3 : 2;                                  // row blocks per phase: 4 MFMAs each
     static constexpr int NPH = NRB / RBP;                                         // phases per K-chunk
-    static constexpr int NSA = 4;                                                 // A ring: one [BM][32] tile per slot
-    static constexpr int AHEAD = NPH == 1 ? 4 : 3;                                // chunks between an A copy and its use
+    // A ring: one [BM][32] tile per slot.  THREE slots for the 256-row tile on four waves (<2,2,4>: 76.8 KiB, two blocks per CU), its weight
+    // tile issued two chunks ahead instead of three (a chunk of that block is 16 MFMAs a wave: ~0.9 us with two blocks on the CU)
+    static constexpr int NSA = (NW == 4 && NRB == 4) ? 3 : 4;
+    static constexpr int AHEAD = NPH == 1 ? 4 : NSA - 1;                          // chunks between an A copy and its use
     static constexpr int SLABI = BN / 16 + (NT > 1 ? 1 : 0);                      // copy instructions per activation slab
     static constexpr int SLABR = SLABI * 16;                                      // slab rows held in LDS
     static constexpr int LB = NT > 1 ? 2 : 3;                                     // groups between a slab copy and its use
@@ -57,7 +59,8 @@ struct AeroRingGeom {
     // (slab + A) and the slab pieces of chunk k.  One phase: it guards chunk k+2 (A issued in chunk k-2): chunks k-1, k.
     static constexpr int vmw(int jt) {
         const int jp = (jt + NT - 1) % NT;
-        return NPH == 1 ? 2 * NA + nb(jp) + nb(jt) : NA + nb(jp) + nb(jt);
+        // (AHEAD == 2, two phases: chunk k+1's A went out in phase 1 of chunk k-1; after it only the slab pieces of chunk k)
+        return NPH == 1 ? 2 * NA + nb(jp) + nb(jt) : (AHEAD == 2 ? nb(jt) : NA + nb(jp) + nb(jt));
     }
 };
 
@@ -680,7 +683,17 @@ AERO_XPART bool aero_conv_ring_try(const aero_conv_desc* d, AeroConvK& p, hipStr
     // the 512-step tiles have no LDS for four full activation tiles)
     const bool slab3 = p.nT == 3 && (p.t_step == 1 || p.t_step == 2);   // (dilation 2: the taps read rows 0 / 2 / 4 of the slab's 16 spare rows)
     if (bm == 256) {
-        if (slab3) aero_conv_ring_go<2, 4, 4, 3>(p, stream, name);
+        // Time tiles: 256 steps on eight waves, or -- when the last 256-step tile would be at most half full, i.e. the number of 128-step
+        // tiles is odd -- 128 steps on FOUR waves with a three-slot weight ring (76.8 KiB: two blocks per CU).  At T = 501 (configs 2 / 3:
+        // two full tiles) the narrow tile is neither faster nor slower per launch and 1 % slower in the pipelined step
+        // (profiles/r05_ring256_narrow_ab.txt); at T = 376 (config 4: 12->48 kHz, hop 256) the wide tile computes 512 columns for 376:
+        // D0 1038 -> 820 us, D1 1118 -> 865 us, config 4's pipelined step 7.07 -> 6.8-6.9 ms (profiles/r05_config4_narrow.txt).
+        // AERO_RING_256X128=0 / 1 forces wide / narrow (A/B).
+        static int narrow256 = -1;
+        if (narrow256 < 0) { const char* e = getenv("AERO_RING_256X128"); narrow256 = e ? atoi(e) : 2; }
+        const bool narrow = narrow256 == 1 || (narrow256 == 2 && (((d->T + 127) / 128) & 1));
+        if (slab3 && narrow) aero_conv_ring_go<2, 2, 4, 3>(p, stream, name);
+        else if (slab3) aero_conv_ring_go<2, 4, 4, 3>(p, stream, name);
         else aero_conv_ring_go<2, 4, 4, 1>(p, stream, name);
     } else if (!slab3) {                                         // (round 4: the 192-row tile with one slab per tap, <2,4,3,1>, was tried for the
         // encoder's strided [8,1] conv with M = 384: 173 us against 168 us on the glds8 tile, and the B = 32 forward no longer matched

@@ -8,10 +8,15 @@ from aero_amd import Aero  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=64)
+ap.add_argument('--config4', action='store_true', help='BASELINE config 4 (12->48 kHz, nfft 1024, hop 256, B = 32) instead of the headline config')
 a = ap.parse_args()
 torch.manual_seed(2036)
-m = Aero(**FULL_CFG).eval().cuda()
-x = torch.randn(a.batch, 1, 8000, generator=torch.Generator().manual_seed(1000)).cuda()
+if a.config4:
+    m = Aero(**dict(FULL_CFG, nfft=1024, hop_length=256, lr_sr=12000, hr_sr=48000)).eval().cuda()
+    x = torch.randn(32 if a.batch == 64 else a.batch, 1, 24000, generator=torch.Generator().manual_seed(1000)).cuda()
+else:
+    m = Aero(**FULL_CFG).eval().cuda()
+    x = torch.randn(a.batch, 1, 8000, generator=torch.Generator().manual_seed(1000)).cuda()
 eng = m._get_engine()
 with torch.no_grad():
     for _ in range(2):
