@@ -44,6 +44,10 @@ def main():
         orig_call(name, *a)
         e1.record()
         nt = note[0]
+        if name == 'aero_conv_fwd':                              # forward convs and data gradients: kernel instantiation + shape
+            d = a[0]._obj
+            kn = lib.cdll.aero_last_kernel_name().decode().replace('void ', '').split('(')[0]
+            nt = f'{kn:40s} B{d.B} F{d.Fin}->{d.Fout} T{d.T} M{d.M} C{d.C0}+{d.C1 if d.src1 else 0} taps{d.ntaps} tr{d.transposed} act{d.act} stat{d.stat_mode}'
         if name.startswith('aero_norm_bwd'):                     # descriptor fields: the shape of this GroupNorm's backward
             d = a[0]._obj
             nt = f'B{d.B} F{d.F} T{d.T} C{d.C} G{d.G} per_row{d.per_row} act{d.act}'
@@ -93,6 +97,17 @@ def main():
         ideal_tot += floor * v[0]
         print(f'{v[1]:8.3f} ms {v[0]:3d} calls  {k}   per call {v[1] / v[0] * 1e3:7.1f} us, floor {floor * 1e3:6.1f} us')
     print(f'   (sum of floors of the rows shown: {ideal_tot:.2f} ms)')
+    print('-- aero_conv_fwd (forward convs + data gradients) by kernel and shape: executed TFLOP/s assume every tap valid')
+    cf = collections.defaultdict(lambda: [0, 0.0])
+    for name, nt, e0, e1 in rec:
+        if name == 'aero_conv_fwd':
+            cf[nt][0] += 1
+            cf[nt][1] += e0.elapsed_time(e1)
+    for k, v in sorted(cf.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('CONV_ROWS', '28'))]:
+        m = re.search(r'B(\d+) F(\d+)->(\d+) T(\d+) M(\d+) C(\d+)\+(\d+) taps(\d+)', k)
+        Bq, Fi, Fo, Tq, Mq, c0, c1, tp = (int(g) for g in m.groups())
+        fl = 2.0 * Bq * Fo * Tq * Mq * (c0 + c1) * tp
+        print(f'{v[1]:8.3f} ms {v[0]:3d} calls  {k}   {v[1] / v[0] * 1e3:7.1f} us  {fl / (v[1] / v[0]) / 1e9:7.1f} TF/s')
     print('-- GroupNorm backward by shape (reduce | apply; floor: x, dy read twice + dx written once at 5 TB/s)')
     nb = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for name, nt, e0, e1 in rec:
