@@ -211,6 +211,8 @@ _PROTOS = {
     'aero_allreduce_f32': (i32, [vp, fp, i64, vp]),
     'aero_allgather': (i32, [vp, vp, vp, i64, vp]),
     'aero_comm_destroy': (i32, [vp]),
+    'aero_stream_create': (i32, [i32, C.POINTER(C.c_uint32), i32, C.POINTER(vp)]),
+    'aero_stream_destroy': (i32, [vp]),
     'aero_pw_rows': (i32, [i32, i32]),
     'aero_pw_ksteps': (i32, [i32]),
     'aero_squeeze_fwd': (i32, [vp, i64, i64, i64, vp, fp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -693,6 +693,48 @@ int aero_comm_destroy(void* comm) {
     return aero_rccl_rc(r, r->CommDestroy((ncclComm_t)comm), "ncclCommDestroy");
 #endif
 }
+// Scheduling (round 6): HIP streams with a dispatch PRIORITY or a CU MASK, for hosts that want the latency-bound segment of a forward
+// (encoder 2-3: LSTM, LocalState and their small launches) dispatched ahead of / beside other batches' MFMA tiles (aero_amd/pipeline.py).
+// priority: 0 = default, < 0 = higher, > 0 = lower (clamped to the device's range).  cu_mask / n_words: NULL / 0 = all CUs; else bit i of the
+// mask enables CU i in the runtime's enumeration (round-robin over the 8 XCDs on gfx950: the low 8 n bits = n CUs of every XCD); a masked
+// stream takes the default priority (the runtime has no call for both).
+int aero_stream_create(int32_t priority, const uint32_t* cu_mask, int32_t n_words, void** stream) {
+#ifdef AERO_EMU
+    return aero_fail(AERO_ERR_UNSUPPORTED, "stream_create: not available in the emulation build");
+#else
+    if (!stream || n_words < 0 || (n_words > 0 && !cu_mask)) return aero_fail(AERO_ERR_ARG, "stream_create: bad arguments");
+    hipStream_t s = nullptr;
+    hipError_t e;
+    if (n_words > 0) {
+        e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask);
+    } else {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);           // (least = numerically largest = lowest priority)
+        int pr = priority < greatest ? greatest : (priority > least ? least : priority);
+        e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr);
+    }
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "stream_create: %s", hipGetErrorString(e));
+        return AERO_ERR_LAUNCH;
+    }
+    *stream = (void*)s;
+    return AERO_OK;
+#endif
+}
+
+int aero_stream_destroy(void* stream) {
+#ifdef AERO_EMU
+    return aero_fail(AERO_ERR_UNSUPPORTED, "stream_destroy: not available in the emulation build");
+#else
+    if (!stream) return aero_fail(AERO_ERR_ARG, "stream_destroy: null stream");
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "stream_destroy: %s", hipGetErrorString(e));
+        return AERO_ERR_LAUNCH;
+    }
+    return AERO_OK;
+#endif
+}
 #endif  // part 0 (cont.)
 
 }  // extern "C"

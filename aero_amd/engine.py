@@ -47,6 +47,36 @@ def side_streams(device, n):
     return lst[:n]
 
 
+_SPECIAL_STREAMS = {}
+
+
+def special_stream(device, priority=0, cu_range=None, tag=0):
+    """A HIP stream with a dispatch priority (< 0 = ahead of default-priority streams) or restricted to the CUs [lo, hi) of the runtime's
+    CU enumeration (round-robin over the XCDs: [0, 8 n) = n CUs of each of the 8 XCDs), created through the C ABI (aero_stream_create)
+    and wrapped as a torch ExternalStream.  One object per (device, priority, cu_range, tag), kept for the life of the process."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    key = (dev.index, int(priority), None if cu_range is None else tuple(cu_range), tag)
+    st = _SPECIAL_STREAMS.get(key)
+    if st is None:
+        lib = _lib.load()
+        handle = C.c_void_p()
+        with torch.cuda.device(dev):
+            if cu_range is None:
+                lib.call('aero_stream_create', int(priority), None, 0, C.byref(handle))
+            else:
+                lo, hi = cu_range
+                ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+                assert 0 <= lo < hi <= ncu, (cu_range, ncu)
+                words = (C.c_uint32 * ((ncu + 31) // 32))()
+                for i in range(lo, hi):
+                    words[i // 32] |= 1 << (i % 32)
+                lib.call('aero_stream_create', 0, words, len(words), C.byref(handle))
+        st = _SPECIAL_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=dev)
+    return st
+
+
 class Ops:
     """Tensor-level wrappers over the C ABI (used by the engine and by the op-level tests)."""
 
@@ -477,6 +507,7 @@ class HipEngine:
     use_pw = os.environ.get('AERO_PW', '1') != '0'              # (class default: tests build bare engines with __new__)
     stagger = 0
     prof_streams = False
+    stage_hook = None
 
     def __init__(self, model, lib=None):
         self.model = model
@@ -856,6 +887,8 @@ class HipEngine:
     def _forward_one(self, mix, want_spec=False, want_lr_spec=False, train=False, defer_istft=False, stage_cb=None):
         m, ops, P = self.model, self.ops, None
         self._train = train
+        if stage_cb is None:
+            stage_cb = self.stage_hook                  # (BatchPipeline: stream switch at layer boundaries, aero_amd/pipeline.py)
         self._check_input(mix)
         if m.in_channels != 1 or m.out_channels != 1:
             raise NotImplementedError('only in_channels = out_channels = 1 (all reference configs)')
@@ -1161,17 +1194,21 @@ class HipEngine:
         nseq = R * nframes
         (pj0, xb0, whh0, fz0), (pj1, xb1, whh1, fz1) = L['lstm']
         out0 = torch.empty(nseq, W, 2 * H, dtype=torch.float16, device=h.device)
+        out1 = torch.empty(R, T, 2 * H, dtype=torch.float16, device=h.device)
+        if self.stage_hook is not None and not getattr(self, '_train', False):
+            self.stage_hook('lstm+')                         # (BatchPipeline: the two recurrent launches on their own stream kind)
         if fz0 is not None and self.fuse_lstm_proj and h.is_contiguous():
             ops.lstm(None, None, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0, x=h.view(R, T, H), fused=fz0)
         else:
             xp0 = ops.conv(pj0, h, None, B, Fo, Fo, T)                              # [B,Fo,T,8H], per position not per frame
             ops.lstm(xp0, xb0, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0)
-        out1 = torch.empty(R, T, 2 * H, dtype=torch.float16, device=h.device)
         if fz1 is not None and self.fuse_lstm_proj:
             ops.lstm(None, None, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1, x=out0, fused=fz1)
         else:
             xp1 = ops.conv(pj1, out0.view(nseq, 1, W, 2 * H), None, nseq, 1, 1, W)  # [nseq,1,W,8H]
             ops.lstm(xp1, xb1, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1)
+        if self.stage_hook is not None and not getattr(self, '_train', False):
+            self.stage_hook('lstm-')
         if self.use_pw and L.get('lstm_lin_pw') is not None:
             return ops.pw(L['lstm_lin_pw'], out1.view(B, Fo, T, 2 * H), B, Fo, T, res=h)
         return ops.conv(L['lstm_lin'], out1.view(B, Fo, T, 2 * H), None, B, Fo, Fo, T, res=h)

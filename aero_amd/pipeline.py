@@ -34,13 +34,42 @@ def _tensors(out):
             yield from _tensors(o)
 
 
-class BatchPipeline:
-    """pipe = BatchPipeline(model, depth=3);  t = pipe.submit(x);  ...;  y = pipe.result(t)   (inference, model.eval())."""
+def parse_schedule(text):
+    """'stages=mmlldddd;l=prio:-1;d=mask:0:224' -> {'stages': 'mmlldddd', 'l': ('prio', -1), 'd': ('mask', 0, 224)}.
+    `stages`: one letter per stage of the forward (encoder layers 1-4, decoder layers 5-8; the STFT / normalisation run with the first, the
+    iSTFT with the last); 'm' is the batch's own stream of the ring.  Every other letter names a stream KIND of which each slot of the ring
+    gets its own object: 'prio:p' a stream of dispatch priority p, 'mask:lo:hi' a stream restricted to the CUs [lo, hi), 'plain' a
+    default stream.  A kind marked 'shared' (e.g. 'l=prio:-1:shared') is ONE stream for all slots."""
+    out = {}
+    for item in text.split(';'):
+        if not item.strip():
+            continue
+        k, v = item.split('=')
+        k, v = k.strip(), v.strip()
+        if k in ('stages', 'lstm'):
+            out[k] = v
+            continue
+        parts = v.split(':')
+        shared = parts[-1] == 'shared'
+        if shared:
+            parts = parts[:-1]
+        out[k] = (parts[0],) + tuple(int(x) for x in parts[1:]) + (('shared',) if shared else ())
+    return out
 
-    def __init__(self, model, depth=3):
+
+class BatchPipeline:
+    """pipe = BatchPipeline(model, depth=3);  t = pipe.submit(x);  ...;  y = pipe.result(t)   (inference, model.eval()).
+    `schedule` (a dict or the text form of parse_schedule): which HIP stream each stage of a batch is issued on -- see DESIGN.md 4.6e."""
+
+    def __init__(self, model, depth=3, schedule=None):
         self.model = model
         self.depth = max(1, int(depth))
+        self.schedule = parse_schedule(schedule) if isinstance(schedule, str) else schedule
+        if self.schedule is not None and set(self.schedule.setdefault('stages', 'mmmmmmmm')) == {'m'} and 'lstm' not in self.schedule:
+            self.schedule = None
         self._streams = {}
+        self._kinds = {}
+        self._slot_done = {}
         self._n = 0
         self._seen = set()
         self._open = []
@@ -50,6 +79,29 @@ class BatchPipeline:
             from .engine import side_streams
             self._streams[dev] = side_streams(dev, self.depth)     # (shared with the engine's half-batch streams: see there)
         return self._streams[dev]
+
+    def _kind_stream(self, dev, slot, letter):
+        """the stream of kind `letter` that belongs to slot `slot` of the ring"""
+        if letter == 'm':
+            return self._ring(dev)[slot]
+        spec = self.schedule[letter]
+        shared = spec[-1] == 'shared'
+        key = (dev, letter, 0 if shared else slot)
+        st = self._kinds.get(key)
+        if st is None:
+            from .engine import special_stream
+            tag = ('pipe', letter, key[2])
+            if spec[0] == 'prio':
+                st = special_stream(dev, priority=spec[1], tag=tag)
+            elif spec[0] == 'mask':
+                st = special_stream(dev, cu_range=(spec[1], spec[2]), tag=tag)
+            else:
+                st = special_stream(dev, priority=0, tag=tag)
+            self._kinds[key] = st
+        return st
+
+    def _all_streams(self, dev):
+        return list(self._ring(dev)) + [s for (d, _, _), s in self._kinds.items() if d == dev]
 
     def submit(self, mix, to_host=False, **kw):
         """enqueue model(mix, **kw) (Aero.forward's keywords) and return a ticket for `result`.
@@ -75,19 +127,55 @@ class BatchPipeline:
         if eng._weights_key(dev) != eng._key:
             # the weights changed since the last pack: the packed images are about to be replaced (and their memory recycled on the caller's
             # stream) while batches in flight may still read them -- let the caller's stream wait for those batches first
-            for s in ring:
+            for s in self._all_streams(dev):
                 cur.wait_stream(s)
         eng._prepare(dev)                                   # weights are (re-)packed on the caller's stream, which the batch stream waits for
-        st = ring[self._n % self.depth]
+        slot = self._n % self.depth
         self._n += 1
+        hook = None
+        if self.schedule is None:
+            st = ring[slot]
+        else:
+            # Stages of this batch on different streams of its slot.  One stage follows the other (fork = event + wait), so a batch is
+            # still ONE chain; what changes is which queue -- priority, CU set -- its launches wait in next to the other batches'.
+            # The caching allocator keeps one pool per stream and reuses a freed block without waiting for OTHER streams: a block of
+            # stream s that a later stage read on stream s' returns to s's pool and is handed out again by the NEXT batch of this slot,
+            # which therefore starts behind this batch's last stage (`_slot_done`).  A 'shared' kind breaks that pairing: its blocks are
+            # marked (record_stream) when a stage on another stream ends.
+            stages = self.schedule['stages']
+            st = self._kind_stream(dev, slot, stages[0])
+            prev = self._slot_done.get((dev, slot))
+            if prev is not None:
+                st.wait_event(prev)
+            state = {'cur': st}
+
+            def hook(i, stages=stages, state=state, dev=dev, slot=slot):
+                if isinstance(i, str):                      # 'lstm+' / 'lstm-': the recurrent launches on the kind named by schedule['lstm']
+                    if 'lstm' not in self.schedule:
+                        return
+                    if i == 'lstm+':
+                        state['back'] = state['cur']
+                        nxt = self._kind_stream(dev, slot, self.schedule['lstm'])
+                    else:
+                        nxt = state['back']
+                elif i >= len(stages):
+                    return
+                else:
+                    nxt = self._kind_stream(dev, slot, stages[i])
+                if nxt is not state['cur']:
+                    ev = torch.cuda.Event()
+                    ev.record(state['cur'])
+                    nxt.wait_event(ev)
+                    torch.cuda.set_stream(nxt)
+                    state['cur'] = nxt
         st.wait_stream(cur)
         if host_in is None:
             mix.record_stream(st)
         # the whole batch on this stream as the plain eager kernel sequence: no half-batch split inside a pipelined batch, and NOT the
         # AERO_GRAPH replay path -- HipEngine._forward_graph keeps one (graph, static input, static output) per shape whatever the stream, so
         # two batches in flight would share the graph's static buffers
-        saved = eng.streams, eng.use_graph
-        eng.streams, eng.use_graph = 1, False
+        saved = eng.streams, eng.use_graph, eng.stage_hook
+        eng.streams, eng.use_graph, eng.stage_hook = 1, False, hook
         try:
             with torch.cuda.stream(st), torch.no_grad():
                 if host_in is not None:
@@ -101,18 +189,23 @@ class BatchPipeline:
                         h.copy_(t, non_blocking=True)
                         return h
                     out = tuple(down(t) for t in out) if isinstance(out, (tuple, list)) else down(out)
+                if hook is not None:
+                    st = state['cur']                       # the stream of the batch's last stage: the one the ticket's event belongs to
         finally:
-            eng.streams, eng.use_graph = saved
+            eng.streams, eng.use_graph, eng.stage_hook = saved
         key = (str(dev), tuple(mix.shape), tuple(sorted(kw.items())))
         if key not in self._seen:
             # the first batch of a shape builds the engine's lazily created device tables (window, envelope, DFT table, constant
             # buffers) on ITS stream: the other streams must not run ahead of that
             self._seen.add(key)
-            for s in ring:
-                s.wait_stream(st)
+            for s in self._all_streams(dev):
+                if s is not st:
+                    s.wait_stream(st)
             cur.wait_stream(st)                             # ... nor a direct model(x) on the caller's stream right behind this submit
         ev = torch.cuda.Event()
         ev.record(st)
+        if hook is not None:
+            self._slot_done[(dev, slot)] = ev
         t = _Ticket(out, ev, st, host=to_host, keep=host_in)
         # tickets are held WEAKLY: a caller that drops a ticket (or dies between submit and result) frees its outputs, pinned buffers and
         # event with it instead of leaving them in this list for the life of the pipeline
@@ -142,9 +235,9 @@ class BatchPipeline:
             if t is not None:
                 self.result(t)
         self._open = []
-        for dev, ring in self._streams.items():             # (batches whose tickets were dropped: their streams are waited for all the same)
+        for dev in self._streams:                           # (batches whose tickets were dropped: their streams are waited for all the same)
             cur = torch.cuda.current_stream(dev)
-            for s in ring:
+            for s in self._all_streams(dev):
                 cur.wait_stream(s)
 
     def run(self, batches, to_host=False, **kw):

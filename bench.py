@@ -428,15 +428,33 @@ def main():
                 roof_stft[kname] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                     'frac': round(ach / PEAK_HBM_GBS, 4), 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
                                     'bytes_per_launch': v['bytes'] / v['launches']}
-        # north_star's named targets INSIDE `roofline` (the driver's record keeps `roofline` and `config`, not extra top-level keys):
-        # conv stack >= 40 % of the MFMA peak, STFT >= 50 % of HBM; the one-at-a-time step next to the pipelined one
+        # north_star's named targets as FLAT scalars inside `roofline` (the driver's record keeps the scalar keys of `roofline` and `config`
+        # and drops nested objects and extra top-level keys): conv stack >= 40 % of the MFMA peak, STFT >= 50 % of HBM, the D2 / D3 tile,
+        # the latency-bound families, the one-at-a-time step next to the pipelined one
         if roof is not None:
             if roof_stack:
-                roof['conv_stack'] = {'frac': roof_stack['frac'], 'achieved': roof_stack['achieved'], 'unit': 'TFLOP/s', 'ms_per_step': roof_stack['ms_per_step'],
-                                      'flops_per_step': roof_stack['flops_per_step']}
+                roof.update(conv_stack_frac=roof_stack['frac'], conv_stack_tflops=roof_stack['achieved'], conv_stack_ms=roof_stack['ms_per_step'],
+                            conv_stack_gflop_per_step=round(roof_stack['flops_per_step'] / 1e9, 1))
             for kname, v in roof_stft.items():
-                roof['istft' if 'istft' in kname else 'stft'] = {'kernel': kname, 'bound': 'hbm', 'frac': v['frac'], 'achieved': v['achieved'], 'unit': 'GB/s',
-                                                                 'avg_launch_ms': v['avg_launch_ms'], 'bytes_per_launch': v['bytes_per_launch']}
+                pre = 'istft' if 'istft' in kname else 'stft'
+                roof.update({pre + '_frac': v['frac'], pre + '_gbs': v['achieved'], pre + '_us': round(v['avg_launch_ms'] * 1e3, 1),
+                             pre + '_mb_per_launch': round(v['bytes_per_launch'] / 1e6, 2)})
+
+            def fam(pred):
+                sel = [v for n, v in kernels.items() if pred(n)]
+                return sum(v['ms'] for v in sel), sum(v['flops'] for v in sel)
+            ms23, fl23 = fam(lambda n: 'aero_conv_ring_kernel<2, 2, 3, 3' in n or 'aero_conv_ring_kernel<2, 4, 3, 3' in n)
+            if ms23 > 0:
+                roof.update(d23_tile_frac=round(fl23 / (ms23 * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS, 4), d23_tile_ms=round(ms23 / nprof, 3))
+            roof.update(lstm_ms=round(fam(lambda n: 'lstm' in n)[0] / nprof, 3), localstate_ms=round(fam(lambda n: 'attn' in n)[0] / nprof, 3))
+            clock = None
+            try:                                              # effective clock under the dominant kernel (GRBM_GUI_ACTIVE / duration, tools/pmc_clock.py)
+                ck = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_clock.json')))
+                if ck.get('_meta', {}).get('kernels_sha') == kernels_sha():
+                    clock = ck.get(dom.replace('void ', '').split('(')[0], {}).get('clock_ghz')
+            except Exception:
+                pass
+            roof['clock_ghz'] = clock
             roof['ms_per_step_one_at_a_time'] = None if dt_serial != dt_serial else round(dt_serial / args.steps * 1e3, 3)
             roof['kernel_sum_ms_per_step'] = round(sum(v['ms'] for v in kernels.values()) / nprof, 3)
     else:
@@ -452,13 +470,19 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(secs, FULL_CFG['lr_sr'])
     audio_s = world * B * secs * args.steps
-    # the other single-GPU configurations, summarised INSIDE `config` (the driver's record drops extra top-level keys)
+    # the other single-GPU configurations as FLAT scalars inside `config` (the driver's record drops nested objects and extra top-level keys)
     other = {}
-    for e, key in zip(extra or [], ('config4_inference', 'config5_train_step', 'config5_adversarial_step')):
+    for e, key in zip(extra or [], ('config4', 'config5_train', 'config5_adv')):
         if not isinstance(e, dict) or 'ms_per_step' not in e:
-            other[key] = {'error': str((e or {}).get('error', 'no result'))[:200]} if isinstance(e, dict) else {'error': 'no result'}
+            other[key + '_error'] = str((e or {}).get('error', 'no result'))[:120] if isinstance(e, dict) else 'no result'
             continue
-        other[key] = {k: e[k] for k in ('value', 'unit', 'ms_per_step', 'ms_per_step_one_at_a_time', 'ms_per_step_hip_graph') if k in e}
+        if key == 'config4':
+            other.update(config4_ms_per_step=e['ms_per_step'], config4_rtf=e['value'], config4_ms_one_at_a_time=e.get('ms_per_step_one_at_a_time'))
+        elif key == 'config5_train':
+            g_ms = e.get('ms_per_step_hip_graph')
+            other.update(config5_train_ms=e['ms_per_step'], config5_train_graph_ms=g_ms if isinstance(g_ms, (int, float)) else None)
+        else:
+            other.update(config5_adv_ms=e['ms_per_step'])
     out = {
         'metric': 'real-time-factor (audio-sec/wall-sec), Aero.forward STFT+U-Net+iSTFT, 4->16kHz nfft=512 hop=64 batch=64 per GPU',
         'value': round(audio_s / dt, 2), 'unit': 'audio-sec/wall-sec', 'n_gpus': ranks_verified, 'steps': args.steps,
@@ -471,7 +495,7 @@ def main():
                                 '(aero_amd/pipeline.py); all K steps complete inside the timed region; ms_per_step_one_at_a_time = model(x) in a loop')
                                if depth > 1 else 'one forward at a time (two half-batch streams inside each)',
                    'ms_per_step_one_at_a_time': None if dt_serial != dt_serial else round(dt_serial / args.steps * 1e3, 3),
-                   'other_configs': other or None,
+                   **other,
                    'global_batch': world * B, 'clip_samples': L, 'frames': 501, 'parallelism': f'clips sharded over {world} GPU(s), no data-path collective',
                    'precision': 'fp16 operands/storage, fp32 accumulate; STFT/iSTFT/statistics fp32'},
         'roofline': roof, 'roofline_conv_stack': roof_stack, 'roofline_stft': roof_stft, 'cpu_baseline': cpu, 'extra_configs': extra,

@@ -601,6 +601,15 @@ int aero_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
 int aero_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
 int aero_comm_destroy(void* comm);
 
+/* HIP streams with a dispatch priority or a CU mask (round 6; the reference has no counterpart: its predict.py:76-80 / enhance.py:11-15 run
+ * one forward at a time on the default stream).  aero_amd/pipeline.py issues the latency-bound segment of each batch in flight (encoder 2-3:
+ * LSTM, LocalState) on such a stream so that its workgroups are dispatched ahead of / beside the other batches' MFMA tiles.
+ * priority: 0 default, < 0 higher, > 0 lower (clamped to the device's range).  cu_mask (n_words 32-bit words, NULL / 0 = every CU): bit i
+ * enables CU i in the runtime's enumeration -- on gfx950 round-robin over the 8 XCDs, so the low 8 n bits are n CUs of every XCD; a masked
+ * stream has the default priority.  The handle is a hipStream_t (usable as the `stream` argument of every entry point above). */
+int aero_stream_create(int32_t priority, const uint32_t* cu_mask, int32_t n_words, void** stream);
+int aero_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif
