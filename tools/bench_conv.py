@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--iters', type=int, default=int(os.environ.get('ITERS', 20)))
     ap.add_argument('--T', type=int, default=501)
     ap.add_argument('--lib', default=None, help='alternative build of the C-ABI library (profiling variants)')
+    ap.add_argument('--zeros', action='store_true', help='zero-filled operands: the same instruction stream at lower switching power (DVFS give-back, MI355X_MICROARCH.md)')
     ap.add_argument('--race', type=int, default=0, help='repeat each launch this many times and require bit-identical outputs')
     a = ap.parse_args()
     dev = 'cuda'
@@ -53,11 +54,15 @@ def main():
             print(f'{name}: {ms * 1e3:8.1f} us  {nb / ms / 1e9:6.2f} TB/s  (C={C} M={M} rows={a.batch * F}, {nb / 1e6:.0f} MB)', flush=True)
             continue
         C0, C1, M, F, null0, glu = LAYERS[name]
-        w = torch.randn(M, C0 + C1, 3, 3) * 0.02
+        w = torch.randn(M, C0 + C1, 3, 3) * (0.0 if a.zeros else 0.02)
         taps, df, dt = pack.conv2d_taps(w, 1, 1)
         spec = pack.make_conv_spec(taps, torch.zeros(M), C0, C1, df, dt, dev, act=_lib.ACT_GLU if glu else _lib.ACT_NONE)
         x = None if null0 else torch.randn(a.batch, F, a.T, C0, device=dev).half()
         sk = torch.randn(a.batch, F, a.T, C1, device=dev).half()
+        if a.zeros:
+            sk.zero_()
+            if x is not None:
+                x.zero_()
         out = torch.empty(a.batch, F, a.T, M // 2 if glu else M, device=dev, dtype=torch.float16)
         for _ in range(3):
             ops.conv(spec, x, sk, a.batch, F, F, a.T, dst=out)
