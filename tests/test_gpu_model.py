@@ -308,3 +308,22 @@ def test_batch_pipeline_repacks_between_batches(meta):
         w.div_(1.5)
     assert all(torch.equal(y, y_old) for y in outs_b)
     assert all(torch.equal(y, y_new) for y in outs_a)
+
+
+def test_planted_faults_are_caught_on_the_device(meta):
+    """tests/sensitivity_cases.py once on the MI355X: with one deliberate fault at a time in the launch sequence (LSTM output, direction
+    halves, stitch map, LocalState decay / key index / head map, Snake, DConv dilations / residual / LayerScale / GLU half, frequency
+    embedding, FTB gate, freq_fc orientation, ...) the reference's stress golden -- or, for the two one-step index slips, its op-level
+    module vector -- must FAIL the 1e-3 bar that the clean run passes.  The goldens see every branch, on the hardware too."""
+    import sensitivity_cases as S
+    from aero_amd import _lib
+    lib = _lib.load()
+    e_spec, e_wav = S.run(meta, lib, None, device='cuda')
+    assert e_spec < S.BAR and e_wav < 5e-3
+    report = {}
+    for fault in S.FAULTS:
+        e, _ = S.run(meta, lib, fault, device='cuda')
+        report[fault] = e
+        if fault not in S.SURVIVORS:
+            assert e > S.BAR, f'{fault} survived on the device: {e:.3e}'
+    print('clean %.3e | ' % e_spec + ' | '.join(f'{k} {v:.2e}' for k, v in report.items()))
