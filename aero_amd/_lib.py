@@ -154,8 +154,11 @@ _PROTOS = {
     'aero_stft_dft_table_bytes': (i64, [i32]),
     'aero_stft_dft_table': (i32, [fp, i32, i32, vp, vp]),
     'aero_stft_dft_fwd': (i32, [fp, i32, i32, i32, i32, i32, i32, vp, fp, i32, dp, i32, vp]),
+    'aero_stft_dft_norm_fwd': (i32, [fp, i32, i32, i32, i32, i32, i32, vp, i32, dp, i32, vp, fp, vp]),
     'aero_spec_normalize': (i32, [fp, i32, i64, dp, vp, fp, vp]),
     'aero_istft_fwd': (i32, [fp, i32, i32, i32, i32, i32, fp, fp, fp, i32, vp]),
+    'aero_istft_pitch': (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+    'aero_istft_pitched_fwd': (i32, [fp, i32, i32, i32, i32, i32, i32, i32, fp, fp, fp, i32, vp]),
     'aero_conv_fwd': (i32, [C.POINTER(ConvDesc), vp]),
     'aero_split_finish': (i32, [fp, i32, fp, i32, vp, i64, i32, vp]),
     'aero_adam_step': (i32, [fp, fp, fp, fp, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float, vp]),
@@ -169,6 +172,7 @@ _PROTOS = {
     'aero_conv_tile_m': (i32, [i32]),
     'aero_conv_ring_bm': (i32, [i32, i32]),
     'aero_convtr_tail_finish': (i32, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, vp]),
+    'aero_convtr_tail_finish_pitched': (i32, [fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'aero_conv_kernel_name': (i32, [C.POINTER(ConvDesc), C.c_char_p, i32]),
     'aero_norm_stats': (i32, [C.POINTER(NormDesc), vp]),
     'aero_norm_apply': (i32, [C.POINTER(NormDesc), vp]),

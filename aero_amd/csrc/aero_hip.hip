@@ -261,6 +261,13 @@ int aero_stft_dft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32
     return aero_finish(rc, err);
 }
 
+int aero_stft_dft_norm_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, int32_t win_off, const void* table,
+                           int32_t T, double* stats, int32_t sig_per_item, void* xn, float* mean_std, void* stream) {
+    const char* err = "";
+    int rc = aero_stft_dft_launch(x, nsig, L, Lp, n_fft, hop, win_off, table, nullptr, T, stats, sig_per_item, (hipStream_t)stream, &err, xn, mean_std);
+    return aero_finish(rc, err);
+}
+
 int aero_spec_normalize(const float* spec, int32_t nitems, int64_t n_per_item, const double* stats, void* xn,
                         float* mean_std, void* stream) {
     const char* err = "";
@@ -281,6 +288,21 @@ int aero_istft_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_
                    const float* inv_env, float* y, int32_t Lout, void* stream) {
     const char* err = "";
     int rc = aero_istft_launch(spec, nsig, F, T, n_fft, hop, window, inv_env, y, Lout, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_istft_pitch(int32_t n_fft, int32_t hop, int32_t T, int32_t* pitch, int32_t* t_off) {
+    if (!pitch || !t_off || n_fft < 2 || hop < 1 || T < 1) return aero_fail(AERO_ERR_ARG, "istft_pitch: bad arguments");
+    int pp, to;
+    aero_istft_pitch_for(n_fft, hop, T, &pp, &to);
+    *pitch = pp; *t_off = to;
+    return AERO_OK;
+}
+
+int aero_istft_pitched_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_t pitch, int32_t t_off, int32_t n_fft, int32_t hop,
+                           const float* window, const float* inv_env, float* y, int32_t Lout, void* stream) {
+    const char* err = "";
+    int rc = aero_istft_launch(spec, nsig, F, T, n_fft, hop, window, inv_env, y, Lout, (hipStream_t)stream, &err, pitch, t_off);
     return aero_finish(rc, err);
 }
 
@@ -598,6 +620,13 @@ int aero_convtr_tail_finish(const float* lo, const float* hi, const float* bias,
                             int32_t B, int32_t Fin, int32_t T, int32_t dst_F, int32_t pad, void* stream) {
     const char* err = "";
     int rc = aero_convtr_tail_finish_launch(lo, hi, bias, scale, shift, dst, B, Fin, T, dst_F, pad, (hipStream_t)stream, &err);
+    return aero_finish(rc, err);
+}
+
+int aero_convtr_tail_finish_pitched(const float* lo, const float* hi, const float* bias, const float* scale, const float* shift, float* dst,
+                                    int32_t B, int32_t Fin, int32_t T, int32_t dst_F, int32_t pad, int32_t pitch, int32_t t_off, void* stream) {
+    const char* err = "";
+    int rc = aero_convtr_tail_finish_launch(lo, hi, bias, scale, shift, dst, B, Fin, T, dst_F, pad, (hipStream_t)stream, &err, pitch, t_off);
     return aero_finish(rc, err);
 }
 

@@ -227,7 +227,7 @@ static __device__ __forceinline__ void aero_ring_tail_epilogue(const AeroConvK& 
 
 // out[b][fo][t][co] = (lo[b][q][t][2k + co] + hi[b][q - 1][t][2k + co] + bias[co]) * scale[b] + shift[b],  q = (fo + pad) / 4, k = (fo + pad) % 4
 __global__ __launch_bounds__(256) void aero_convtr_tail_finish_kernel(const float* lo, const float* hi, const float* bias, const float* scale,
-                                                                      const float* shift, float* dst, int Fin, int T, int dstF, int pad) {
+                                                                      const float* shift, float* dst, int Fin, int T, int dstF, int pad, int P, int toff) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int q = blockIdx.y, b = blockIdx.z;
     if (t >= T) return;
@@ -249,16 +249,18 @@ __global__ __launch_bounds__(256) void aero_convtr_tail_finish_kernel(const floa
     for (int k = 0; k < 4; ++k) {
         const int fo = 4 * q + k - pad;
         if (fo < 0 || fo >= dstF) continue;
-        *(f32x2*)(dst + (((int64_t)b * dstF + fo) * T + t) * 2) = (f32x2){fmaf(v[2 * k] + b0, sc, sh), fmaf(v[2 * k + 1] + b1, sc, sh)};
+        *(f32x2*)(dst + (((int64_t)b * dstF + fo) * P + toff + t) * 2) = (f32x2){fmaf(v[2 * k] + b0, sc, sh), fmaf(v[2 * k + 1] + b1, sc, sh)};
     }
 }
 
 static int aero_convtr_tail_finish_launch(const float* lo, const float* hi, const float* bias, const float* scale, const float* shift, float* dst,
-                                          int B, int Fin, int T, int dstF, int pad, hipStream_t stream, const char** err) {
+                                          int B, int Fin, int T, int dstF, int pad, hipStream_t stream, const char** err, int pitch = 0, int toff = 0) {
     if (!lo || !hi || !dst || B < 1 || Fin < 1 || T < 1 || dstF < 1 || pad < 0 || pad > 3) { *err = "convtr_tail_finish: bad arguments"; return AERO_ERR_ARG; }
+    if (pitch == 0) pitch = T;
+    if (toff < 0 || pitch < toff + T) { *err = "convtr_tail_finish: pitch < toff + T"; return AERO_ERR_ARG; }
     if (((uintptr_t)lo & 15) || ((uintptr_t)hi & 15) || ((uintptr_t)dst & 7) || B > 65535 || Fin + 1 > 65535) { *err = "convtr_tail_finish: alignment / size"; return AERO_ERR_ARG; }
     AERO_LAUNCH(aero_convtr_tail_finish_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)(Fin + 1), (unsigned)B), dim3(256), stream, lo, hi, bias, scale, shift,
-                dst, Fin, T, dstF, pad);
+                dst, Fin, T, dstF, pad, pitch, toff);
     return AERO_OK;
 }
 

@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void aero_spec_normalize_kernel(const float* s
 struct AeroIstftK {
     const float* spec; const float* window; const float* inv_env; float* y;
     int nsig, F, T, n_fft, hop, hsh, Lout, FPB, SEG;         // hsh = log2(hop) if hop is a power of two, else -1
+    int P, toff;                                             // row pitch of `spec` in frames (>= toff + T) and the column of frame 0 (aero_istft2_kernel only)
 #ifdef AERO_ISTFT_DEBUG
     // tools/dbg builds only (never the product library): bit 0 = re-read every spectrum value past the caches (sc0 sc1) and count the
     // values that differ from the ordinary load in dbg[0] (first mismatch: dbg[1..5]); bit 1 = take the cache-bypassing loads as THE loads
@@ -531,7 +532,11 @@ __global__ __launch_bounds__(512) void aero_istft2_kernel(AeroIstftK p) {
     const int h2 = n >> hsh;                                                       // frames before the first kept sample
     const int F0 = seg * AERO_ISTFT2_SEGF + h2 - AERO_ISTFT2_HALO;                 // first frame this block transforms (may be < 0: zeros)
     aero_fft_init_twiddles(tw, n_fft);
-    const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * T;
+    // Rows of `spec` have a pitch of P frames and start at column toff: with P * 8 B a multiple of 128 B and toff chosen so that the
+    // 16-frame groups below start on a line (aero_istft_pitch), a group's 128-byte run per bin is ONE cache line instead of a straddle of two
+    // (round 5 PMC: 115 MB fetched for 74 MB with rows of 4 008 B).  P = T, toff = 0 is the plain complex64 [F][T] layout.
+    const int P = p.P;
+    const f32x2* X = (const f32x2*)p.spec + (int64_t)sig * p.F * P + p.toff;
     float* ys = p.y + (int64_t)sig * p.Lout;
     const float scale = sqrtf((float)n_fft) / (float)n;
     const int fr = tid & 15, k0 = tid >> 4;                                         // this thread's frame of the group, first pair index
@@ -551,10 +556,10 @@ __global__ __launch_bounds__(512) void aero_istft2_kernel(AeroIstftK p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int k = k0 + 32 * it;
-            xa[it] = X[k * T + t];
-            xq[it] = X[(k == 0 ? n - 1 : n - k) * T + t];             // (k = 0 pairs with the implicit zero Nyquist bin: value unused)
+            xa[it] = X[k * P + t];
+            xq[it] = X[(k == 0 ? n - 1 : n - k) * P + t];             // (k = 0 pairs with the implicit zero Nyquist bin: value unused)
         }
-        xm = X[NP * T + (tid < 16 ? t : 0)];
+        xm = X[NP * P + (tid < 16 ? t : 0)];
     };
     auto deposit = [&](int tg, int rel0) {                              // rel0: tg - F0, the group's first ring position
         const int t = tg + fr;
@@ -754,6 +759,7 @@ static int aero_stft_launch(const float* x, int nsig, int L, int Lp, int n_fft, 
 struct AeroStftDftK {
     const float* x; const h16* table; float* spec; double* stats;
     int nsig, L, Lp, n_fft, hop, win_off, T, sig_per_item;
+    h16* xn; float* mean_std;                                    // MODE 2: the normalised fp16 spectrogram and (mean, std) per item
 };
 
 // table image: fp16 [part hi|lo][chunk 0..3][n_fft rows (2f + {re, im})][32], rows in tile order (aero_tile_off); value * 2^10
@@ -777,10 +783,18 @@ __global__ __launch_bounds__(256) void aero_stft_dft_table_kernel(const float* w
     }
 }
 
+// MODE 0: fp32 spectrogram + per-item sums (the form above).  Round 6: the forward does not need the fp32 spectrogram
+// unless the caller asks for it (`return_lr_spec`) -- what the U-Net reads is the per-item NORMALISED fp16 tensor (aero.py:459-464), and the
+// pair "DFT writes 66 MB fp32 + sums; aero_spec_normalize re-reads them and writes 33 MB" moved 166 MB for a 33-MB result.  The DFT is 4 GF:
+// cheaper to run twice than to round-trip its output.  MODE 1: the sums only (nothing stored; the same code, the same summation order:
+// mean / std are BIT-identical to MODE 0's).  MODE 2: recompute and store (v - mean) / (1e-5 + std) as fp16, the arithmetic of
+// aero_spec_normalize_kernel on the same fp32 values -- the output equals the unfused pair's bit for bit.
+template <int MODE>
 __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
     __shared__ AERO_LDS_ALIGN h16 As[4][2][128 * 32];             // [chunk][hi | lo][128 rows][32]: the block's whole table slice
     __shared__ AERO_LDS_ALIGN h16 xh[AERO_DFT_SPAN + 8], xl[AERO_DFT_SPAN + 8];
     __shared__ double red[2][8];
+    __shared__ float nrm[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = aero_uniform(tid >> 6);
     const int kg = lane >> 4, col = lane & 15;
     const int wr = wave >> 1, wc = wave & 1;                     // wave tile: rows wr*32 .. +32, frames wc*64 .. +64
@@ -803,7 +817,21 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
     // Per-item statistics (sum, sum of squares of the spectrogram: aero.py:462-464): fp32 per thread over the tiles its block walks.  WHICH
     // tiles a block walks must therefore not depend on the batch size -- see the launcher: gridDim.x is a function of T only.
     float s = 0.f, ss = 0.f;
-    float* out = p.spec + (int64_t)sig * n_bins * p.T * 2;
+    float* out = MODE == 0 ? p.spec + (int64_t)sig * n_bins * p.T * 2 : nullptr;
+    h16* outn = MODE == 2 ? p.xn + (int64_t)sig * n_bins * p.T * 2 : nullptr;
+    if (MODE == 2 && tid == 0) {                                 // (aero_spec_normalize_kernel's arithmetic, once per block)
+        const int item = sig / p.sig_per_item;
+        const double N = (double)p.sig_per_item * n_bins * p.T * 2;
+        const double S = p.stats[2 * item], SS = p.stats[2 * item + 1];
+        const double mean = S / N;
+        double var = (SS - S * S / N) / (N - 1.0);
+        if (var < 0) var = 0;
+        const float fm = (float)mean, fs = (float)sqrt(var);
+        nrm[0] = fm;
+        nrm[1] = 1.0f / (1e-5f + fs);
+        if (blockIdx.x == 0 && quarter == 0 && sig % p.sig_per_item == 0) { p.mean_std[2 * item] = fm; p.mean_std[2 * item + 1] = fs; }
+    }
+    float fm = 0.f, inv = 0.f;
     // the span of the (hop-padded, reflect-padded) signal a tile's 128 frames read, one load batch per tile, REQUESTED a tile ahead (their
     // latency runs under the MFMAs and stores of the tile before); the barriers between tiles order LDS only (aero_lds_barrier) -- a
     // __syncthreads() there also waited for the tile's output stores to be acknowledged; only the first one covers the table copies.
@@ -850,8 +878,10 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (tile == (int)blockIdx.x) __syncthreads();                // first tile: the table slice's direct copies have landed (vmcnt drained) ...
-    else aero_lds_barrier();                                     // ... later tiles: the span only
+    if (tile == (int)blockIdx.x) {
+        __syncthreads();                                         // first tile: the table slice's direct copies have landed (vmcnt drained) ...
+        if (MODE == 2) { fm = nrm[0]; inv = nrm[1]; }
+    } else aero_lds_barrier();                                   // ... later tiles: the span only
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
         h16x8 ah[2], al[2];
@@ -883,14 +913,21 @@ __global__ __launch_bounds__(512) void aero_stft_dft_kernel(AeroStftDftK p) {
         for (int i = 0; i < 2; ++i) {
             const int f = (quarter * 128 + wr * 32 + i * 16 + kg * 4) >> 1;
             const f32x4 v = acc[i][n] * (1.0f / 1024.0f);
-            *(f32x2*)(out + ((int64_t)f * p.T + t) * 2) = (f32x2){v[0], v[1]};
-            *(f32x2*)(out + ((int64_t)(f + 1) * p.T + t) * 2) = (f32x2){v[2], v[3]};
-            s += (v[0] + v[1]) + (v[2] + v[3]);
-            ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            if (MODE == 0) {
+                *(f32x2*)(out + ((int64_t)f * p.T + t) * 2) = (f32x2){v[0], v[1]};
+                *(f32x2*)(out + ((int64_t)(f + 1) * p.T + t) * 2) = (f32x2){v[2], v[3]};
+            }
+            if (MODE == 2) {
+                *(h16x2*)(outn + ((int64_t)f * p.T + t) * 2) = (h16x2){(h16)((v[0] - fm) * inv), (h16)((v[1] - fm) * inv)};
+                *(h16x2*)(outn + ((int64_t)(f + 1) * p.T + t) * 2) = (h16x2){(h16)((v[2] - fm) * inv), (h16)((v[3] - fm) * inv)};
+            } else {
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+                ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
         }
     }
     }
-    if (p.stats) {
+    if (MODE != 2 && p.stats) {
         const double ds = aero_wave_sum((double)s), dss = aero_wave_sum((double)ss);
         if (lane == 0) { red[0][wave] = ds; red[1][wave] = dss; }
         __syncthreads();
@@ -918,9 +955,12 @@ static int aero_stft_dft_table_launch(const float* window, int n_fft, int win_of
     return AERO_OK;
 }
 
+// spec != NULL: MODE 0 (xn / mean_std unused).  spec == NULL: the fused form -- MODE 1 then MODE 2 on the same stream (stats, xn, mean_std required)
 static int aero_stft_dft_launch(const float* x, int nsig, int L, int Lp, int n_fft, int hop, int win_off, const void* table, float* spec,
-                                int T, double* stats, int sig_per_item, hipStream_t stream, const char** err) {
-    if (!x || !table || !spec) { *err = "stft_dft: null pointer"; return AERO_ERR_ARG; }
+                                int T, double* stats, int sig_per_item, hipStream_t stream, const char** err, void* xn = nullptr,
+                                float* mean_std = nullptr) {
+    if (!x || !table || (!spec && !(xn && mean_std && stats))) { *err = "stft_dft: null pointer"; return AERO_ERR_ARG; }
+    if (!spec && ((uintptr_t)xn & 3)) { *err = "stft_dft: misaligned output"; return AERO_ERR_ARG; }
     if (!aero_stft_dft_ok(n_fft, hop, win_off)) { *err = "stft_dft: n_fft % 256, hop % 8, hop <= 16 and a window of <= 128 samples are required"; return AERO_ERR_UNSUPPORTED; }
     if (Lp < L || T != 1 + Lp / hop || Lp <= n_fft / 2) { *err = "stft_dft: inconsistent L/Lp/hop/T"; return AERO_ERR_ARG; }
     if ((stats && sig_per_item < 1) || ((uintptr_t)table & 15) || ((uintptr_t)spec & 7)) { *err = "stft_dft: bad arguments"; return AERO_ERR_ARG; }
@@ -929,6 +969,7 @@ static int aero_stft_dft_launch(const float* x, int nsig, int L, int Lp, int n_f
     p.x = x; p.table = (const h16*)table; p.spec = spec; p.stats = stats;
     p.nsig = nsig; p.L = L; p.Lp = Lp; p.n_fft = n_fft; p.hop = hop; p.win_off = win_off; p.T = T;
     p.sig_per_item = sig_per_item > 0 ? sig_per_item : 1;
+    p.xn = (h16*)xn; p.mean_std = mean_std;
     // blocks walk the time tiles of their (signal, table quarter) with the table slice resident: TWO blocks per (signal, quarter), each
     // walking every second tile (B = 64: 512 blocks = the chip twice over, two 74-KiB blocks fit a CU; measured 26.0 / 23.3 / 28.4 / 26.5 us
     // with 1 / 2 / 3 / 4).  The count must NOT follow the batch size (until round 5 it was "enough blocks for 512": 2 at B = 64, 4 at
@@ -941,7 +982,12 @@ static int aero_stft_dft_launch(const float* x, int nsig, int L, int Lp, int n_f
     int gx = tpb_env > 0 ? tpb_env : 2;
     if (gx > ntile) gx = ntile;
     dim3 grid((unsigned)gx, (unsigned)nsig, (unsigned)(n_fft / 128)), block(512);
-    AERO_LAUNCH(aero_stft_dft_kernel, grid, block, stream, p);
+    if (spec) {
+        AERO_LAUNCH(aero_stft_dft_kernel<0>, grid, block, stream, p);
+    } else {
+        AERO_LAUNCH(aero_stft_dft_kernel<1>, grid, block, stream, p);
+        AERO_LAUNCH(aero_stft_dft_kernel<2>, grid, block, stream, p);
+    }
     return AERO_OK;
 }
 
@@ -961,16 +1007,28 @@ static int aero_spec_normalize_launch(const float* spec, int nitems, int64_t n_p
     return AERO_OK;
 }
 
+// the layout aero_istft2_kernel reads with whole cache lines: pitch (frames per row) and the column of frame 0; (T, 0) when the geometry
+// runs on the other kernel
+static void aero_istft_pitch_for(int n_fft, int hop, int T, int* pitch, int* toff) {
+    *pitch = T; *toff = 0;
+    if (!aero_istft2_ok(n_fft, hop, T)) return;
+    const int h2 = (n_fft / 2) / hop;                          // a block's 16-frame groups start at frame seg * 64 + h2 + 16 g
+    *toff = (16 - (h2 & 15)) & 15;
+    *pitch = (*toff + T + 15) / 16 * 16;
+}
+
 static int aero_istft_launch(const float* spec, int nsig, int F, int T, int n_fft, int hop, const float* window,
-                             const float* inv_env, float* y, int Lout, hipStream_t stream, const char** err) {
+                             const float* inv_env, float* y, int Lout, hipStream_t stream, const char** err, int pitch = 0, int toff = 0) {
     if (!spec || !window || !inv_env || !y) { *err = "istft: null pointer"; return AERO_ERR_ARG; }
+    if (pitch == 0) pitch = T;
+    if (toff < 0 || pitch < toff + T) { *err = "istft: pitch < toff + T"; return AERO_ERR_ARG; }
     const int n = n_fft / 2;
     if (n_fft < 16 || (1 << aero_ilog2(n_fft)) != n_fft || n > AERO_FFT_MAX_N) { *err = "istft: n_fft must be a power of two in [16,1024]"; return AERO_ERR_UNSUPPORTED; }
     if (F != n) { *err = "istft: F must be n_fft/2"; return AERO_ERR_ARG; }
     if (hop < 1 || hop > n_fft || T < 1 || Lout < 1 || Lout > hop * (T - 1)) { *err = "istft: bad hop/T/Lout"; return AERO_ERR_ARG; }
     AeroIstftK p;
     p.spec = spec; p.window = window; p.inv_env = inv_env; p.y = y;
-    p.nsig = nsig; p.F = F; p.T = T; p.n_fft = n_fft; p.hop = hop; p.Lout = Lout;
+    p.nsig = nsig; p.F = F; p.T = T; p.n_fft = n_fft; p.hop = hop; p.Lout = Lout; p.P = pitch; p.toff = toff;
     static const int v2 = [] { const char* e = getenv("AERO_ISTFT_V2"); return e ? atoi(e) : 1; }();
     if (v2 && aero_istft2_ok(n_fft, hop, T)) {
         p.hsh = aero_ilog2(hop);
@@ -989,6 +1047,7 @@ static int aero_istft_launch(const float* spec, int nsig, int F, int T, int n_ff
 #undef AERO_ISTFT2_GO
         return AERO_OK;
     }
+    if (pitch != T || toff != 0) { *err = "istft: a pitched spectrogram needs the geometry aero_istft_pitch reports"; return AERO_ERR_UNSUPPORTED; }
     const int fpb = aero_istft_fpb(n);
     const int need = (n_fft + hop - 1) / hop;              // frames overlapping one sample
     if (fpb <= need) { *err = "istft: hop too small for the LDS frame ring"; return AERO_ERR_UNSUPPORTED; }

@@ -84,6 +84,7 @@ class Ops:
         self.lib = lib
         self.prof = None          # bench.py sets this to a list to collect per-launch HIP-event timings
         self.dft_stft = os.environ.get('AERO_STFT_DFT', '1') != '0'      # short-window STFT as a GEMM (k_stft.h)
+        self.fused_stft = os.environ.get('AERO_STFT_FUSED', '1') != '0'  # ... run twice (sums, then normalised fp16) instead of stft + spec_normalize
         self._dft_tables = {}
         self.prof_shapes = None   # (tools/launch_table.py) one short shape note per profiled launch
         self.tag = ''             # engine-set label of the launches being issued ('stack' = Conv2d / ConvTranspose2d of the U-Net)
@@ -118,20 +119,9 @@ class Ops:
         nsig = x.shape[0]
         T = 1 + Lp // hop
         spec = torch.empty(nsig, n_bins, T, 2, dtype=torch.float32, device=x.device)
-        if (self.dft_stft and win_len is not None and win_len <= 128 and n_bins == n_fft // 2 and n_fft % 256 == 0 and n_fft <= 4096
-                and hop % 8 == 0 and hop <= 16 and nsig <= 65535 and Lp > n_fft // 2):
+        if self._dft_applies(nsig, Lp, n_fft, hop, n_bins, win_len):
             win_off = (n_fft - win_len) // 2
-            key = (window.data_ptr(), n_fft, win_len, str(x.device))
-            table = self._dft_tables.get(key)
-            if table is None:
-                nbytes = int(self.lib.cdll.aero_stft_dft_table_bytes(n_fft))
-                table = torch.empty(nbytes // 2, dtype=torch.float16, device=x.device)
-                self.lib.call('aero_stft_dft_table', _ptr(window), n_fft, win_off, _ptr(table), self.stream(x))
-                if len(self._dft_tables) >= 8:
-                    self._dft_tables.pop(next(iter(self._dft_tables)))
-                self._dft_tables[key] = (table, window)                    # (the window tensor is kept alive with its table)
-            else:
-                table = table[0]
+            table = self._dft_table(x, window, n_fft, win_len)
             self._call('aero_stft_dft_fwd', 'aero_stft_dft_kernel', 2.0 * nsig * T * n_fft * 128, nsig * (L * 4 + n_bins * T * 8),
                        _ptr(x), nsig, L, Lp, n_fft, hop, win_off, _ptr(table), _ptr(spec), T, _ptr(stats), sig_per_item, self.stream(x))
             return spec
@@ -139,6 +129,41 @@ class Ops:
                    _ptr(x), nsig, L, Lp, n_fft, hop, _ptr(window), n_bins, _ptr(spec), T,
                    _ptr(stats), sig_per_item, self.stream(x))
         return spec
+
+    def _dft_applies(self, nsig, Lp, n_fft, hop, n_bins, win_len):
+        return (self.dft_stft and win_len is not None and win_len <= 128 and n_bins == n_fft // 2 and n_fft % 256 == 0 and n_fft <= 4096
+                and hop % 8 == 0 and hop <= 16 and nsig <= 65535 and Lp > n_fft // 2)
+
+    def _dft_table(self, x, window, n_fft, win_len):
+        win_off = (n_fft - win_len) // 2
+        key = (window.data_ptr(), n_fft, win_len, str(x.device))
+        table = self._dft_tables.get(key)
+        if table is None:
+            nbytes = int(self.lib.cdll.aero_stft_dft_table_bytes(n_fft))
+            table = torch.empty(nbytes // 2, dtype=torch.float16, device=x.device)
+            self.lib.call('aero_stft_dft_table', _ptr(window), n_fft, win_off, _ptr(table), self.stream(x))
+            if len(self._dft_tables) >= 8:
+                self._dft_tables.pop(next(iter(self._dft_tables)))
+            self._dft_tables[key] = (table, window)                    # (the window tensor is kept alive with its table)
+            return table
+        return table[0]
+
+    def stft_normalized(self, x, L, Lp, n_fft, hop, window, n_bins, stats, sig_per_item, win_len):
+        """STFT + per-item normalisation in one call (aero_stft_dft_norm_fwd: the DFT-as-GEMM run twice, sums then normalised fp16 store; no
+        fp32 spectrogram in HBM) -> (xn fp16 [nsig, n_bins, T, 2], mean_std fp32 [nitems, 2]), or None when the geometry is not the
+        short-window one that kernel takes (the caller then runs stft + spec_normalize)."""
+        nsig = x.shape[0]
+        if not self.fused_stft or not self._dft_applies(nsig, Lp, n_fft, hop, n_bins, win_len):
+            return None
+        T = 1 + Lp // hop
+        table = self._dft_table(x, window, n_fft, win_len)
+        xn = torch.empty(nsig, n_bins, T, 2, dtype=torch.float16, device=x.device)
+        mean_std = torch.empty(nsig // sig_per_item, 2, dtype=torch.float32, device=x.device)
+        # bytes: what the two launches move (the signal twice, the fp16 result once); FLOPs: the GEMM twice
+        self._call('aero_stft_dft_norm_fwd', 'aero_stft_dft_kernel', 2 * 2.0 * nsig * T * n_fft * 128, nsig * (2 * L * 4 + n_bins * T * 4),
+                   _ptr(x), nsig, L, Lp, n_fft, hop, (n_fft - win_len) // 2, _ptr(table), T, _ptr(stats), sig_per_item, _ptr(xn), _ptr(mean_std),
+                   self.stream(x))
+        return xn, mean_std
 
     def spec_normalize(self, spec, nitems, stats):
         n_per = spec.numel() // nitems
@@ -149,11 +174,25 @@ class Ops:
         return xn, mean_std
 
     def istft(self, spec, n_fft, hop, window, inv_env, Lout):
+        """spec fp32 [nsig, F, T, 2]; or a PITCHED buffer [nsig, F, pitch, 2] marked by `spec._aero_pitched = (T, t_off)` (the layout
+        convtr_tail_finish writes for the iSTFT kernel: whole cache lines per 16-frame run, include/aero_hip.h aero_istft_pitch)"""
         nsig, F, T, _ = spec.shape
         y = torch.empty(nsig, Lout, dtype=torch.float32, device=spec.device)
+        pitched = getattr(spec, '_aero_pitched', None)
+        if pitched is not None:
+            pitch, (T, toff) = T, pitched
+            self._call('aero_istft_pitched_fwd', 'aero_istft_kernel', 0, nsig * (F * T * 8 + Lout * 4),
+                       _ptr(spec), nsig, F, T, pitch, toff, n_fft, hop, _ptr(window), _ptr(inv_env), _ptr(y), Lout, self.stream(spec))
+            return y
         self._call('aero_istft_fwd', 'aero_istft_kernel', 0, nsig * (F * T * 8 + Lout * 4),
                    _ptr(spec), nsig, F, T, n_fft, hop, _ptr(window), _ptr(inv_env), _ptr(y), Lout, self.stream(spec))
         return y
+
+    def istft_pitch(self, n_fft, hop, T):
+        """(pitch, t_off) of the spectrogram layout the iSTFT kernel reads with whole cache lines; (T, 0): the plain layout only"""
+        pitch, toff = C.c_int32(0), C.c_int32(0)
+        self.lib.call('aero_istft_pitch', n_fft, hop, T, C.byref(pitch), C.byref(toff))
+        return pitch.value, toff.value
 
     # -- convolution family --------------------------------------------------------------------
     def conv(self, spec, src0, src1, B, Fin, Fout, T, dst=None, dst_f32=False, dst_f_off=0, dst_F=None, res=None,
@@ -238,11 +277,19 @@ class Ops:
             return tail_lo, tail_hi
         return dst
 
-    def convtr_tail_finish(self, lo, hi, bias, scale, shift, dst_F, pad, cin):
-        """second half of the fused last layer (aero_convtr_tail_finish): (lo, hi) [B, Fin, T, 8] -> fp32 [B, dst_F, T, 2]"""
+    def convtr_tail_finish(self, lo, hi, bias, scale, shift, dst_F, pad, cin, pitched=None):
+        """second half of the fused last layer (aero_convtr_tail_finish): (lo, hi) [B, Fin, T, 8] -> fp32 [B, dst_F, T, 2];
+        pitched = (pitch, t_off): -> [B, dst_F, pitch, 2] with time step t in column t_off + t, marked `_aero_pitched` for Ops.istft"""
         B, Fin, T, _ = lo.shape
-        dst = torch.empty(B, dst_F, T, 2, dtype=torch.float32, device=lo.device)
         self._shape_note = f'convtr tail finish F={Fin}->{dst_F}'
+        if pitched is not None and pitched != (T, 0):
+            pitch, toff = pitched
+            dst = torch.empty(B, dst_F, pitch, 2, dtype=torch.float32, device=lo.device)
+            self._call('aero_convtr_tail_finish_pitched', 'aero_convtr_tail_finish_kernel', 2.0 * B * Fin * T * 16 * cin, lo.numel() * 8 + B * dst_F * T * 8,
+                       _ptr(lo), _ptr(hi), _ptr(bias), _ptr(scale), _ptr(shift), _ptr(dst), B, Fin, T, dst_F, pad, pitch, toff, self.stream(lo))
+            dst._aero_pitched = (T, toff)
+            return dst
+        dst = torch.empty(B, dst_F, T, 2, dtype=torch.float32, device=lo.device)
         self._call('aero_convtr_tail_finish', 'aero_convtr_tail_finish_kernel', 2.0 * B * Fin * T * 16 * cin, lo.numel() * 8 + dst.numel() * 4,
                    _ptr(lo), _ptr(hi), _ptr(bias), _ptr(scale), _ptr(shift), _ptr(dst), B, Fin, T, dst_F, pad, self.stream(lo))
         return dst
@@ -508,6 +555,8 @@ class HipEngine:
     stagger = 0
     prof_streams = False
     stage_hook = None
+    _mark_base = None
+    _out_pitch = None                   # (pitch, t_off) of the output spectrogram while a forward that hands it straight to the iSTFT runs
 
     def __init__(self, model, lib=None):
         self.model = model
@@ -542,6 +591,7 @@ class HipEngine:
         self.fuse_dconv_row = os.environ.get('AERO_DCONV_ROW', '1') != '0'    # DConv branches without LSTM / attention: one launch, the row stays in LDS (k_dconv.h)
         self.fuse_enc0 = os.environ.get('AERO_FUSE_ENC0', '1') != '0'     # ... and fused with the layer's strided conv (k_enc0.h)
         self.fuse_tail = os.environ.get('AERO_FUSE_TAIL', '1') != '0'     # last decoder layer: the transposed conv inside the rewrite conv's epilogue (k_conv_ring.h)
+        self.pitched_out = os.environ.get('AERO_PITCHED_OUT', '1') != '0' # ... its output rows at the cache-line pitch the iSTFT kernel reads (aero_istft_pitch)
 
     # ------------------------------------------------------------------ weights
     def _weights_key(self, device):
@@ -899,10 +949,20 @@ class HipEngine:
         mix = mix.contiguous()
         ops.begin_step(dev)
         stats = ops.new_stats(B, 1, 1, False, dev)
-        zc = self.spec(mix, stats=stats)                                   # complex64 [B,1,F0,T]
-        F0, T = zc.shape[2], zc.shape[3]
-        z = torch.view_as_real(zc).view(B, F0, T, 2)
-        x, mean_std = ops.spec_normalize(z, B, stats)                      # fp16 [B,F0,T,2]
+        fused = None
+        if not want_lr_spec:                                               # nobody reads the fp32 low-rate spectrogram: normalised fp16 directly
+            hop_in, pad_in = m.hop_length, (m.hop_length - L % m.hop_length) % m.hop_length
+            fused = ops.stft_normalized(mix.view(B, L), L, L + pad_in, m.nfft, hop_in, self._window(m.win_length, dev), m.nfft // 2, stats, 1,
+                                        m.win_length)
+        if fused is not None:
+            zc = None
+            x, mean_std = fused
+            F0, T = x.shape[1], x.shape[2]
+        else:
+            zc = self.spec(mix, stats=stats)                               # complex64 [B,1,F0,T]
+            F0, T = zc.shape[2], zc.shape[3]
+            z = torch.view_as_real(zc).view(B, F0, T, 2)
+            x, mean_std = ops.spec_normalize(z, B, stats)                  # fp16 [B,F0,T,2]
         mean = mean_std[:, 0].contiguous()
         std = mean_std[:, 1].contiguous()
 
@@ -914,14 +974,19 @@ class HipEngine:
             if stage_cb is not None:
                 stage_cb(i + 1)
         x = None
-        for j, dec in enumerate(m.decoder):
-            skip, Fs = saved.pop()
-            x = self._decode(j, dec, P[f'decoder.{j}'], x, skip, B, Fs, T, mean, std)
-            if stage_cb is not None:
-                stage_cb(len(m.encoder) + j + 1)
-        assert not saved
-        spec_out = x                                                       # fp32 [B,F0,T,2] de-normalised
         hop, win = int(m.hop_length * m.scale), int(m.win_length * m.scale)
+        # nobody but the iSTFT reads the output spectrogram: its producer writes rows at the line-aligned pitch that kernel asks for
+        self._out_pitch = None if (want_spec or not self.pitched_out) else ops.istft_pitch(m.nfft, hop, T)
+        try:
+            for j, dec in enumerate(m.decoder):
+                skip, Fs = saved.pop()
+                x = self._decode(j, dec, P[f'decoder.{j}'], x, skip, B, Fs, T, mean, std)
+                if stage_cb is not None:
+                    stage_cb(len(m.encoder) + j + 1)
+        finally:
+            self._out_pitch = None
+        assert not saved
+        spec_out = x                                                       # fp32 [B,F0,T,2] de-normalised (pitched: [B,F0,pitch,2], see Ops.istft)
         Lout = min(hop * (T - 1), int(L * m.scale))
         out_spec = torch.view_as_complex(spec_out).view(B, 1, F0, T) if want_spec else None
         if defer_istft:                                  # (two-stream forward: the caller runs the iSTFT after the streams have joined)
@@ -1056,8 +1121,12 @@ class HipEngine:
 
     def _encode_rest(self, i, enc, L, y, B, Fo, T):
         ops = self.ops
+        self._mark(i + 0.25)                                # (stage marks for BatchPipeline's stagger: the layer's conv is out)
         if 'dconv' in L:
+            self._mark_base = i
             y = self._dconv(enc.dconv, L['dconv'], y, B, Fo, T)
+            self._mark_base = None
+            self._mark(i + 0.75)
         if 'rewrite' in L:
             emb = self.P.get('freq_emb') if i == 0 else None
             if enc.norm:
@@ -1082,13 +1151,19 @@ class HipEngine:
             raise NotImplementedError('frequency embedding without a rewrite conv')
         return y, Fo
 
+    def _mark(self, stage):
+        if self.stage_hook is not None and not getattr(self, '_train', False):
+            self.stage_hook(stage)
+
     def _dconv(self, dc, layers, x, B, Fo, T):
         ops = self.ops
         act = {'snake': ACT_SNAKE, 'gelu': ACT_GELU}.get(dc.act_func, ACT_RELU)
         if (self.fuse_dconv_row and all('row' in L for L in layers) and len(layers) <= _lib.DCONV_MAX_DEPTH and x.is_contiguous()
                 and ops.dconv_row_fits(T, layers[0]['row']['C'], layers[0]['row']['hidden'], max(L['row']['dilation'] for L in layers))):
             return ops.dconv_row(x, [dict(L['row'], snake_a=L.get('snake_a')) for L in layers], act, Fo)
-        for L in layers:
+        for li, L in enumerate(layers):
+            if li == 1 and getattr(self, '_mark_base', None) is not None:
+                self._mark(self._mark_base + 0.5)            # (between the two DConv layers of an encoder)
             g1 = L['gn1']
             st1 = None
             if g1 is not None and self._want_stats(L['conv1']) and L['conv1'].M > 16 and L['conv1'].M % 8 == 0:       # (M <= 16 runs on the streaming kernel)
@@ -1228,7 +1303,8 @@ class HipEngine:
                 # activation never reaches memory), then the row combination + bias + x*std + mean (aero.py:189-215, 497-498)
                 timg, tbias = L['tail']
                 lo, hi = ops.conv(L['rewrite'], x, skip, B, Fq, Fq, T, tail=timg)
-                return ops.convtr_tail_finish(lo, hi, tbias, std, mean, (Fq - 1) * dec.stride + dec.kernel_size - 2 * dec.pad, dec.pad, timg.shape[1])
+                return ops.convtr_tail_finish(lo, hi, tbias, std, mean, (Fq - 1) * dec.stride + dec.kernel_size - 2 * dec.pad, dec.pad, timg.shape[1],
+                                              pitched=self._out_pitch)
             if dec.norm:
                 st = self._stats_for(L['rewrite'].M, dec.norm_groups, B, Fq, skip.device, spec=L['rewrite'])
                 r = ops.conv(L['rewrite'], x, skip, B, Fq, Fq, T, stat=self._acc(st, dec.norm_groups))

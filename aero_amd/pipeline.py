@@ -14,6 +14,7 @@ Stream semantics are PyTorch's: `submit` orders the batch behind everything the 
 ready), `result` makes the caller's current stream wait for that batch.  Collect results a few submissions late (or call `drain`), not
 right after each `submit` -- a `result` immediately behind its `submit` serialises the batches again.
 """
+import os
 import weakref
 
 import torch
@@ -49,6 +50,9 @@ def parse_schedule(text):
         if k in ('stages', 'lstm'):
             out[k] = v
             continue
+        if k == 'stagger':
+            out[k] = float(v)
+            continue
         parts = v.split(':')
         shared = parts[-1] == 'shared'
         if shared:
@@ -61,12 +65,30 @@ class BatchPipeline:
     """pipe = BatchPipeline(model, depth=3);  t = pipe.submit(x);  ...;  y = pipe.result(t)   (inference, model.eval()).
     `schedule` (a dict or the text form of parse_schedule): which HIP stream each stage of a batch is issued on -- see DESIGN.md 4.6e."""
 
-    def __init__(self, model, depth=3, schedule=None):
+    def __init__(self, model, depth=3, schedule=None, stagger=0, waits='auto'):
         self.model = model
         self.depth = max(1, int(depth))
         self.schedule = parse_schedule(schedule) if isinstance(schedule, str) else schedule
+        # stagger = s > 0: batch i + 1 does not START before batch i has finished stage s of its forward (1-4: encoder layers, 5-8: decoder
+        # layers).  Left alone, the streams do not drift into an even spacing: two of the three lock onto each other and run the same kernel
+        # families side by side (completion gaps 13.6 / 13.3 / 0.3 ms instead of 8.7 / 8.7 / 8.7; tools/dbg/pipeline_fill_drain.py)
+        self.stagger = float((self.schedule or {}).get('stagger', stagger) or 0)
         if self.schedule is not None and set(self.schedule.setdefault('stages', 'mmmmmmmm')) == {'m'} and 'lstm' not in self.schedule:
             self.schedule = None
+        # waits: [(a, b), ...] -- having finished stage a (0: before it starts) a batch waits until the batch before it has finished stage b;
+        # `stagger = s` is the pair (0, s)
+        if waits == 'auto':
+            # the default of the serving loop (round 6, profiles/r06_waits_sweep*.txt, same-box A/B: 8.72 -> 8.50 ms, 8.87 -> 8.73, 8.75 -> 8.53 per
+            # batch at K = 20, first completion 21 -> 16 ms): a batch starts when the batch before it enters its LAST encoder layer, and enters
+            # its decoder when the batch before it enters its last decoder layer -- the MFMA-bound decoders run one after the other (two of them
+            # side by side only time-slice the CUs) with the next batches' latency-bound encoder layers underneath, and no two batches can lock
+            # into running the same layer at the same time
+            ne, nd = len(getattr(model, 'encoder', ())), len(getattr(model, 'decoder', ()))
+            waits = [] if (self.stagger or os.environ.get('AERO_PIPELINE_WAITS') == '0' or ne < 2 or nd < 2) else [(0, ne - 1), (ne, ne + nd - 1)]
+        self.waits = [(float(a), float(b)) for a, b in (waits or [])]
+        if self.stagger:
+            self.waits.append((0.0, self.stagger))
+        self._stage_ev = {}
         self._streams = {}
         self._kinds = {}
         self._slot_done = {}
@@ -135,6 +157,24 @@ class BatchPipeline:
         hook = None
         if self.schedule is None:
             st = ring[slot]
+            if self.waits:
+                prev_evs = self._stage_ev.get(dev, {})
+                mine = self._stage_ev[dev] = {}
+                for a, b in self.waits:
+                    if a == 0.0 and b in prev_evs:
+                        st.wait_event(prev_evs[b])
+
+                def hook(i, st=st, prev_evs=prev_evs, mine=mine):
+                    if isinstance(i, str):
+                        return
+                    for a, b in self.waits:
+                        if abs(i - b) < 1e-6 and b not in mine:
+                            ev = torch.cuda.Event()
+                            ev.record(st)
+                            mine[b] = ev
+                    for a, b in self.waits:
+                        if a != 0.0 and abs(i - a) < 1e-6 and b in prev_evs:
+                            st.wait_event(prev_evs[b])
         else:
             # Stages of this batch on different streams of its slot.  One stage follows the other (fork = event + wait), so a batch is
             # still ONE chain; what changes is which queue -- priority, CU set -- its launches wait in next to the other batches'.
@@ -158,7 +198,7 @@ class BatchPipeline:
                         nxt = self._kind_stream(dev, slot, self.schedule['lstm'])
                     else:
                         nxt = state['back']
-                elif i >= len(stages):
+                elif not isinstance(i, int) or i >= len(stages):
                     return
                 else:
                     nxt = self._kind_stream(dev, slot, stages[i])
@@ -189,7 +229,7 @@ class BatchPipeline:
                         h.copy_(t, non_blocking=True)
                         return h
                     out = tuple(down(t) for t in out) if isinstance(out, (tuple, list)) else down(out)
-                if hook is not None:
+                if self.schedule is not None:
                     st = state['cur']                       # the stream of the batch's last stage: the one the ticket's event belongs to
         finally:
             eng.streams, eng.use_graph, eng.stage_hook = saved
@@ -204,7 +244,7 @@ class BatchPipeline:
             cur.wait_stream(st)                             # ... nor a direct model(x) on the caller's stream right behind this submit
         ev = torch.cuda.Event()
         ev.record(st)
-        if hook is not None:
+        if self.schedule is not None:
             self._slot_done[(dev, slot)] = ev
         t = _Ticket(out, ev, st, host=to_host, keep=host_in)
         # tickets are held WEAKLY: a caller that drops a ticket (or dies between submit and result) frees its outputs, pinned buffers and

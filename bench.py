@@ -491,7 +491,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
         'config': {'workload': f'batch={B} synthetic 2s white-noise clips per GPU, 4->16 kHz, aero_4-16_512_64 '
                                f'(nfft=512 hop=64), random-init weights seed 2036, inference, inputs resident in HBM',
-                   'schedule': (f'serving loop, {depth} batches in flight: step i enqueued on HIP stream i mod {depth} without waiting for step i-1 '
+                   'schedule': (f'serving loop, {depth} batches in flight on {depth} HIP streams, step i+1 starts when step i enters its last encoder layer '
                                 '(aero_amd/pipeline.py); all K steps complete inside the timed region; ms_per_step_one_at_a_time = model(x) in a loop')
                                if depth > 1 else 'one forward at a time (two half-batch streams inside each)',
                    'ms_per_step_one_at_a_time': None if dt_serial != dt_serial else round(dt_serial / args.steps * 1e3, 3),

@@ -73,6 +73,13 @@ int aero_stft_dft_table(const float* window, int32_t n_fft, int32_t win_off, voi
 int aero_stft_dft_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, int32_t win_off,
                       const void* table, float* spec, int32_t T, double* stats, int32_t sig_per_item, void* stream);
 
+/* K1'+K2 fused (round 6) -- Aero.forward needs the low-rate spectrogram only per-item NORMALISED, as fp16 (aero.py:459-464): the GEMM above
+ * run twice instead of once plus a round trip of its fp32 output -- a first pass that only forms the per-item sums (stats: zeroed by the
+ * caller, as for aero_stft_dft_fwd), a second that recomputes and stores xn = (v - mean) / (1e-5 + std) as fp16 [nsig][n_fft/2][T][2] and
+ * (mean, std) per item.  Same arithmetic, same summation order: xn and mean_std equal aero_stft_dft_fwd + aero_spec_normalize bit for bit. */
+int aero_stft_dft_norm_fwd(const float* x, int32_t nsig, int32_t L, int32_t Lp, int32_t n_fft, int32_t hop, int32_t win_off,
+                           const void* table, int32_t T, double* stats, int32_t sig_per_item, void* xn, float* mean_std, void* stream);
+
 /* K2 -- aero.py:430-434,462-464: complex -> 2 channels + per-item normalisation.
  * spec viewed as [nitems][n_per_item] fp32; xn fp16 same shape = (v-mean)/(1e-5+std) with the
  * unbiased std; mean_std[2*i], [2*i+1] receive mean and std (used again by K14). */
@@ -86,6 +93,13 @@ int aero_spec_normalize(const float* spec, int32_t nitems, int64_t n_per_item, c
  * n_fft/2 .. n_fft/2+Lout-1 of the overlap-add (Lout <= hop*(T-1); crop of aero.py:513 included). */
 int aero_istft_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_t n_fft, int32_t hop,
                    const float* window, const float* inv_env, float* y, int32_t Lout, void* stream);
+/* ... with the spectrogram rows at a pitch of `pitch` frames (pitch * 8 bytes per bin row) and frame 0 in column t_off: the layout in which
+ * every 16-frame run the kernel reads is one 128-byte cache line.  aero_istft_pitch reports (pitch, t_off) for a geometry -- (T, 0) where
+ * the plain layout is the only one supported; a producer (aero_convtr_tail_finish_pitched) writes rows accordingly.  The pad columns are
+ * never read. */
+int aero_istft_pitch(int32_t n_fft, int32_t hop, int32_t T, int32_t* pitch, int32_t* t_off);
+int aero_istft_pitched_fwd(const float* spec, int32_t nsig, int32_t F, int32_t T, int32_t pitch, int32_t t_off, int32_t n_fft, int32_t hop,
+                           const float* window, const float* inv_env, float* y, int32_t Lout, void* stream);
 
 /* K3/K4/K5/K6/K9 and every 1x1 -- one implicit-GEMM MFMA kernel family replaces nn.Conv2d
  * (aero.py:89,95,101,179), nn.ConvTranspose2d (aero.py:172), nn.Conv1d (modules.py:206,209,
@@ -166,6 +180,9 @@ int aero_split_finish(const float* acc, int32_t nsplit, const float* bias, int32
  * per-item affine is the de-normalisation of aero.py:497-498); bias / scale / shift may be NULL */
 int aero_convtr_tail_finish(const float* lo, const float* hi, const float* bias, const float* scale, const float* shift, float* dst,
                             int32_t B, int32_t Fin, int32_t T, int32_t dst_F, int32_t pad, void* stream);
+/* ... writing dst rows at a pitch of `pitch` time steps starting at column t_off (dst fp32 [B][dst_F][pitch][2]): see aero_istft_pitch */
+int aero_convtr_tail_finish_pitched(const float* lo, const float* hi, const float* bias, const float* scale, const float* shift, float* dst,
+                                    int32_t B, int32_t Fin, int32_t T, int32_t dst_F, int32_t pad, int32_t pitch, int32_t t_off, void* stream);
 int aero_conv_tile_m(int32_t M);
 /* rows per block (256/128/64) of the software-pipelined kernel for a contraction with M rows and Ktot = ntaps * Cp
  * columns, or 0 if that kernel does not take the shape: the tile height `weight_tiled` must be prepared for */

@@ -82,6 +82,13 @@ def case_stft(lib, dev, nfft, hop, win, L, B=2, nyquist=False, dft=False):
     std = vr.std(dim=(1, 2, 3), keepdim=True)
     assert torch.allclose(ms.cpu(), torch.cat([mean.view(B, 1), std.view(B, 1)], 1), rtol=1e-5, atol=1e-6)
     assert rel_l2(xn.cpu().float(), (vr - mean) / (1e-5 + std)) < 1e-3
+    if dft:
+        # round 6: the same GEMM run twice (sums, then the normalised fp16 store; aero_stft_dft_norm_fwd) -- no fp32 spectrogram in HBM.
+        # Same arithmetic and summation order: BIT-identical to the pair above (index paths exact)
+        stats2 = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+        fused = ops.stft_normalized(x.to(dev), L, L + pad, nfft, hop, _hann_padded(win, nfft, dev), nfft // 2, stats2, 1, win)
+        assert fused is not None
+        assert torch.equal(fused[0].cpu(), xn.cpu()) and torch.equal(fused[1].cpu(), ms.cpu()) and torch.equal(stats2.cpu(), stats.cpu())
 
 
 def case_istft(lib, dev, nfft, hop, win, T, crop=5, B=2):
@@ -95,6 +102,16 @@ def case_istft(lib, dev, nfft, hop, win, T, crop=5, B=2):
     y = ops.istft(torch.view_as_real(z).contiguous().to(dev), nfft, hop, w.to(dev), (1 / env).float().to(dev), Lout)
     yr = O.istft(F.pad(z, (0, 0, 0, 1)), hop, win)[..., :Lout]
     assert rel_l2(y.cpu(), yr) < TOL32
+    # round 6: the pitched layout (rows at a multiple of 16 frames, frame 0 in column t_off; pad columns poisoned): same bits
+    pitch, toff = ops.istft_pitch(nfft, hop, T)
+    if (pitch, toff) != (T, 0):
+        assert pitch % 16 == 0 and pitch >= toff + T
+        buf = torch.full((B, nfft // 2, pitch, 2), float('nan'))
+        buf[:, :, toff:toff + T] = torch.view_as_real(z)
+        buf = buf.to(dev)
+        buf._aero_pitched = (T, toff)
+        y2 = ops.istft(buf, nfft, hop, w.to(dev), (1 / env).float().to(dev), Lout)
+        assert torch.equal(y2.cpu(), y.cpu())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -314,6 +331,10 @@ def case_conv_tail(lib, dev, Fin, T, B=2, seed=36):
     kname = ops.lib.cdll.aero_last_kernel_name().decode()
     assert 'aero_conv_ring_kernel' in kname and ('<2, 2, 3, 3' in kname or '<2, 4, 3, 3' in kname or lib.is_emulator), kname
     y = ops.convtr_tail_finish(lo, hi, bt.to(dev), sc.to(dev), sh.to(dev), 4 * Fin, pad, M // 2)
+    # round 6: the same rows at a cache-line pitch (the layout the iSTFT kernel asks for): identical values in columns t_off .. t_off + T
+    Tt = lo.shape[2]
+    yp = ops.convtr_tail_finish(lo, hi, bt.to(dev), sc.to(dev), sh.to(dev), 4 * Fin, pad, M // 2, pitched=((Tt + 12 + 15) // 16 * 16, 12))
+    assert yp.shape[2] % 16 == 0 and yp._aero_pitched == (Tt, 12) and torch.equal(yp[:, :, 12:12 + Tt].cpu(), y.cpu())
     assert y.shape == (B, 4 * Fin, T, 2)
     # reference
     r = F.glu(F.conv2d(q16(x), q16(w), b, padding=1), dim=1)
