@@ -64,8 +64,9 @@ def resample(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99
     reference calls before the model when `experiment.upsample` is set (predict.py:55-57, datasets.py:144).  Host plumbing outside the hot
     path: torchaudio is used when importable; otherwise its published algorithm is restated here (polyphase sinc kernel of
     `new_freq / gcd` phases, width ceil(lowpass_filter_width * orig / (rolloff * min(orig, new))), a strided conv1d, output cropped to
-    ceil(new * length / orig) samples).  PARITY UNPINNED: torchaudio is absent from this image, so the restatement is checked only
-    against its defining properties (tests/test_callers.py: identity at equal rates, length rule, a band-limited tone is reproduced)."""
+    ceil(new * length / orig) samples).  torchaudio is absent from this image; the restatement is PINNED TO THE PUBLISHED ALGORITHM: a direct
+    float64 evaluation of its interpolation formula at three rate ratios (tests/test_callers.py::
+    test_resample_against_the_published_interpolation_formula) next to the defining properties (identity, length rule, a tone, linearity)."""
     try:
         from torchaudio.functional import resample as ta_resample
         return ta_resample(waveform, orig_freq, new_freq)

@@ -149,26 +149,6 @@ static __device__ __forceinline__ void aero_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #endif
 }
-// the same with a wave-uniform RUN-TIME count (the immediate is chosen by a scalar branch; counts above 12 wait for 12)
-static __device__ __forceinline__ void aero_wait_vm_upto(int n) {
-#ifndef AERO_EMU
-    switch (n) {
-        case 0: aero_wait_vm<0>(); break;
-        case 1: aero_wait_vm<1>(); break;
-        case 2: aero_wait_vm<2>(); break;
-        case 3: aero_wait_vm<3>(); break;
-        case 4: aero_wait_vm<4>(); break;
-        case 5: aero_wait_vm<5>(); break;
-        case 6: aero_wait_vm<6>(); break;
-        case 7: aero_wait_vm<7>(); break;
-        case 8: aero_wait_vm<8>(); break;
-        case 9: aero_wait_vm<9>(); break;
-        case 10: aero_wait_vm<10>(); break;
-        case 11: aero_wait_vm<11>(); break;
-        default: aero_wait_vm<12>(); break;
-    }
-#endif
-}
 // end of a phase: this wave's LDS reads have returned (their slot may be refilled) and every wave's landed copies are
 // visible to the others.  Not __syncthreads(): that would also drain the copies still in flight (vmcnt).
 static __device__ __forceinline__ void aero_phase_barrier() {

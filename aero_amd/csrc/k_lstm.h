@@ -709,7 +709,9 @@ static int aero_lstm_launch(const aero_lstm_desc* d, hipStream_t stream, const c
     {   // the ring kernel keeps per-thread row indices / output element offsets in 32 bits
         const int64_t rows_in = d->in_mode == 1 ? (int64_t)(d->nseq / d->nframes) * d->T : (int64_t)d->nseq * d->W;
         const int64_t rows_out = d->out_mode == 1 ? (int64_t)(d->nseq / d->nframes) * d->T : (int64_t)d->nseq * d->W;
-        if (rows_in + d->W >= (1ll << 31) || (rows_out + d->W) * 2 * d->H >= (1ll << 31)) { *err = "lstm: tensor too large for 32-bit offsets"; return AERO_ERR_UNSUPPORTED; }
+        // (padding lanes of the last block form -- and never use -- offsets of up to 15 sequences past the end: the margin covers them too)
+        const int64_t slack = (int64_t)16 * d->W + d->W;
+        if (rows_in + slack >= (1ll << 31) || (rows_out + slack) * 2 * d->H >= (1ll << 31)) { *err = "lstm: tensor too large for 32-bit offsets"; return AERO_ERR_UNSUPPORTED; }
     }
     int nw, tpw, kt;
     if (aero_lstm_pick(d->H, &nw, &tpw, &kt)) { *err = "lstm: hidden size > 128 unsupported"; return AERO_ERR_UNSUPPORTED; }

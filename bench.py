@@ -439,6 +439,12 @@ def main():
                 pre = 'istft' if 'istft' in kname else 'stft'
                 roof.update({pre + '_frac': v['frac'], pre + '_gbs': v['achieved'], pre + '_us': round(v['avg_launch_ms'] * 1e3, 1),
                              pre + '_mb_per_launch': round(v['bytes_per_launch'] / 1e6, 2)})
+                if pre == 'stft' and '<2>' in kname:
+                    # the fused pair (two DFT passes, normalised fp16 out) against the algorithmic bytes of the ops it REPLACES (SURVEY 8d:
+                    # torch.stft 4 L + 8 F T per clip, the normalisation 4 + 2 B per value): the figure comparable with earlier rounds' stft_frac,
+                    # which charged the STFT kernel alone with the fp32 spectrogram it no longer writes
+                    repl = B * (L * 4 + 256 * 501 * 8) + B * 256 * 501 * 2 * 6
+                    roof['stft_frac_vs_replaced_ops'] = round(repl / (v['avg_launch_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
 
             def fam(pred):
                 sel = [v for n, v in kernels.items() if pred(n)]

@@ -63,14 +63,14 @@ def _torch_critic(d, x, rounded=False):
     return results
 
 
-def case_critic_backward(dev, lib=None, T=1024):
+def case_critic_backward(dev, lib=None, T=1024, ndf=4, rel_to_g=False):
     """discriminator_loss (gradients of every weight_g / weight_v / bias) and generator_losses (gradient of the fake waveform) on the
     HIP kernels against torch.autograd through the same modules with the feature maps rounded to fp16 where the product stores them
     (a LeakyReLU mask is a discontinuous function of its pre-activation: see tests/train_cases.py)"""
     import torch.nn.functional as Fn
     from aero_amd.discriminators import Discriminator
     torch.manual_seed(5)
-    d = Discriminator(num_D=3, ndf=4, n_layers=4, downsampling_factor=4)
+    d = Discriminator(num_D=3, ndf=ndf, n_layers=4, downsampling_factor=4)
     with torch.no_grad():
         for p in d.parameters():
             p.copy_(p.half().float())
@@ -107,6 +107,8 @@ def case_critic_backward(dev, lib=None, T=1024):
     loss.backward()
     for n, p in d.named_parameters():
         errs['d.' + n] = float((p.grad.cpu().double() - ref['d'][n].double()).norm()) / max(ref['dn'][n], 1e-30)
+        if rel_to_g:                                            # ... and against the size of the (nearly cancelling) SUM itself
+            errs['g.' + n] = float((p.grad.cpu().double() - ref['d'][n].double()).norm()) / max(float(ref['d'][n].double().norm()), 1e-30)
     xh = xf.to(dev).clone().requires_grad_()
     a2, f2 = d.generator_losses(xh, xr.to(dev))
     errs['adv'] = abs(float(a2) - float(adv)) / float(adv)

@@ -267,3 +267,35 @@ def test_resample_restatement_properties():
     assert float((up - torch.sin(2 * math.pi * 440 * t2)[None])[:, 200:-200].abs().max()) < 2e-3
     a, b = x[:1], x[1:]
     assert torch.allclose(audio_io.resample(a + 2 * b, 4000, 16000), audio_io.resample(a, 4000, 16000) + 2 * audio_io.resample(b, 4000, 16000), atol=1e-5)
+
+
+def test_resample_against_the_published_interpolation_formula():
+    """Pins `audio_io.resample` to torchaudio's published algorithm (torchaudio.functional.resample, `sinc_interp_hann`, defaults
+    lowpass_filter_width = 6, rolloff = 0.99) evaluated DIRECTLY, sample by sample, in float64:
+        y[n] = sum_k x[k] h(k / orig - n / new),   h(t) = (base / orig) sinc(pi base t) cos^2(pi base t / (2 lpw))  for |base t| < lpw, else 0,
+        base = rolloff * min(orig, new),  orig / new = the rates divided by their gcd,  len(y) = ceil(new len(x) / orig)
+    -- no polyphase kernel bank, no padding, no strided convolution: a different evaluation of the same definition.  Three ratios (1:4 as in
+    the aero configs, 4:1, and the non-integer 2:3), 32 input samples each."""
+    import math
+    from aero_amd import audio_io
+    lpw, rolloff = 6, 0.99
+    for orig_f, new_f in ((4000, 16000), (44100, 11025), (8000, 12000)):
+        g = math.gcd(orig_f, new_f)
+        orig, new = orig_f // g, new_f // g
+        base = rolloff * min(orig, new)
+        x = torch.randn(1, 32, generator=torch.Generator().manual_seed(orig_f + new_f), dtype=torch.float64)
+        n_out = math.ceil(new * 32 / orig)
+        ref = []
+        for n in range(n_out):
+            acc = 0.0
+            for k in range(32):
+                bt = base * (k / orig - n / new)
+                if abs(bt) >= lpw:
+                    continue
+                sinc = 1.0 if bt == 0 else math.sin(math.pi * bt) / (math.pi * bt)
+                acc += float(x[0, k]) * (base / orig) * sinc * math.cos(math.pi * bt / (2 * lpw)) ** 2
+            ref.append(acc)
+        y = audio_io.resample(x.float(), orig_f, new_f)
+        assert y.shape == (1, n_out)
+        err = float((y[0].double() - torch.tensor(ref, dtype=torch.float64)).abs().max())
+        assert err < 2e-6, (orig_f, new_f, err)
