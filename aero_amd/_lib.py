@@ -85,7 +85,7 @@ class LstmDesc(C.Structure):
                 ('H', i32), ('nseq', i32), ('W', i32), ('in_mode', i32), ('out_mode', i32),
                 ('nframes', i32), ('S', i32), ('T', i32),
                 ('x', vp), ('wih', vp), ('bias', fp), ('in_ch', i32), ('x_pitch', i32),
-                ('save_gates', vp), ('save_c', fp)]
+                ('save_gates', vp), ('save_c', fp), ('frame_major', i32)]
 
 
 class LstmBwdDesc(C.Structure):

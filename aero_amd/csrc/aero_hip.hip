@@ -651,11 +651,11 @@ int aero_squeeze_fwd(const void* x, int64_t x_b, int64_t x_f, int64_t x_t, const
 }
 
 int aero_pw_rows(int32_t C, int32_t M) {
-    if (C < 8 || C % 8 || C > 384 || M < 16 || M % 16) return 0;
+    if (C < 8 || C % 8 || C > 96 || M < 16 || M % 16) return 0;
     return 128 * aero_pw_gw(C, M);
 }
 
-int aero_pw_ksteps(int32_t C) { return (C < 8 || C > 384) ? 0 : aero_pw_ks(C); }
+int aero_pw_ksteps(int32_t C) { return (C < 8 || C > 96) ? 0 : aero_pw_ks(C); }
 
 #endif  // part 7
 

@@ -25,6 +25,7 @@
 struct AeroLstmK {
     aero_lstm_desc d;
     int MP, KP;
+    int dv;              // the divisor of the sequence -> (row, frame) map: nframes (frame-minor) or rows = nseq / nframes (frame-major)
 };
 
 // smallest instantiated (NW waves, TPW gate tiles per wave, KT k-steps) with 16*NW*TPW >= 4H and 32*KT >= H.
@@ -58,6 +59,15 @@ static inline int aero_lstm_kti(int H, int in_ch) {
     if (tpw == 2) return need <= 2 ? 2 : (need <= 4 ? 4 : -1);
     if (tpw == 3) return need <= 3 ? 3 : (need <= 6 ? 6 : -1);
     return -1;
+}
+
+// sequence index -> (row r of the [R, T] input, frame k): frame-minor (seq = r * nframes + k: the order `unfold` + reshape gives,
+// modules.py:49-51) or, with aero_lstm_desc.frame_major, frame-major (seq = k * R + r): a block's 16 sequences then belong to ONE frame
+// (two where R % 16 != 0), which is what lets the stitching layer stop at the last step its frame keeps (round 6)
+static __device__ __forceinline__ void aero_lstm_rk(const AeroLstmK& p, int seq, int& r, int& k) {
+    const int q = seq / p.dv, rem = seq - q * p.dv;        // (one division by a launch constant, as the frame-minor form always had)
+    r = p.d.frame_major ? rem : q;
+    k = p.d.frame_major ? q : rem;
 }
 
 template <int NW, int TPW, int KT, int KTI>
@@ -112,7 +122,8 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
     int64_t in_base = 0;   // position index of step tau = 0
     int t_first = 0;       // in_mode 1: absolute time of tau = 0
     if (d.in_mode == 1) {
-        const int r = seq / d.nframes, k = seq % d.nframes;
+        int r, k;
+        aero_lstm_rk(p, seq, r, k);
         t_first = k * d.S;
         in_base = (int64_t)r * d.T + t_first;
     } else {
@@ -180,7 +191,8 @@ __global__ __launch_bounds__(NW * 64) void aero_lstm_kernel(AeroLstmK p) {
         st_base[it] = 0;
         if (st_ok[it]) {
             if (d.out_mode == 1) {
-                const int r = s2 / d.nframes, k = s2 % d.nframes;
+                int r, k;
+                aero_lstm_rk(p, s2, r, k);
                 const int lim = d.S / 2;
                 st_lo[it] = (k == 0) ? 0 : lim;
                 st_hi[it] = (k == d.nframes - 1 && k != 0) ? W : W - lim;
@@ -368,7 +380,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
         lx_c[v] = slot * 8;
         lx_dst[v] = (i * 16 + row) * XS + slot * 8;
         if (d.in_mode == 1) {
-            const int r = seq / d.nframes, k = seq - r * d.nframes;
+            int r, k;
+            aero_lstm_rk(p, seq, r, k);
             lx_tmax[v] = ok ? d.T - k * d.S : -1;
             lx_base[v] = r * d.T + k * d.S;
         } else {
@@ -419,7 +432,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
         sg_tlo[k2] = 0;
         sg_thi[k2] = ok ? W : -1;
         if (d.out_mode == 1) {
-            const int r = s2 / d.nframes, kf = s2 - r * d.nframes;
+            int r, kf;
+            aero_lstm_rk(p, s2, r, kf);
             const int lim = d.S / 2;
             const int hi = (kf == d.nframes - 1 && kf != 0) ? W : W - lim;
             const int tl = d.T - kf * d.S;                          // t = kf*S + tau must stay below T
@@ -430,9 +444,34 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
             sg_base[k2] = (s2 * W) * H2 + dir * H + e * 8;
         }
     }
+    // Round 6: the STITCHING layer of an inference forward runs only the steps some sequence of the block keeps.  The stitch (modules.py:52-62)
+    // keeps tau in [lo, hi) of a frame -- lo = 0 (first frame) or S/2, hi = W - S/2 or W (last frame), and t = k S + tau < T -- so the forward
+    // direction (step = tau) may stop at max hi and the backward one (step = W - 1 - tau) at W - min lo: a quarter of the steps of a middle
+    // frame in either direction.  The steps not run are exactly those whose h nothing reads: the result is bit-identical.  Block-uniform,
+    // rounded up to whole groups (the unrolled group loop stays straight-line code); only with frame-major sequences (aero_lstm_desc.frame_major):
+    // in the reference's frame-minor order every block mixes first, middle and last frames and would keep W anyway.
+    int Wrun = W;
+    if (!SAVE && d.out_mode == 1 && d.frame_major) {
+        // the block's sequences seq0 .. seq0 + 15 lie in frames k0 .. k1 (consecutive; more than two only when a frame has < 16 rows)
+        const int s_last = seq0 + 15 < d.nseq ? seq0 + 15 : d.nseq - 1;
+        const int k0 = seq0 / p.dv, k1 = s_last / p.dv;
+        const int lim = d.S / 2;
+        int need = k1 > k0 + 1 ? W : 0;
+        for (int kf = k0; kf <= k1 && kf <= k0 + 1; ++kf) {
+            const int lo = kf == 0 ? 0 : lim;
+            int hi = (kf == d.nframes - 1 && kf != 0) ? W : W - lim;
+            const int tl = d.T - kf * d.S;
+            hi = hi < tl ? hi : tl;
+            const int n = hi <= lo ? 0 : (dir ? W - lo : hi);
+            need = n > need ? n : need;
+        }
+        need = (need + G - 1) / G * G;
+        Wrun = need < G ? G : (need < W ? need : W);
+    }
+    Wrun = aero_uniform(Wrun);
     auto store_group = [&](int g) {
         const int s_base = g * G;
-        const int nst = W - s_base < G ? W - s_base : G;
+        const int nst = Wrun - s_base < G ? Wrun - s_base : G;
         if (sg_fast) {
 #pragma unroll
             for (int k2 = 0; k2 < NSV; ++k2) {
@@ -453,7 +492,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
             const int tau = dir ? W - 1 - step : step;
             int64_t opos;
             if (d.out_mode == 1) {
-                const int r = s2 / d.nframes, k = s2 - r * d.nframes;
+                int r, k;
+                aero_lstm_rk(p, s2, r, k);
                 const int lim = d.S / 2;
                 const int lo = (k == 0) ? 0 : lim;
                 const int hi = (k == d.nframes - 1 && k != 0) ? W : W - lim;
@@ -474,7 +514,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
     for (int i = 0; i < TPW; ++i) c[i] = 0.f;
     f32x4 accx[TPW];                    // bias + W_ih x for the step about to run
 #if AERO_LSTM_IMM
-    const int ngroups = (W + G - 1) / G;
+    const int ngroups = (Wrun + G - 1) / G;
     load_x(0);
     park_x(0);
     __syncthreads();
@@ -583,7 +623,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
             step_barrier();
         }
     };
-    const int nfull = W / G;
+    const int nfull = Wrun / G;
     int g = 0;
     for (; g + 2 <= nfull; g += 2) {
         group_full(std::integral_constant<int, 0>{}, g);
@@ -595,7 +635,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
     }
     if (g < ngroups) {                                                  // ragged last group (W % G steps): run-time slots
         if (g > 0) store_group(g - 1);
-        const int nst = W - g * G;
+        const int nst = Wrun - g * G;
         const int pofs = (g & 1) * (G * 16);
         const h16* hcur = hbase + pofs * HS;
         const h16* hoth = hbase + (G * 16 - pofs) * HS;
@@ -619,14 +659,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 12 && TPW == 1 && !SAVE) ? 6 : 1) v
 #pragma unroll
             for (int t = 0; t < TPW; ++t) accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wi[t][kt], xf[kt], accx[t], 0, 0, 0);
     };
-    const int ngroups = (W + G - 1) / G;
+    const int ngroups = (Wrun + G - 1) / G;
     load_x(0);
     park_x(0);
     __syncthreads();
     for (int g = 0; g < ngroups; ++g) {
         if (g + 1 < ngroups) load_x(g + 1);
         if (g > 0) store_group(g - 1);
-        const int nst = W - g * G < G ? W - g * G : G;
+        const int nst = Wrun - g * G < G ? Wrun - g * G : G;
         for (int i = 0; i < nst; ++i) {
             const int s = g * G + i;
             const h16* hprev = hring + (((s + R - 1) & (R - 1)) * 16 + col) * HS;
@@ -721,6 +761,8 @@ static int aero_lstm_launch(const aero_lstm_desc* d, hipStream_t stream, const c
     p.d = *d;
     p.MP = 16 * nw * tpw;
     p.KP = 32 * kt;
+    p.dv = 1;
+    if (d->in_mode == 1 || d->out_mode == 1) p.dv = d->frame_major ? d->nseq / d->nframes : d->nframes;
     dim3 grid((unsigned)((d->nseq + 15) / 16), 2), block((unsigned)(nw * 64));
     // AERO_LSTM_RING=0: step-wise kernel above (A/B);  AERO_LSTM_WIDE=0: keep the tiles on 6/8 waves instead of 12
     static int ring = -1, wide = -1;

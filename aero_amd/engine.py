@@ -414,7 +414,7 @@ class Ops:
         return stats
 
     # -- LSTM / attention / FTB ----------------------------------------------------------------
-    def lstm(self, xproj, xbias, whh, H, nseq, W, in_mode, out_mode, nframes, S, T, out, x=None, fused=None, save=None):
+    def lstm(self, xproj, xbias, whh, H, nseq, W, in_mode, out_mode, nframes, S, T, out, x=None, fused=None, save=None, frame_major=0):
         """one bidirectional layer.  Either (xproj, xbias) = precomputed input projection, or (x, fused=(wih, bias, in_ch)):
         the projection is computed inside the recurrent kernel from the raw input rows x [npos, in_ch].
         save = (gates fp16, c fp32) buffers (train_ops.lstm_save_buffers): the training-mode forward keeps what BPTT needs."""
@@ -423,6 +423,7 @@ class Ops:
             d.save_gates, d.save_c = _ptr(save[0]), _ptr(save[1])
         d.xproj, d.xbias, d.whh, d.out = _ptr(xproj), _ptr(xbias), _ptr(whh), _ptr(out)
         d.H, d.nseq, d.W, d.in_mode, d.out_mode, d.nframes, d.S, d.T = H, nseq, W, in_mode, out_mode, nframes, S, T
+        d.frame_major = int(frame_major)
         flops, nbytes = 2.0 * nseq * W * 2 * 4 * H * H, out.numel() * 2
         if fused is not None:
             wih, bias, in_ch = fused
@@ -520,6 +521,18 @@ Ops.dconv_row = _dconv_row
 Ops.dconv_row_fits = _dconv_row_fits
 
 
+def blstm_frames(T, W=200, S=100):
+    """frames of `unfold(x, W, S)` whose outputs survive the BLSTM's stitch (models/utils.py:22-35, modules.py:52-62: frame 0 keeps [0, W - S/2),
+    a middle frame [S/2, W - S/2), the last one [S/2, W)).  The reference cuts n = ceil(T / S) frames; when T <= (n - 1) S + S/2 the LAST one
+    covers [(n - 1) S + S/2, ...) -- entirely beyond T: every step of it is computed (over zero padding) and discarded.  Dropping it makes
+    frame n - 2 the last one, whose kept range then reaches T with the very values it had (a frame's recurrence does not depend on the other
+    frames): bit-identical output for 1 / n less recurrent work (T = 501: 6 -> 5 frames, T = 1724: 18 -> 17; T = 376 keeps its 4)."""
+    n = math.ceil(T / S)
+    if n >= 3 and T <= (n - 1) * S + S // 2:
+        n -= 1
+    return n
+
+
 def _hann_padded(win_length, n_fft, device):
     w = torch.zeros(n_fft, dtype=torch.float32)
     left = (n_fft - win_length) // 2
@@ -555,6 +568,7 @@ class HipEngine:
     stagger = 0
     prof_streams = False
     stage_hook = None
+    lstm_frame_major = os.environ.get('AERO_LSTM_FRAME_MAJOR', '1') != '0'     # (class default: tests build bare engines with __new__)
     _mark_base = None
     _out_pitch = None                   # (pitch, t_off) of the output spectrogram while a forward that hands it straight to the iSTFT runs
 
@@ -1263,25 +1277,29 @@ class HipEngine:
         framed = T > max_steps
         if framed:
             W, S = max_steps, max_steps // 2
-            nframes = math.ceil(T / S)                      # models/utils.py:29
+            nframes = blstm_frames(T, W, S)                 # models/utils.py:29 (minus a last frame nothing of which survives the stitch)
         else:
             W, S, nframes = T, 1, 1
         nseq = R * nframes
+        # frame-major sequence order: a block of 16 sequences belongs to one frame, so the stitching layer stops where its frame's kept range
+        # ends (k_lstm.h: a quarter of a middle frame's steps); the unfused projection path indexes its [B,Fo,T,8H] tensor per row and keeps the
+        # reference's order
+        fm = 1 if (framed and self.lstm_frame_major) else 0
         (pj0, xb0, whh0, fz0), (pj1, xb1, whh1, fz1) = L['lstm']
         out0 = torch.empty(nseq, W, 2 * H, dtype=torch.float16, device=h.device)
         out1 = torch.empty(R, T, 2 * H, dtype=torch.float16, device=h.device)
         if self.stage_hook is not None and not getattr(self, '_train', False):
             self.stage_hook('lstm+')                         # (BatchPipeline: the two recurrent launches on their own stream kind)
         if fz0 is not None and self.fuse_lstm_proj and h.is_contiguous():
-            ops.lstm(None, None, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0, x=h.view(R, T, H), fused=fz0)
+            ops.lstm(None, None, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0, x=h.view(R, T, H), fused=fz0, frame_major=fm)
         else:
             xp0 = ops.conv(pj0, h, None, B, Fo, Fo, T)                              # [B,Fo,T,8H], per position not per frame
-            ops.lstm(xp0, xb0, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0)
+            ops.lstm(xp0, xb0, whh0, H, nseq, W, 1 if framed else 0, 0, nframes, S, T, out0, frame_major=fm)
         if fz1 is not None and self.fuse_lstm_proj:
-            ops.lstm(None, None, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1, x=out0, fused=fz1)
+            ops.lstm(None, None, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1, x=out0, fused=fz1, frame_major=fm)
         else:
             xp1 = ops.conv(pj1, out0.view(nseq, 1, W, 2 * H), None, nseq, 1, 1, W)  # [nseq,1,W,8H]
-            ops.lstm(xp1, xb1, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1)
+            ops.lstm(xp1, xb1, whh1, H, nseq, W, 0, 1 if framed else 0, nframes, S, T, out1, frame_major=fm)
         if self.stage_hook is not None and not getattr(self, '_train', False):
             self.stage_hook('lstm-')
         if self.use_pw and L.get('lstm_lin_pw') is not None:

@@ -118,12 +118,11 @@ def make_squeeze_spec(w, bias, act, device):
 
 def make_pw_spec(w, bias, act, lib, device, max_c=96):
     """w [M, C] fp32 in the reference's row order; GLU: rows / bias interleaved (value, gate) as make_conv_spec does.  None if the
-    geometry is not served by the streaming pointwise kernel.  max_c: the kernel also takes 96 < C <= 384 (weights in LDS), but on the
-    MI355X that form is 15-80% SLOWER than the LDS-tiled conv at the model's widths (profiles/r04_pw_wlds_ab.txt), so the engine keeps
-    the default and only the op tests ask for more."""
+    geometry is not served by the streaming pointwise kernel (C <= 96, NONE / RELU / GLU: the weights-in-LDS form for wider inputs was
+    15-80% SLOWER than the LDS-tiled conv at the model's widths, profiles/r04_pw_wlds_ab.txt, and is no longer built)."""
     M, C = w.shape
     rows = int(lib.cdll.aero_pw_rows(C, M)) if C <= max_c else 0
-    if not rows:
+    if not rows or act not in (_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_GLU):
         return None
     if act == _lib.ACT_GLU:
         w = glu_interleave(w)

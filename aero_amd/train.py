@@ -24,7 +24,7 @@ import torch
 
 from . import _lib, backward as bw, pack, train_ops as TO
 from ._lib import ACT_GELU, ACT_GLU, ACT_NONE, ACT_RELU, ACT_SNAKE
-from .engine import Ops, _hann_padded
+from .engine import Ops, _hann_padded, blstm_frames
 
 GRAD_TARGET = 64.0          # a stage's input gradient has its largest magnitude in [32, 64]: three orders of magnitude of headroom
                             # to the fp16 maximum for growth inside the stage, six down to the smallest normal number
@@ -414,7 +414,7 @@ class TrainEngine:
         framed = T > 200
         if framed:
             W, S = 200, 100
-            nf = math.ceil(T / S)
+            nf = blstm_frames(T, W, S)                       # (engine.blstm_frames: a last frame that the stitch discards whole is not computed)
             fr0 = TO.frames_op(ops, a.view(R, T, H), 0, R, T, H, nf, W, S)
         else:
             W, S, nf = T, 1, 1

@@ -233,7 +233,7 @@ typedef struct aero_gram_desc {
 } aero_gram_desc;
 int aero_gram_stats(const aero_gram_desc* d, void* stream);
 
-/* K9' -- a pointwise (1x1) convolution with a SHORT contraction (C <= 384) and a wide output, as ONE streaming pass (k_pw.h): the tail of a
+/* K9' -- a pointwise (1x1) convolution with a SHORT contraction (C <= 96; activation NONE / RELU / GLU; statistics with GLU only) and a wide output, as ONE streaming pass (k_pw.h): the tail of a
  * DConv layer behind a BLSTM / LocalState (modules.py:240-247: Conv1d(hidden, 2C, 1) -> GroupNorm(1, 2C) -> GLU -> LayerScale, + x) and the
  * encoder's rewrite conv + GLU (+ frequency embedding) where no GroupNorm sits between them (aero.py:133, 475-480).
  *   x fp16 [B][F][T][C] channels-last; dst fp16 [B][F][T][Mout], Mout = M/2 with AERO_ACT_GLU (rows 2u, 2u+1 = value, gate) else M.
@@ -263,8 +263,8 @@ int aero_squeeze_fwd(const void* x, int64_t x_b, int64_t x_f, int64_t x_t, const
                      int32_t T, int32_t C, int32_t M, int32_t rp, int32_t act, void* stream);
 /* conv rows one block covers (128 * GW) for a C -> M pointwise conv, 0 if the geometry is not served (C > 96, C % 8, M % 16) */
 int aero_pw_rows(int32_t C, int32_t M);
-/* k-steps KS of the weight image for C input channels (ceil(C/32) up to 6, then 8 or 12: the image is zero padded to 32*KS columns).
- * C <= 96: the fragments stay in registers; 96 < C <= 384: in LDS (one ds_read_b128 per MFMA), rows per block = 128 */
+/* k-steps KS of the weight image for C <= 96 input channels (ceil(C/32): the image is zero padded to 32*KS columns; the fragments stay in
+ * registers); 0 for wider inputs (their weights-in-LDS form measured slower than aero_conv_fwd and is no longer built) */
 int aero_pw_ksteps(int32_t C);
 
 /* K10 -- the recurrent part of nn.LSTM(bidirectional) inside BLSTM (modules.py:28,46), both
@@ -290,6 +290,11 @@ typedef struct {
      * activations i,f,g,o as fp16 [H][16][4] at save_gates + (((ib*2 + dir)*W + tau)*H*64) and the cell state c_tau as fp32
      * [H][16] at save_c + (((ib*2 + dir)*W + tau)*H*16): what aero_lstm_bwd reads.  Runs the step-wise kernel. */
     void* save_gates; float* save_c;
+    /* round 6 -- 0: sequence s is frame s % nframes of row s / nframes (the order of `unfold` + reshape, modules.py:49-51); 1: frame-major,
+     * s = k * (nseq / nframes) + r.  Both framed layers of a BLSTM must use the same order (the layer-1 output is indexed by s).  With
+     * frame-major sequences a block's 16 sequences share a frame, and the stitching layer (out_mode 1, no save buffers) stops at the last
+     * step its frame keeps -- a quarter of a middle frame's steps in either direction; the output is bit-identical either way. */
+    int32_t frame_major;
 } aero_lstm_desc;
 /* AERO_ERR_UNSUPPORTED ("tensor too large for 32-bit offsets") when the input holds 2^31 rows of W steps or the output 2^31 elements or
  * more: the kernel keeps per-thread row indices / element offsets in 32 bits (a 64-bit pair per entry spilled registers). */

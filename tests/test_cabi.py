@@ -44,3 +44,23 @@ def test_argument_errors_are_reported_not_thrown():
     ld.H, ld.nseq, ld.W = 48, 1 << 20, 400                       # 2^20 x 400 rows x 96 = 4e10 elements
     rc = lib.cdll.aero_lstm_fwd(C.byref(ld), None)
     assert rc == -3 and b'32-bit' in lib.cdll.aero_last_error()
+
+
+def test_round6_entry_points_without_a_device():
+    """the pitch query is host arithmetic; the stream / pitched entry points validate their arguments before touching the device"""
+    import ctypes as C
+    from aero_amd import _lib
+    lib = _lib.load()
+    p, t = C.c_int32(), C.c_int32()
+    assert lib.cdll.aero_istft_pitch(512, 64, 501, C.byref(p), C.byref(t)) == 0 and (p.value, t.value) == (528, 12)   # headline geometry
+    assert p.value * 8 % 128 == 0 and (64 * 0 + 4 + t.value) % 16 == 0            # rows are whole lines; a block's 16-frame groups (first at frame 4) start on one
+    assert lib.cdll.aero_istft_pitch(1024, 256, 376, C.byref(p), C.byref(t)) == 0 and p.value % 16 == 0 and p.value >= t.value + 376
+    assert lib.cdll.aero_istft_pitch(512, 50, 100, C.byref(p), C.byref(t)) == 0 and (p.value, t.value) == (100, 0)    # not the frame-run kernel: plain layout
+    assert lib.cdll.aero_istft_pitch(512, 64, 501, None, C.byref(t)) == -1
+    assert lib.cdll.aero_stream_create(0, None, 0, None) == -1 and b'stream_create' in lib.cdll.aero_last_error()
+    assert lib.cdll.aero_stream_create(0, None, 4, C.byref(C.c_void_p())) == -1        # a mask length without a mask
+    assert lib.cdll.aero_stream_destroy(None) == -1
+    rc = lib.cdll.aero_istft_pitched_fwd(16, 1, 256, 501, 400, 0, 512, 64, 16, 16, 16, 100, None)
+    assert rc == -1 and b'pitch' in lib.cdll.aero_last_error()                        # pitch < t_off + T
+    rc = lib.cdll.aero_convtr_tail_finish_pitched(16, 16, None, None, None, 16, 1, 4, 501, 16, 2, 500, 12, None)
+    assert rc == -1 and b'pitch' in lib.cdll.aero_last_error()

@@ -344,6 +344,11 @@ def test_ftb_autograd(emu, a):
     oc.case_ftb_autograd(emu, DEV, *a)
 
 
+def test_blstm_without_the_discarded_last_frame(emu):
+    """round 6: T = 501 cuts 6 frames of which the last is stitched away whole -- not computing it changes no bit (8 lengths, 6 with a drop)"""
+    assert oc.case_blstm_frame_skip(emu, DEV) == 6
+
+
 @pytest.mark.parametrize('tag', ['blstm', 'localstate', 'snake', 'ftb', 'dconv', 'henc', 'hdec'])
 def test_reference_module_vectors(emu, tag):
     """the REFERENCE's own module outputs (tests/golden/modules.npz) reproduced by the kernels: <= 1e-3, the north-star bar"""

@@ -327,3 +327,29 @@ def test_planted_faults_are_caught_on_the_device(meta):
         if fault not in S.SURVIVORS:
             assert e > S.BAR, f'{fault} survived on the device: {e:.3e}'
     print('clean %.3e | ' % e_spec + ' | '.join(f'{k} {v:.2e}' for k, v in report.items()))
+
+
+def test_batch_pipeline_schedules_are_bit_identical(meta):
+    """Round 6: whatever the serving loop does with streams -- the default's two event waits per batch, free-running streams, stages of a
+    batch on a high-priority or a CU-masked stream created through the C ABI (aero_stream_create), the recurrent launches alone on one --
+    every batch's output is the single-stream forward's, bit for bit: the schedule decides WHEN a launch runs, never what it computes."""
+    from aero_amd.pipeline import BatchPipeline
+    m = build_model(meta, 'full').cuda().eval()
+    eng = m._get_engine()
+    g = torch.Generator().manual_seed(21)
+    xs = [torch.randn(16, 1, 8000, generator=g).cuda(), torch.randn(8, 1, 6000, generator=g).cuda()]
+    try:
+        eng.streams = 1
+        with torch.no_grad():
+            refs = [m(x, return_spec=True) for x in xs]
+    finally:
+        eng.streams = 0
+    order = [i % 2 for i in range(12)]
+    for kw in (dict(), dict(waits=[]), dict(stagger=2.5), dict(waits=[(0, 3), (4, 8)], depth=4),
+               dict(schedule='stages=mmllmmmm;l=prio:-1'), dict(schedule='lstm=l;l=prio:-1'), dict(schedule='stages=mmlldddd;l=mask:0:128;d=prio:1')):
+        pipe = BatchPipeline(m, **{'depth': 3, **kw})
+        outs = pipe.run([xs[i] for i in order], return_spec=True)
+        torch.cuda.synchronize()
+        for i, (y, s) in zip(order, outs):
+            assert torch.equal(y, refs[i][0]) and torch.equal(s, refs[i][1]), kw
+    assert eng.stage_hook is None and eng.streams == 0

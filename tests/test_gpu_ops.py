@@ -316,6 +316,10 @@ def test_ftb_autograd(lib, a):
     oc.case_ftb_autograd(lib, DEV, *a)
 
 
+def test_blstm_without_the_discarded_last_frame(lib):
+    assert oc.case_blstm_frame_skip(lib, DEV, H=48, R=5) == 6
+
+
 @pytest.mark.parametrize('tag', ['blstm', 'localstate', 'snake', 'ftb', 'dconv', 'henc', 'hdec'])
 def test_reference_module_vectors(lib, tag):
     """the REFERENCE's own module outputs (tests/golden/modules.npz: BLSTM framed / unframed, LocalState, FTB eval + train, Snake,
