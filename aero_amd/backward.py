@@ -160,7 +160,7 @@ def norm_bwd(ops, x, dy, stats, G, per_row, gamma, beta, act, layer_scale=None, 
         if sz and out.get(k) is None:
             offs[k] = n
             n += (sz + 3) // 4 * 4
-    scratch = torch.zeros(n, dtype=torch.float32, device=x.device) if n else None
+    scratch = ops.zeros32(n, x.device) if n else None
     res = {}
     for k, sz in want.items():
         if not sz:

@@ -346,6 +346,22 @@ class Ops:
         ar[1] = ar[2] = 0
         self._cur = ar
 
+    _bwd = None           # [fp32 buffer, used, demanded]: the zero-filled scratch of the backward pass that is running (aero_amd/train.py)
+
+    def zeros32(self, n, device, dtype=torch.float32):
+        """n zero-initialised 4-byte words for a kernel that accumulates into them: a slice of the running backward pass's ONE zero-filled
+        buffer (a single fill launch per backward instead of one per GroupNorm / rescale / weight-gradient call: 55 at the config-5 shape),
+        torch.zeros outside a backward pass or when the buffer is exhausted (it is sized from the previous step's demand)."""
+        ar = self._bwd
+        if ar is not None and ar[0].device == torch.device(device):
+            m = (n + 3) // 4 * 4                                 # 16-byte aligned slices
+            ar[2] += m
+            if ar[1] + m <= ar[0].numel():
+                out = ar[0][ar[1]:ar[1] + n]
+                ar[1] += m
+                return out if dtype == torch.float32 else out.view(dtype)
+        return torch.zeros(n, dtype=dtype, device=device)
+
     def new_stats(self, B, F, G, per_row, device):
         n = (B * F if per_row == 1 else (1 if per_row == 2 else B)) * G * 2
         ar = self._cur

@@ -114,6 +114,7 @@ class TrainEngine:
     _replay, _replay_dev, replay_enabled = None, None, os.environ.get('AERO_REPACK_GATHER', '1') != '0'
     _bias_sums = None
     _stat_need = 0
+    _bwd_need = 0
 
     def w(self, name):
         return self.sd[name].float()
@@ -512,12 +513,16 @@ class TrainEngine:
         B, T, F0 = ctx.B, ctx.T, ctx.F0
         self.g = grads
         self._side = self._param_stream(dev)
+        # one zero-filled scratch buffer for every small accumulator of this pass (Ops.zeros32), sized from the previous pass's demand
+        ar = [torch.zeros(max(self._bwd_need, 1 << 14), dtype=torch.float32, device=dev), 0, 0]
+        ops._bwd = ar if os.environ.get('AERO_BWD_ARENA', '1') != '0' else None
         try:
             self._backward(ctx, dy, stage_done, m, ops, dev, B, T, F0)
         finally:
             if self._side is not None:
                 torch.cuda.current_stream(dev).wait_stream(self._side)
             self._side = None
+            self._bwd_need, ops._bwd = max(self._bwd_need, ar[2]), None
 
     def _backward(self, ctx, dy, stage_done, m, ops, dev, B, T, F0):
         dz = bw.istft_bwd(ops, dy.reshape(B, ctx.Lout).contiguous().float(), m.nfft, ctx.hop_o, self._window(ctx.win_o, dev),

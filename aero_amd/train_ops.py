@@ -21,7 +21,7 @@ def freqfc_wgrad(ops, dfc, x, gate, nslab=None):
     if nslab is None:
         chunks = B * ((T * Cc + 31) // 32)
         nslab = max(1, min(256, chunks // 64, 1024 // max(1, ((F + 63) // 64) ** 2) + 1))
-    dw = torch.zeros(F, F, dtype=torch.float32, device=x.device)
+    dw = ops.zeros32(F * F, x.device).view(F, F)
     slabs = torch.empty(nslab, F, F, dtype=torch.float32, device=x.device)
     ops.lib.call('aero_freqfc_wgrad', _ptr(dfc), _ptr(x), _ptr(gate), _ptr(dw), _ptr(slabs), nslab, B, F, T, Cc, ops.stream(x))
     return dw
@@ -137,7 +137,7 @@ def scale_cast(ops, x, item_scale, target):
     nitems = x.shape[0]
     assert x.is_contiguous()
     dst = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-    amax = torch.zeros(1, dtype=torch.int32, device=x.device)
+    amax = ops.zeros32(1, x.device, torch.int32)
     scale = torch.empty(2, dtype=torch.float32, device=x.device)
     ops.lib.call('aero_scale_cast', _ptr(x), nitems, x.numel() // nitems, _ptr(item_scale), _ptr(amax), C.c_float(target), _ptr(dst), _ptr(scale),
                  ops.stream(x))
@@ -155,7 +155,7 @@ def rescale_f16(ops, a, sa, b=None, sb=None, target=4096.0):
     sa / sb: the {S, 1/S} device pairs the operands carry (None = 1)."""
     assert a.is_contiguous() and (b is None or (b.is_contiguous() and b.shape == a.shape))
     out = torch.empty_like(a)
-    amax = torch.zeros(1, dtype=torch.int32, device=a.device)
+    amax = ops.zeros32(1, a.device, torch.int32)
     scale = torch.empty(2, dtype=torch.float32, device=a.device)
     ops.lib.call('aero_rescale_f16', _ptr(a), _ptr(sa), _ptr(b), _ptr(sb), a.numel(), _ptr(amax), C.c_float(target), _ptr(out), _ptr(scale), ops.stream(a))
     return out, scale
