@@ -325,9 +325,9 @@ class Aero(nn.Module):
             # pass needs (aero_amd/train.py).  The waveform output carries the gradient; the spectrogram outputs are detached views
             # (the reference's losses act on the waveform: solver.py:560-584).
             from .train import AeroFunction
+            # (a partially frozen generator -- `requires_grad_(False)` on some parameters, as fine-tuning recipes do -- runs the same backward
+            # pass: every gradient is formed, autograd keeps those of the parameters that ask for one; round 6)
             names, params = zip(*self.named_parameters())
-            if any(not p.requires_grad for p in params):
-                raise NotImplementedError('aero_amd: partially frozen generators are not supported by the HIP backward pass')
             x, spec_r, lr_spec = AeroFunction.apply(self._get_train_engine(), names, mix, *params)
             spec = torch.view_as_complex(spec_r).view(mix.shape[0], 1, spec_r.shape[1], spec_r.shape[2])
             if return_spec:

@@ -13,6 +13,11 @@ def test_training_step_small_model_on_the_emulator():
     assert len(rows) > 250                                    # every parameter with a gradient was compared
 
 
+def test_partially_frozen_generator_on_the_emulator():
+    from emu.build_emu import build
+    assert tc.case_partially_frozen('cpu', lib=_lib.load(build())) > 20
+
+
 def test_weight_images_replayed_by_gather_match_their_closures():
     from emu.build_emu import build
     assert tc.case_weight_replay('cpu', lib=_lib.load(build())) > 50

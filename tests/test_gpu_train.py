@@ -17,6 +17,10 @@ def meta():
     return json.load(open(os.path.join(GOLDEN, 'meta.json')))
 
 
+def test_partially_frozen_generator():
+    assert tc.case_partially_frozen('cuda') > 20
+
+
 def test_training_step_small_model_vs_reference_golden():
     rows = tc.case_training_step_small('cuda')
     assert len(rows) > 250

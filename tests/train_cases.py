@@ -125,6 +125,43 @@ def case_training_step_small(dev, lib=None, L=400):
             losses.use_library(None)
 
 
+def case_partially_frozen(dev, lib=None, L=400):
+    """`requires_grad_(False)` on a part of the generator (the reference's nn.Module allows it: aero.py:446-523 under any autograd state):
+    the trainable parameters receive EXACTLY the gradients of the all-trainable run (same kernels, same order), the frozen ones none."""
+    import json
+    import os
+    from conftest import GOLDEN
+    meta = json.load(open(os.path.join(GOLDEN, 'meta.json')))
+    inp = meta['train_small_inputs']
+    x = seeded((2, 1, L), inp['x_seed'])
+    dy = torch.from_numpy(load_npz('train_small_grads.npz')['dy'])
+
+    def run(freeze):
+        m = build_model(meta, 'small').train()
+        if lib is not None:
+            from aero_amd.engine import HipEngine
+            object.__setattr__(m, '_engine', HipEngine(m, lib=lib))
+        m.to(dev)
+        for n, p in m.named_parameters():
+            if any(n.startswith(f) for f in freeze):
+                p.requires_grad_(False)
+        y = m(x.to(dev))
+        assert y.requires_grad
+        y.backward(dy.to(dev))
+        return {n: (None if p.grad is None else p.grad.detach().cpu().clone()) for n, p in m.named_parameters()}
+    full = run(())
+    part = run(('encoder.0.', 'encoder.1.', 'freq_emb.', 'decoder.3.conv_tr.'))
+    nfrozen = 0
+    for n, g in part.items():
+        if n.startswith(('encoder.0.', 'encoder.1.', 'freq_emb.', 'decoder.3.conv_tr.')):
+            assert g is None, n
+            nfrozen += 1
+        else:
+            assert g is not None and torch.equal(g, full[n]), n
+    assert nfrozen > 20 and all(g is not None for g in full.values())
+    return nfrozen
+
+
 def case_weight_replay(dev, lib=None, steps=2):
     """After the first optimizer step the training engine stops re-packing its weight images with torch ops and replays them with
     aero_gather_pack (aero_amd/repack.py).  A few training steps of the small model; after every optimizer step each replayed image
