@@ -40,7 +40,10 @@ def parse_schedule(text):
     `stages`: one letter per stage of the forward (encoder layers 1-4, decoder layers 5-8; the STFT / normalisation run with the first, the
     iSTFT with the last); 'm' is the batch's own stream of the ring.  Every other letter names a stream KIND of which each slot of the ring
     gets its own object: 'prio:p' a stream of dispatch priority p, 'mask:lo:hi' a stream restricted to the CUs [lo, hi), 'plain' a
-    default stream.  A kind marked 'shared' (e.g. 'l=prio:-1:shared') is ONE stream for all slots."""
+    default stream.  A kind marked 'shared' (e.g. 'l=prio:-1:shared') is ONE stream for all slots -- TIMING EXPERIMENTS ONLY: the per-slot
+    pairing that keeps the caching allocator's per-stream pools safe (see submit) does not hold for it.  'stagger=s' / 'lstm=<kind>': see
+    BatchPipeline.  These schedules are the round-6 experiments of DESIGN.md 4.4 (priorities and CU masks measured NOT to pay); the serving
+    loop's default is plain streams with `waits`."""
     out = {}
     for item in text.split(';'):
         if not item.strip():
@@ -63,7 +66,8 @@ def parse_schedule(text):
 
 class BatchPipeline:
     """pipe = BatchPipeline(model, depth=3);  t = pipe.submit(x);  ...;  y = pipe.result(t)   (inference, model.eval()).
-    `schedule` (a dict or the text form of parse_schedule): which HIP stream each stage of a batch is issued on -- see DESIGN.md 4.6e."""
+    `waits` ('auto' = the default): event waits between consecutive batches that keep the streams out of phase.
+    `schedule` (a dict or the text form of parse_schedule): which HIP stream each stage of a batch is issued on -- experiments, DESIGN.md 4.4a/b."""
 
     def __init__(self, model, depth=3, schedule=None, stagger=0, waits='auto'):
         self.model = model
@@ -180,8 +184,7 @@ class BatchPipeline:
             # still ONE chain; what changes is which queue -- priority, CU set -- its launches wait in next to the other batches'.
             # The caching allocator keeps one pool per stream and reuses a freed block without waiting for OTHER streams: a block of
             # stream s that a later stage read on stream s' returns to s's pool and is handed out again by the NEXT batch of this slot,
-            # which therefore starts behind this batch's last stage (`_slot_done`).  A 'shared' kind breaks that pairing: its blocks are
-            # marked (record_stream) when a stage on another stream ends.
+            # which therefore starts behind this batch's last stage (`_slot_done`).  (A 'shared' kind breaks that pairing: experiments only.)
             stages = self.schedule['stages']
             st = self._kind_stream(dev, slot, stages[0])
             prev = self._slot_done.get((dev, slot))
