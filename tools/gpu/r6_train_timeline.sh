@@ -3,7 +3,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r06_trace_train" -o t -- python "$GRAFT_REPO_ROOT/tools/config5.py" 2 6 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r06_trace_train" -o t -- python "$GRAFT_REPO_ROOT/tools/dbg/train_loop_nosync.py" 8 2>&1 | grep "ms per step"
 f=$(find "$GRAFT_REPO_ROOT/gpurun_out/r06_trace_train" -name "*kernel_trace.csv" | head -1)
 python "$GRAFT_REPO_ROOT/tools/step_timeline.py" "$f" > "$GRAFT_REPO_ROOT/gpurun_out/r06_train_timeline.txt" 2>&1
 python - "$f" >> "$GRAFT_REPO_ROOT/gpurun_out/r06_train_timeline.txt" <<'PY'
@@ -26,4 +26,3 @@ PY
 rm -rf "$GRAFT_REPO_ROOT/gpurun_out/r06_trace_train"
 cat "$GRAFT_REPO_ROOT/gpurun_out/r06_train_timeline.txt" | cut -c1-200 | head -90
 cd "$GRAFT_REPO_ROOT"
-timeout 300 python -m pytest tests/test_disc.py -m gpu -q -s -k per_scale 2>&1 | grep "critic gradients per scale" | tee gpurun_out/r06_critic_per_scale.txt
